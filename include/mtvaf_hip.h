@@ -1,0 +1,154 @@
+/* mtvaf_hip.h -- C ABI of libmtvaf_hip.so: the MI355X (gfx950) kernels behind MTVAF's prefix-fused
+ * BERT/RoBERTa forward/backward path.
+ *
+ * The reference (MKMaS-GUET/MTVAF) has no FFI layer: the path sits behind Python nn.Modules
+ * (models/bert_model.py::TVNetSAModel2, models/modeling_bert.py::BertModel).  Each entry point below
+ * replaces the eager torch ops of the cited reference lines; the Python side (mtvaf_amd/hip.py) binds
+ * them with ctypes and wraps them in torch.autograd.Functions inside modules that keep the reference's
+ * class names, constructor/forward signatures and parameter names.
+ *
+ * Conventions
+ *   - all tensors are dense row-major fp32 device buffers owned by the caller (torch); the library never
+ *     allocates; scratch is passed in (`*_workspace_bytes` queries give the size);
+ *   - every call only enqueues work on `stream` (a hipStream_t) and never synchronises;
+ *   - return 0 on success, <0 = MTVAF_ERR_* (bad shape / alignment / argument / workspace), >0 = hipError_t;
+ *   - float4 vector access: row strides are multiples of 4 floats and bases 16-byte aligned unless a
+ *     function says otherwise (the GEMM falls back to scalar loads when they are not);
+ *   - dropout masks are a pure function of (seed, offset, element index): backward calls take the same
+ *     (p_drop, seed, offset) as their forward and regenerate the mask;
+ *   - `accumulate` != 0 adds parameter gradients into the destination instead of overwriting it.
+ */
+#ifndef MTVAF_HIP_H
+#define MTVAF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mtvaf_stream_t; /* hipStream_t */
+
+#define MTVAF_OK 0
+#define MTVAF_ERR_SHAPE (-1)
+#define MTVAF_ERR_ALIGN (-2)
+#define MTVAF_ERR_ARG (-3)
+#define MTVAF_ERR_WORKSPACE (-4)
+
+/* operand layouts of mtvaf_gemm_f32: KC = reduction index contiguous, KM = reduction index is the row */
+#define MTVAF_KC 0
+#define MTVAF_KM 1
+/* epilogues */
+#define MTVAF_EPI_NONE 0
+#define MTVAF_EPI_GELU 1  /* C = gelu_erf(acc + bias), pre-activation -> aux  (modeling_bert.py:420-421) */
+#define MTVAF_EPI_TANH 2  /* C = tanh(acc + bias)                            (bert_model.py:446-454)   */
+#define MTVAF_EPI_DGELU 3 /* C = acc * gelu_erf'(aux)                                                   */
+#define MTVAF_EPI_DTANH 4 /* C = acc * (1 - aux^2)                                                      */
+
+int mtvaf_version(void);
+int mtvaf_device_cus(void);
+
+/* ---- dense projections (fp32 MFMA): nn.Linear forward / dX / dW ------------------------------------
+ * replaces query/key/value (modeling_bert.py:266,283-284), BertSelfOutput.dense (:353),
+ * BertIntermediate.dense + GELU (:420-421), BertOutput.dense (:433), encoder_conv / projectors /
+ * img_classifier (bert_model.py:446-459, 541-542, 552, 568), fc (bert_model.py:510) and their autograd
+ * backward.  C[M,N] = opA[M,K] . opB[K,N] (+bias[N]) with epilogue `epi`; cfg/splits < 0 = heuristic.
+ * allow_split enables a deterministic split-K (ordered slab reduction) through `workspace`. */
+size_t mtvaf_gemm_f32_workspace_bytes(int M, int N, int K, int allow_split);
+int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                   int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                   mtvaf_stream_t stream);
+
+/* ---- fused prefix self-attention ---------------------------------------------------------------------
+ * replaces BertSelfAttention.forward's prefix concat + scores + mask + softmax + dropout + PV + head merge
+ * (modeling_bert.py:282-286, 303, 320-337; modeling_roberta.py:218-222) and its backward.
+ * qkv [B*S,3H] token-major (Q|K|V); pk/pv [B,P*H] raw reshape(bsz,12,-1,64) slabs (bert_model.py:585);
+ * addmask [B,P+S] = (1-mask)*-10000; ctx [B*S,H]; lse [B,NH,S].  head_dim must be 64. */
+int mtvaf_prefix_attn_fwd(const float* qkv, const float* pk, const float* pv, const float* addmask, float* ctx,
+                          float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                          uint64_t offset, mtvaf_stream_t stream);
+int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv,
+                          const float* addmask, const float* ctx, const float* lse, float* delta, float* dqkv,
+                          float* dpk, float* dpv, int B, int S, int P, int NH, int head_dim, float p_drop,
+                          uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
+
+/* ---- embeddings + LayerNorm + dropout -----------------------------------------------------------------
+ * replaces BertEmbeddings.forward (modeling_bert.py:212-222) / RobertaEmbeddings.forward
+ * (modeling_roberta.py:102-140) and create_position_ids_from_input_ids (:1706-1719).  pos_ids == NULL
+ * means arange(S) (BERT, past_key_values_length hard-coded 0 at modeling_bert.py:1050). */
+int mtvaf_roberta_position_ids(const int64_t* ids, int32_t* pos_ids, int B, int S, int pad_idx, mtvaf_stream_t stream);
+int mtvaf_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids, const float* word,
+                       const float* pos, const float* type, const float* gamma, const float* beta, float* out,
+                       float* mean, float* rstd, int B, int S, int H, float eps, float p_drop, uint64_t seed,
+                       uint64_t offset, mtvaf_stream_t stream);
+int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                       const float* word, const float* pos, const float* type, const float* gamma, const float* mean,
+                       const float* rstd, float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta,
+                       int accumulate, int B, int S, int H, int vocab, int max_pos, int type_vocab, int word_pad,
+                       int pos_pad, float p_drop, uint64_t seed, uint64_t offset, float* dz_ws, void* workspace,
+                       size_t workspace_bytes, mtvaf_stream_t stream);
+
+/* ---- dropout + residual + LayerNorm --------------------------------------------------------------------
+ * replaces BertSelfOutput / BertOutput `LayerNorm(dropout(dense_out) + input)` (modeling_bert.py:354-355,
+ * 434-435); the dense bias is added by the GEMM epilogue. */
+size_t mtvaf_ln_bwd_workspace_bytes(int M, int H);
+int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
+                             float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
+                             uint64_t offset, mtvaf_stream_t stream);
+int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma,
+                             const float* mean, const float* rstd, float* dx, float* dres, int dres_accumulate,
+                             float* dgamma, float* dbeta, int accumulate, int M, int H, float p_drop, uint64_t seed,
+                             uint64_t offset, void* workspace, size_t workspace_bytes, mtvaf_stream_t stream);
+
+/* ---- small reductions / elementwise ---------------------------------------------------------------------
+ * bias gradients (column sums of dY) and nn.Dropout on the sequence output (bert_model.py:506). */
+size_t mtvaf_colsum_workspace_bytes(int rows, int cols);
+int mtvaf_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* workspace,
+                 size_t workspace_bytes, mtvaf_stream_t stream);
+int mtvaf_dropout(const float* x, float* y, long n, float p_drop, uint64_t seed, uint64_t offset,
+                  mtvaf_stream_t stream);
+
+/* ---- linear-chain CRF head --------------------------------------------------------------------------------
+ * replaces torchcrf.CRF(num_tags, batch_first=True): forward(..., reduction='mean') negated at
+ * bert_model.py:521 and decode at :511.  emissions [B,S,C], tags int64 [B,S], mask uint8 [B,S] with
+ * mask[:,0] == 1, C <= 16.  loss[0] = -mean_b(score(gold) - logZ).  The workspace written by the forward
+ * is read by the backward.  tags_out int32 [B,S] (-1 padded), lens_out int32 [B]. */
+size_t mtvaf_crf_workspace_bytes(int B, int S, int C);
+int mtvaf_crf_nll_fwd(const float* emissions, const int64_t* tags, const uint8_t* mask, const float* start,
+                      const float* end, const float* trans, float* loss, int B, int S, int C, void* workspace,
+                      size_t workspace_bytes, mtvaf_stream_t stream);
+int mtvaf_crf_nll_bwd(const float* grad_out, const float* emissions, const int64_t* tags, const uint8_t* mask,
+                      const float* start, const float* end, const float* trans, float* demissions, float* dstart,
+                      float* dend, float* dtrans, int accumulate, int B, int S, int C, void* workspace,
+                      size_t workspace_bytes, mtvaf_stream_t stream);
+int mtvaf_crf_viterbi(const float* emissions, const uint8_t* mask, const float* start, const float* end,
+                      const float* trans, int32_t* tags_out, int32_t* lens_out, int B, int S, int C,
+                      mtvaf_stream_t stream);
+
+/* ---- visual prompt generator + VAO loss ----------------------------------------------------------------------
+ * replaces TVNetSAModel2.get_visual_prompt's split-mean / gates / gated sums / cat / reshape
+ * (bert_model.py:544-545, 566-585) and the KLDiv(batchmean) ANP loss (:549-563).
+ * enc [NI,B,L,4W] (encoder_conv output, NI = 1+n_aux), sm [NI*B,L*W], gate/logits [NI*B,NL*4],
+ * pkv [NL,2,B,(NI*L)*(W/2)] -- the slabs mtvaf_prefix_attn_* read. */
+int mtvaf_split_mean(const float* enc, float* sm, long rows, int W, mtvaf_stream_t stream);
+int mtvaf_gate_fwd(const float* logits, float* gate, long ngroups, mtvaf_stream_t stream);
+int mtvaf_prompt_mix_fwd(const float* enc, const float* gate, float* pkv, int NI, int B, int L, int W, int NL,
+                         mtvaf_stream_t stream);
+int mtvaf_prompt_mix_bwd_gate(const float* enc, const float* dpkv, const float* logits, const float* gate,
+                              float* dgate_part, float* dlogits, int NI, int B, int L, int W, int NL,
+                              mtvaf_stream_t stream);
+int mtvaf_prompt_mix_bwd_enc(const float* gate, const float* dpkv, const float* dsm, float* denc, int NI, int B,
+                             int L, int W, int NL, mtvaf_stream_t stream);
+int mtvaf_kl_logsoftmax_fwd(const float* logits, const float* target, float* loss, float* row_ws, int B, int N,
+                            mtvaf_stream_t stream);
+int mtvaf_kl_logsoftmax_bwd(const float* grad_out, float gscale, const float* logits, const float* target,
+                            float* dlogits, int B, int N, mtvaf_stream_t stream);
+int mtvaf_mean_l_fwd(const float* enc, float* out, long n, int L, int W4, mtvaf_stream_t stream);
+int mtvaf_mean_l_bwd(const float* dmean, float* denc, long n, int L, int W4, mtvaf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTVAF_HIP_H */

@@ -1,0 +1,90 @@
+// Shared device/host helpers for the MTVAF gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MTVAF_OK 0
+#define MTVAF_ERR_SHAPE (-1)
+#define MTVAF_ERR_ALIGN (-2)
+#define MTVAF_ERR_ARG (-3)
+#define MTVAF_ERR_WORKSPACE (-4)
+
+#define MTVAF_LAUNCH_CHECK()                      \
+  do {                                            \
+    hipError_t e_ = hipGetLastError();            \
+    if (e_ != hipSuccess) return (int)e_;         \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace mtvaf {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (Salmon et al. 2011).  Dropout masks are a pure function of
+// (seed, site/offset, element index) so the backward pass regenerates them instead of storing them.
+// ---------------------------------------------------------------------------------------------
+struct uint4_ { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint4_ philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                             uint32_t k1) {
+  constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += W0; k1 += W1;
+  }
+  return {c0, c1, c2, c3};
+}
+
+// keep-mask for 4 consecutive elements whose first linear index is idx4*4.
+// returns 4 bits; element j kept iff bit j set.  p_drop in [0,1).
+__device__ __forceinline__ uint32_t dropout_keep4(uint64_t seed, uint64_t offset, uint64_t idx4, float p_drop) {
+  uint4_ r = philox4x32((uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)offset, (uint32_t)(offset >> 32),
+                        (uint32_t)seed, (uint32_t)(seed >> 32));
+  // keep iff u >= p  with u = r * 2^-32
+  uint32_t thr = (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f);
+  return (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
+}
+// Per-element keep decision for attention probabilities: the three attention kernels hold a
+// (query, key) element in different lanes/registers, so a 4-wide Philox call would be 4x wasted in
+// two of them.  A 2-round multiply-xorshift hash of (seed, offset, element index) is enough for
+// dropout and costs ~8 VALU ops per element.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t attn_dropout_key(uint64_t seed, uint64_t offset) {
+  return mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) ^ mix32((uint32_t)offset ^ 0x9E3779B9u)));
+}
+__device__ __forceinline__ bool attn_dropout_keep(uint32_t key, uint32_t row, uint32_t col, uint32_t thr) {
+  // row = (b*NH+h)*S + q  (< 2^32 for every supported shape), col = key index
+  uint32_t h = mix32(row * 0x9E3779B1u + key) ^ (col * 0x85EBCA77u);
+  return mix32(h) >= thr;
+}
+__device__ __forceinline__ uint32_t dropout_threshold(float p_drop) {
+  return (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+}  // namespace mtvaf

@@ -1,0 +1,435 @@
+// HBM-bound row kernels of the path (one wavefront per token row, float4 per lane, wave shuffles for
+// the statistics):
+//   K1  embeddings gather + LayerNorm + dropout      models/modeling_bert.py:212-222,
+//                                                    models/modeling_roberta.py:105-140, 1706-1719
+//   K5/K7 dropout + residual + LayerNorm             models/modeling_bert.py:354-355, 434-435
+//   bias / LayerNorm-affine gradient column sums, elementwise dropout (models/bert_model.py:506).
+// Dropout masks are regenerated from (seed, offset, element index) in the backward kernels.
+#include "common.h"
+
+namespace mtvaf {
+
+constexpr int MAXC = 4;  // float4 chunks per lane -> H <= 1024
+
+struct RowCtx {
+  int lane, nchunk, H;
+};
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+// MODE 0: z = dropout(x) + res ; y = LN(z)
+// MODE 1: z = word[id] + type[tt] + pos[p] ; y = dropout(LN(z))
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                    const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
+                                                    const int32_t* __restrict__ pos_ids, const float* __restrict__ wword,
+                                                    const float* __restrict__ wpos, const float* __restrict__ wtype,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ out, float* __restrict__ mean_o,
+                                                    float* __restrict__ rstd_o, int M, int S, int H, float eps,
+                                                    float p_drop, uint64_t seed, uint64_t offset) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nch = H >> 2;
+  const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    f32x4 z[MAXC];
+    float s = 0.f;
+    const float* wr = nullptr; const float* tr = nullptr; const float* pr = nullptr;
+    if (MODE == 1) {
+      wr = wword + (long)ids[row] * H;
+      tr = wtype + (long)tts[row] * H;
+      const int p = pos_ids ? pos_ids[row] : (row % S);
+      pr = wpos + (long)p * H;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nch) {
+        if (MODE == 0) {
+          f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)row * H + c * 4);
+          f32x4 rv = *reinterpret_cast<const f32x4*>(res + (long)row * H + c * 4);
+          if (p_drop > 0.f) {
+            const uint32_t k = dropout_keep4(seed, offset, (uint64_t)row * nch + c, p_drop);
+            xv.x = (k & 1) ? xv.x * scale : 0.f; xv.y = (k & 2) ? xv.y * scale : 0.f;
+            xv.z = (k & 4) ? xv.z * scale : 0.f; xv.w = (k & 8) ? xv.w * scale : 0.f;
+          }
+          z[i] = xv + rv;
+        } else {
+          z[i] = *reinterpret_cast<const f32x4*>(wr + c * 4) + *reinterpret_cast<const f32x4*>(tr + c * 4) +
+                 *reinterpret_cast<const f32x4*>(pr + c * 4);
+        }
+        s += z[i].x + z[i].y + z[i].z + z[i].w;
+      }
+    }
+    const float mu = wave_sum(s) / H;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const f32x4 d = z[i] - mu;
+        v += d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / H + eps);
+    if (lane == 0) { mean_o[row] = mu; rstd_o[row] = rstd; }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c * 4);
+        f32x4 y = (z[i] - mu) * rstd * g + b;
+        if (MODE == 1 && p_drop > 0.f) {
+          const uint32_t k = dropout_keep4(seed, offset, (uint64_t)row * nch + c, p_drop);
+          y.x = (k & 1) ? y.x * scale : 0.f; y.y = (k & 2) ? y.y * scale : 0.f;
+          y.z = (k & 4) ? y.z * scale : 0.f; y.w = (k & 8) ? y.w * scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(out + (long)row * H + c * 4) = y;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward.  partials layout: [gridDim.x][NP][H] with NP = 2 (dgamma, dbeta) (+2 token-type rows
+// in MODE 1).  MODE 0 writes dx (grad wrt the dropout input) and dres (grad wrt the residual);
+// MODE 1 writes dz (grad wrt the summed embeddings) to dx.
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                    const float* __restrict__ res, const int64_t* __restrict__ ids,
+                                                    const int64_t* __restrict__ tts, const int32_t* __restrict__ pos_ids,
+                                                    const float* __restrict__ wword, const float* __restrict__ wpos,
+                                                    const float* __restrict__ wtype, const float* __restrict__ gamma,
+                                                    const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                    float* __restrict__ dx, float* __restrict__ dres, int dres_acc,
+                                                    float* __restrict__ partials, int M, int S, int H, float p_drop,
+                                                    uint64_t seed, uint64_t offset) {
+  constexpr int NP = MODE == 1 ? 4 : 2;
+  __shared__ f32x4 red[4][MAXC * 64];  // [wave][H/4 <= 256]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nch = H >> 2;
+  const float scale = p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f;
+  f32x4 ag[MAXC], ab[MAXC], at0[MAXC], at1[MAXC];
+#pragma unroll
+  for (int i = 0; i < MAXC; ++i) ag[i] = ab[i] = at0[i] = at1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean_i[row], rstd = rstd_i[row];
+    f32x4 xh[MAXC], g[MAXC];
+    const float* wr = nullptr; const float* tr = nullptr; const float* pr = nullptr;
+    int tt = 0;
+    if (MODE == 1) {
+      wr = wword + (long)ids[row] * H;
+      tt = (int)tts[row];
+      tr = wtype + (long)tt * H;
+      const int p = pos_ids ? pos_ids[row] : (row % S);
+      pr = wpos + (long)p * H;
+    }
+    float s1 = 0.f, s2 = 0.f;
+    uint32_t keep[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      keep[i] = 0xF;
+      xh[i] = g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < nch) {
+        if (p_drop > 0.f) keep[i] = dropout_keep4(seed, offset, (uint64_t)row * nch + c, p_drop);
+        f32x4 z;
+        if (MODE == 0) {
+          f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)row * H + c * 4);
+          const f32x4 rv = *reinterpret_cast<const f32x4*>(res + (long)row * H + c * 4);
+          if (p_drop > 0.f) {
+            xv.x = (keep[i] & 1) ? xv.x * scale : 0.f; xv.y = (keep[i] & 2) ? xv.y * scale : 0.f;
+            xv.z = (keep[i] & 4) ? xv.z * scale : 0.f; xv.w = (keep[i] & 8) ? xv.w * scale : 0.f;
+          }
+          z = xv + rv;
+        } else {
+          z = *reinterpret_cast<const f32x4*>(wr + c * 4) + *reinterpret_cast<const f32x4*>(tr + c * 4) +
+              *reinterpret_cast<const f32x4*>(pr + c * 4);
+        }
+        xh[i] = (z - mu) * rstd;
+        f32x4 dy = *reinterpret_cast<const f32x4*>(dout + (long)row * H + c * 4);
+        if (MODE == 1 && p_drop > 0.f) {
+          dy.x = (keep[i] & 1) ? dy.x * scale : 0.f; dy.y = (keep[i] & 2) ? dy.y * scale : 0.f;
+          dy.z = (keep[i] & 4) ? dy.z * scale : 0.f; dy.w = (keep[i] & 8) ? dy.w * scale : 0.f;
+        }
+        ag[i] += dy * xh[i];
+        ab[i] += dy;
+        g[i] = dy * *reinterpret_cast<const f32x4*>(gamma + c * 4);
+        s1 += g[i].x + g[i].y + g[i].z + g[i].w;
+        s2 += g[i].x * xh[i].x + g[i].y * xh[i].y + g[i].z * xh[i].z + g[i].w * xh[i].w;
+      }
+    }
+    const float m1 = wave_sum(s1) / H, m2 = wave_sum(s2) / H;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const f32x4 dz = (g[i] - m1 - xh[i] * m2) * rstd;
+        if (MODE == 0) {
+          f32x4 r = dz;
+          float* dr = dres + (long)row * H + c * 4;
+          if (dres_acc) r += *reinterpret_cast<const f32x4*>(dr);
+          *reinterpret_cast<f32x4*>(dr) = r;
+          f32x4 d = dz;
+          if (p_drop > 0.f) {
+            d.x = (keep[i] & 1) ? d.x * scale : 0.f; d.y = (keep[i] & 2) ? d.y * scale : 0.f;
+            d.z = (keep[i] & 4) ? d.z * scale : 0.f; d.w = (keep[i] & 8) ? d.w * scale : 0.f;
+          }
+          *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = d;
+        } else {
+          *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = dz;
+          if (tt == 0) at0[i] += dz; else if (tt == 1) at1[i] += dz;
+        }
+      }
+    }
+  }
+  // block reduction of the per-wave column partials, in fixed wave order (deterministic)
+#pragma unroll
+  for (int np = 0; np < NP; ++np) {
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+      const int c = lane + 64 * i;
+      red[wave][c] = np == 0 ? ag[i] : np == 1 ? ab[i] : np == 2 ? at0[i] : at1[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+      const f32x4 t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+      *reinterpret_cast<f32x4*>(partials + ((long)blockIdx.x * NP + np) * H + c * 4) = t;
+    }
+    __syncthreads();
+  }
+}
+
+// out[c] = (acc ? out[c] : 0) + sum_r x[r*ld + c]   (single block column strip; rows small)
+__global__ void colsum_final_kernel(const float* __restrict__ x, int rows, int cols, long ld, float* __restrict__ out,
+                                    int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += x[(long)r * ld + c];
+  if (accumulate) s += out[c];
+  out[c] = s;
+}
+
+// stage 1 of a tall column sum: partial[chunk][c] = sum over this chunk's rows
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int cols, long ld,
+                                                            float* __restrict__ partial, int rows_per_chunk) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(rows, r0 + rows_per_chunk);
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + rg; r < r1; r += 4) s += x[(long)r * ld + c];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) partial[(long)blockIdx.y * cols + c] = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+}
+
+__global__ void embed_scatter_kernel(const float* __restrict__ dz, const int64_t* __restrict__ ids,
+                                     const int32_t* __restrict__ pos_ids, float* __restrict__ dword,
+                                     float* __restrict__ dpos, int M, int H, int word_pad, int pos_pad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const long id = ids[row];
+    const int p = pos_ids ? pos_ids[row] : -1;
+    for (int c = lane; c < H; c += 64) {
+      const float v = dz[(long)row * H + c];
+      if (id != word_pad) atomicAdd(dword + id * H + c, v);
+      if (pos_ids && p != pos_pad) atomicAdd(dpos + (long)p * H + c, v);
+    }
+  }
+}
+
+// BERT positions are arange(S): dpos[s] (+)= sum_b dz[b*S+s]   (deterministic)
+__global__ void pos_reduce_kernel(const float* __restrict__ dz, float* __restrict__ dpos, int B, int S, int H,
+                                  int accumulate) {
+  const int s = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += blockDim.x) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dz[((long)b * S + s) * H + c];
+    if (accumulate) a += dpos[(long)s * H + c];
+    dpos[(long)s * H + c] = a;
+  }
+}
+
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, float p_drop,
+                               uint64_t seed, uint64_t offset) {
+  const float scale = 1.f / (1.f - p_drop);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    const uint32_t k = dropout_keep4(seed, offset, (uint64_t)i, p_drop);
+    v.x = (k & 1) ? v.x * scale : 0.f; v.y = (k & 2) ? v.y * scale : 0.f;
+    v.z = (k & 4) ? v.z * scale : 0.f; v.w = (k & 8) ? v.w * scale : 0.f;
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+// RoBERTa position ids: cumsum(ids != pad) * (ids != pad) + pad   (one wave per sequence)
+__global__ void roberta_pos_kernel(const int64_t* __restrict__ ids, int32_t* __restrict__ pos, int B, int S, int pad) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  int carry = 0;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const int m = (s < S && ids[(long)b * S + s] != pad) ? 1 : 0;
+    int v = m;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o, 64);
+      if (lane >= o) v += t;
+    }
+    if (s < S) pos[(long)b * S + s] = (carry + v) * m + pad;
+    carry += __shfl(v, 63, 64);
+  }
+}
+
+static inline int row_grid(int M) { return std::max(1, std::min((M + 3) / 4, 1024)); }
+
+}  // namespace mtvaf
+
+using namespace mtvaf;
+
+extern "C" {
+
+size_t mtvaf_ln_bwd_workspace_bytes(int M, int H) { return (size_t)row_grid(M) * 4 * H * sizeof(float); }
+
+int mtvaf_roberta_position_ids(const int64_t* ids, int32_t* pos_ids, int B, int S, int pad_idx, hipStream_t st) {
+  if (B <= 0 || S <= 0) return MTVAF_ERR_SHAPE;
+  hipLaunchKernelGGL(roberta_pos_kernel, dim3(B), dim3(64), 0, st, ids, pos_ids, B, S, pad_idx);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+int mtvaf_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids, const float* word,
+                       const float* pos, const float* type, const float* gamma, const float* beta, float* out,
+                       float* mean, float* rstd, int B, int S, int H, float eps, float p_drop, uint64_t seed,
+                       uint64_t offset, hipStream_t st) {
+  if (H % 4 || H > MAXC * 256 || B <= 0 || S <= 0) return MTVAF_ERR_SHAPE;
+  const int M = B * S;
+  hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3(row_grid(M)), dim3(256), 0, st, nullptr, nullptr, ids, type_ids, pos_ids,
+                     word, pos, type, gamma, beta, out, mean, rstd, M, S, H, eps, p_drop, seed, offset);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
+                             float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
+                             uint64_t offset, hipStream_t st) {
+  if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
+  hipLaunchKernelGGL((ln_fwd_kernel<0>), dim3(row_grid(M)), dim3(256), 0, st, x, res, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, nullptr, gamma, beta, out, mean, rstd, M, 1, H, eps, p_drop, seed, offset);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+// dgamma/dbeta: overwritten (accumulate = 0) or added to.  dres_accumulate: dres += instead of =.
+int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma,
+                             const float* mean, const float* rstd, float* dx, float* dres, int dres_accumulate,
+                             float* dgamma, float* dbeta, int accumulate, int M, int H, float p_drop, uint64_t seed,
+                             uint64_t offset, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
+  const int g = row_grid(M);
+  if (workspace_bytes < (size_t)g * 2 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
+                     offset);
+  MTVAF_LAUNCH_CHECK();
+  const int cb = (H + 255) / 256;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part, g, H, (long)2 * H, dgamma, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + H, g, H, (long)2 * H, dbeta, accumulate);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+// Backward of K1.  dz_ws: [M,H] scratch for the gradient of the summed embeddings.  Word-table rows
+// equal to word_pad (and position rows equal to pos_pad when pos_ids != NULL) receive no gradient
+// (nn.Embedding padding_idx, models/modeling_bert.py:170, models/modeling_roberta.py:97-100).
+// accumulate = 0 zero-fills dword/dpos/dtype first.
+int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
+                       const float* word, const float* pos, const float* type, const float* gamma, const float* mean,
+                       const float* rstd, float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta,
+                       int accumulate, int B, int S, int H, int vocab, int max_pos, int type_vocab, int word_pad,
+                       int pos_pad, float p_drop, uint64_t seed, uint64_t offset, float* dz_ws, void* workspace,
+                       size_t workspace_bytes, hipStream_t st) {
+  if (H % 4 || H > MAXC * 256 || B <= 0 || S <= 0 || type_vocab > 2) return MTVAF_ERR_SHAPE;
+  const int M = B * S;
+  const int g = row_grid(M);
+  if (workspace_bytes < (size_t)g * 4 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(g), dim3(256), 0, st, dout, nullptr, nullptr, ids, type_ids, pos_ids,
+                     word, pos, type, gamma, mean, rstd, dz_ws, nullptr, 0, part, M, S, H, p_drop, seed, offset);
+  MTVAF_LAUNCH_CHECK();
+  const int cb = (H + 255) / 256;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part, g, H, (long)4 * H, dgamma, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + H, g, H, (long)4 * H, dbeta, accumulate);
+  for (int t = 0; t < type_vocab; ++t)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + (2 + t) * H, g, H, (long)4 * H,
+                       dtype + (long)t * H, accumulate);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(dword, 0, (size_t)vocab * H * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    if (pos_ids) {
+      e = hipMemsetAsync(dpos, 0, (size_t)max_pos * H * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(g), dim3(256), 0, st, dz_ws, ids, pos_ids, dword, dpos, M, H, word_pad,
+                     pos_pad);
+  if (!pos_ids) {
+    if (!accumulate && max_pos > S) {
+      hipError_t e = hipMemsetAsync(dpos + (long)S * H, 0, (size_t)(max_pos - S) * H * sizeof(float), st);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(pos_reduce_kernel, dim3(S), dim3(256), 0, st, dz_ws, dpos, B, S, H, accumulate);
+  }
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+size_t mtvaf_colsum_workspace_bytes(int rows, int cols) { return (size_t)64 * cols * sizeof(float); }
+
+// out[c] (+)= sum_r x[r*ld + c], deterministic two-stage reduction.
+int mtvaf_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* workspace,
+                 size_t workspace_bytes, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return MTVAF_ERR_SHAPE;
+  int chunks = std::min(64, (rows + 63) / 64);
+  if (workspace_bytes < (size_t)chunks * cols * sizeof(float)) return MTVAF_ERR_WORKSPACE;
+  const int rpc = (rows + chunks - 1) / chunks;
+  chunks = (rows + rpc - 1) / rpc;
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, st, x, rows, cols, (long)ld,
+                     part, rpc);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part, chunks, cols, (long)cols,
+                     out, accumulate);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+// y = dropout(x) (n % 4 == 0); the same call with the same (seed, offset) on a gradient is the backward.
+int mtvaf_dropout(const float* x, float* y, long n, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+  if (n <= 0 || n % 4) return MTVAF_ERR_SHAPE;
+  if (p_drop <= 0.f) {
+    if (x != y) {
+      hipError_t e = hipMemcpyAsync(y, x, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return (int)e;
+    }
+    return MTVAF_OK;
+  }
+  const long n4 = n / 4;
+  const int blocks = (int)std::min<long>((n4 + 255) / 256, 2048);
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, st, x, y, n4, p_drop, seed, offset);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+"""ctypes binding of the C-ABI shared library (include/mtvaf_hip.h) + thin tensor-level wrappers.
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+PyTorch only supplies device memory (``tensor.data_ptr()``) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_long, c_size_t, c_uint64, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmtvaf_hip.so")
+
+_ERR = {-1: "bad shape", -2: "bad alignment", -3: "bad argument", -4: "workspace too small"}
+
+P, I, L, F, U64, SZ = c_void_p, c_int, c_long, c_float, c_uint64, c_size_t
+
+_SIGS = {
+    "mtvaf_version": (c_int, []),
+    "mtvaf_device_cus": (c_int, []),
+    "mtvaf_gemm_f32_workspace_bytes": (SZ, [I, I, I, I]),
+    "mtvaf_gemm_f32": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
+    "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_ln_bwd_workspace_bytes": (SZ, [I, I]),
+    "mtvaf_roberta_position_ids": (c_int, [P, P, I, I, I, P]),
+    "mtvaf_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, U64, P]),
+    "mtvaf_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U64,
+                                   U64, P, P, SZ, P]),
+    "mtvaf_dropout_res_ln_fwd": (c_int, [P, P, P, P, P, P, P, I, I, F, F, U64, U64, P]),
+    "mtvaf_dropout_res_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, I, P, P, I, I, I, F, U64, U64, P, SZ, P]),
+    "mtvaf_colsum_workspace_bytes": (SZ, [I, I]),
+    "mtvaf_colsum": (c_int, [P, I, I, I, P, I, P, SZ, P]),
+    "mtvaf_dropout": (c_int, [P, P, L, F, U64, U64, P]),
+    "mtvaf_crf_workspace_bytes": (SZ, [I, I, I]),
+    "mtvaf_crf_nll_fwd": (c_int, [P, P, P, P, P, P, P, I, I, I, P, SZ, P]),
+    "mtvaf_crf_nll_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "mtvaf_crf_viterbi": (c_int, [P, P, P, P, P, P, P, I, I, I, P]),
+    "mtvaf_split_mean": (c_int, [P, P, L, I, P]),
+    "mtvaf_gate_fwd": (c_int, [P, P, L, P]),
+    "mtvaf_prompt_mix_fwd": (c_int, [P, P, P, I, I, I, I, I, P]),
+    "mtvaf_prompt_mix_bwd_gate": (c_int, [P, P, P, P, P, P, I, I, I, I, I, P]),
+    "mtvaf_prompt_mix_bwd_enc": (c_int, [P, P, P, P, I, I, I, I, I, P]),
+    "mtvaf_kl_logsoftmax_fwd": (c_int, [P, P, P, P, I, I, P]),
+    "mtvaf_kl_logsoftmax_bwd": (c_int, [P, F, P, P, P, I, I, P]),
+    "mtvaf_mean_l_fwd": (c_int, [P, P, L, I, I, P]),
+    "mtvaf_mean_l_bwd": (c_int, [P, P, L, I, I, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"mtvaf_amd: HIP extension {LIB_PATH} not found -- run `python -m mtvaf_amd.build` "
+                "(there is no CPU fallback for the product path)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ck(rc: int, name: str):
+    if rc != 0:
+        msg = _ERR.get(rc, f"hipError {rc}" if rc > 0 else f"error {rc}")
+        raise RuntimeError(f"{name} failed: {msg}")
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), (t.device, t.dtype, t.is_contiguous())
+
+
+# -------------------------------------------------------------------------------------------------
+# workspace: one growing scratch buffer per device (the library never allocates)
+# -------------------------------------------------------------------------------------------------
+_ws = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    key = (torch.device(device).index or 0)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+KC, KM = 0, 1
+EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH = 0, 1, 2, 3, 4
+
+
+def gemm(a: torch.Tensor, layout_a: int, b: torch.Tensor, layout_b: int, out: torch.Tensor, M: int, N: int, K: int,
+         bias: Optional[torch.Tensor] = None, epi: int = EPI_NONE, aux: Optional[torch.Tensor] = None,
+         accumulate: bool = False, allow_split: bool = False, lda: Optional[int] = None, ldb: Optional[int] = None,
+         ldc: Optional[int] = None, cfg: int = -1, splits: int = -1):
+    """out[M,N] = opA[M,K] . opB[K,N] (+bias, epilogue).  KC: reduction index contiguous; KM: k-major."""
+    _f32(a, b, out, bias, aux)
+    lda = a.stride(0) if lda is None else lda
+    ldb = b.stride(0) if ldb is None else ldb
+    ldc = out.stride(0) if ldc is None else ldc
+    ws, wsb = None, 0
+    if allow_split:
+        wsb = lib().mtvaf_gemm_f32_workspace_bytes(M, N, K, 1)
+        ws = workspace(wsb, out.device)
+    _ck(lib().mtvaf_gemm_f32(layout_a, layout_b, _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, _p(bias), epi, _p(aux),
+                             aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws), wsb,
+                             cfg, splits, _st()), "mtvaf_gemm_f32")
+    return out
+
+
+def linear_fwd(x, w, bias, out, epi=EPI_NONE, aux=None):
+    """out[M,N] = x[M,K] . w[N,K]^T + bias  (nn.Linear)."""
+    M, K = x.shape
+    N = w.shape[0]
+    return gemm(x, KC, w, KC, out, M, N, K, bias=bias, epi=epi, aux=aux)
+
+
+def linear_bwd_input(dy, w, dx, accumulate=False, epi=EPI_NONE, aux=None):
+    """dx[M,K] (+)= dy[M,N] . w[N,K]"""
+    M, N = dy.shape
+    K = w.shape[1]
+    return gemm(dy, KC, w, KM, dx, M, K, N, accumulate=accumulate, epi=epi, aux=aux)
+
+
+def linear_bwd_weight(dy, x, dw, accumulate=False):
+    """dw[N,K] (+)= dy[M,N]^T . x[M,K]   (deterministic split-K over M)"""
+    M, N = dy.shape
+    K = x.shape[1]
+    return gemm(dy, KM, x, KM, dw, N, K, M, accumulate=accumulate, allow_split=True)
+
+
+def colsum(x, out, accumulate=False):
+    rows, cols = x.shape
+    wsb = lib().mtvaf_colsum_workspace_bytes(rows, cols)
+    ws = workspace(wsb, x.device)
+    _ck(lib().mtvaf_colsum(_p(x), rows, cols, x.stride(0), _p(out), int(accumulate), _p(ws), wsb, _st()), "mtvaf_colsum")
+    return out
+
+
+def dropout(x, out, p, seed, offset):
+    _ck(lib().mtvaf_dropout(_p(x), _p(out), x.numel(), float(p), seed, offset, _st()), "mtvaf_dropout")
+    return out
+
+
+def embed_ln_fwd(ids, tts, pos_ids, word, pos, typ, gamma, beta, out, mean, rstd, eps, p, seed, offset):
+    B, S = ids.shape
+    H = word.shape[1]
+    _ck(lib().mtvaf_embed_ln_fwd(_p(ids), _p(tts), _p(pos_ids), _p(word), _p(pos), _p(typ), _p(gamma), _p(beta), _p(out),
+                                 _p(mean), _p(rstd), B, S, H, float(eps), float(p), seed, offset, _st()),
+        "mtvaf_embed_ln_fwd")
+
+
+def embed_ln_bwd(dout, ids, tts, pos_ids, word, pos, typ, gamma, mean, rstd, dword, dpos, dtype, dgamma, dbeta,
+                 accumulate, word_pad, pos_pad, p, seed, offset, dz_ws):
+    B, S = ids.shape
+    H = word.shape[1]
+    wsb = lib().mtvaf_ln_bwd_workspace_bytes(B * S, H)
+    ws = workspace(wsb, dout.device)
+    _ck(lib().mtvaf_embed_ln_bwd(_p(dout), _p(ids), _p(tts), _p(pos_ids), _p(word), _p(pos), _p(typ), _p(gamma), _p(mean),
+                                 _p(rstd), _p(dword), _p(dpos), _p(dtype), _p(dgamma), _p(dbeta), int(accumulate), B, S, H,
+                                 word.shape[0], pos.shape[0], typ.shape[0], word_pad, pos_pad, float(p), seed, offset,
+                                 _p(dz_ws), _p(ws), wsb, _st()), "mtvaf_embed_ln_bwd")
+
+
+def roberta_position_ids(ids, out, pad_idx):
+    B, S = ids.shape
+    _ck(lib().mtvaf_roberta_position_ids(_p(ids), _p(out), B, S, pad_idx, _st()), "mtvaf_roberta_position_ids")
+    return out
+
+
+def dropout_res_ln_fwd(x, res, gamma, beta, out, mean, rstd, eps, p, seed, offset):
+    M, H = x.shape
+    _ck(lib().mtvaf_dropout_res_ln_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), M, H, float(eps),
+                                       float(p), seed, offset, _st()), "mtvaf_dropout_res_ln_fwd")
+
+
+def dropout_res_ln_bwd(dout, x, res, gamma, mean, rstd, dx, dres, dres_accumulate, dgamma, dbeta, accumulate, p, seed,
+                       offset):
+    M, H = x.shape
+    wsb = lib().mtvaf_ln_bwd_workspace_bytes(M, H)
+    ws = workspace(wsb, x.device)
+    _ck(lib().mtvaf_dropout_res_ln_bwd(_p(dout), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres),
+                                       int(dres_accumulate), _p(dgamma), _p(dbeta), int(accumulate), M, H, float(p), seed,
+                                       offset, _p(ws), wsb, _st()), "mtvaf_dropout_res_ln_bwd")
+
+
+def prefix_attn_fwd(qkv, pk, pv, addmask, ctx, lse, B, S, Pn, NH, p, seed, offset):
+    _ck(lib().mtvaf_prefix_attn_fwd(_p(qkv), _p(pk), _p(pv), _p(addmask), _p(ctx), _p(lse), B, S, Pn, NH, 64, float(p),
+                                    seed, offset, _st()), "mtvaf_prefix_attn_fwd")
+
+
+def prefix_attn_bwd(dctx, qkv, pk, pv, addmask, ctx, lse, delta, dqkv, dpk, dpv, B, S, Pn, NH, p, seed, offset):
+    _ck(lib().mtvaf_prefix_attn_bwd(_p(dctx), _p(qkv), _p(pk), _p(pv), _p(addmask), _p(ctx), _p(lse), _p(delta), _p(dqkv),
+                                    _p(dpk), _p(dpv), B, S, Pn, NH, 64, float(p), seed, offset, _st()),
+        "mtvaf_prefix_attn_bwd")
+
+
+def crf_workspace(B, S, C, device):
+    n = lib().mtvaf_crf_workspace_bytes(B, S, C)
+    return torch.empty(n, dtype=torch.uint8, device=device), n
+
+
+def crf_nll_fwd(em, tags, mask_u8, start, end, trans, loss, ws, wsb):
+    B, S, C = em.shape
+    _ck(lib().mtvaf_crf_nll_fwd(_p(em), _p(tags), _p(mask_u8), _p(start), _p(end), _p(trans), _p(loss), B, S, C, _p(ws), wsb,
+                                _st()), "mtvaf_crf_nll_fwd")
+
+
+def crf_nll_bwd(gout, em, tags, mask_u8, start, end, trans, dem, dstart, dend, dtrans, accumulate, ws, wsb):
+    B, S, C = em.shape
+    _ck(lib().mtvaf_crf_nll_bwd(_p(gout), _p(em), _p(tags), _p(mask_u8), _p(start), _p(end), _p(trans), _p(dem), _p(dstart),
+                                _p(dend), _p(dtrans), int(accumulate), B, S, C, _p(ws), wsb, _st()), "mtvaf_crf_nll_bwd")
+
+
+def crf_viterbi(em, mask_u8, start, end, trans, tags_out, lens_out):
+    B, S, C = em.shape
+    _ck(lib().mtvaf_crf_viterbi(_p(em), _p(mask_u8), _p(start), _p(end), _p(trans), _p(tags_out), _p(lens_out), B, S, C,
+                                _st()), "mtvaf_crf_viterbi")

@@ -1,0 +1,441 @@
+"""Parity of every HIP kernel (through the C-ABI) against the CPU oracle / plain torch fp32 math.
+Runs only on the MI355X box (`-m gpu`)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import params as P
+from oracle import mtvaf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mtvaf_amd import hip as h
+    h.lib()
+    return h
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, ref, rtol=2e-4, atol=None, name=""):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    if atol is None:
+        atol = rtol * float(ref.abs().max()) + 1e-7
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bool(bad.any()), f"{name}: max err {float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e}), " \
+                                f"{int(bad.sum())}/{bad.numel()} bad"
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(256, 288, 64), (130, 100, 72), (48, 11, 128), (512, 768, 768)])
+def test_gemm_nt(hip, cfg, M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    out = torch.empty(M, N, device=DEV)
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, bias=b.to(DEV), cfg=cfg)
+    close(out, F.linear(x.double(), w.double(), b.double()), name="nt")
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 3])
+@pytest.mark.parametrize("M,N,K", [(256, 96, 160), (77, 130, 11), (48, 128, 256)])
+def test_gemm_nn_and_accumulate(hip, cfg, M, N, K):
+    dy, w = rnd(M, K, seed=4), rnd(K, N, seed=5)  # out[M,N] = dy[M,K] . w[K,N]
+    out = rnd(M, N, seed=6).to(DEV)
+    ref = out.cpu().double() + dy.double() @ w.double()
+    hip.gemm(dy.to(DEV), hip.KC, w.to(DEV), hip.KM, out, M, N, K, accumulate=True, cfg=cfg)
+    close(out, ref, name="nn+acc")
+
+
+@pytest.mark.parametrize("cfg,splits", [(0, 1), (3, 4), (1, 3), (-1, -1)])
+@pytest.mark.parametrize("M,N,K", [(768, 768, 4096), (11, 768, 1000), (100, 60, 48), (128, 256, 2051)])
+def test_gemm_tn_splitk(hip, cfg, splits, M, N, K):
+    dy, x = rnd(K, M, seed=7), rnd(K, N, seed=8)  # out[M,N] = dy^T . x (reduction over rows)
+    out = torch.empty(M, N, device=DEV)
+    hip.gemm(dy.to(DEV), hip.KM, x.to(DEV), hip.KM, out, M, N, K, allow_split=True, cfg=cfg, splits=splits)
+    close(out, dy.double().t() @ x.double(), rtol=3e-4, name="tn")
+    base = rnd(M, N, seed=9)
+    out2 = base.clone().to(DEV)
+    hip.gemm(dy.to(DEV), hip.KM, x.to(DEV), hip.KM, out2, M, N, K, allow_split=True, accumulate=True, cfg=cfg,
+             splits=splits)
+    close(out2, base.double() + dy.double().t() @ x.double(), rtol=3e-4, name="tn+acc")
+
+
+def test_gemm_epilogues(hip):
+    M, N, K = 192, 160, 96
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+    pre = F.linear(x.double(), w.double(), b.double())
+    out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, bias=b.to(DEV), epi=hip.EPI_GELU, aux=aux)
+    close(aux, pre, name="gelu-pre")
+    close(out, F.gelu(pre), name="gelu")
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, bias=b.to(DEV), epi=hip.EPI_TANH)
+    close(out, torch.tanh(pre), name="tanh")
+    # dgelu: out = (x.w^T) * gelu'(aux)
+    a = rnd(M, N, seed=5)
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, epi=hip.EPI_DGELU, aux=a.to(DEV))
+    ad = a.double().requires_grad_(True)
+    F.gelu(ad).sum().backward()
+    close(out, F.linear(x.double(), w.double()) * ad.grad, name="dgelu")
+    t = torch.tanh(a)
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, epi=hip.EPI_DTANH, aux=t.to(DEV))
+    close(out, F.linear(x.double(), w.double()) * (1 - t.double() ** 2), name="dtanh")
+
+
+def test_gemm_deterministic(hip):
+    M, N, K = 768, 768, 4096
+    dy, x = rnd(K, M, seed=7).to(DEV), rnd(K, N, seed=8).to(DEV)
+    o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(dy, hip.KM, x, hip.KM, o1, M, N, K, allow_split=True)
+    hip.gemm(dy, hip.KM, x, hip.KM, o2, M, N, K, allow_split=True)
+    assert torch.equal(o1, o2)
+
+
+# ---------------------------------------------------------------------------------------------
+# row ops
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,H", [(48, 128), (4096, 768), (37, 1024)])
+def test_dropout_res_ln(hip, M, H):
+    x, r = rnd(M, H, seed=1), rnd(M, H, seed=2)
+    g, b = 1 + 0.1 * rnd(H, seed=3), 0.1 * rnd(H, seed=4)
+    dout = rnd(M, H, seed=5)
+    xd, rd, gd, bd = (t.double().requires_grad_(True) for t in (x, r, g, b))
+    y = F.layer_norm(xd + rd, (H,), gd, bd, 1e-12)
+    (y * dout.double()).sum().backward()
+    out, mean, rstd = torch.empty(M, H, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.dropout_res_ln_fwd(x.to(DEV), r.to(DEV), g.to(DEV), b.to(DEV), out, mean, rstd, 1e-12, 0.0, 1, 2)
+    close(out, y, name="ln fwd")
+    dx, dres = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
+    dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    hip.dropout_res_ln_bwd(dout.to(DEV), x.to(DEV), r.to(DEV), g.to(DEV), mean, rstd, dx, dres, False, dg, db, False, 0.0,
+                           1, 2)
+    close(dx, xd.grad, name="ln dx")
+    close(dres, rd.grad, name="ln dres")
+    close(dg, gd.grad, rtol=5e-4, name="ln dgamma")
+    close(db, bd.grad, rtol=5e-4, name="ln dbeta")
+    # accumulate flags
+    dres2 = torch.ones(M, H, device=DEV)
+    dg2, db2 = torch.ones(H, device=DEV), torch.ones(H, device=DEV)
+    hip.dropout_res_ln_bwd(dout.to(DEV), x.to(DEV), r.to(DEV), g.to(DEV), mean, rstd, dx, dres2, True, dg2, db2, True, 0.0,
+                           1, 2)
+    close(dres2, rd.grad + 1, name="ln dres acc")
+    close(dg2, gd.grad + 1, rtol=5e-4, name="ln dgamma acc")
+
+
+def test_dropout_res_ln_with_dropout(hip):
+    M, H, p = 512, 768, 0.1
+    x, r = rnd(M, H, seed=1), rnd(M, H, seed=2)
+    g, b = 1 + 0.1 * rnd(H, seed=3), 0.1 * rnd(H, seed=4)
+    # recover the mask with the plain dropout kernel semantics: same (seed, offset, index) -> same mask
+    ones = torch.ones(M, H, device=DEV)
+    keep = torch.empty(M, H, device=DEV)
+    hip.dropout(ones, keep, p, 11, 22)
+    keep = keep.cpu()
+    frac = float((keep > 0).float().mean())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    assert torch.allclose(keep[keep > 0], torch.tensor(1 / (1 - p)))
+    out, mean, rstd = torch.empty(M, H, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.dropout_res_ln_fwd(x.to(DEV), r.to(DEV), g.to(DEV), b.to(DEV), out, mean, rstd, 1e-12, p, 11, 22)
+    xd, rd = x.double().requires_grad_(True), r.double().requires_grad_(True)
+    y = F.layer_norm(xd * keep.double() + rd, (H,), g.double(), b.double(), 1e-12)
+    close(out, y, name="ln+dropout fwd")
+    dout = rnd(M, H, seed=5)
+    (y * dout.double()).sum().backward()
+    dx, dres = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
+    dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    hip.dropout_res_ln_bwd(dout.to(DEV), x.to(DEV), r.to(DEV), g.to(DEV), mean, rstd, dx, dres, False, dg, db, False, p, 11,
+                           22)
+    close(dx, xd.grad, name="ln+dropout dx")
+    close(dres, rd.grad, name="ln+dropout dres")
+    # a different offset gives a different mask
+    keep2 = torch.empty(M, H, device=DEV)
+    hip.dropout(ones, keep2, p, 11, 23)
+    assert not torch.equal(keep2.cpu(), keep)
+
+
+@pytest.mark.parametrize("cfg", [P.TINY_BERT, P.TINY_ROBERTA, P.EncCfg(vocab_size=1000, hidden=768, max_pos=512)])
+def test_embed_ln(hip, cfg):
+    B, S = 5, 24
+    sd = {k: v for k, v in P.encoder_params(cfg, 5).items() if k.startswith("embeddings.")}
+    ids, mask, tt, _ = P.text_batch(cfg, 6, B, S)
+    if cfg.roberta:
+        ids[1, 3] = 1
+        ids[2, 0] = 1
+    else:
+        tt[:, S // 2:] = 1 if cfg.type_vocab > 1 else 0
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.embeddings(sdg, "embeddings.", ids, tt, cfg.eps, cfg.roberta, cfg.pad_idx)
+    dout = rnd(B, S, cfg.hidden, seed=9)
+    (ref * dout).sum().backward()
+    d = {k: v.to(DEV) for k, v in sd.items()}
+    H = cfg.hidden
+    out, mean, rstd = torch.empty(B * S, H, device=DEV), torch.empty(B * S, device=DEV), torch.empty(B * S, device=DEV)
+    pos_ids = None
+    if cfg.roberta:
+        pos_ids = torch.empty(B, S, dtype=torch.int32, device=DEV)
+        hip.roberta_position_ids(ids.to(DEV), pos_ids, cfg.pad_idx)
+        assert torch.equal(pos_ids.cpu().long(), O.roberta_position_ids(ids, cfg.pad_idx))
+    args = (ids.to(DEV), tt.to(DEV), pos_ids, d["embeddings.word_embeddings.weight"],
+            d["embeddings.position_embeddings.weight"], d["embeddings.token_type_embeddings.weight"],
+            d["embeddings.LayerNorm.weight"])
+    hip.embed_ln_fwd(*args, d["embeddings.LayerNorm.bias"], out, mean, rstd, cfg.eps, 0.0, 1, 2)
+    close(out.view(B, S, H), ref, name="embed fwd")
+    gw, gp, gt = (torch.full_like(d[f"embeddings.{n}_embeddings.weight"], 7.0) for n in ("word", "position", "token_type"))
+    gg, gb = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    dz = torch.empty(B * S, H, device=DEV)
+    hip.embed_ln_bwd(dout.view(B * S, H).to(DEV), *args, mean, rstd, gw, gp, gt, gg, gb, False, cfg.pad_idx,
+                     cfg.pad_idx if cfg.roberta else -1, 0.0, 1, 2, dz)
+    close(gw, sdg["embeddings.word_embeddings.weight"].grad, rtol=5e-4, name="dword")
+    close(gp, sdg["embeddings.position_embeddings.weight"].grad, rtol=5e-4, name="dpos")
+    close(gt, sdg["embeddings.token_type_embeddings.weight"].grad, rtol=5e-4, name="dtype")
+    close(gg, sdg["embeddings.LayerNorm.weight"].grad, rtol=5e-4, name="dgamma")
+    close(gb, sdg["embeddings.LayerNorm.bias"].grad, rtol=5e-4, name="dbeta")
+
+
+def test_colsum(hip):
+    for rows, cols in [(4096, 768), (100, 11), (5000, 2304)]:
+        x = rnd(rows, cols, seed=rows)
+        out = torch.ones(cols, device=DEV)
+        hip.colsum(x.to(DEV), out, accumulate=True)
+        close(out, x.double().sum(0) + 1, rtol=5e-4, name="colsum")
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+def attn_ref(qkv, pk, pv, addmask, B, S, Pn, NH):
+    H = NH * 64
+    q, k, v = (qkv.view(B, S, 3, NH, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    if Pn:
+        k = torch.cat([pk.view(B, NH, Pn, 64), k], 2)
+        v = torch.cat([pv.view(B, NH, Pn, 64), v], 2)
+    s = q @ k.transpose(-1, -2) / 8.0 + addmask[:, None, None, :]
+    p = torch.softmax(s, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * S, H), p
+
+
+@pytest.mark.parametrize("B,S,Pn,NH", [(3, 16, 0, 2), (3, 16, 4, 2), (2, 128, 36, 12), (2, 100, 16, 3), (1, 200, 36, 2),
+                                       (2, 64, 100, 1)])
+def test_prefix_attention(hip, B, S, Pn, NH):
+    H, T = NH * 64, Pn + S
+    qkv = rnd(B * S, 3 * H, seed=1)
+    pk, pv = rnd(B, max(Pn, 1) * H, seed=2), rnd(B, max(Pn, 1) * H, seed=3)
+    lens = [S] + [max(1, S // (i + 2)) for i in range(B - 1)]
+    mask = torch.zeros(B, T)
+    for b, Lb in enumerate(lens):
+        mask[b, : Pn + Lb] = 1
+    addmask = (1 - mask) * -10000.0
+    dctx = rnd(B * S, H, seed=4)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (qkv, pk, pv))
+    ref, _ = attn_ref(qd, kd, vd, addmask.double(), B, S, Pn, NH)
+    (ref * dctx.double()).sum().backward()
+    g = lambda t: t.to(DEV)
+    ctx, lse = torch.empty(B * S, H, device=DEV), torch.empty(B, NH, S, device=DEV)
+    gq, gk, gv, gm = g(qkv), g(pk) if Pn else None, g(pv) if Pn else None, g(addmask)
+    hip.prefix_attn_fwd(gq, gk, gv, gm, ctx, lse, B, S, Pn, NH, 0.0, 0, 0)
+    close(ctx, ref, name="attn fwd")
+    delta = torch.empty(B, NH, S, device=DEV)
+    dqkv = torch.full((B * S, 3 * H), float("nan"), device=DEV)
+    dpk = torch.full((B, max(Pn, 1) * H), float("nan"), device=DEV) if Pn else None
+    dpv = torch.full((B, max(Pn, 1) * H), float("nan"), device=DEV) if Pn else None
+    hip.prefix_attn_bwd(g(dctx), gq, gk, gv, gm, ctx, lse, delta, dqkv, dpk, dpv, B, S, Pn, NH, 0.0, 0, 0)
+    close(dqkv, qd.grad, rtol=5e-4, name="attn dqkv")
+    if Pn:
+        close(dpk, kd.grad, rtol=5e-4, name="attn dpk")
+        close(dpv, vd.grad, rtol=5e-4, name="attn dpv")
+
+
+def test_prefix_attention_dropout(hip):
+    B, S, Pn, NH, p = 2, 64, 16, 2, 0.3
+    H, T = NH * 64, Pn + S
+    g = lambda t: t.to(DEV)
+    qkv, pk, pv = rnd(B * S, 3 * H, seed=1, scale=0.5), rnd(B, Pn * H, seed=2, scale=0.5), rnd(B, Pn * H, seed=3)
+    addmask = torch.zeros(B, T)
+    # V = one-hot rows (first 64 keys) exposes the dropped probabilities directly: ctx[:, d] = P~[:, key d]
+    pv2 = torch.zeros(B, NH, Pn, 64)
+    vt = torch.zeros(B, S, NH, 64)
+    for t in range(64):
+        if t < Pn:
+            pv2[:, :, t, t] = 1
+        else:
+            vt[:, t - Pn, :, t] = 1
+    qkv3 = qkv.view(B * S, 3, H).clone()
+    qkv3[:, 2] = vt.reshape(B * S, H)
+    qkv3 = qkv3.view(B * S, 3 * H)
+    ctx, lse = torch.empty(B * S, H, device=DEV), torch.empty(B, NH, S, device=DEV)
+    hip.prefix_attn_fwd(g(qkv3), g(pk), g(pv2.reshape(B, Pn * H)), g(addmask), ctx, lse, B, S, Pn, NH, p, 5, 6)
+    _, probs = attn_ref(qkv3.double(), pk.double(), pv2.reshape(B, Pn * H).double(), addmask.double(), B, S, Pn, NH)
+    pt = ctx.cpu().view(B, S, NH, 64).permute(0, 2, 1, 3).double()  # P~[b,h,q,key<64]
+    pref = probs[..., :64]
+    kept = pt > 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    assert torch.allclose(pt[kept], (pref / (1 - p))[kept], rtol=1e-3, atol=1e-6)
+    # lse is the log-sum-exp of the UNdropped scores
+    q, k = qkv3.view(B, S, 3, NH, 64)[:, :, 0].permute(0, 2, 1, 3), None
+    # backward consistency under dropout: directional derivative by central differences (same mask)
+    dctx = rnd(B * S, H, seed=4)
+    delta = torch.empty(B, NH, S, device=DEV)
+    dqkv, dpk, dpv = torch.empty(B * S, 3 * H, device=DEV), torch.empty(B, Pn * H, device=DEV), torch.empty(B, Pn * H, device=DEV)
+    gpv = g(pv)
+    hip.prefix_attn_fwd(g(qkv), g(pk), gpv, g(addmask), ctx, lse, B, S, Pn, NH, p, 5, 6)
+    hip.prefix_attn_bwd(g(dctx), g(qkv), g(pk), gpv, g(addmask), ctx, lse, delta, dqkv, dpk, dpv, B, S, Pn, NH, p, 5, 6)
+    dirq, dirk = rnd(B * S, 3 * H, seed=7), rnd(B, Pn * H, seed=8)
+    eps = 1e-2
+
+    def f(sign):
+        c = torch.empty(B * S, H, device=DEV)
+        l2 = torch.empty(B, NH, S, device=DEV)
+        hip.prefix_attn_fwd(g(qkv + sign * eps * dirq), g(pk + sign * eps * dirk), gpv, g(addmask), c, l2, B, S, Pn, NH, p, 5, 6)
+        return float((c.double().cpu() * dctx.double()).sum())
+
+    num = (f(+1) - f(-1)) / (2 * eps)
+    ana = float((dqkv.cpu().double() * dirq.double()).sum() + (dpk.cpu().double() * dirk.double()).sum())
+    assert abs(num - ana) < 2e-2 * max(1.0, abs(ana)), (num, ana)
+
+
+# ---------------------------------------------------------------------------------------------
+# CRF
+# ---------------------------------------------------------------------------------------------
+def _crf_inputs(B, S, C, seed, lengths=None):
+    gnr = torch.Generator().manual_seed(seed)
+    em = torch.randn(B, S, C, generator=gnr)
+    start, end = torch.rand(C, generator=gnr) - 0.5, torch.rand(C, generator=gnr) - 0.5
+    trans = torch.rand(C, C, generator=gnr) - 0.5
+    if lengths is None:
+        lengths = [S] + [int(x) for x in torch.randint(1, S + 1, (B - 1,), generator=gnr)]
+    mask = torch.zeros(B, S, dtype=torch.uint8)
+    for b, Lb in enumerate(lengths):
+        mask[b, :Lb] = 1
+    tags = torch.randint(0, C, (B, S), generator=gnr)
+    return em, tags, mask, start, end, trans
+
+
+@pytest.mark.parametrize("B,S,C", [(4, 5, 11), (32, 128, 11), (3, 70, 5), (2, 1, 11)])
+def test_crf(hip, B, S, C):
+    em, tags, mask, start, end, trans = _crf_inputs(B, S, C, 3 + S)
+    g = lambda t: t.to(DEV)
+    emd, sd_, ed, td = (t.double().requires_grad_(True) for t in (em, start, end, trans))
+    ref = -O.crf_log_likelihood(emd, tags, mask, sd_, ed, td, "mean")
+    (ref * 1.7).backward()
+    ws, wsb = hip.crf_workspace(B, S, C, DEV)
+    loss = torch.empty(1, device=DEV)
+    args = (g(em), g(tags), g(mask), g(start), g(end), g(trans))
+    hip.crf_nll_fwd(*args, loss, ws, wsb)
+    close(loss, ref.reshape(1), rtol=1e-5, name="crf loss")
+    dem = torch.empty(B, S, C, device=DEV)
+    ds, de, dt = torch.ones(C, device=DEV), torch.ones(C, device=DEV), torch.ones(C, C, device=DEV)
+    gout = torch.tensor([1.7], device=DEV)
+    hip.crf_nll_bwd(gout, *args, dem, ds, de, dt, True, ws, wsb)
+    close(dem, emd.grad, rtol=1e-4, atol=1e-6, name="crf dem")
+    close(ds, sd_.grad + 1, rtol=1e-4, name="crf dstart")
+    close(de, ed.grad + 1, rtol=1e-4, name="crf dend")
+    close(dt, td.grad + 1, rtol=1e-4, name="crf dtrans")
+    tg, ln = torch.empty(B, S, dtype=torch.int32, device=DEV), torch.empty(B, dtype=torch.int32, device=DEV)
+    hip.crf_viterbi(g(em), g(mask), g(start), g(end), g(trans), tg, ln)
+    want = O.crf_decode(em, mask, start, end, trans)
+    got = [[int(t) for t in row[: int(n)]] for row, n in zip(tg.cpu(), ln.cpu())]
+    assert got == want
+    assert all(int((row[int(n):] != -1).sum()) == 0 for row, n in zip(tg.cpu(), ln.cpu()))
+
+
+def test_crf_bruteforce_known_answer(hip):
+    em, tags, mask, start, end, trans = _crf_inputs(3, 5, 11, 77, lengths=[4, 3, 1])
+    logZ, best = O.crf_bruteforce(em, mask, start, end, trans)
+    g = lambda t: t.to(DEV)
+    tg, ln = torch.empty(3, 5, dtype=torch.int32, device=DEV), torch.empty(3, dtype=torch.int32, device=DEV)
+    hip.crf_viterbi(g(em), g(mask), g(start), g(end), g(trans), tg, ln)
+    got = [[int(t) for t in row[: int(n)]] for row, n in zip(tg.cpu(), ln.cpu())]
+    assert got == best
+    ws, wsb = hip.crf_workspace(3, 5, 11, DEV)
+    loss = torch.empty(1, device=DEV)
+    hip.crf_nll_fwd(g(em), g(tags), g(mask), g(start), g(end), g(trans), loss, ws, wsb)
+    sc = O.crf_sequence_score(em, tags, mask, start, end, trans)
+    want = -float((sc.double() - torch.tensor(logZ)).mean())
+    assert abs(float(loss) - want) < 1e-4 * max(1, abs(want))
+
+
+# ---------------------------------------------------------------------------------------------
+# prompt generator pieces + KL
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("NL,W", [(12, 1536), (2, 256)])
+def test_prompt_mix(hip, NL, W):
+    NI, B, Lp = 4, 3, 4
+    hid = W // 2
+    enc = rnd(NI, B, Lp, 4 * W, seed=1)
+    wp, bp = rnd(NL * 4, Lp * W, seed=2, scale=0.05), rnd(NL * 4, seed=3, scale=0.1)
+    gk = rnd(NL, 2, B, NI * Lp * hid, seed=4)
+    encd, wpd, bpd = (t.double().requires_grad_(True) for t in (enc, wp, bp))
+
+    def ref_fn(e):
+        outs = []
+        sm = e.view(NI, B, Lp, 4, W).mean(3).reshape(NI * B, Lp * W)
+        gate = torch.softmax(F.leaky_relu(F.linear(sm, wpd, bpd)).view(NI * B, NL, 4), -1)
+        kv = torch.einsum("nik,nlkc->nilc", gate, e.view(NI * B, Lp, 4, W))  # [n, NL, L, W]
+        kv = kv.view(NI, B, NL, Lp, W).permute(2, 1, 0, 3, 4).reshape(NL, B, NI * Lp, W)
+        return torch.stack([kv[..., :hid].reshape(NL, B, -1), kv[..., hid:].reshape(NL, B, -1)], 1)
+
+    ref = ref_fn(encd)
+    (ref * gk.double()).sum().backward()
+    g = lambda t: t.to(DEV)
+    n = NI * B
+    sm = torch.empty(n, Lp * W, device=DEV)
+    from mtvaf_amd.hip import _ck, _p, _st, lib
+    _ck(lib().mtvaf_split_mean(_p(g(enc)), _p(sm), n * Lp, W, _st()), "split_mean")
+    close(sm, enc.view(NI, B, Lp, 4, W).mean(3).reshape(n, Lp * W), name="split mean")
+    logits = torch.empty(n, NL * 4, device=DEV)
+    hip.linear_fwd(sm, g(wp), g(bp), logits)
+    gate = torch.empty_like(logits)
+    _ck(lib().mtvaf_gate_fwd(_p(logits), _p(gate), n * NL, _st()), "gate")
+    pkv = torch.empty(NL, 2, B, NI * Lp * hid, device=DEV)
+    genc = g(enc)
+    _ck(lib().mtvaf_prompt_mix_fwd(_p(genc), _p(gate), _p(pkv), NI, B, Lp, W, NL, _st()), "mix")
+    close(pkv, ref, name="mix fwd")
+    dpart = torch.empty(n * Lp, NL * 4, device=DEV)
+    dlog = torch.empty(n, NL * 4, device=DEV)
+    ggk = g(gk)
+    _ck(lib().mtvaf_prompt_mix_bwd_gate(_p(genc), _p(ggk), _p(logits), _p(gate), _p(dpart), _p(dlog), NI, B, Lp, W, NL, _st()),
+        "mix bwd gate")
+    dwp = torch.empty(NL * 4, Lp * W, device=DEV)
+    hip.linear_bwd_weight(dlog, sm, dwp)
+    close(dwp, wpd.grad, rtol=1e-3, name="mix dWp")
+    dbp = torch.empty(NL * 4, device=DEV)
+    hip.colsum(dlog, dbp)
+    close(dbp, bpd.grad, rtol=1e-3, name="mix dbp")
+    dsm = torch.empty(n, Lp * W, device=DEV)
+    hip.linear_bwd_input(dlog, g(wp), dsm)
+    denc = torch.empty(NI, B, Lp, 4 * W, device=DEV)
+    _ck(lib().mtvaf_prompt_mix_bwd_enc(_p(gate), _p(ggk), _p(dsm), _p(denc), NI, B, Lp, W, NL, _st()), "mix bwd enc")
+    close(denc, encd.grad, rtol=1e-3, name="mix denc")
+
+
+def test_kl_logsoftmax(hip):
+    B, N = 5, 2089
+    z = rnd(B, N, seed=1, scale=2.0)
+    t = torch.softmax(rnd(B, N, seed=2), -1)
+    t[0, :10] = 0
+    zd = z.double().requires_grad_(True)
+    ref = O.kl_batchmean_log_softmax(zd, t.double())
+    (ref * 0.7 * 2.0).backward()
+    from mtvaf_amd.hip import _ck, _p, _st, lib
+    g = lambda x: x.to(DEV)
+    loss, row = torch.empty(1, device=DEV), torch.empty(B, device=DEV)
+    gz, gt = g(z), g(t)
+    _ck(lib().mtvaf_kl_logsoftmax_fwd(_p(gz), _p(gt), _p(loss), _p(row), B, N, _st()), "kl fwd")
+    close(loss, ref.reshape(1), rtol=1e-5, name="kl")
+    dz = torch.empty(B, N, device=DEV)
+    gout = torch.tensor([0.7], device=DEV)
+    _ck(lib().mtvaf_kl_logsoftmax_bwd(_p(gout), 2.0, _p(gz), _p(gt), _p(dz), B, N, _st()), "kl bwd")
+    close(dz, zd.grad, rtol=1e-4, atol=1e-8, name="kl dz")
