@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""Headline benchmark: training sentences/sec (fwd+bwd) of the MTVAF hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): TVNetSAModel2 (BERT-base, random init N(0,0.02)), fp32, per-GPU
+batch 32, seq_len 128, 36 visual prefix slots (main image + 8 aux crops through the prompt generator),
+Twitter-shaped synthetic batch, train mode (all 37+ dropout sites live), one step = forward (incl. CRF
+Viterbi decode, as the reference forward does) + loss.backward() + AdamW step.  Weak scaling: per-GPU
+work is fixed; N > 1 adds the RCCL gradient all-reduce (overlapped with backward) inside the timed region.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"fp32": 157.3}  # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md)
+LABELS = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
+
+
+def f_fwd(S, P, H=768, L=12, C=11):
+    """Algorithmic forward FLOPs per sentence."""
+    return L * (24 * S * H * H + 4 * S * (S + P) * H) + 2 * S * H * C
+
+
+def synthetic_batch(B, S, n_aux, vocab, seed, device, full_length=False):
+    """Twitter-shaped synthetic batch."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.full((B,), S) if full_length else torch.randint(16, S + 1, (B,), generator=g)
+    lens[0] = S
+    ids = torch.randint(1000, vocab, (B, S), generator=g)
+    labels = torch.randint(1, 11, (B, S), generator=g)
+    mask = (torch.arange(S)[None, :] < lens[:, None]).long()
+    ids[:, 0] = 101
+    ids[torch.arange(B), lens - 1] = 102
+    ids = ids * mask
+    labels = labels * mask
+    labels[:, 0] = 9
+    feats = torch.randn(B, 3840, 2, 2, generator=g).abs()
+    aux = torch.randn(B, n_aux, 3840, 2, 2, generator=g).abs()
+    tt = torch.zeros_like(ids)
+    return tuple(t.to(device) for t in (ids, mask, tt, labels, feats, aux))
+
+
+def build_model(device):
+    from transformers import BertConfig
+    from mtvaf_amd.models.bert_model import TVNetSAModel2
+    cfg = BertConfig()  # bert-base-uncased architecture, hidden/attention dropout 0.1
+    args = types.SimpleNamespace(bert_name="bert-base-uncased", bert_config=cfg, use_prefix=True, vao=False,
+                                 noauxloss=True, use_probe=False, n_gpu=1, alpha=0.0, prefix_len=4, prefix_dim=768,
+                                 device=device, resnet_root=None, use_152=False)
+    torch.manual_seed(1234)
+    return TVNetSAModel2(LABELS, None, args).to(device), cfg
+
+
+def cpu_baseline(S, P, seconds_budget=25.0):
+    """The reference algorithm on the host cores: the CPU oracle (a line-by-line restatement of the
+    reference modules, proven equal to them by tests/test_oracle_golden.py) doing fwd+bwd on a bounded
+    sample of the same workload."""
+    from oracle import mtvaf_oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import params as PR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = PR.BASE_BERT
+    Bc = 8
+    sd = {**{"bert." + k: v.requires_grad_(True) for k, v in PR.encoder_params(cfg, 1, std=0.02).items()},
+          **{k: v.requires_grad_(True) for k, v in PR.head_params(cfg, 2).items()}}
+    ids, mask, tt, labels = PR.text_batch(cfg, 3, Bc, S, lo_id=1000)
+    labels[:, 0] = 9
+    pkv = PR.prefix_kv(4, cfg.layers, Bc, cfg.heads, P, std=0.02)
+
+    def step():
+        loss, _, _, _ = O.tvnet2_forward(sd, ids, mask, tt, labels, pkv, cfg.layers, cfg.heads, cfg.eps)
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 3 or (time.perf_counter() - t0 < seconds_budget and n < 12):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc * n / dt, 3), "unit": "sentences/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fwd+bwd steps of B={Bc}, S={S}, P={P} BERT-base fp32 on torch CPU ({cores} threads), "
+                      f"encoder+fc+CRF (prompt generator excluded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--seq", type=int, default=128)
+    ap.add_argument("--aux", type=int, default=8, help="aux crops: prefix slots = 4*(1+aux)")
+    ap.add_argument("--full-length", action="store_true", help="all sequences at full length (worst case)")
+    ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    from mtvaf_amd import hip
+    hip.lib()
+
+    B, S, P = a.batch, a.seq, 4 * (1 + a.aux)
+    model, cfg = build_model(device)
+    model.train()
+    sync = None
+    if world > 1:
+        from mtvaf_amd.parallel import GradSync
+        sync = GradSync(model)
+    opt = None if a.no_optimizer else torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5,
+                                                        weight_decay=1e-2, foreach=True)
+    batch = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, a.full_length)
+    ids, mask, tt, labels, feats, aux = batch
+
+    def step():
+        out = model(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None, images=feats,
+                    aux_imgs=aux)
+        out.loss.backward()
+        if opt is not None:
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        else:
+            for p in model.parameters():
+                p.grad = None
+        return out
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_val = float(out.loss)
+    value = world * B * a.steps / dt
+    per_gpu = value / world
+    ftrain = 3 * f_fwd(S, P)
+
+    res = {"metric": "training sentences/sec (fwd+bwd)", "value": round(value, 2), "unit": "sentences/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+           "config": {"workload": f"TVNetSAModel2 BERT-base random-init, fwd+bwd{'' if a.no_optimizer else '+AdamW'}, "
+                                  f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
+                                  f"images through the prompt generator), train mode (dropout live), "
+                                  f"{'full-length' if a.full_length else 'ragged 16..S'} sequences",
+                      "global_batch": B * world, "seq_len": S, "prefix": P,
+                      "parallelism": f"dp{world}" + (" (RCCL all-reduce overlapped with backward)" if world > 1 else "")},
+           "loss": round(loss_val, 4),
+           "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS["fp32"] * 1e12), 4),
+           "flop_per_sentence_train": ftrain}
+
+    # ---- roofline of the dominant kernel: fp32 MFMA GEMM, measured live with HIP events -----------
+    if rank == 0 and not a.no_roofline:
+        if sync is not None:
+            sync.enabled = False
+        hip.PROFILE = []
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        recs, hip.PROFILE = hip.PROFILE, None
+        agg = {}
+        for key, e0, e1 in recs:
+            d = agg.setdefault(key, [0.0, 0])
+            d[0] += e0.elapsed_time(e1)
+            d[1] += 1
+        tot_ms = sum(v[0] for v in agg.values()) / 3
+        tot_fl = sum(2.0 * k[2] * k[3] * k[4] * v[1] for k, v in agg.items()) / 3
+        top = max(agg.items(), key=lambda kv: kv[1][0])
+        (la, lb, M, N, K, epi, split), (ms, cnt) = top
+        tile, splits = hip.gemm_plan(M, N, K, split)
+        avg_us = 1e3 * ms / cnt
+        ach = 2.0 * M * N * K / (avg_us * 1e-6) / 1e12
+        shapes = []
+        for (la2, lb2, M2, N2, K2, epi2, sp2), (ms2, c2) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
+            t2, s2 = hip.gemm_plan(M2, N2, K2, sp2)
+            shapes.append({"op": f"{'KM' if la2 else 'KC'}x{'KM' if lb2 else 'KC'}", "M": M2, "N": N2, "K": K2,
+                           "epi": epi2, "tile": hip.TILE_NAMES[t2], "splits": s2, "launches_per_step": c2 // 3,
+                           "avg_us": round(1e3 * ms2 / c2, 1),
+                           "tflops": round(2.0 * M2 * N2 * K2 / (1e3 * ms2 / c2 * 1e-6) / 1e12, 1)})
+        res["roofline"] = {
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": None,
+            "kernel": f"gemm_f32_kernel<{hip.TILE_NAMES[tile]}> {'KM' if la else 'KC'}x{'KM' if lb else 'KC'} "
+                      f"M={M} N={N} K={K} splits={splits}",
+            "avg_launch_us": round(avg_us, 1), "flops_per_launch": 2.0 * M * N * K,
+            "all_gemms": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                          "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], 4)},
+            "top_shapes": shapes}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(S, P)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,7 @@ int mtvaf_device_cus(void);
  * backward.  C[M,N] = opA[M,K] . opB[K,N] (+bias[N]) with epilogue `epi`; cfg/splits < 0 = heuristic.
  * allow_split enables a deterministic split-K (ordered slab reduction) through `workspace`. */
 size_t mtvaf_gemm_f32_workspace_bytes(int M, int N, int K, int allow_split);
+int mtvaf_gemm_f32_plan(int M, int N, int K, int allow_split, int* cfg, int* splits);
 int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
                    int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,

@@ -299,6 +299,14 @@ size_t mtvaf_gemm_f32_workspace_bytes(int M, int N, int K, int allow_split) {
   return (size_t)16 * M * N * sizeof(float);
 }
 
+// Reports the tile configuration / split count the heuristic would pick (for profiling tools).
+// tile: 0 = 128x128, 1 = 128x96, 2 = 128x288, 3 = 64x64, 4 = 128x64 (BMxBN, 256 threads).
+int mtvaf_gemm_f32_plan(int M, int N, int K, int allow_split, int* cfg, int* splits) {
+  if (M <= 0 || N <= 0 || K <= 0 || !cfg || !splits) return MTVAF_ERR_ARG;
+  choose(M, N, K, allow_split, cfg, splits);
+  return MTVAF_OK;
+}
+
 // C[M,N] = opA[M,K] . opB[K,N] (+bias) with fused epilogue.  layout_a / layout_b: 0 = KC, 1 = KM.
 // epi: 0 none, 1 bias+GELU (pre-activation stored to aux), 2 bias+tanh, 3 dGELU (multiply by
 // gelu'(aux)), 4 dtanh (multiply by 1-aux^2).  accumulate: C += result.  allow_split: permit a

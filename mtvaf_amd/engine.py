@@ -1,0 +1,397 @@
+"""Autograd glue between torch and the HIP kernels (mtvaf_amd.hip).
+
+Each Function owns the forward/backward orchestration of one stage of the reference path and calls
+nothing but the C-ABI kernels for arithmetic; torch is used for buffer allocation and graph wiring.
+
+  EmbeddingsFunction   BertEmbeddings / RobertaEmbeddings      models/modeling_bert.py:188-222
+  EncoderFunction      BertEncoder (all layers, prefix K/V)     models/modeling_bert.py:532-620
+  LinearFunction       nn.Linear (+tanh)                        bert_model.py:446-454, 465, 510
+  DropoutFunction      nn.Dropout                               bert_model.py:506
+  CRFNLLFunction       -torchcrf.CRF(...)(reduction='mean')     bert_model.py:521
+  PromptFunction       get_visual_prompt gates/mix              bert_model.py:544-585
+  KLFunction           KLDivLoss(batchmean)(log softmax)        bert_model.py:553-554
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import hip
+
+# -------------------------------------------------------------------------------------------------
+# dropout RNG state: (seed, running offset).  One offset per dropout site per forward.
+# -------------------------------------------------------------------------------------------------
+
+
+class _Rng:
+    def __init__(self):
+        self.offset = 0
+
+    def seed(self) -> int:
+        return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+
+    def next(self, n: int = 1) -> int:
+        o = self.offset
+        self.offset += n
+        return o
+
+
+RNG = _Rng()
+
+
+def _empty(*shape, like: torch.Tensor, dtype=torch.float32):
+    return torch.empty(*shape, device=like.device, dtype=dtype)
+
+
+def _grad_target(param: torch.Tensor, flat_view: Optional[torch.Tensor]):
+    """Where a parameter gradient is written: a fresh tensor (autograd steals or accumulates it)."""
+    return flat_view if flat_view is not None else torch.empty_like(param)
+
+
+# -------------------------------------------------------------------------------------------------
+class EmbeddingsFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, word, pos, typ, gamma, beta, input_ids, token_type_ids, eps, p_drop, roberta, pad_idx):
+        B, S = input_ids.shape
+        H = word.shape[1]
+        ids = input_ids.contiguous()
+        tts = token_type_ids.contiguous()
+        pos_ids = None
+        if roberta:
+            pos_ids = _empty(B, S, like=word, dtype=torch.int32)
+            hip.roberta_position_ids(ids, pos_ids, pad_idx)
+        out = _empty(B * S, H, like=word)
+        mean, rstd = _empty(B * S, like=word), _empty(B * S, like=word)
+        seed, off = RNG.seed(), RNG.next()
+        hip.embed_ln_fwd(ids, tts, pos_ids, word, pos, typ, gamma, beta, out, mean, rstd, eps, p_drop, seed, off)
+        ctx.stash = (word, pos, typ, gamma, ids, tts, pos_ids, mean, rstd, p_drop, seed, off, roberta, pad_idx)
+        return out.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dout):
+        word, pos, typ, gamma, ids, tts, pos_ids, mean, rstd, p_drop, seed, off, roberta, pad_idx = ctx.stash
+        B, S = ids.shape
+        H = word.shape[1]
+        dout = dout.contiguous().view(B * S, H)
+        dword, dpos, dtyp = torch.empty_like(word), torch.empty_like(pos), torch.empty_like(typ)
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        dz = _empty(B * S, H, like=word)
+        hip.embed_ln_bwd(dout, ids, tts, pos_ids, word, pos, typ, gamma, mean, rstd, dword, dpos, dtyp, dg, db, False,
+                         pad_idx, pad_idx if roberta else -1, p_drop, seed, off, dz)
+        return dword, dpos, dtyp, dg, db, None, None, None, None, None, None
+
+
+# -------------------------------------------------------------------------------------------------
+class LayerWeights:
+    """Device pointers of one encoder layer in kernel-ready (QKV-packed) form."""
+    __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2")
+
+
+N_LAYER_PARAMS = 16  # q.w q.b k.w k.b v.w v.b ao.w ao.b ln1.w ln1.b i.w i.b o.w o.b ln2.w ln2.b
+
+
+class EncoderFunction(torch.autograd.Function):
+    """All encoder layers in one autograd node.
+
+    inputs : h0 [B,S,H], pkv [L,2,B,P*H] or None, addmask [B,P+S], cfg tuple, weights (list of
+             LayerWeights), then the 16*L layer parameters (so autograd routes their gradients).
+    outputs: the L hidden states h_1..h_L, each [B,S,H].
+    """
+
+    @staticmethod
+    def forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, *params):
+        B, S, H = h0.shape
+        NH, eps, p_hidden, p_attn = cfg
+        L = len(weights)
+        M = B * S
+        Pn = 0 if pkv is None else pkv.shape[3] // H
+        x = h0.contiguous().view(M, H)
+        seed = RNG.seed()
+        saved = []
+        outs = []
+        for li, w in enumerate(weights):
+            I = w.w1.shape[0]
+            off = RNG.next(3)
+            qkv = _empty(M, 3 * H, like=x)
+            hip.linear_fwd(x, w.wqkv, w.bqkv, qkv)
+            cx, lse = _empty(M, H, like=x), _empty(B, NH, S, like=x)
+            pk = pkv[li, 0] if Pn else None
+            pv = pkv[li, 1] if Pn else None
+            hip.prefix_attn_fwd(qkv, pk, pv, addmask, cx, lse, B, S, Pn, NH, p_attn, seed, off)
+            a = _empty(M, H, like=x)
+            hip.linear_fwd(cx, w.wo, w.bo, a)
+            h1, mean1, rstd1 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
+            hip.dropout_res_ln_fwd(a, x, w.g1, w.b1, h1, mean1, rstd1, eps, p_hidden, seed, off + 1)
+            pre, act = _empty(M, I, like=x), _empty(M, I, like=x)
+            hip.linear_fwd(h1, w.w1, w.bi1, act, epi=hip.EPI_GELU, aux=pre)
+            f = _empty(M, H, like=x)
+            hip.linear_fwd(act, w.w2, w.bi2, f)
+            h2, mean2, rstd2 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
+            hip.dropout_res_ln_fwd(f, h1, w.g2, w.b2, h2, mean2, rstd2, eps, p_hidden, seed, off + 2)
+            saved.append((x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2, off))
+            outs.append(h2.view(B, S, H))
+            x = h2
+        ctx.stash = (saved, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        saved, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params = ctx.stash
+        NH, eps, p_hidden, p_attn = cfg
+        L = len(weights)
+        M = B * S
+        dev_like = saved[0][0]
+        dpkv = torch.empty_like(pkv) if Pn else None
+        need_param_grads = any(p.requires_grad for p in params)
+        # parameter-gradient destinations: the module's flat per-layer gradient buffers when they are
+        # free (param.grad is None), otherwise fresh tensors that autograd accumulates.
+        gviews = grad_sink.acquire(params) if grad_sink is not None else None
+        pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
+
+        dh = None  # gradient wrt the current layer's OUTPUT, [M,H], owned by us
+        for li in range(L - 1, -1, -1):
+            x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2, off = saved[li]
+            w = weights[li]
+            I = w.w1.shape[0]
+            g_out = douts[li]
+            if dh is None:
+                if g_out is None:
+                    if Pn:
+                        dpkv[li].zero_()  # layers above the last used hidden state get no gradient
+                    continue
+                dh = g_out.contiguous().view(M, H)
+                if dh.data_ptr() == g_out.data_ptr():
+                    dh = dh.clone()  # we modify / free it
+            elif g_out is not None:
+                dh = dh + g_out.reshape(M, H)
+            base = li * N_LAYER_PARAMS
+            if gviews is not None:
+                G = gviews[base:base + N_LAYER_PARAMS]
+                # QKV packed views: G[0] spans the [3H,H] weight block, G[1] the [3H] bias block
+                dwqkv, dbqkv = grad_sink.packed_qkv(li)
+            else:
+                G = [torch.empty_like(p) for p in params[base:base + N_LAYER_PARAMS]]
+                dwqkv, dbqkv = _empty(3 * H, H, like=dev_like), _empty(3 * H, like=dev_like)
+            # ---- FFN block ----
+            df, dh1 = _empty(M, H, like=dev_like), _empty(M, H, like=dev_like)
+            hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, df, dh1, False, G[14], G[15], False, p_hidden, seed,
+                                   off + 2)
+            hip.colsum(df, G[13])
+            hip.linear_bwd_weight(df, act, G[12])
+            dpre = _empty(M, I, like=dev_like)
+            hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
+            hip.colsum(dpre, G[11])
+            hip.linear_bwd_weight(dpre, h1, G[10])
+            hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
+            # ---- attention block ----
+            da, dh0 = df, dh  # reuse buffers
+            hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
+                                   off + 1)
+            hip.colsum(da, G[7])
+            hip.linear_bwd_weight(da, cx, G[6])
+            dctx = dh1
+            hip.linear_bwd_input(da, w.wo, dctx)
+            dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
+            hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
+                                delta, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, B, S, Pn, NH,
+                                p_attn, seed, off)
+            hip.colsum(dqkv, dbqkv)
+            hip.linear_bwd_weight(dqkv, x, dwqkv)
+            hip.linear_bwd_input(dqkv, w.wqkv, dh0, accumulate=True)
+            dh = dh0
+            if gviews is None:
+                G[0], G[2], G[4] = dwqkv[:H], dwqkv[H:2 * H], dwqkv[2 * H:]
+                G[1], G[3], G[5] = dbqkv[:H], dbqkv[H:2 * H], dbqkv[2 * H:]
+            pgrads[base:base + N_LAYER_PARAMS] = G
+            if grad_sink is not None:
+                grad_sink.layer_done(li)
+        dh0_out = dh.view(B, S, H) if dh is not None else None
+        if not need_param_grads:
+            pgrads = [None] * len(params)
+        return (dh0_out, dpkv, None, None, None, None, *pgrads)
+
+
+# -------------------------------------------------------------------------------------------------
+class LinearFunction(torch.autograd.Function):
+    """y = act(x . W^T + b), act in {identity, tanh}; x is [..., K]."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, tanh):
+        K = x.shape[-1]
+        x2 = x.contiguous().view(-1, K)
+        y = _empty(x2.shape[0], weight.shape[0], like=x2)
+        hip.linear_fwd(x2, weight, bias, y, epi=hip.EPI_TANH if tanh else hip.EPI_NONE)
+        ctx.stash = (x2, weight, y if tanh else None, bias is not None, x.shape)
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight, y_tanh, has_bias, xshape = ctx.stash
+        N, K = weight.shape
+        dy2 = dy.contiguous().view(-1, N)
+        if y_tanh is not None:
+            # d(pre) = dy * (1 - y^2): run it through the dtanh epilogue of an identity-free GEMM is
+            # overkill; the product dy.W needs d(pre) as its A operand, so materialise it once.
+            dpre = torch.addcmul(dy2, dy2 * y_tanh, y_tanh, value=-1.0)
+        else:
+            dpre = dy2
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(x2.shape[0], K, like=x2)
+            hip.linear_bwd_input(dpre, weight, dx)
+            dx = dx.view(xshape)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            hip.linear_bwd_weight(dpre, x2, dw)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _empty(N, like=x2)
+            hip.colsum(dpre, db)
+        return dx, dw, db, None
+
+
+class DropoutFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        xc = x.contiguous()
+        y = torch.empty_like(xc)
+        seed, off = RNG.seed(), RNG.next()
+        hip.dropout(xc, y, p, seed, off)
+        ctx.stash = (p, seed, off)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed, off = ctx.stash
+        dyc = dy.contiguous()
+        dx = torch.empty_like(dyc)
+        hip.dropout(dyc, dx, p, seed, off)
+        return dx, None
+
+
+def dropout(x, p, training):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFunction.apply(x, p)
+
+
+# -------------------------------------------------------------------------------------------------
+class CRFNLLFunction(torch.autograd.Function):
+    """loss = -mean_b log p(tags_b | emissions_b)  (0-dim tensor)."""
+
+    @staticmethod
+    def forward(ctx, emissions, start, end, trans, tags, mask_u8):
+        B, S, C = emissions.shape
+        em = emissions.contiguous()
+        ws, wsb = hip.crf_workspace(B, S, C, em.device)
+        loss = _empty(1, like=em)
+        hip.crf_nll_fwd(em, tags, mask_u8, start, end, trans, loss, ws, wsb)
+        ctx.stash = (em, start, end, trans, tags, mask_u8, ws, wsb)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        em, start, end, trans, tags, mask_u8, ws, wsb = ctx.stash
+        g = gout.contiguous().view(1).float()
+        dem = torch.empty_like(em)
+        ds, de, dt = torch.empty_like(start), torch.empty_like(end), torch.empty_like(trans)
+        hip.crf_nll_bwd(g, em, tags, mask_u8, start, end, trans, dem, ds, de, dt, False, ws, wsb)
+        return dem, ds, de, dt, None, None
+
+
+# -------------------------------------------------------------------------------------------------
+class PromptFunction(torch.autograd.Function):
+    """enc [NI,B,L,4W] + packed projector weights -> pkv [NL,2,B,(NI*L)*(W/2)].
+
+    The 2*NL projector parameters are passed so that autograd routes their gradients; the kernels read
+    the packed [NL*4, L*W] / [NL*4] buffers they are views of."""
+
+    @staticmethod
+    def forward(ctx, enc, wp, bp, NL, *proj_params):
+        NI, B, Lp, W4 = enc.shape
+        W = W4 // 4
+        n = NI * B
+        encc = enc.contiguous()
+        sm = _empty(n, Lp * W, like=encc)
+        hip._ck(hip.lib().mtvaf_split_mean(hip._p(encc), hip._p(sm), n * Lp, W, hip._st()), "mtvaf_split_mean")
+        logits = _empty(n, NL * 4, like=encc)
+        hip.linear_fwd(sm, wp, bp, logits)
+        gate = torch.empty_like(logits)
+        hip._ck(hip.lib().mtvaf_gate_fwd(hip._p(logits), hip._p(gate), n * NL, hip._st()), "mtvaf_gate_fwd")
+        pkv = _empty(NL, 2, B, NI * Lp * (W // 2), like=encc)
+        hip._ck(hip.lib().mtvaf_prompt_mix_fwd(hip._p(encc), hip._p(gate), hip._p(pkv), NI, B, Lp, W, NL, hip._st()),
+                "mtvaf_prompt_mix_fwd")
+        ctx.stash = (encc, wp, sm, logits, gate, NL)
+        return pkv
+
+    @staticmethod
+    def backward(ctx, dpkv):
+        encc, wp, sm, logits, gate, NL = ctx.stash
+        NI, B, Lp, W4 = encc.shape
+        W = W4 // 4
+        n = NI * B
+        dpkv = dpkv.contiguous()
+        dpart = _empty(n * Lp, NL * 4, like=encc)
+        dlog = _empty(n, NL * 4, like=encc)
+        L_ = hip.lib()
+        hip._ck(L_.mtvaf_prompt_mix_bwd_gate(hip._p(encc), hip._p(dpkv), hip._p(logits), hip._p(gate), hip._p(dpart),
+                                             hip._p(dlog), NI, B, Lp, W, NL, hip._st()), "mtvaf_prompt_mix_bwd_gate")
+        dwp = torch.empty_like(wp)
+        hip.linear_bwd_weight(dlog, sm, dwp)
+        dbp = _empty(NL * 4, like=encc)
+        hip.colsum(dlog, dbp)
+        dsm = torch.empty_like(sm)
+        hip.linear_bwd_input(dlog, wp, dsm)
+        denc = torch.empty_like(encc)
+        hip._ck(L_.mtvaf_prompt_mix_bwd_enc(hip._p(gate), hip._p(dpkv), hip._p(dsm), hip._p(denc), NI, B, Lp, W, NL,
+                                            hip._st()), "mtvaf_prompt_mix_bwd_enc")
+        pg = []
+        for i in range(NL):
+            pg.append(dwp[4 * i:4 * i + 4])
+            pg.append(dbp[4 * i:4 * i + 4])
+        return (denc, None, None, None, *pg)
+
+
+class MeanLFunction(torch.autograd.Function):
+    """[n, L, W] -> mean over L  (prefix_guids.mean(dim=1), bert_model.py:550)."""
+
+    @staticmethod
+    def forward(ctx, enc):
+        n, Lp, W4 = enc.shape
+        e = enc.contiguous()
+        out = _empty(n, W4, like=e)
+        hip._ck(hip.lib().mtvaf_mean_l_fwd(hip._p(e), hip._p(out), n, Lp, W4, hip._st()), "mtvaf_mean_l_fwd")
+        ctx.shape = (n, Lp, W4)
+        return out
+
+    @staticmethod
+    def backward(ctx, dmean):
+        n, Lp, W4 = ctx.shape
+        d = dmean.contiguous()
+        denc = torch.zeros(n, Lp, W4, device=d.device, dtype=d.dtype)
+        hip._ck(hip.lib().mtvaf_mean_l_bwd(hip._p(d), hip._p(denc), n, Lp, W4, hip._st()), "mtvaf_mean_l_bwd")
+        return denc
+
+
+class KLFunction(torch.autograd.Function):
+    """KLDivLoss(reduction='batchmean')(log_softmax(logits), target) -> 0-dim tensor."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        B, N = logits.shape
+        z, t = logits.contiguous(), target.contiguous().float()
+        loss, row = _empty(1, like=z), _empty(B, like=z)
+        hip._ck(hip.lib().mtvaf_kl_logsoftmax_fwd(hip._p(z), hip._p(t), hip._p(loss), hip._p(row), B, N, hip._st()),
+                "mtvaf_kl_logsoftmax_fwd")
+        ctx.stash = (z, t)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        z, t = ctx.stash
+        B, N = z.shape
+        g = gout.contiguous().view(1).float()
+        dz = torch.empty_like(z)
+        hip._ck(hip.lib().mtvaf_kl_logsoftmax_bwd(hip._p(g), 1.0, hip._p(z), hip._p(t), hip._p(dz), B, N, hip._st()),
+                "mtvaf_kl_logsoftmax_bwd")
+        return dz, None

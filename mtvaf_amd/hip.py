@@ -23,6 +23,7 @@ _SIGS = {
     "mtvaf_version": (c_int, []),
     "mtvaf_device_cus": (c_int, []),
     "mtvaf_gemm_f32_workspace_bytes": (SZ, [I, I, I, I]),
+    "mtvaf_gemm_f32_plan": (c_int, [I, I, I, I, P, P]),
     "mtvaf_gemm_f32": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -109,6 +110,16 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
+PROFILE = None  # set to a list to record (key, start_event, stop_event) around every GEMM launch
+TILE_NAMES = {0: "128x128", 1: "128x96", 2: "128x288", 3: "64x64", 4: "128x64"}
+
+
+def gemm_plan(M, N, K, allow_split):
+    c, s = ctypes.c_int(0), ctypes.c_int(0)
+    _ck(lib().mtvaf_gemm_f32_plan(M, N, K, int(allow_split), ctypes.byref(c), ctypes.byref(s)), "mtvaf_gemm_f32_plan")
+    return c.value, s.value
+
+
 KC, KM = 0, 1
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH = 0, 1, 2, 3, 4
 
@@ -126,9 +137,16 @@ def gemm(a: torch.Tensor, layout_a: int, b: torch.Tensor, layout_b: int, out: to
     if allow_split:
         wsb = lib().mtvaf_gemm_f32_workspace_bytes(M, N, K, 1)
         ws = workspace(wsb, out.device)
+    prof = PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _ck(lib().mtvaf_gemm_f32(layout_a, layout_b, _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, _p(bias), epi, _p(aux),
                              aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws), wsb,
                              cfg, splits, _st()), "mtvaf_gemm_f32")
+    if prof is not None:
+        e1.record()
+        prof.append(((layout_a, layout_b, M, N, K, epi, int(allow_split)), e0, e1))
     return out
 
 

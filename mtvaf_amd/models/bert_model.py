@@ -1,0 +1,216 @@
+"""TVNetSAModel2 -- the live MTVAF task model (BERT/RoBERTa + visual prefix + CRF tagger), MI355X-native.
+
+Drop-in for the reference's ``models/bert_model.py::TVNetSAModel2`` (:416-588): same constructor
+``(label_list, tokenizer, args, type_num=None, use_weight=False)``, same ``forward`` signature and
+``TokenClassifierOutput(loss, logits=List[List[int]])`` result, same ``get_visual_prompt`` contract and
+the same parameter names (``bert.*``, ``fc.*``, ``crf.*``, ``encoder_conv.{0,2}.*``, ``projectors.{i}.*``,
+``img_classifier.*``, ``aux_img_classifier.{k}.*``, ``image_model.resnet.*``), so it can be handed to the
+reference's ``modules/train.py::SATrainer2`` unchanged.  All arithmetic of the path
+runs in the gfx950 kernels behind ``mtvaf_amd.engine``; the sub-modules are parameter containers.
+
+Reference defects the boundary survives: undefined ``args.use_101/use_34/use_18``
+flags are read with ``getattr(..., False)``; ``args.n_gpu > 1`` takes the plain loss path (one process
+per GPU; the reference's DataParallelCriterion branch, bert_model.py:515-519, cannot run).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+from transformers.modeling_outputs import TokenClassifierOutput
+
+from .. import engine
+from ..modules.crf import CRF
+from .modeling_bert import BertModel, PrefixKV
+from .modeling_roberta import RobertaModel
+
+
+def _arg(args, name, default=False):
+    return getattr(args, name, default)
+
+
+class ImageModel(nn.Module):
+    """Frozen ResNet pyramid front-end (reference: models/bert_model.py:63-111).  It is UPSTREAM of the
+    accelerated path and runs in plain torch/torchvision when raw images are
+    fed; pre-extracted region features bypass it (see ``TVNetSAModel2.get_visual_prompt``)."""
+
+    def __init__(self, use_152=False, use_101=False, use_34=False, use_18=False, resnet_root=None):
+        super().__init__()
+        try:
+            from torchvision.models import resnet18, resnet34, resnet50, resnet101, resnet152
+        except ImportError as e:  # pragma: no cover - torchvision is absent in the build container
+            raise ImportError("raw-image input needs torchvision for the frozen ResNet front-end; feed "
+                              "pre-extracted region features [B,3840,2,2] instead") from e
+        name, ctor = (("resnet152", resnet152) if use_152 else ("resnet101", resnet101) if use_101 else
+                      ("resnet34", resnet34) if use_34 else ("resnet18", resnet18) if use_18 else ("resnet50", resnet50))
+        self.resnet = ctor()
+        if resnet_root is not None:
+            self.resnet.load_state_dict(torch.load(f"{resnet_root}/{name}.pth", map_location="cpu"))
+
+    def forward(self, x, aux_imgs=None):
+        prefix_guids = self.get_resnet_prompt(x)
+        if aux_imgs is not None:
+            aux_imgs = aux_imgs.permute([1, 0, 2, 3, 4])
+            return prefix_guids, [self.get_resnet_prompt(aux_imgs[i]) for i in range(len(aux_imgs))]
+        return prefix_guids, None
+
+    def get_resnet_prompt(self, x):
+        out = []
+        for name, layer in self.resnet.named_children():
+            if name in ("fc", "avgpool"):
+                continue
+            x = layer(x)
+            if "layer" in name:
+                kernel = x.size(2) // 2
+                out.append(nn.functional.avg_pool2d(x, kernel_size=(kernel, kernel), stride=kernel))
+        return out
+
+
+class _PackedLinears:
+    """Views the weights of a ModuleList of equal nn.Linear(in, out) as one [n*out, in] operand."""
+
+    def __init__(self, mods: nn.ModuleList):
+        n, out, inn = len(mods), mods[0].out_features, mods[0].in_features
+        dev = mods[0].weight.device
+        self.w = torch.empty(n * out, inn, device=dev)
+        self.b = torch.empty(n * out, device=dev)
+        with torch.no_grad():
+            for i, m in enumerate(mods):
+                self.w[i * out:(i + 1) * out].copy_(m.weight.data)
+                self.b[i * out:(i + 1) * out].copy_(m.bias.data)
+                m.weight.data = self.w[i * out:(i + 1) * out]
+                m.bias.data = self.b[i * out:(i + 1) * out]
+        self.ptrs = [m.weight.data_ptr() for m in mods] + [m.bias.data_ptr() for m in mods]
+
+    def valid(self, mods) -> bool:
+        return self.ptrs == [m.weight.data_ptr() for m in mods] + [m.bias.data_ptr() for m in mods]
+
+
+class TVNetSAModel2(nn.Module):
+    def __init__(self, label_list, tokenizer, args, type_num=None, use_weight=False):
+        super().__init__()
+        self.args = args
+        self.type_num = type_num
+        self.tokenizer = tokenizer
+        self.prefix_dim = _arg(args, "prefix_dim", 768)
+        self.prefix_len = _arg(args, "prefix_len", 4)
+
+        enc_cls = RobertaModel if "roberta" in args.bert_name else BertModel
+        bert_config = _arg(args, "bert_config", None)  # extension: explicit config => random-init encoder
+        if bert_config is not None:
+            self.bert = enc_cls(bert_config)
+        else:
+            self.bert = enc_cls.from_pretrained(args.bert_name)
+        hidden = self.bert.config.hidden_size
+        self.num_labels = len(label_list) + 1
+
+        if _arg(args, "use_prefix"):
+            small = _arg(args, "use_34") or _arg(args, "use_18")
+            self.feat_dim = 960 if small else 3840
+            if _arg(args, "resnet_root", None) is not None:
+                self.image_model = ImageModel(use_152=_arg(args, "use_152"), use_101=_arg(args, "use_101"),
+                                              use_34=_arg(args, "use_34"), use_18=_arg(args, "use_18"),
+                                              resnet_root=args.resnet_root)
+            else:
+                self.image_model = None  # region features are fed directly (synthetic / cached features)
+            self.encoder_conv = nn.Sequential(nn.Linear(self.feat_dim, 800), nn.Tanh(), nn.Linear(800, 4 * 2 * hidden))
+            n_layers = self.bert.config.num_hidden_layers
+            self.projectors = nn.ModuleList([nn.Linear(4 * hidden * 2, 4) for _ in range(n_layers)])
+            self.img_dropout = nn.Dropout(0.2)
+            self.img_classifier = nn.Linear(4 * 2 * hidden, 2089)
+            self.aux_img_classifier = nn.ModuleList([nn.Linear(4 * 2 * hidden, 2089) for _ in range(3)])
+            self._packed_proj: Optional[_PackedLinears] = None
+
+        self.crf = CRF(self.num_labels, batch_first=True)
+        self.fc = nn.Linear(hidden, self.num_labels)
+        self.dropout = nn.Dropout(0.1)
+        if _arg(args, "use_probe"):
+            raise NotImplementedError("the structural probe (probes/) is off the hot path and its import chain is "
+                                      "broken in the reference (models/bert_model.py:468-475)")
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, labels=None, imagelabel=None,
+                images=None, aux_imgs=None):
+        """reference: models/bert_model.py:480-532"""
+        bsz = input_ids.size(0)
+        img_tag_loss = 0
+        if _arg(self.args, "use_prefix"):
+            prefix_guids, img_tag_loss, aux_img_tag_loss = self.get_visual_prompt(images, aux_imgs, imagelabel)
+            img_tag_loss = img_tag_loss if _arg(self.args, "noauxloss") else img_tag_loss + sum(aux_img_tag_loss)
+            prefix_len = prefix_guids[0][0].shape[2]
+            prefix_mask = torch.ones((bsz, prefix_len), device=attention_mask.device, dtype=attention_mask.dtype)
+            prompt_attention_mask = torch.cat((prefix_mask, attention_mask), dim=1)
+        else:
+            prefix_guids = None
+            prompt_attention_mask = attention_mask
+        bert_output = self.bert(input_ids=input_ids, attention_mask=prompt_attention_mask,
+                                token_type_ids=token_type_ids, past_key_values=prefix_guids, output_attentions=True,
+                                output_hidden_states=True, return_dict=True)
+        sequence_output = engine.dropout(bert_output["last_hidden_state"], self.dropout.p, self.training)
+        emissions = engine.LinearFunction.apply(sequence_output, self.fc.weight, self.fc.bias, False)
+        mask_u8 = attention_mask.to(torch.uint8)
+        logits = self.crf.decode(emissions, mask_u8)
+        loss = None
+        if labels is not None:
+            loss = -1 * self.crf(emissions, labels, mask=mask_u8, reduction="mean")
+            loss = loss + _arg(self.args, "alpha", 0.0) * img_tag_loss
+        return TokenClassifierOutput(loss=loss, logits=logits)
+
+    # ------------------------------------------------------------------------------------------------
+    def _region_features(self, images, aux_imgs):
+        """-> (feats [B,4,F], [aux feats [B,4,F]]).  Accepts raw images (through the frozen ResNet,
+        bert_model.py:536-539) or pre-extracted pyramid features [B,F,2,2] / [B,4,F] (aux: [B,n,...])."""
+        bsz = images.size(0)
+        L = self.prefix_len if self.prefix_len == 4 else 4  # Linear(3840, .) fixes prefix_len = 4
+        raw = images.dim() == 4 and images.shape[1] == 3
+        if raw:
+            if self.image_model is None:
+                raise RuntimeError("raw images were passed but the model was built without args.resnet_root")
+            pyr, aux_pyr = self.image_model(images, aux_imgs)
+            feats = torch.cat(pyr, dim=1).view(bsz, L, -1)
+            aux = [torch.cat(a, dim=1).view(bsz, L, -1) for a in (aux_pyr or [])]
+            return feats.float(), [a.float() for a in aux]
+        feats = images.reshape(bsz, L, -1).float()
+        aux = []
+        if aux_imgs is not None:
+            aux = [aux_imgs[:, i].reshape(bsz, L, -1).float() for i in range(aux_imgs.shape[1])]
+        return feats, aux
+
+    def get_visual_prompt(self, images, aux_imgs, imagelabel):
+        """reference: models/bert_model.py:534-588.  Returns (list of num_layers (K, V) [B,NH,P,64],
+        img_tag_loss, [aux_img_tag_loss])."""
+        feats, aux = self._region_features(images, aux_imgs)
+        bsz, L, Fd = feats.shape
+        cfg = self.bert.config
+        hidden = cfg.hidden_size
+        NI = 1 + len(aux)
+        x = torch.stack([feats] + aux).reshape(NI * bsz * L, Fd)  # image-major rows
+        e0, e2 = self.encoder_conv[0], self.encoder_conv[2]
+        t = engine.LinearFunction.apply(x, e0.weight, e0.bias, True)
+        enc = engine.LinearFunction.apply(t, e2.weight, e2.bias, False).view(NI, bsz, L, 8 * hidden)
+
+        img_tag_loss = 0
+        aux_img_tag_loss = []
+        if _arg(self.args, "vao"):
+            means = engine.MeanLFunction.apply(enc.view(NI * bsz, L, 8 * hidden)).view(NI, bsz, 8 * hidden)
+            target = imagelabel.to(means.device)
+            heads = [self.img_classifier] + list(self.aux_img_classifier)
+            if NI - 1 > len(self.aux_img_classifier):
+                raise ValueError("the VAO branch supports at most 3 aux images (bert_model.py:459)")
+            for k in range(NI):
+                m = engine.dropout(means[k], self.img_dropout.p, self.training)
+                z = engine.LinearFunction.apply(m, heads[k].weight, heads[k].bias, False)
+                l = engine.KLFunction.apply(z, target)
+                if k == 0:
+                    img_tag_loss = l
+                else:
+                    aux_img_tag_loss.append(l)
+
+        if self._packed_proj is None or not self._packed_proj.valid(self.projectors):
+            self._packed_proj = _PackedLinears(self.projectors)
+        pp = self._packed_proj
+        NL = len(self.projectors)
+        proj_params = [p for m in self.projectors for p in (m.weight, m.bias)]
+        pkv = engine.PromptFunction.apply(enc, pp.w, pp.b, NL, *proj_params)
+        return PrefixKV(pkv, cfg.num_attention_heads, hidden // cfg.num_attention_heads), img_tag_loss, aux_img_tag_loss

@@ -1,0 +1,82 @@
+"""Linear-chain CRF module with the public surface of ``torchcrf.CRF`` as the reference uses it
+(models/bert_model.py:464 ``CRF(num_labels, batch_first=True)``, :511 ``decode``, :521
+``crf(emissions, labels, mask=..., reduction='mean')``), computed by the gfx950 kernels
+mtvaf_crf_nll_{fwd,bwd} / mtvaf_crf_viterbi.  Parameter names (``start_transitions``,
+``end_transitions``, ``transitions``) and the uniform(-0.1, 0.1) initialisation follow pytorch-crf.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .. import engine, hip
+
+
+class CRF(nn.Module):
+    def __init__(self, num_tags: int, batch_first: bool = False) -> None:
+        if num_tags <= 0:
+            raise ValueError(f"invalid number of tags: {num_tags}")
+        if num_tags > 16:
+            raise NotImplementedError("the CRF kernels keep one tag per lane with a 16-wide transition tile")
+        super().__init__()
+        self.num_tags = num_tags
+        self.batch_first = batch_first
+        self.start_transitions = nn.Parameter(torch.empty(num_tags))
+        self.end_transitions = nn.Parameter(torch.empty(num_tags))
+        self.transitions = nn.Parameter(torch.empty(num_tags, num_tags))
+        self.reset_parameters()
+
+    def reset_parameters(self) -> None:
+        nn.init.uniform_(self.start_transitions, -0.1, 0.1)
+        nn.init.uniform_(self.end_transitions, -0.1, 0.1)
+        nn.init.uniform_(self.transitions, -0.1, 0.1)
+
+    def __repr__(self) -> str:
+        return f"{self.__class__.__name__}(num_tags={self.num_tags})"
+
+    def _prep(self, emissions, tags, mask):
+        if emissions.dim() != 3 or emissions.size(2) != self.num_tags:
+            raise ValueError(f"expected emissions [*, *, {self.num_tags}], got {tuple(emissions.shape)}")
+        if not self.batch_first:
+            emissions = emissions.transpose(0, 1)
+            tags = tags.transpose(0, 1) if tags is not None else None
+            mask = mask.transpose(0, 1) if mask is not None else None
+        B, S, _ = emissions.shape
+        if mask is None:
+            mask = torch.ones(B, S, dtype=torch.uint8, device=emissions.device)
+        mask = mask.to(torch.uint8).contiguous()
+        if tags is not None:
+            tags = tags.to(torch.long).contiguous()
+        return emissions.float(), tags, mask
+
+    def forward(self, emissions, tags, mask: Optional[torch.Tensor] = None, reduction: str = "sum"):
+        """Log-likelihood of ``tags`` (like torchcrf).  The fused kernel produces the batch-mean NLL, so
+        'mean' is exact and 'sum' is mean * B; 'none' / 'token_mean' are not on the MTVAF path."""
+        emissions, tags, mask = self._prep(emissions, tags, mask)
+        nll_mean = engine.CRFNLLFunction.apply(emissions, self.start_transitions, self.end_transitions,
+                                               self.transitions, tags, mask)
+        if reduction == "mean":
+            return -nll_mean
+        if reduction == "sum":
+            return -nll_mean * emissions.shape[0]
+        raise NotImplementedError(f"reduction={reduction!r} is not on the MTVAF path (the reference uses 'mean')")
+
+    @torch.no_grad()
+    def decode_packed(self, emissions, mask: Optional[torch.Tensor] = None):
+        """Viterbi on device -> (tags int32 [B,S] padded with -1, lengths int32 [B]); no host sync."""
+        emissions, _, mask = self._prep(emissions, None, mask)
+        B, S, _ = emissions.shape
+        em = emissions.contiguous()
+        tags = torch.empty(B, S, dtype=torch.int32, device=em.device)
+        lens = torch.empty(B, dtype=torch.int32, device=em.device)
+        hip.crf_viterbi(em, mask, self.start_transitions.data, self.end_transitions.data, self.transitions.data, tags,
+                        lens)
+        return tags, lens
+
+    def decode(self, emissions, mask: Optional[torch.Tensor] = None) -> List[List[int]]:
+        tags, lens = self.decode_packed(emissions, mask)
+        packed = torch.cat([tags, lens[:, None]], dim=1).cpu()  # ONE D2H copy
+        S = tags.shape[1]
+        return [row[:n].tolist() for row, n in zip(packed[:, :S], packed[:, S].tolist())]

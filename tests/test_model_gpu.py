@@ -1,0 +1,251 @@
+"""End-to-end parity of the drop-in modules (BertModel / RobertaModel / TVNetSAModel2) on the MI355X
+against the golden vectors captured from the reference and against the CPU oracle."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+from transformers import BertConfig, RobertaConfig
+
+import params as P
+from oracle import mtvaf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def hf_config(cfg: P.EncCfg, dropout=0.0):
+    kw = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.layers,
+              num_attention_heads=cfg.heads, intermediate_size=cfg.inter, max_position_embeddings=cfg.max_pos,
+              type_vocab_size=cfg.type_vocab, layer_norm_eps=cfg.eps, hidden_dropout_prob=dropout,
+              attention_probs_dropout_prob=dropout, hidden_act="gelu")
+    return RobertaConfig(pad_token_id=cfg.pad_idx, **kw) if cfg.roberta else BertConfig(pad_token_id=0, **kw)
+
+
+def close(got, ref, rtol=1e-3, atol=None, name=""):
+    got = torch.as_tensor(got).detach().float().cpu()
+    ref = torch.as_tensor(ref).detach().float().cpu()
+    if atol is None:
+        atol = rtol * float(ref.abs().max()) + 1e-7
+    err = (got - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    assert not bool(bad.any()), f"{name}: max err {float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e}), " \
+                                f"{int(bad.sum())}/{bad.numel()} bad"
+
+
+def build_encoder(cfg):
+    from mtvaf_amd.models.modeling_bert import BertModel
+    from mtvaf_amd.models.modeling_roberta import RobertaModel
+    m = (RobertaModel if cfg.roberta else BertModel)(hf_config(cfg))
+    return m
+
+
+@pytest.mark.parametrize("name,cfg", [("enc_tiny_bert_P0", P.TINY_BERT), ("enc_tiny_bert_P4", P.TINY_BERT),
+                                      ("enc_tiny_bert_P16", P.TINY_BERT), ("enc_tiny_bert_P36", P.TINY_BERT),
+                                      ("enc_tiny_roberta_P4", P.TINY_ROBERTA)])
+def test_encoder_matches_reference_golden(name, cfg):
+    fx = load(name)
+    seed, B, S, Pfx = int(fx["seed"]), int(fx["B"]), int(fx["S"]), int(fx["P"])
+    m = build_encoder(cfg)
+    missing, unexpected = m.load_state_dict(P.encoder_params(cfg, seed), strict=False)
+    assert not unexpected and all("position_ids" in k for k in missing), (missing, unexpected)
+    m.to(DEV).train()
+    ids, mask, tt = (torch.from_numpy(fx[k]).to(DEV) for k in ("ids", "mask", "tt"))
+    pkv = P.prefix_kv(seed + 2, cfg.layers, B, cfg.heads, Pfx)
+    if pkv is not None:
+        pkv = [(k.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)) for k, v in pkv]
+    full = torch.cat([torch.ones(B, Pfx, dtype=mask.dtype, device=DEV), mask], 1) if Pfx else mask
+    out = m(input_ids=ids, attention_mask=full, token_type_ids=tt, past_key_values=pkv, output_attentions=True,
+            output_hidden_states=True, return_dict=True)
+    hs = out["hidden_states"]
+    assert len(hs) == cfg.layers + 1
+    for i, h in enumerate(hs):
+        close(h, fx[f"h{i}"], name=f"h{i}")
+    close(out["pooler_output"], fx["pooler"], name="pooler")
+    (out["last_hidden_state"] * torch.from_numpy(fx["grad_seed_w"]).to(DEV)).sum().backward()
+    named = dict(m.named_parameters())
+    L = cfg.layers - 1
+    pairs = {"g_word": "embeddings.word_embeddings.weight", "g_pos": "embeddings.position_embeddings.weight",
+             "g_type": "embeddings.token_type_embeddings.weight", "g_emb_ln_w": "embeddings.LayerNorm.weight",
+             "g_q0_w": "encoder.layer.0.attention.self.query.weight",
+             "g_k0_b": "encoder.layer.0.attention.self.key.bias",
+             "g_v1_w": f"encoder.layer.{L}.attention.self.value.weight",
+             "g_ao0_w": "encoder.layer.0.attention.output.dense.weight",
+             "g_ln0_w": "encoder.layer.0.attention.output.LayerNorm.weight",
+             "g_ln0_b": "encoder.layer.0.attention.output.LayerNorm.bias",
+             "g_i0_w": "encoder.layer.0.intermediate.dense.weight",
+             "g_o0_w": "encoder.layer.0.output.dense.weight", "g_o0_b": "encoder.layer.0.output.dense.bias"}
+    for k, pn in pairs.items():
+        close(named[pn].grad, fx[k], rtol=2e-3, name=k)
+    if pkv is not None:
+        close(pkv[0][0].grad, fx["g_pk0"], rtol=2e-3, name="g_pk0")
+        close(pkv[0][1].grad, fx["g_pv0"], rtol=2e-3, name="g_pv0")
+        close(pkv[-1][0].grad, fx["g_pkL"], rtol=2e-3, name="g_pkL")
+
+
+def _prompt_inputs(seed, B, n_aux):
+    rng = np.random.default_rng(seed)
+    feats = torch.from_numpy(np.abs(rng.standard_normal((B, 3840, 2, 2), dtype=np.float32)))
+    aux = [torch.from_numpy(np.abs(rng.standard_normal((B, 3840, 2, 2), dtype=np.float32))) for _ in range(n_aux)]
+    lab = torch.softmax(torch.from_numpy(rng.standard_normal((B, 2089), dtype=np.float32)), -1)
+    return feats, torch.stack(aux, 1), lab
+
+
+def make_args(**kw):
+    base = dict(bert_name="bert-base-uncased", use_prefix=True, vao=False, noauxloss=True, use_probe=False, n_gpu=1,
+                alpha=0.5, beta=0.0, prefix_len=4, prefix_dim=768, device=DEV, resnet_root=None, use_152=False)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+LABELS = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
+
+
+def build_tvnet2(cfg, args, sde=None, sdh=None, sdp=None):
+    from mtvaf_amd.models.bert_model import TVNetSAModel2
+    args.bert_config = hf_config(cfg)
+    m = TVNetSAModel2(LABELS, None, args)
+    sd = {}
+    if sde is not None:
+        sd.update({"bert." + k: v for k, v in sde.items()})
+    if sdh is not None:
+        sd.update(sdh)
+    if sdp is not None:
+        sd.update(sdp)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name", ["prompt_novao", "prompt_vao"])
+def test_visual_prompt_matches_reference_golden(name):
+    fx = load(name)
+    seed, B, n_aux, vao = int(fx["seed"]), int(fx["B"]), int(fx["n_aux"]), bool(fx["vao"])
+    args = make_args(vao=vao)
+    m = build_tvnet2(P.EncCfg(vocab_size=64, hidden=768, heads=12, inter=128, layers=12, max_pos=32), args,
+                     sdp=P.prompt_params(seed))
+    m.eval()  # VAO dropout(0.2) off, as in the fixture
+    feats, aux, lab = _prompt_inputs(seed + 1, B, n_aux)
+    res, loss, auxl = m.get_visual_prompt(feats.to(DEV), aux.to(DEV), lab.to(DEV))
+    assert len(res) == 12 and tuple(res[0][0].shape) == (B, 12, 4 * (1 + n_aux), 64)
+    close(res[0][0], fx["k0"], name="k0")
+    close(res[0][1], fx["v0"], name="v0")
+    close(res[7][0], fx["k7"], name="k7")
+    close(res[11][1], fx["v11"], name="v11")
+    gk = torch.from_numpy(fx["grad_seed_k"]).to(DEV)
+    tot = sum(((k * gk).sum() + (v * gk).sum() * 0.5) * (1 + 0.1 * i) for i, (k, v) in enumerate(res))
+    if vao:
+        close(loss, fx["loss"], rtol=1e-4, name="vao loss")
+        close(torch.stack(auxl), fx["aux_losses"], rtol=1e-4, name="vao aux")
+        tot = tot + 3.0 * (loss + sum(auxl))
+    tot.backward()
+    named = dict(m.named_parameters())
+    chk = {"g_enc0_b": named["encoder_conv.0.bias"].grad, "g_enc2_b": named["encoder_conv.2.bias"].grad,
+           "g_enc0_w_rows": named["encoder_conv.0.weight"].grad[:4],
+           "g_enc2_w_rows": named["encoder_conv.2.weight"].grad[:4],
+           "g_proj0_w": named["projectors.0.weight"].grad, "g_proj11_b": named["projectors.11.bias"].grad}
+    if vao:
+        chk["g_cls_b"] = named["img_classifier.bias"].grad
+        chk["g_aux2_b"] = named["aux_img_classifier.2.bias"].grad
+    for k, g in chk.items():
+        close(g, fx[k], rtol=3e-3, name=k)
+
+
+def test_tvnet2_matches_reference_golden_base_dims():
+    fx = load("tvnet2_base_B2S16")
+    seed, B, S, n_aux = int(fx["seed"]), int(fx["B"]), int(fx["S"]), int(fx["n_aux"])
+    cfg = P.BASE_BERT
+    m = build_tvnet2(cfg, make_args(), sde=P.encoder_params(cfg, seed, std=0.03), sdh=P.head_params(cfg, seed + 10),
+                     sdp=P.prompt_params(seed + 20))
+    m.eval()
+    ids, mask, tt, labels = P.text_batch(cfg, seed + 1, B, S, lo_id=1000)
+    labels[:, 0] = 9
+    feats, aux, lab = _prompt_inputs(seed + 2, B, n_aux)
+    captured = {}
+    h = m.bert.register_forward_hook(lambda mod, inp, out: captured.update(out=out))
+    out = m(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), token_type_ids=tt.to(DEV), labels=labels.to(DEV),
+            imagelabel=lab.to(DEV), images=feats.to(DEV), aux_imgs=aux.to(DEV))
+    h.remove()
+    close(captured["out"]["last_hidden_state"], fx["h12"], name="h12")
+    close(captured["out"]["hidden_states"][7], fx["h7"], name="h7")
+    em = torch.nn.functional.linear(captured["out"]["last_hidden_state"], m.fc.weight, m.fc.bias)
+    close(em, fx["emissions"], name="emissions")
+    assert abs(float(out.loss) - float(fx["loss"])) <= 1e-3 * abs(float(fx["loss"]))
+    exp = [[int(t) for t in row if t >= 0] for row in fx["tags"]]
+    assert out.logits == exp  # predicted-class indices bit-exact
+    out.loss.backward()
+    named = dict(m.named_parameters())
+    close(named["fc.weight"].grad, fx["g_fc_w"], rtol=3e-3, name="g_fc_w")
+    close(named["crf.transitions"].grad, fx["g_trans"], rtol=3e-3, name="g_trans")
+    close(named["bert.encoder.layer.11.attention.self.query.bias"].grad, fx["g_q11_b"], rtol=3e-3, name="g_q11_b")
+    close(named["encoder_conv.2.bias"].grad, fx["g_enc2_b"], rtol=3e-3, name="g_enc2_b")
+
+
+def test_full_size_step_vs_oracle_and_grad_sink():
+    """BASELINE config-2 shape (S=128, P=36) at B=4 against the CPU oracle: emissions/loss 1e-3,
+    tags bit-exact; gradients land in the flat per-layer buffers without a copy."""
+    cfg = P.BASE_BERT
+    B, S, Pn = 4, 128, 36
+    sde, sdh = P.encoder_params(cfg, 7, std=0.03), P.head_params(cfg, 8)
+    m = build_tvnet2(cfg, make_args(use_prefix=False), sde=sde, sdh=sdh)
+    m.eval()
+    ids, mask, tt, labels = P.text_batch(cfg, 9, B, S, lo_id=1000)
+    labels[:, 0] = 9
+    pkv = P.prefix_kv(10, cfg.layers, B, cfg.heads, Pn, std=0.5)
+    sd = {**{"bert." + k: v for k, v in sde.items()}, **sdh}
+    oloss, oem, otags, ohs = O.tvnet2_forward(sd, ids, mask, tt, labels, pkv, cfg.layers, cfg.heads, cfg.eps)
+    full = torch.cat([torch.ones(B, Pn, dtype=mask.dtype), mask], 1).to(DEV)
+    gp = [(k.to(DEV), v.to(DEV)) for k, v in pkv]
+    bo = m.bert(input_ids=ids.to(DEV), attention_mask=full, token_type_ids=tt.to(DEV), past_key_values=gp,
+                output_hidden_states=True)
+    close(bo["last_hidden_state"], ohs[-1], name="last hidden")
+    em = torch.nn.functional.linear(bo["last_hidden_state"], m.fc.weight, m.fc.bias)
+    close(em, oem, name="emissions")
+    mask_u8 = mask.to(DEV).to(torch.uint8)
+    assert m.crf.decode(em, mask_u8) == otags
+    loss = -m.crf(em, labels.to(DEV), mask=mask_u8, reduction="mean")
+    assert abs(float(loss) - float(oloss)) <= 1e-3 * abs(float(oloss))
+    loss.backward()
+    st = m.bert.encoder._stores[3]
+    g = m.bert.encoder.layer[3].intermediate.dense.weight.grad
+    assert st.grad is not None and st.grad.data_ptr() <= g.data_ptr() < st.grad.data_ptr() + st.grad.numel() * 4, \
+        "parameter gradient was copied instead of adopted from the flat layer buffer"
+    # second backward without zero_grad must ACCUMULATE (fallback path)
+    g1 = g.clone()
+    bo = m.bert(input_ids=ids.to(DEV), attention_mask=full, token_type_ids=tt.to(DEV), past_key_values=gp)
+    em = torch.nn.functional.linear(bo["last_hidden_state"], m.fc.weight, m.fc.bias)
+    (-m.crf(em, labels.to(DEV), mask=mask_u8, reduction="mean")).backward()
+    close(m.bert.encoder.layer[3].intermediate.dense.weight.grad, 2 * g1, rtol=1e-4, name="grad accumulation")
+
+
+def test_training_reduces_loss_and_dropout_is_live():
+    cfg = P.EncCfg(vocab_size=500, hidden=128, heads=2, inter=256, layers=2, max_pos=64)
+    from mtvaf_amd.models.bert_model import TVNetSAModel2
+    args = make_args(use_prefix=False)
+    args.bert_config = hf_config(cfg, dropout=0.1)
+    torch.manual_seed(0)
+    m = TVNetSAModel2(LABELS, None, args).to(DEV)
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 3, 16, 32, lo_id=5))
+    opt = torch.optim.AdamW(m.parameters(), lr=3e-3)
+    m.train()
+    a = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss
+    b = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss
+    assert float(a) != float(b), "dropout masks must differ between forwards in train mode"
+    losses = []
+    for _ in range(30):
+        out = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels)
+        out.loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(out.loss))
+    assert losses[-1] < 0.5 * losses[0], losses
+    m.eval()
+    e1 = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss
+    e2 = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss
+    assert float(e1) == float(e2)

@@ -342,7 +342,8 @@ def test_crf(hip, B, S, C):
     close(dem, emd.grad, rtol=1e-4, atol=1e-6, name="crf dem")
     close(ds, sd_.grad + 1, rtol=1e-4, name="crf dstart")
     close(de, ed.grad + 1, rtol=1e-4, name="crf dend")
-    close(dt, td.grad + 1, rtol=1e-4, name="crf dtrans")
+    tgrad = td.grad if td.grad is not None else torch.zeros_like(td)  # S == 1: no transition is used
+    close(dt, tgrad + 1, rtol=1e-4, name="crf dtrans")
     tg, ln = torch.empty(B, S, dtype=torch.int32, device=DEV), torch.empty(B, dtype=torch.int32, device=DEV)
     hip.crf_viterbi(g(em), g(mask), g(start), g(end), g(trans), tg, ln)
     want = O.crf_decode(em, mask, start, end, trans)
