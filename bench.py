@@ -68,15 +68,20 @@ def build_model(device):
     return TVNetSAModel2(LABELS, None, args).to(device), cfg
 
 
-def cpu_baseline(S, P, seconds_budget=25.0):
+def cpu_baseline(S, P, seconds_budget=20.0):
     """The reference algorithm on the host cores: the CPU oracle (a line-by-line restatement of the
     reference modules, proven equal to them by tests/test_oracle_golden.py) doing fwd+bwd on a bounded
     sample of the same workload."""
     from oracle import mtvaf_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import params as PR
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads")
     cfg = PR.BASE_BERT
     Bc = 8
     sd = {**{"bert." + k: v.requires_grad_(True) for k, v in PR.encoder_params(cfg, 1, std=0.02).items()},
@@ -91,16 +96,23 @@ def cpu_baseline(S, P, seconds_budget=25.0):
         for v in sd.values():
             v.grad = None
 
+    tw = time.perf_counter()
     step()
+    tw = time.perf_counter() - tw
+    log(f"cpu baseline warm-up step: {tw:.2f}s")
     t0 = time.perf_counter()
     n = 0
-    while n < 3 or (time.perf_counter() - t0 < seconds_budget and n < 12):
+    while n < 1 or (time.perf_counter() - t0 + tw < seconds_budget and n < 12):
         step()
         n += 1
     dt = time.perf_counter() - t0
     return {"value": round(Bc * n / dt, 3), "unit": "sentences/s", "cores": cores, "kind": "port",
             "sample": f"{n} fwd+bwd steps of B={Bc}, S={S}, P={P} BERT-base fp32 on torch CPU ({cores} threads), "
                       f"encoder+fc+CRF (prompt generator excluded)"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -173,7 +185,8 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    loss_val = float(out.loss)
+    loss_val = float(out.loss.detach())
+    log(f"timed region done: {dt:.3f}s for {a.steps} steps, loss {loss_val:.4f}")
     value = world * B * a.steps / dt
     per_gpu = value / world
     ftrain = 3 * f_fwd(S, P)
@@ -228,8 +241,11 @@ def main():
             "all_gemms": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                           "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], 4)},
             "top_shapes": shapes}
+    if rank == 0:
+        log("roofline pass done")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(S, P)
+        log("cpu baseline done")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

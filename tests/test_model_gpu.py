@@ -82,7 +82,9 @@ def test_encoder_matches_reference_golden(name, cfg):
              "g_i0_w": "encoder.layer.0.intermediate.dense.weight",
              "g_o0_w": "encoder.layer.0.output.dense.weight", "g_o0_b": "encoder.layer.0.output.dense.bias"}
     for k, pn in pairs.items():
-        close(named[pn].grad, fx[k], rtol=2e-3, name=k)
+        # the key bias shifts every score of a query equally: its true gradient is 0 and the reference
+        # value is pure rounding noise (~1e-7), so compare it absolutely
+        close(named[pn].grad, fx[k], rtol=2e-3, atol=2e-6 if k == "g_k0_b" else None, name=k)
     if pkv is not None:
         close(pkv[0][0].grad, fx["g_pk0"], rtol=2e-3, name="g_pk0")
         close(pkv[0][1].grad, fx["g_pv0"], rtol=2e-3, name="g_pv0")
