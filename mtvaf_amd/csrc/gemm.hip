@@ -46,16 +46,18 @@ __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int nvalid, bo
   return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+// FAST: M % BM == 0, N % BN == 0, every k-chunk a multiple of BK, 16-byte aligned operands -> no bounds
+// checks or scalar tails anywhere in the main loop.
+template <int BM, int BN, int WM, int WN, int BK, bool A_KM, bool B_KM, bool FAST>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
-  constexpr int BK = 16;
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int KC_LD = BK + 4;
   constexpr int A_SZ = A_KM ? BK * BM : BM * KC_LD;
   constexpr int B_SZ = B_KM ? BK * BN : BN * KC_LD;
-  constexpr int LA = (BM * 4 + NT - 1) / NT;
-  constexpr int LB = (BN * 4 + NT - 1) / NT;
+  constexpr int KQ = BK / 4;  // float4 per KC row
+  constexpr int LA = (BM * KQ + NT - 1) / NT;
+  constexpr int LB = (BN * KQ + NT - 1) / NT;
   static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "tile/wave mismatch");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -89,34 +91,50 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int idx = tid + i * NT;
-      if (LA * NT == BM * 4 || idx < BM * 4) {
+      if (LA * NT == BM * KQ || idx < BM * KQ) {
         if (!A_KM) {
-          const int r = idx >> 2, c = (idx & 3) * 4;
+          const int r = idx / KQ, c = (idx % KQ) * 4;
           const int row = m0 + r, k = k0 + c;
-          const int nv = row < p.M ? max(0, min(4, kend - k)) : 0;
-          ra[i] = ld4(p.A + (long)row * p.lda + k, nv, p.a_vec);
+          if (FAST) {
+            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long)row * p.lda + k);
+          } else {
+            const int nv = row < p.M ? max(0, min(4, kend - k)) : 0;
+            ra[i] = ld4(p.A + (long)row * p.lda + k, nv, p.a_vec);
+          }
         } else {
           const int k = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
           const int row = m0 + c;
-          const int nv = (k0 + k) < kend ? max(0, min(4, p.M - row)) : 0;
-          ra[i] = ld4(p.A + (long)(k0 + k) * p.lda + row, nv, p.a_vec);
+          if (FAST) {
+            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long)(k0 + k) * p.lda + row);
+          } else {
+            const int nv = (k0 + k) < kend ? max(0, min(4, p.M - row)) : 0;
+            ra[i] = ld4(p.A + (long)(k0 + k) * p.lda + row, nv, p.a_vec);
+          }
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       const int idx = tid + i * NT;
-      if (LB * NT == BN * 4 || idx < BN * 4) {
+      if (LB * NT == BN * KQ || idx < BN * KQ) {
         if (!B_KM) {
-          const int r = idx >> 2, c = (idx & 3) * 4;
+          const int r = idx / KQ, c = (idx % KQ) * 4;
           const int col = n0 + r, k = k0 + c;
-          const int nv = col < p.N ? max(0, min(4, kend - k)) : 0;
-          rb[i] = ld4(p.B + (long)col * p.ldb + k, nv, p.b_vec);
+          if (FAST) {
+            rb[i] = *reinterpret_cast<const f32x4*>(p.B + (long)col * p.ldb + k);
+          } else {
+            const int nv = col < p.N ? max(0, min(4, kend - k)) : 0;
+            rb[i] = ld4(p.B + (long)col * p.ldb + k, nv, p.b_vec);
+          }
         } else {
           const int k = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
           const int col = n0 + c;
-          const int nv = (k0 + k) < kend ? max(0, min(4, p.N - col)) : 0;
-          rb[i] = ld4(p.B + (long)(k0 + k) * p.ldb + col, nv, p.b_vec);
+          if (FAST) {
+            rb[i] = *reinterpret_cast<const f32x4*>(p.B + (long)(k0 + k) * p.ldb + col);
+          } else {
+            const int nv = (k0 + k) < kend ? max(0, min(4, p.N - col)) : 0;
+            rb[i] = ld4(p.B + (long)(k0 + k) * p.ldb + col, nv, p.b_vec);
+          }
         }
       }
     }
@@ -127,9 +145,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < LA; ++i) {
       const int idx = tid + i * NT;
-      if (LA * NT == BM * 4 || idx < BM * 4) {
+      if (LA * NT == BM * KQ || idx < BM * KQ) {
         if (!A_KM) {
-          *reinterpret_cast<f32x4*>(a + (idx >> 2) * KC_LD + (idx & 3) * 4) = ra[i];
+          *reinterpret_cast<f32x4*>(a + (idx / KQ) * KC_LD + (idx % KQ) * 4) = ra[i];
         } else {
           *reinterpret_cast<f32x4*>(a + (idx / (BM / 4)) * BM + (idx % (BM / 4)) * 4) = ra[i];
         }
@@ -138,9 +156,9 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < LB; ++i) {
       const int idx = tid + i * NT;
-      if (LB * NT == BN * 4 || idx < BN * 4) {
+      if (LB * NT == BN * KQ || idx < BN * KQ) {
         if (!B_KM) {
-          *reinterpret_cast<f32x4*>(b + (idx >> 2) * KC_LD + (idx & 3) * 4) = rb[i];
+          *reinterpret_cast<f32x4*>(b + (idx / KQ) * KC_LD + (idx % KQ) * 4) = rb[i];
         } else {
           *reinterpret_cast<f32x4*>(b + (idx / (BN / 4)) * BN + (idx % (BN / 4)) * 4) = rb[i];
         }
@@ -204,12 +222,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + li;
-      if (col >= p.N) continue;
+      if (!FAST && col >= p.N) continue;
       const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= p.M) continue;
+        if (!FAST && row >= p.M) continue;
         float v = acc[i][j][r] + bv;
         if (!split) {
           if (p.epi == EPI_GELU) {
@@ -246,40 +264,62 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
   }
 }
 
-struct TileCfg { int bm, bn, threads; };
-static const TileCfg kCfgs[] = {{128, 128, 256}, {128, 96, 256}, {128, 288, 256}, {64, 64, 256}, {128, 64, 256}};
-constexpr int kNumCfgs = 5;
+struct TileCfg { int bm, bn, bk; };
+static const TileCfg kCfgs[] = {{128, 128, 16}, {128, 96, 16}, {128, 288, 16}, {64, 64, 16}, {128, 64, 16},
+                                {128, 128, 32}, {128, 96, 32}, {128, 192, 16}, {128, 192, 32}};
+constexpr int kNumCfgs = 9;
 
-template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
-  constexpr int BK = 16, KC_LD = BK + 4;
+template <int BM, int BN, int WM, int WN, int BK, bool FAST>
+static int launch_l(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
+  constexpr int KC_LD = BK + 4;
   const int asz = la ? BK * BM : BM * KC_LD, bsz = lb ? BK * BN : BN * KC_LD;
   const size_t smem = (size_t)2 * (asz + bsz) * sizeof(float);
   dim3 block(WM * WN * 64);
-  if (la == 0 && lb == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, block, smem, st, a);
-  else if (la == 0 && lb == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, block, smem, st, a);
-  else if (la == 1 && lb == 1) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, block, smem, st, a);
-  else if (la == 1 && lb == 0) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, block, smem, st, a);
+  if (la == 0 && lb == 0)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, false, false, FAST>), grid, block, smem, st, a);
+  else if (la == 0 && lb == 1)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, false, true, FAST>), grid, block, smem, st, a);
+  else if (la == 1 && lb == 1)
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, true, true, FAST>), grid, block, smem, st, a);
+  else if (!FAST)  // KM x KC is not produced by the path; only the checked kernel carries it
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, true, false, false>), grid, block, smem, st, a);
+  else
+    return MTVAF_ERR_ARG;
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
 
+template <int BM, int BN, int WM, int WN, int BK>
+static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, bool fast, hipStream_t st) {
+  if (fast && !(la == 1 && lb == 0)) return launch_l<BM, BN, WM, WN, BK, true>(a, la, lb, grid, st);
+  return launch_l<BM, BN, WM, WN, BK, false>(a, la, lb, grid, st);
+}
+
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
-// Cost model: the MFMA pipe of a CU is shared by its resident blocks, so time ~ rounds over the
-// 256 CUs x work per tile.  Larger tiles re-use LDS fragments better (small efficiency bonus).
+// Cost model (units: fp32 MFMA cycles of one CU).  The MFMA pipe of a CU is shared by its resident
+// blocks, so time ~ rounds over the 256 CUs x work per tile / efficiency of that tile shape (calibrated
+// with tools/gemm_sweep.py on MI355X at M = 4096), plus, for split-K, the slab write + ordered reduce.
 static void choose(int M, int N, int K, int allow_split, int* cfg_out, int* splits_out) {
-  static const double eff[kNumCfgs] = {1.0, 0.95, 1.0, 0.70, 0.88};
+  //                                  128x128 128x96 128x288 64x64 128x64 128x128x32 128x96x32 128x192 128x192x32
+  static const double eff[kNumCfgs] = {0.80,   0.86,  0.72,   0.45, 0.80,  0.70,      1.00,     0.92,   0.78};
   double best = 1e300;
   int bc = 0, bs = 1;
   for (int c = 0; c < kNumCfgs; ++c) {
-    const long tiles = cdiv(M, kCfgs[c].bm) * cdiv(N, kCfgs[c].bn);
+    const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = kCfgs[c].bk;
+    const long tiles = cdiv(M, bm) * cdiv(N, bn);
     const int max_s = allow_split ? 16 : 1;
     for (int s = 1; s <= max_s; ++s) {
       if (s > 1 && K / s < 256) break;
       const long rounds = cdiv(tiles * s, 256);
-      double cost = (double)rounds * kCfgs[c].bm * kCfgs[c].bn * (double)cdiv(cdiv(K, s), 16) * 16 / eff[c];
-      if (s > 1) cost += 2.0e5 + (double)tiles * s * kCfgs[c].bm * kCfgs[c].bn / 256.0 * 8;  // slab pass
+      const double kc = (double)cdiv(cdiv(K, s), bk) * bk;
+      // per tile: (bm*bn*kc*2 flop) / (256 flop/clk/CU) cycles at 100 %
+      double cost = (double)rounds * bm * bn * kc / 128.0 / eff[c];
+      cost += 3000.0;  // fill/drain + launch
+      if (s > 1) {
+        // slabs: s*M*N floats written then read once (plus the final write) at ~4 TB/s ~ 1.7 KB/clk chip-wide
+        cost += ((double)s * 2.0 + 1.0) * M * N * 4.0 / 1700.0 + 8000.0;
+      }
       if (cost < best) { best = cost; bc = c; bs = s; }
     }
   }
@@ -300,7 +340,8 @@ size_t mtvaf_gemm_f32_workspace_bytes(int M, int N, int K, int allow_split) {
 }
 
 // Reports the tile configuration / split count the heuristic would pick (for profiling tools).
-// tile: 0 = 128x128, 1 = 128x96, 2 = 128x288, 3 = 64x64, 4 = 128x64 (BMxBN, 256 threads).
+// tile (BMxBNxBK, 256 threads): 0 128x128x16, 1 128x96x16, 2 128x288x16, 3 64x64x16, 4 128x64x16,
+// 5 128x128x32, 6 128x96x32, 7 128x192x16, 8 128x192x32.
 int mtvaf_gemm_f32_plan(int M, int N, int K, int allow_split, int* cfg, int* splits) {
   if (M <= 0 || N <= 0 || K <= 0 || !cfg || !splits) return MTVAF_ERR_ARG;
   choose(M, N, K, allow_split, cfg, splits);
@@ -334,7 +375,8 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
   a.epi = epi; a.accumulate = accumulate;
   a.a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
   a.b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
-  int kc = (int)cdiv(cdiv(K, splits), 16) * 16;
+  const int bk = kCfgs[cfg].bk;
+  int kc = (int)cdiv(cdiv(K, splits), bk) * bk;
   splits = (int)cdiv(K, kc);
   a.k_chunk = kc;
   if (splits > 1) {
@@ -345,13 +387,18 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
   const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
   a.tiles_n = (int)cdiv(N, bn);
   dim3 grid((unsigned)(cdiv(M, bm) * a.tiles_n), 1, (unsigned)splits);
+  const bool fast = (M % bm == 0) && (N % bn == 0) && (K % bk == 0) && a.a_vec && a.b_vec && (kc % bk == 0);
   int rc;
   switch (cfg) {
-    case 0: rc = launch_cfg<128, 128, 2, 2>(a, layout_a, layout_b, grid, stream); break;
-    case 1: rc = launch_cfg<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;
-    case 2: rc = launch_cfg<128, 288, 4, 1>(a, layout_a, layout_b, grid, stream); break;
-    case 3: rc = launch_cfg<64, 64, 2, 2>(a, layout_a, layout_b, grid, stream); break;
-    default: rc = launch_cfg<128, 64, 4, 1>(a, layout_a, layout_b, grid, stream); break;
+    case 0: rc = launch_cfg<128, 128, 2, 2, 16>(a, layout_a, layout_b, grid, fast, stream); break;
+    case 1: rc = launch_cfg<128, 96, 4, 1, 16>(a, layout_a, layout_b, grid, fast, stream); break;
+    case 2: rc = launch_cfg<128, 288, 4, 1, 16>(a, layout_a, layout_b, grid, fast, stream); break;
+    case 3: rc = launch_cfg<64, 64, 2, 2, 16>(a, layout_a, layout_b, grid, fast, stream); break;
+    case 4: rc = launch_cfg<128, 64, 4, 1, 16>(a, layout_a, layout_b, grid, fast, stream); break;
+    case 5: rc = launch_cfg<128, 128, 2, 2, 32>(a, layout_a, layout_b, grid, fast, stream); break;
+    case 6: rc = launch_cfg<128, 96, 4, 1, 32>(a, layout_a, layout_b, grid, fast, stream); break;
+    case 7: rc = launch_cfg<128, 192, 2, 2, 16>(a, layout_a, layout_b, grid, fast, stream); break;
+    default: rc = launch_cfg<128, 192, 2, 2, 32>(a, layout_a, layout_b, grid, fast, stream); break;
   }
   if (rc != MTVAF_OK) return rc;
   if (splits > 1) {

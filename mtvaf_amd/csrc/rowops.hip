@@ -207,15 +207,33 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// out[c] = (acc ? out[c] : 0) + sum_r x[r*ld + c]   (single block column strip; rows small)
-__global__ void colsum_final_kernel(const float* __restrict__ x, int rows, int cols, long ld, float* __restrict__ out,
-                                    int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += x[(long)r * ld + c];
-  if (accumulate) s += out[c];
-  out[c] = s;
+// out[c] = (acc ? out[c] : 0) + sum_r x[r*ld + c].  Block = 32 columns x 8 row groups; the 8 partial sums
+// are combined in fixed order through LDS (deterministic).  grid = ceil(cols / 32).
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ x, int rows, int cols, long ld,
+                                                          float* __restrict__ out, int accumulate) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int r = rg;
+    for (; r + 24 < rows; r += 32) {
+      s0 += x[(long)r * ld + c];
+      s1 += x[(long)(r + 8) * ld + c];
+      s2 += x[(long)(r + 16) * ld + c];
+      s3 += x[(long)(r + 24) * ld + c];
+    }
+    for (; r < rows; r += 8) s0 += x[(long)r * ld + c];
+  }
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float s = red[0][cl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += red[i][cl];
+    if (accumulate) s += out[c];
+    out[c] = s;
+  }
 }
 
 // stage 1 of a tall column sum: partial[chunk][c] = sum over this chunk's rows
@@ -293,6 +311,8 @@ __global__ void roberta_pos_kernel(const int64_t* __restrict__ ids, int32_t* __r
 }
 
 static inline int row_grid(int M) { return std::max(1, std::min((M + 3) / 4, 1024)); }
+// LN backward keeps per-block column partials: fewer, fatter blocks (2 per CU) keep the partial slab small
+static inline int row_grid_bwd(int M) { return std::max(1, std::min((M + 3) / 4, 512)); }
 
 }  // namespace mtvaf
 
@@ -300,7 +320,7 @@ using namespace mtvaf;
 
 extern "C" {
 
-size_t mtvaf_ln_bwd_workspace_bytes(int M, int H) { return (size_t)row_grid(M) * 4 * H * sizeof(float); }
+size_t mtvaf_ln_bwd_workspace_bytes(int M, int H) { return (size_t)row_grid_bwd(M) * 4 * H * sizeof(float); }
 
 int mtvaf_roberta_position_ids(const int64_t* ids, int32_t* pos_ids, int B, int S, int pad_idx, hipStream_t st) {
   if (B <= 0 || S <= 0) return MTVAF_ERR_SHAPE;
@@ -337,14 +357,14 @@ int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res
                              float* dgamma, float* dbeta, int accumulate, int M, int H, float p_drop, uint64_t seed,
                              uint64_t offset, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
-  const int g = row_grid(M);
+  const int g = row_grid_bwd(M);
   if (workspace_bytes < (size_t)g * 2 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
                      offset);
   MTVAF_LAUNCH_CHECK();
-  const int cb = (H + 255) / 256;
+  const int cb = (H + 31) / 32;
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part, g, H, (long)2 * H, dgamma, accumulate);
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + H, g, H, (long)2 * H, dbeta, accumulate);
   MTVAF_LAUNCH_CHECK();
@@ -363,13 +383,13 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
                        size_t workspace_bytes, hipStream_t st) {
   if (H % 4 || H > MAXC * 256 || B <= 0 || S <= 0 || type_vocab > 2) return MTVAF_ERR_SHAPE;
   const int M = B * S;
-  const int g = row_grid(M);
+  const int g = row_grid_bwd(M);
   if (workspace_bytes < (size_t)g * 4 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(g), dim3(256), 0, st, dout, nullptr, nullptr, ids, type_ids, pos_ids,
                      word, pos, type, gamma, mean, rstd, dz_ws, nullptr, 0, part, M, S, H, p_drop, seed, offset);
   MTVAF_LAUNCH_CHECK();
-  const int cb = (H + 255) / 256;
+  const int cb = (H + 31) / 32;
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part, g, H, (long)4 * H, dgamma, accumulate);
   hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + H, g, H, (long)4 * H, dbeta, accumulate);
   for (int t = 0; t < type_vocab; ++t)
@@ -409,7 +429,7 @@ int mtvaf_colsum(const float* x, int rows, int cols, int ld, float* out, int acc
   float* part = (float*)workspace;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, st, x, rows, cols, (long)ld,
                      part, rpc);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part, chunks, cols, (long)cols,
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, part, chunks, cols, (long)cols,
                      out, accumulate);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;

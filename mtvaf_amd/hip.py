@@ -111,7 +111,8 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 PROFILE = None  # set to a list to record (key, start_event, stop_event) around every GEMM launch
-TILE_NAMES = {0: "128x128", 1: "128x96", 2: "128x288", 3: "64x64", 4: "128x64"}
+TILE_NAMES = {0: "128x128x16", 1: "128x96x16", 2: "128x288x16", 3: "64x64x16", 4: "128x64x16", 5: "128x128x32",
+              6: "128x96x32", 7: "128x192x16", 8: "128x192x32"}
 
 
 def gemm_plan(M, N, K, allow_split):

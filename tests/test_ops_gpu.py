@@ -40,8 +40,8 @@ def close(got, ref, rtol=2e-4, atol=None, name=""):
 # ---------------------------------------------------------------------------------------------
 # GEMM
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(256, 288, 64), (130, 100, 72), (48, 11, 128), (512, 768, 768)])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("M,N,K", [(256, 288, 64), (130, 100, 72), (48, 11, 128), (512, 768, 768), (384, 576, 96)])
 def test_gemm_nt(hip, cfg, M, N, K):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
     out = torch.empty(M, N, device=DEV)
@@ -49,8 +49,8 @@ def test_gemm_nt(hip, cfg, M, N, K):
     close(out, F.linear(x.double(), w.double(), b.double()), name="nt")
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 3])
-@pytest.mark.parametrize("M,N,K", [(256, 96, 160), (77, 130, 11), (48, 128, 256)])
+@pytest.mark.parametrize("cfg", [0, 1, 3, 5, 6, 7, 8])
+@pytest.mark.parametrize("M,N,K", [(256, 96, 160), (77, 130, 11), (48, 128, 256), (384, 768, 384)])
 def test_gemm_nn_and_accumulate(hip, cfg, M, N, K):
     dy, w = rnd(M, K, seed=4), rnd(K, N, seed=5)  # out[M,N] = dy[M,K] . w[K,N]
     out = rnd(M, N, seed=6).to(DEV)
@@ -59,7 +59,7 @@ def test_gemm_nn_and_accumulate(hip, cfg, M, N, K):
     close(out, ref, name="nn+acc")
 
 
-@pytest.mark.parametrize("cfg,splits", [(0, 1), (3, 4), (1, 3), (-1, -1)])
+@pytest.mark.parametrize("cfg,splits", [(0, 1), (3, 4), (1, 3), (-1, -1), (5, 2), (6, 4), (8, 2)])
 @pytest.mark.parametrize("M,N,K", [(768, 768, 4096), (11, 768, 1000), (100, 60, 48), (128, 256, 2051)])
 def test_gemm_tn_splitk(hip, cfg, splits, M, N, K):
     dy, x = rnd(K, M, seed=7), rnd(K, N, seed=8)  # out[M,N] = dy^T . x (reduction over rows)
