@@ -151,7 +151,7 @@ def main():
         from mtvaf_amd.parallel import GradSync
         sync = GradSync(model)
     opt = None if a.no_optimizer else torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5,
-                                                        weight_decay=1e-2, foreach=True)
+                                                        weight_decay=1e-2, fused=True)
     batch = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, a.full_length)
     ids, mask, tt, labels, feats, aux = batch
 
@@ -194,7 +194,7 @@ def main():
     res = {"metric": "training sentences/sec (fwd+bwd)", "value": round(value, 2), "unit": "sentences/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
-           "config": {"workload": f"TVNetSAModel2 BERT-base random-init, fwd+bwd{'' if a.no_optimizer else '+AdamW'}, "
+           "config": {"workload": f"TVNetSAModel2 BERT-base random-init, fwd+bwd{'' if a.no_optimizer else '+AdamW(torch fused)'}, "
                                   f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
                                   f"images through the prompt generator), train mode (dropout live), "
                                   f"{'full-length' if a.full_length else 'ragged 16..S'} sequences",
@@ -222,12 +222,12 @@ def main():
         tot_fl = sum(2.0 * k[2] * k[3] * k[4] * v[1] for k, v in agg.items()) / 3
         top = max(agg.items(), key=lambda kv: kv[1][0])
         (la, lb, M, N, K, epi, split), (ms, cnt) = top
-        tile, splits = hip.gemm_plan(M, N, K, split)
+        tile, splits = hip.gemm_plan(M, N, K, split, la, lb, epi)
         avg_us = 1e3 * ms / cnt
         ach = 2.0 * M * N * K / (avg_us * 1e-6) / 1e12
         shapes = []
         for (la2, lb2, M2, N2, K2, epi2, sp2), (ms2, c2) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
-            t2, s2 = hip.gemm_plan(M2, N2, K2, sp2)
+            t2, s2 = hip.gemm_plan(M2, N2, K2, sp2, la2, lb2, epi2)
             shapes.append({"op": f"{'KM' if la2 else 'KC'}x{'KM' if lb2 else 'KC'}", "M": M2, "N": N2, "K": K2,
                            "epi": epi2, "tile": hip.TILE_NAMES[t2], "splits": s2, "launches_per_step": c2 // 3,
                            "avg_us": round(1e3 * ms2 / c2, 1),

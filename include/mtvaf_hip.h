@@ -56,7 +56,8 @@ int mtvaf_device_cus(void);
  * backward.  C[M,N] = opA[M,K] . opB[K,N] (+bias[N]) with epilogue `epi`; cfg/splits < 0 = heuristic.
  * allow_split enables a deterministic split-K (ordered slab reduction) through `workspace`. */
 size_t mtvaf_gemm_f32_workspace_bytes(int M, int N, int K, int allow_split);
-int mtvaf_gemm_f32_plan(int M, int N, int K, int allow_split, int* cfg, int* splits);
+int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi, int allow_split, int* cfg,
+                        int* splits);
 int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
                    int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
@@ -93,15 +94,17 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
 
 /* ---- dropout + residual + LayerNorm --------------------------------------------------------------------
  * replaces BertSelfOutput / BertOutput `LayerNorm(dropout(dense_out) + input)` (modeling_bert.py:354-355,
- * 434-435); the dense bias is added by the GEMM epilogue. */
+ * 434-435); the dense bias is added by the GEMM epilogue.  The backward also emits the column sums of dx
+ * (dbias_x, nullable) = the gradient of that dense bias, saving a separate reduction pass. */
 size_t mtvaf_ln_bwd_workspace_bytes(int M, int H);
 int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                              float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
                              uint64_t offset, mtvaf_stream_t stream);
 int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma,
                              const float* mean, const float* rstd, float* dx, float* dres, int dres_accumulate,
-                             float* dgamma, float* dbeta, int accumulate, int M, int H, float p_drop, uint64_t seed,
-                             uint64_t offset, void* workspace, size_t workspace_bytes, mtvaf_stream_t stream);
+                             float* dgamma, float* dbeta, float* dbias_x, int accumulate, int M, int H, float p_drop,
+                             uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes,
+                             mtvaf_stream_t stream);
 
 /* ---- small reductions / elementwise ---------------------------------------------------------------------
  * bias gradients (column sums of dY) and nn.Dropout on the sequence output (bert_model.py:506). */

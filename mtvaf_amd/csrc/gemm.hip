@@ -14,6 +14,7 @@
 // KC operand is fetched with one ds_read_b128 per four MFMAs.  A and B use the same permutation,
 // so the sum over k is unchanged.
 #include "common.h"
+#include <cstdlib>
 
 namespace mtvaf {
 
@@ -249,6 +250,226 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA pipelined variant (FAST shapes only): tiles go global -> LDS directly with
+// global_load_lds_dwordx4 into a 3-stage ring; ONE raw s_barrier and one counted s_waitcnt vmcnt per
+// k-tile, with the loads of tile kt+2 issued right after the barrier of iteration kt, so two tiles
+// are always in flight behind the MFMAs (no register staging, no ds_write pass).
+// A LDS-DMA write is lane-linear (wave-uniform base + lane*16 B), so KC tiles are stored UNPADDED
+// ([rows][BK] floats, 128-B rows) and bank conflicts of the ds_read_b128 fragment reads are removed
+// by an XOR swizzle of the 16-B chunk index applied on the per-lane SOURCE address and again on the
+// read (chunk' = chunk ^ ((row >> 1) & 7)).  KM tiles ([BK][rows]) are read with conflict-free
+// ds_read_b32 and need no swizzle.
+// ---------------------------------------------------------------------------------------------
+#define MTVAF_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) MTVAF_WAIT_VMCNT(0);
+  else if constexpr (N == 5) MTVAF_WAIT_VMCNT(5);
+  else if constexpr (N == 6) MTVAF_WAIT_VMCNT(6);
+  else if constexpr (N == 7) MTVAF_WAIT_VMCNT(7);
+  else if constexpr (N == 8) MTVAF_WAIT_VMCNT(8);
+  else if constexpr (N == 10) MTVAF_WAIT_VMCNT(10);
+  else static_assert(N == 0, "add the count");
+}
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p) {
+  constexpr int BK = 32, NSTAGE = 3;
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int A_SZ = BM * BK, B_SZ = BN * BK, STAGE = A_SZ + B_SZ;  // floats
+  constexpr int IA = A_SZ / 256 / NW, IB = B_SZ / 256 / NW;           // 1-KiB DMA instructions per wave
+  static_assert(A_SZ % (256 * NW) == 0 && B_SZ % (256 * NW) == 0, "tile must split into whole DMA pieces per wave");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [NSTAGE][A_SZ + B_SZ]  (the ONLY LDS object)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, h = lane >> 5;
+
+  const int bid = blockIdx.x;
+  const int m0 = (bid / p.tiles_n) * BM;
+  const int n0 = (bid % p.tiles_n) * BN;
+  const int kbeg = blockIdx.z * p.k_chunk;
+  const int kend = min(p.K, kbeg + p.k_chunk);
+  const int nk = (kend - kbeg) / BK;
+
+  // per-lane source pointers of this wave's DMA pieces (advance by one k-tile per issue)
+  const float* pa[IA];
+  const float* pb[IB];
+  long stepA, stepB;
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int f = (wave * IA + i) * 64 + lane;  // float4 index inside the tile image
+    if (!A_KM) {
+      const int r = f >> 3, cp = f & 7;
+      pa[i] = p.A + (long)(m0 + r) * p.lda + kbeg + ((cp ^ ((r >> 1) & 7)) << 2);
+    } else {
+      const int k = f / (BM / 4), c4 = f % (BM / 4);
+      pa[i] = p.A + (long)(kbeg + k) * p.lda + m0 + c4 * 4;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int f = (wave * IB + i) * 64 + lane;
+    if (!B_KM) {
+      const int r = f >> 3, cp = f & 7;
+      pb[i] = p.B + (long)(n0 + r) * p.ldb + kbeg + ((cp ^ ((r >> 1) & 7)) << 2);
+    } else {
+      const int k = f / (BN / 4), c4 = f % (BN / 4);
+      pb[i] = p.B + (long)(kbeg + k) * p.ldb + n0 + c4 * 4;
+    }
+  }
+  stepA = A_KM ? (long)BK * p.lda : BK;
+  stepB = B_KM ? (long)BK * p.ldb : BK;
+
+  auto issue = [&](int stage) {
+    float* sa = smem + stage * STAGE + wave * IA * 256;
+    float* sb = smem + stage * STAGE + A_SZ + wave * IB * 256;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      glds16(pa[i], sa + i * 256);
+      pa[i] += stepA;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      glds16(pb[i], sb + i * 256);
+      pb[i] += stepB;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read offsets (floats) that do not depend on the stage
+  int offA[TM], offB[TN], swA[TM], swB[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int row = (wm * TM + i) * 32 + li;
+    offA[i] = A_KM ? row : row * BK;
+    swA[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = (wn * TN + j) * 32 + li;
+    offB[j] = B_KM ? col : col * BK;
+    swB[j] = (col >> 1) & 7;
+  }
+
+  // Fragments are double-buffered in registers: the ds_reads of k-block kb+1 are issued BEFORE the MFMAs
+  // of k-block kb, and the DMA pieces of tile kt+2 are issued behind the first MFMA group, so neither
+  // LDS latency nor DMA issue sits between two MFMA bursts.
+  auto load_frags = [&](const float* a, const float* b, int kb, f32x4 (&fa)[TM], f32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (!A_KM) {
+        fa[i] = *reinterpret_cast<const f32x4*>(a + offA[i] + (((2 * kb + h) ^ swA[i]) << 2));
+      } else {
+        const float* q = a + (kb * 8 + 4 * h) * BM + offA[i];
+        fa[i].x = q[0]; fa[i].y = q[BM]; fa[i].z = q[2 * BM]; fa[i].w = q[3 * BM];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (!B_KM) {
+        fb[j] = *reinterpret_cast<const f32x4*>(b + offB[j] + (((2 * kb + h) ^ swB[j]) << 2));
+      } else {
+        const float* q = b + (kb * 8 + 4 * h) * BN + offB[j];
+        fb[j].x = q[0]; fb[j].y = q[BN]; fb[j].z = q[2 * BN]; fb[j].w = q[3 * BN];
+      }
+    }
+  };
+  auto mfma_group = [&](const f32x4 (&fa)[TM], const f32x4 (&fb)[TN]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+  };
+  auto compute = [&](int stage, bool do_issue, int issue_stage) {
+    const float* a = smem + stage * STAGE;
+    const float* b = a + A_SZ;
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN], fa2[TM], fb2[TN];
+    // sched_barrier(0) pins this order (hipcc otherwise sinks the prefetch reads back next to their use).
+    // Three fragment sets: the only exposed LDS latency is the first read burst after the barrier.
+    load_frags(a, b, 0, fa0, fb0);
+    load_frags(a, b, 1, fa1, fb1);
+    load_frags(a, b, 2, fa2, fb2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_issue) issue(issue_stage);
+    load_frags(a, b, 3, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(fa2, fb2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  issue(0);
+  if (nk > 1) issue(1);
+  int st_c = 0, st_l = 2;  // stage computed this iteration / stage loaded (tile kt+2)
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) wait_vmcnt<IA + IB>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(st_c, kt + 2 < nk, st_l);
+    asm volatile("" ::: "memory");
+    st_c = st_c == NSTAGE - 1 ? 0 : st_c + 1;
+    st_l = st_l == NSTAGE - 1 ? 0 : st_l + 1;
+  }
+
+  float* C = p.C + (long)blockIdx.z * p.slab_stride;
+  const bool split = gridDim.z > 1;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + li;
+      const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        float v = acc[i][j][r] + bv;
+        if (!split) {
+          if (p.epi == EPI_GELU) {
+            p.aux[(long)row * p.ldaux + col] = v;
+            v = gelu_erf(v);
+          } else if (p.epi == EPI_TANH) {
+            v = tanhf(v);
+          } else if (p.epi == EPI_DGELU) {
+            v *= gelu_erf_grad(p.aux[(long)row * p.ldaux + col]);
+          } else if (p.epi == EPI_DTANH) {
+            const float t = p.aux[(long)row * p.ldaux + col];
+            v *= (1.f - t * t);
+          }
+          if (p.accumulate) v += C[(long)row * p.ldc + col];
+        }
+        C[(long)row * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
 // dst[r][c] (ld ldd) = (accumulate ? dst : 0) + sum_z slabs[z][r][c] (+ bias[c])
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long slab_stride, float* dst,
                                      int rows, int cols, int ldd, const float* bias, int accumulate) {
@@ -266,8 +487,34 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
 
 struct TileCfg { int bm, bn, bk; };
 static const TileCfg kCfgs[] = {{128, 128, 16}, {128, 96, 16}, {128, 288, 16}, {64, 64, 16}, {128, 64, 16},
-                                {128, 128, 32}, {128, 96, 32}, {128, 192, 16}, {128, 192, 32}};
-constexpr int kNumCfgs = 9;
+                                {128, 128, 32}, {128, 96, 32}, {128, 192, 16}, {128, 192, 32},
+                                {128, 96, 32}, {128, 128, 32}, {128, 192, 32}};  // 9..11: LDS-DMA pipeline (FAST only)
+constexpr int kNumCfgs = 12;
+constexpr int kFirstDma = 9;
+
+template <int BM, int BN, int WM, int WN>
+static int launch_dma(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
+  const size_t smem = (size_t)3 * (BM + BN) * 32 * sizeof(float);
+  dim3 block(WM * WN * 64);
+#define MTVAF_DMA_LAUNCH(AK, BKM)                                                                                   \
+  do {                                                                                                               \
+    auto kern = gemm_f32_dma_kernel<BM, BN, WM, WN, AK, BKM>;                                                        \
+    static bool attr_set = false;                                                                                    \
+    if (smem > 64 * 1024 && !attr_set) {                                                                             \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
+      if (e != hipSuccess) return (int)e;                                                                            \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, grid, block, smem, st, a);                                                              \
+  } while (0)
+  if (la == 0 && lb == 0) MTVAF_DMA_LAUNCH(false, false);
+  else if (la == 0 && lb == 1) MTVAF_DMA_LAUNCH(false, true);
+  else if (la == 1 && lb == 1) MTVAF_DMA_LAUNCH(true, true);
+  else return MTVAF_ERR_ARG;
+#undef MTVAF_DMA_LAUNCH
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
 
 template <int BM, int BN, int WM, int WN, int BK, bool FAST>
 static int launch_l(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
@@ -300,12 +547,28 @@ static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 // Cost model (units: fp32 MFMA cycles of one CU).  The MFMA pipe of a CU is shared by its resident
 // blocks, so time ~ rounds over the 256 CUs x work per tile / efficiency of that tile shape (calibrated
 // with tools/gemm_sweep.py on MI355X at M = 4096), plus, for split-K, the slab write + ordered reduce.
-static void choose(int M, int N, int K, int allow_split, int* cfg_out, int* splits_out) {
+static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi, int* cfg_out, int* splits_out) {
   //                                  128x128 128x96 128x288 64x64 128x64 128x128x32 128x96x32 128x192 128x192x32
-  static const double eff[kNumCfgs] = {0.80,   0.86,  0.72,   0.45, 0.80,  0.70,      1.00,     0.92,   0.78};
+  static const double eff_base[kNumCfgs] = {0.80, 0.86, 0.72, 0.45, 0.80, 0.70, 1.00, 0.92, 0.78,
+                                            1.08, 0.90, 0.80};  // 9..11: LDS-DMA pipeline
+  double eff[kNumCfgs];
+  const bool km_km = (la == 1 && lb == 1);
+  for (int c = 0; c < kNumCfgs; ++c) {
+    eff[c] = eff_base[c];
+    if (c >= kFirstDma) {
+      const bool aligned = (M % kCfgs[c].bm == 0) && (N % kCfgs[c].bn == 0) && (K % 32 == 0);
+      // k-major operands are read with 4 ds_read_b32 per fragment in the pinned DMA schedule: the
+      // register-staged kernel wins for dW (KM x KM); KM x KC never occurs on the path.
+      if (!aligned || km_km || (la == 1 && lb == 0)) eff[c] = 0.0;
+      // one 84-KB block per CU cannot overlap a GELU-class epilogue with the next tile's main loop;
+      // the staged kernels (2 blocks/CU) do
+      if (epi == EPI_GELU || epi == EPI_DGELU) eff[c] *= 0.80;
+    }
+  }
   double best = 1e300;
   int bc = 0, bs = 1;
   for (int c = 0; c < kNumCfgs; ++c) {
+    if (eff[c] <= 0.0) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
     const int max_s = allow_split ? 16 : 1;
@@ -341,10 +604,12 @@ size_t mtvaf_gemm_f32_workspace_bytes(int M, int N, int K, int allow_split) {
 
 // Reports the tile configuration / split count the heuristic would pick (for profiling tools).
 // tile (BMxBNxBK, 256 threads): 0 128x128x16, 1 128x96x16, 2 128x288x16, 3 64x64x16, 4 128x64x16,
-// 5 128x128x32, 6 128x96x32, 7 128x192x16, 8 128x192x32.
-int mtvaf_gemm_f32_plan(int M, int N, int K, int allow_split, int* cfg, int* splits) {
+// 5 128x128x32, 6 128x96x32, 7 128x192x16, 8 128x192x32; 9 128x96x32, 10 128x128x32, 11 128x192x32 on the
+// LDS-DMA pipeline (aligned shapes, KC x KC / KC x KM).
+int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi, int allow_split, int* cfg,
+                        int* splits) {
   if (M <= 0 || N <= 0 || K <= 0 || !cfg || !splits) return MTVAF_ERR_ARG;
-  choose(M, N, K, allow_split, cfg, splits);
+  choose(M, N, K, allow_split && epi == EPI_NONE, layout_a, layout_b, epi, cfg, splits);
   return MTVAF_OK;
 }
 
@@ -361,8 +626,9 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
   if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1) return MTVAF_ERR_ARG;
   int c_auto, s_auto;
-  choose(M, N, K, allow_split && epi == EPI_NONE, &c_auto, &s_auto);
-  if (cfg < 0 || cfg >= kNumCfgs) cfg = c_auto;
+  choose(M, N, K, allow_split && epi == EPI_NONE, layout_a, layout_b, epi, &c_auto, &s_auto);
+  const bool cfg_forced = cfg >= 0 && cfg < kNumCfgs;
+  if (!cfg_forced) cfg = c_auto;
   if (splits <= 0) splits = s_auto;
   if (!(allow_split && epi == EPI_NONE)) splits = 1;
   if (splits > 1 && (size_t)splits * M * N * sizeof(float) > workspace_bytes) {
@@ -388,8 +654,16 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
   a.tiles_n = (int)cdiv(N, bn);
   dim3 grid((unsigned)(cdiv(M, bm) * a.tiles_n), 1, (unsigned)splits);
   const bool fast = (M % bm == 0) && (N % bn == 0) && (K % bk == 0) && a.a_vec && a.b_vec && (kc % bk == 0);
+  if (cfg >= kFirstDma && !(fast && !(layout_a == 1 && layout_b == 0))) {
+    if (cfg_forced) return MTVAF_ERR_SHAPE;
+    static const int staged_twin[3] = {6, 5, 8};  // same tile, register-staged kernel (handles any alignment)
+    cfg = staged_twin[cfg - kFirstDma];
+  }
   int rc;
   switch (cfg) {
+    case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;
+    case 10: rc = launch_dma<128, 128, 2, 2>(a, layout_a, layout_b, grid, stream); break;
+    case 11: rc = launch_dma<128, 192, 2, 2>(a, layout_a, layout_b, grid, stream); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 16>(a, layout_a, layout_b, grid, fast, stream); break;
     case 1: rc = launch_cfg<128, 96, 4, 1, 16>(a, layout_a, layout_b, grid, fast, stream); break;
     case 2: rc = launch_cfg<128, 288, 4, 1, 16>(a, layout_a, layout_b, grid, fast, stream); break;

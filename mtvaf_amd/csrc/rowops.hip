@@ -95,8 +95,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------
-// backward.  partials layout: [gridDim.x][NP][H] with NP = 2 (dgamma, dbeta) (+2 token-type rows
-// in MODE 1).  MODE 0 writes dx (grad wrt the dropout input) and dres (grad wrt the residual);
+// backward.  partials layout: [gridDim.x][NP][H] with NP = 3 in MODE 0 (dgamma, dbeta, column sums of dx
+// = the bias gradient of the dense layer that produced x) and NP = 4 in MODE 1 (dgamma, dbeta, 2 token-type rows).  MODE 0 writes dx (grad wrt the dropout input) and dres (grad wrt the residual);
 // MODE 1 writes dz (grad wrt the summed embeddings) to dx.
 // ------------------------------------------------------------------------------------------
 template <int MODE>
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                     float* __restrict__ dx, float* __restrict__ dres, int dres_acc,
                                                     float* __restrict__ partials, int M, int S, int H, float p_drop,
                                                     uint64_t seed, uint64_t offset) {
-  constexpr int NP = MODE == 1 ? 4 : 2;
+  constexpr int NP = MODE == 1 ? 4 : 3;
   __shared__ f32x4 red[4][MAXC * 64];  // [wave][H/4 <= 256]
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             d.z = (keep[i] & 4) ? d.z * scale : 0.f; d.w = (keep[i] & 8) ? d.w * scale : 0.f;
           }
           *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = d;
+          at0[i] += d;
         } else {
           *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = dz;
           if (tt == 0) at0[i] += dz; else if (tt == 1) at1[i] += dz;
@@ -352,21 +353,25 @@ int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamm
 }
 
 // dgamma/dbeta: overwritten (accumulate = 0) or added to.  dres_accumulate: dres += instead of =.
+// dbias_x (nullable): column sums of dx, i.e. the bias gradient of the dense layer whose output is x.
 int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma,
                              const float* mean, const float* rstd, float* dx, float* dres, int dres_accumulate,
-                             float* dgamma, float* dbeta, int accumulate, int M, int H, float p_drop, uint64_t seed,
-                             uint64_t offset, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                             float* dgamma, float* dbeta, float* dbias_x, int accumulate, int M, int H, float p_drop,
+                             uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
   const int g = row_grid_bwd(M);
-  if (workspace_bytes < (size_t)g * 2 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
+  if (workspace_bytes < (size_t)g * 3 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
                      offset);
   MTVAF_LAUNCH_CHECK();
   const int cb = (H + 31) / 32;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part, g, H, (long)2 * H, dgamma, accumulate);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + H, g, H, (long)2 * H, dbeta, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part, g, H, (long)3 * H, dgamma, accumulate);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + H, g, H, (long)3 * H, dbeta, accumulate);
+  if (dbias_x)
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + 2 * H, g, H, (long)3 * H, dbias_x,
+                       accumulate);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

@@ -176,8 +176,7 @@ class EncoderFunction(torch.autograd.Function):
             # ---- FFN block ----
             df, dh1 = _empty(M, H, like=dev_like), _empty(M, H, like=dev_like)
             hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, df, dh1, False, G[14], G[15], False, p_hidden, seed,
-                                   off + 2)
-            hip.colsum(df, G[13])
+                                   off + 2, dbias_x=G[13])
             hip.linear_bwd_weight(df, act, G[12])
             dpre = _empty(M, I, like=dev_like)
             hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
@@ -187,8 +186,7 @@ class EncoderFunction(torch.autograd.Function):
             # ---- attention block ----
             da, dh0 = df, dh  # reuse buffers
             hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
-                                   off + 1)
-            hip.colsum(da, G[7])
+                                   off + 1, dbias_x=G[7])
             hip.linear_bwd_weight(da, cx, G[6])
             dctx = dh1
             hip.linear_bwd_input(da, w.wo, dctx)

@@ -23,7 +23,7 @@ _SIGS = {
     "mtvaf_version": (c_int, []),
     "mtvaf_device_cus": (c_int, []),
     "mtvaf_gemm_f32_workspace_bytes": (SZ, [I, I, I, I]),
-    "mtvaf_gemm_f32_plan": (c_int, [I, I, I, I, P, P]),
+    "mtvaf_gemm_f32_plan": (c_int, [I, I, I, I, I, I, I, P, P]),
     "mtvaf_gemm_f32": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -33,7 +33,7 @@ _SIGS = {
     "mtvaf_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U64,
                                    U64, P, P, SZ, P]),
     "mtvaf_dropout_res_ln_fwd": (c_int, [P, P, P, P, P, P, P, I, I, F, F, U64, U64, P]),
-    "mtvaf_dropout_res_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, I, P, P, I, I, I, F, U64, U64, P, SZ, P]),
+    "mtvaf_dropout_res_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, I, P, P, P, I, I, I, F, U64, U64, P, SZ, P]),
     "mtvaf_colsum_workspace_bytes": (SZ, [I, I]),
     "mtvaf_colsum": (c_int, [P, I, I, I, P, I, P, SZ, P]),
     "mtvaf_dropout": (c_int, [P, P, L, F, U64, U64, P]),
@@ -112,12 +112,14 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 PROFILE = None  # set to a list to record (key, start_event, stop_event) around every GEMM launch
 TILE_NAMES = {0: "128x128x16", 1: "128x96x16", 2: "128x288x16", 3: "64x64x16", 4: "128x64x16", 5: "128x128x32",
-              6: "128x96x32", 7: "128x192x16", 8: "128x192x32"}
+              6: "128x96x32", 7: "128x192x16", 8: "128x192x32", 9: "128x96x32dma", 10: "128x128x32dma",
+              11: "128x192x32dma"}
 
 
-def gemm_plan(M, N, K, allow_split):
+def gemm_plan(M, N, K, allow_split, layout_a=0, layout_b=0, epi=0):
     c, s = ctypes.c_int(0), ctypes.c_int(0)
-    _ck(lib().mtvaf_gemm_f32_plan(M, N, K, int(allow_split), ctypes.byref(c), ctypes.byref(s)), "mtvaf_gemm_f32_plan")
+    _ck(lib().mtvaf_gemm_f32_plan(layout_a, layout_b, M, N, K, epi, int(allow_split), ctypes.byref(c), ctypes.byref(s)),
+        "mtvaf_gemm_f32_plan")
     return c.value, s.value
 
 
@@ -218,12 +220,13 @@ def dropout_res_ln_fwd(x, res, gamma, beta, out, mean, rstd, eps, p, seed, offse
 
 
 def dropout_res_ln_bwd(dout, x, res, gamma, mean, rstd, dx, dres, dres_accumulate, dgamma, dbeta, accumulate, p, seed,
-                       offset):
+                       offset, dbias_x=None):
     M, H = x.shape
     wsb = lib().mtvaf_ln_bwd_workspace_bytes(M, H)
     ws = workspace(wsb, x.device)
     _ck(lib().mtvaf_dropout_res_ln_bwd(_p(dout), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres),
-                                       int(dres_accumulate), _p(dgamma), _p(dbeta), int(accumulate), M, H, float(p), seed,
+                                       int(dres_accumulate), _p(dgamma), _p(dbeta), _p(dbias_x), int(accumulate), M, H,
+                                       float(p), seed,
                                        offset, _p(ws), wsb, _st()), "mtvaf_dropout_res_ln_bwd")
 
 

@@ -119,8 +119,10 @@ def test_dropout_res_ln(hip, M, H):
     close(out, y, name="ln fwd")
     dx, dres = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
     dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    dbx = torch.empty(H, device=DEV)
     hip.dropout_res_ln_bwd(dout.to(DEV), x.to(DEV), r.to(DEV), g.to(DEV), mean, rstd, dx, dres, False, dg, db, False, 0.0,
-                           1, 2)
+                           1, 2, dbias_x=dbx)
+    close(dbx, xd.grad.sum(0), rtol=5e-4, name="ln dbias_x")
     close(dx, xd.grad, name="ln dx")
     close(dres, rd.grad, name="ln dres")
     close(dg, gd.grad, rtol=5e-4, name="ln dgamma")
@@ -440,3 +442,37 @@ def test_kl_logsoftmax(hip):
     gout = torch.tensor([0.7], device=DEV)
     _ck(lib().mtvaf_kl_logsoftmax_bwd(_p(gout), 2.0, _p(gz), _p(gt), _p(dz), B, N, _st()), "kl bwd")
     close(dz, zd.grad, rtol=1e-4, atol=1e-8, name="kl dz")
+
+
+@pytest.mark.parametrize("cfg", [9, 10, 11])
+def test_gemm_dma_pipeline(hip, cfg):
+    """LDS-DMA pipelined kernels (aligned shapes only): all three operand-layout combinations, short and
+    long K (1, 2, 3 and many k-tiles exercise the 3-stage ring prologue/drain), split-K, epilogues."""
+    bn = {9: 96, 10: 128, 11: 192}[cfg]
+    for K in (32, 64, 96, 768):
+        M, N = 256, 2 * bn
+        x, w, b = rnd(M, K, seed=K), rnd(N, K, seed=K + 1), rnd(N, seed=3)
+        out = torch.empty(M, N, device=DEV)
+        hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, bias=b.to(DEV), cfg=cfg)
+        close(out, F.linear(x.double(), w.double(), b.double()), name=f"dma nt K={K}")
+    M, N, K = 384, 3 * bn, 160
+    dy, w = rnd(M, K, seed=4), rnd(K, N, seed=5)
+    out = rnd(M, N, seed=6).to(DEV)
+    ref = out.cpu().double() + dy.double() @ w.double()
+    hip.gemm(dy.to(DEV), hip.KC, w.to(DEV), hip.KM, out, M, N, K, accumulate=True, cfg=cfg)
+    close(out, ref, name="dma nn+acc")
+    M, N, K = 256, 2 * bn, 2048
+    dy, x = rnd(K, M, seed=7), rnd(K, N, seed=8)
+    for splits in (1, 4):
+        out = torch.empty(M, N, device=DEV)
+        hip.gemm(dy.to(DEV), hip.KM, x.to(DEV), hip.KM, out, M, N, K, allow_split=True, cfg=cfg, splits=splits)
+        close(out, dy.double().t() @ x.double(), rtol=3e-4, name=f"dma tn s={splits}")
+    M, N, K = 128, bn, 96
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+    pre = F.linear(x.double(), w.double(), b.double())
+    out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, bias=b.to(DEV), epi=hip.EPI_GELU, aux=aux, cfg=cfg)
+    close(aux, pre, name="dma gelu-pre")
+    close(out, F.gelu(pre), name="dma gelu")
+    with pytest.raises(RuntimeError):
+        hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M - 1, N, K, cfg=cfg)  # unaligned shape is refused

@@ -29,12 +29,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--cfgs", default="0,1,2,4,5,6,7,8")
+    ap.add_argument("--zeros", action="store_true", help="zero operands (DVFS check: MI355X_MICROARCH.md give-back)")
     a = ap.parse_args()
     M, H, I = a.M, 768, 3072
     dev = "cuda"
     cfgs = [int(c) for c in a.cfgs.split(",")]
     g = torch.Generator(device=dev).manual_seed(0)
-    R = lambda *s: torch.randn(*s, device=dev, generator=g)
+    R = (lambda *s: torch.zeros(*s, device=dev)) if a.zeros else (lambda *s: torch.randn(*s, device=dev, generator=g))
     shapes = [  # name, la, lb, M, N, K, epi, split
         ("qkv_fwd", 0, 0, M, 3 * H, H, 0, 0), ("ao_fwd", 0, 0, M, H, H, 0, 0), ("ffn1_fwd", 0, 0, M, I, H, 1, 0),
         ("ffn2_fwd", 0, 0, M, H, I, 0, 0),
@@ -62,7 +63,7 @@ def main():
                 rows.append((cfg, s, round(us, 1), round(tf, 1)))
                 if best is None or us < best[2]:
                     best = (cfg, s, us, tf)
-        auto = hip.gemm_plan(m, n, k, split)
+        auto = hip.gemm_plan(m, n, k, split, la, lb, epi)
         out[name] = {"best": best, "auto": auto, "rows": rows}
         print(f"{name:9s} M={m:5d} N={n:5d} K={k:5d} best cfg={hip.TILE_NAMES[best[0]]:11s} splits={best[1]:2d} "
               f"{best[2]:7.1f} us {best[3]:6.1f} TF | auto cfg={hip.TILE_NAMES[auto[0]]} s={auto[1]} | " +
