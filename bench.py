@@ -204,43 +204,47 @@ def main():
            "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS["fp32"] * 1e12), 4),
            "flop_per_sentence_train": ftrain}
 
-    # ---- roofline of the dominant kernel: fp32 MFMA GEMM, measured live with HIP events -----------
+    # ---- roofline of the dominant kernel (fp32 MFMA GEMM), measured live with HIP events recorded by the
+    # library on the launch stream, directly around each main GEMM kernel of 3 further identical steps ----
     if rank == 0 and not a.no_roofline:
         if sync is not None:
             sync.enabled = False
-        hip.PROFILE = []
-        for _ in range(3):
+        NPROF = 3
+        hip.prof_start(8192)
+        for _ in range(NPROF):
             step()
         torch.cuda.synchronize()
-        recs, hip.PROFILE = hip.PROFILE, None
-        agg = {}
-        for key, e0, e1 in recs:
-            d = agg.setdefault(key, [0.0, 0])
-            d[0] += e0.elapsed_time(e1)
+        recs = hip.prof_stop(8192)
+        by_sym, by_shape = {}, {}
+        for k, ms in recs:
+            sym = hip.kernel_symbol(k["cfg"], k["la"], k["lb"], k["fast"])
+            d = by_sym.setdefault(sym, [0.0, 0, 0.0])
+            d[0] += ms
             d[1] += 1
-        tot_ms = sum(v[0] for v in agg.values()) / 3
-        tot_fl = sum(2.0 * k[2] * k[3] * k[4] * v[1] for k, v in agg.items()) / 3
-        top = max(agg.items(), key=lambda kv: kv[1][0])
-        (la, lb, M, N, K, epi, split), (ms, cnt) = top
-        tile, splits = hip.gemm_plan(M, N, K, split, la, lb, epi)
+            d[2] += 2.0 * k["M"] * k["N"] * k["K"]
+            sk = (sym, k["M"], k["N"], k["K"], k["splits"])
+            e = by_shape.setdefault(sk, [0.0, 0])
+            e[0] += ms
+            e[1] += 1
+        tot_ms = sum(v[0] for v in by_sym.values()) / NPROF
+        tot_fl = sum(v[2] for v in by_sym.values()) / NPROF
+        sym, (ms, cnt, fl) = max(by_sym.items(), key=lambda kv: kv[1][0])
         avg_us = 1e3 * ms / cnt
-        ach = 2.0 * M * N * K / (avg_us * 1e-6) / 1e12
-        shapes = []
-        for (la2, lb2, M2, N2, K2, epi2, sp2), (ms2, c2) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]:
-            t2, s2 = hip.gemm_plan(M2, N2, K2, sp2, la2, lb2, epi2)
-            shapes.append({"op": f"{'KM' if la2 else 'KC'}x{'KM' if lb2 else 'KC'}", "M": M2, "N": N2, "K": K2,
-                           "epi": epi2, "tile": hip.TILE_NAMES[t2], "splits": s2, "launches_per_step": c2 // 3,
-                           "avg_us": round(1e3 * ms2 / c2, 1),
-                           "tflops": round(2.0 * M2 * N2 * K2 / (1e3 * ms2 / c2 * 1e-6) / 1e12, 1)})
+        ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": None,
-            "kernel": f"gemm_f32_kernel<{hip.TILE_NAMES[tile]}> {'KM' if la else 'KC'}x{'KM' if lb else 'KC'} "
-                      f"M={M} N={N} K={K} splits={splits}",
-            "avg_launch_us": round(avg_us, 1), "flops_per_launch": 2.0 * M * N * K,
-            "all_gemms": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                          "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], 4)},
-            "top_shapes": shapes}
+            "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": None, "kernel": sym,
+            "avg_launch_us": round(avg_us, 1), "launches_per_step": cnt // NPROF,
+            "flops_per_launch_avg": fl / cnt,
+            "all_gemm_kernels": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                 "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], 4)},
+            "per_kernel": [{"kernel": s_, "launches_per_step": c_ // NPROF, "avg_us": round(1e3 * m_ / c_, 1),
+                            "tflops": round(f_ / (m_ * 1e-3) / 1e12, 1)}
+                           for s_, (m_, c_, f_) in sorted(by_sym.items(), key=lambda kv: -kv[1][0])[:8]],
+            "per_shape": [{"kernel": k_[0].split("<")[0], "M": k_[1], "N": k_[2], "K": k_[3], "splits": k_[4],
+                           "launches_per_step": c_ // NPROF, "avg_us": round(1e3 * m_ / c_, 1),
+                           "tflops": round(2.0 * k_[1] * k_[2] * k_[3] / (1e3 * m_ / c_ * 1e-6) / 1e12, 1)}
+                          for k_, (m_, c_) in sorted(by_shape.items(), key=lambda kv: -kv[1][0])[:12]]}
     if rank == 0:
         log("roofline pass done")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

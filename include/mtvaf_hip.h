@@ -56,6 +56,9 @@ int mtvaf_device_cus(void);
  * backward.  C[M,N] = opA[M,K] . opB[K,N] (+bias[N]) with epilogue `epi`; cfg/splits < 0 = heuristic.
  * allow_split enables a deterministic split-K (ordered slab reduction) through `workspace`. */
 size_t mtvaf_gemm_f32_workspace_bytes(int M, int N, int K, int allow_split);
+/* launch profiler (bench.py roofline): HIP events around the main GEMM kernel of every call, on its stream */
+int mtvaf_prof_start(int capacity);
+int mtvaf_prof_stop(int* n_out, int* keys /* [n][8] */, float* ms /* [n] */, int max_records);
 int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi, int allow_split, int* cfg,
                         int* splits);
 int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,

@@ -544,6 +544,13 @@ static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, bool fast, h
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
+// ---- optional launch profiler (bench.py roofline): HIP events recorded on the launch stream directly
+// around the main GEMM kernel (the split-K reduction is outside the bracket), so that the averages are
+// comparable with rocprofv3's per-kernel durations.
+struct ProfRec { hipEvent_t e0, e1; int key[8]; };
+static ProfRec* g_prof = nullptr;
+static int g_prof_cap = 0, g_prof_n = 0;
+
 // Cost model (units: fp32 MFMA cycles of one CU).  The MFMA pipe of a CU is shared by its resident
 // blocks, so time ~ rounds over the 256 CUs x work per tile / efficiency of that tile shape (calibrated
 // with tools/gemm_sweep.py on MI355X at M = 4096), plus, for split-K, the slab write + ordered reduce.
@@ -600,6 +607,42 @@ extern "C" {
 size_t mtvaf_gemm_f32_workspace_bytes(int M, int N, int K, int allow_split) {
   if (!allow_split) return 0;
   return (size_t)16 * M * N * sizeof(float);
+}
+
+// Launch profiler: after mtvaf_prof_start(capacity) every mtvaf_gemm_f32 call records a HIP-event pair around
+// its main kernel on the launch stream.  mtvaf_prof_stop synchronises those events and returns, per record,
+// key = {tile cfg, layout_a, layout_b, fast path, M, N, K, splits} and the kernel duration in ms.
+int mtvaf_prof_start(int capacity) {
+  if (g_prof || capacity <= 0) return MTVAF_ERR_ARG;
+  g_prof = new ProfRec[capacity];
+  for (int i = 0; i < capacity; ++i) {
+    if (hipEventCreate(&g_prof[i].e0) != hipSuccess || hipEventCreate(&g_prof[i].e1) != hipSuccess) return MTVAF_ERR_ARG;
+  }
+  g_prof_cap = capacity;
+  g_prof_n = 0;
+  return MTVAF_OK;
+}
+
+int mtvaf_prof_stop(int* n_out, int* keys, float* ms, int max_records) {
+  if (!g_prof || !n_out) return MTVAF_ERR_ARG;
+  const int n = g_prof_n < max_records ? g_prof_n : max_records;
+  for (int i = 0; i < n; ++i) {
+    hipEventSynchronize(g_prof[i].e1);
+    float t = 0.f;
+    hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1);
+    if (ms) ms[i] = t;
+    if (keys)
+      for (int j = 0; j < 8; ++j) keys[i * 8 + j] = g_prof[i].key[j];
+  }
+  *n_out = n;
+  for (int i = 0; i < g_prof_cap; ++i) {
+    hipEventDestroy(g_prof[i].e0);
+    hipEventDestroy(g_prof[i].e1);
+  }
+  delete[] g_prof;
+  g_prof = nullptr;
+  g_prof_cap = g_prof_n = 0;
+  return MTVAF_OK;
 }
 
 // Reports the tile configuration / split count the heuristic would pick (for profiling tools).
@@ -659,6 +702,13 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
     static const int staged_twin[3] = {6, 5, 8};  // same tile, register-staged kernel (handles any alignment)
     cfg = staged_twin[cfg - kFirstDma];
   }
+  ProfRec* pr = nullptr;
+  if (g_prof && g_prof_n < g_prof_cap) {
+    pr = &g_prof[g_prof_n++];
+    const int key[8] = {cfg, layout_a, layout_b, fast ? 1 : 0, M, N, K, splits};
+    for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
+    hipEventRecord(pr->e0, stream);
+  }
   int rc;
   switch (cfg) {
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;
@@ -674,6 +724,7 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
     case 7: rc = launch_cfg<128, 192, 2, 2, 16>(a, layout_a, layout_b, grid, fast, stream); break;
     default: rc = launch_cfg<128, 192, 2, 2, 32>(a, layout_a, layout_b, grid, fast, stream); break;
   }
+  if (pr) hipEventRecord(pr->e1, stream);
   if (rc != MTVAF_OK) return rc;
   if (splits > 1) {
     const long n = (long)M * N;

@@ -23,6 +23,8 @@ _SIGS = {
     "mtvaf_version": (c_int, []),
     "mtvaf_device_cus": (c_int, []),
     "mtvaf_gemm_f32_workspace_bytes": (SZ, [I, I, I, I]),
+    "mtvaf_prof_start": (c_int, [I]),
+    "mtvaf_prof_stop": (c_int, [P, P, P, I]),
     "mtvaf_gemm_f32_plan": (c_int, [I, I, I, I, I, I, I, P, P]),
     "mtvaf_gemm_f32": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -110,7 +112,36 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-PROFILE = None  # set to a list to record (key, start_event, stop_event) around every GEMM launch
+PROFILE = None  # set to a list to record (key, start_event, stop_event) around every GEMM call (incl. reduce)
+
+
+def prof_start(capacity: int = 4096):
+    """Start the in-library launch profiler (HIP events around each main GEMM kernel, on its stream)."""
+    _ck(lib().mtvaf_prof_start(capacity), "mtvaf_prof_start")
+
+
+def prof_stop(capacity: int = 4096):
+    """-> list of (key dict, ms).  Synchronises the recorded events."""
+    n = ctypes.c_int(0)
+    keys = (ctypes.c_int * (8 * capacity))()
+    ms = (ctypes.c_float * capacity)()
+    _ck(lib().mtvaf_prof_stop(ctypes.byref(n), keys, ms, capacity), "mtvaf_prof_stop")
+    out = []
+    for i in range(n.value):
+        k = keys[8 * i:8 * i + 8]
+        out.append((dict(cfg=k[0], la=k[1], lb=k[2], fast=k[3], M=k[4], N=k[5], K=k[6], splits=k[7]), ms[i]))
+    return out
+
+
+def kernel_symbol(cfg, la, lb, fast):
+    """The template instantiation rocprofv3 reports for a (tile cfg, layouts, fast) launch."""
+    dims = {0: (128, 128, 2, 2, 16), 1: (128, 96, 4, 1, 16), 2: (128, 288, 4, 1, 16), 3: (64, 64, 2, 2, 16),
+            4: (128, 64, 4, 1, 16), 5: (128, 128, 2, 2, 32), 6: (128, 96, 4, 1, 32), 7: (128, 192, 2, 2, 16),
+            8: (128, 192, 2, 2, 32), 9: (128, 96, 4, 1), 10: (128, 128, 2, 2), 11: (128, 192, 2, 2)}[cfg]
+    b = lambda x: "true" if x else "false"
+    if cfg >= 9:
+        return f"gemm_f32_dma_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {b(la)}, {b(lb)}>"
+    return f"gemm_f32_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {dims[4]}, {b(la)}, {b(lb)}, {b(fast)}>"
 TILE_NAMES = {0: "128x128x16", 1: "128x96x16", 2: "128x288x16", 3: "64x64x16", 4: "128x64x16", 5: "128x128x32",
               6: "128x96x32", 7: "128x192x16", 8: "128x192x32", 9: "128x96x32dma", 10: "128x128x32dma",
               11: "128x192x32dma"}

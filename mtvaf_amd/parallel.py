@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model: torch.nn.Module, process_group=None):
+    def __init__(self, model: torch.nn.Module, process_group=None, force: bool = False):
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised process group (backend 'nccl' = RCCL on ROCm)")
         self.model = model
@@ -35,10 +35,11 @@ class GradSync:
         self._slow_layers: List[int] = []
         self._armed = False
         self.enabled = True
+        self.force = force  # run the collectives even with world_size == 1 (single-GPU test of the N > 1 path)
 
     # -- called from inside EncoderFunction.backward, newest layer first ---------------------------------
     def _layer_done(self, li: int, flat_grad: Optional[torch.Tensor]):
-        if not self.enabled or self.world == 1:
+        if not self.enabled or (self.world == 1 and not self.force):
             return
         if not self._armed:
             self._armed = True
