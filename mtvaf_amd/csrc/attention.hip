@@ -112,8 +112,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     f32x4 s[4];
     float tmax = NEG_BIG;
+    const int nsub = min(4, (T - t0 + 15) >> 4);  // 16-key sub-tiles of this tile that hold real keys
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      s[j] = f32x4{NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG};
+      if (j >= nsub) continue;
       s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
@@ -153,13 +156,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j) {
+      if (j >= nsub) continue;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const float* vrow = Vs + (16 * j + 4 * g + t) * LDT + lq;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[dt] = MFMA16(vrow[16 * dt], s[j][t], oacc[dt]);
       }
+    }
   }
   if (qok) {
     const float inv_l = 1.f / l_run;
@@ -211,8 +216,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     stage_kv(Ks, a, b, h, t0, 1);
     stage_kv(Vs, a, b, h, t0, 2);
     __syncthreads();
+    const int nsub = min(4, (T - t0 + 15) >> 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
+      if (j >= nsub) continue;
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int db = 0; db < 4; ++db) {

@@ -34,6 +34,16 @@ struct GemmArgs {
   int tiles_n;
 };
 
+// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so
+// consecutive blockIdx values never share an L2.  This bijective remap gives each XCD a CONTIGUOUS run of
+// tiles (whole rows of the tile grid), so an A row-panel is fetched by one XCD only and the B panels it is
+// multiplied with stay hot in that XCD's L2.  Placement is a speed hint only -- results never depend on it.
+__device__ __forceinline__ int xcd_remap(int bid, int nb) {
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q = nb >> 3, r = nb & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int nvalid, bool vec) {
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   if (nvalid >= 4 && vec) {
@@ -47,9 +57,10 @@ __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int nvalid, bo
   return v;
 }
 
-// FAST: M % BM == 0, N % BN == 0, every k-chunk a multiple of BK, 16-byte aligned operands -> no bounds
-// checks or scalar tails anywhere in the main loop.
-template <int BM, int BN, int WM, int WN, int BK, bool A_KM, bool B_KM, bool FAST>
+// FAST: every k-chunk a multiple of BK and 16-byte aligned operands (M, N multiples of 4 for KM operands):
+// the main loop has no bounds checks or scalar tails -- rows beyond M / N are CLAMPED to the last valid row
+// (their products land in accumulator rows/columns the epilogue never stores).
+template <int BM, int BN, int WM, int WN, int BK, bool A_KM, bool B_KM, bool FAST, bool ALIGNED = false>
 __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -70,7 +81,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, h = lane >> 5;
 
-  const int bid = blockIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
   const int kbeg = blockIdx.z * p.k_chunk;
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
           const int r = idx / KQ, c = (idx % KQ) * 4;
           const int row = m0 + r, k = k0 + c;
           if (FAST) {
-            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long)row * p.lda + k);
+            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long)(ALIGNED ? row : min(row, p.M - 1)) * p.lda + k);
           } else {
             const int nv = row < p.M ? max(0, min(4, kend - k)) : 0;
             ra[i] = ld4(p.A + (long)row * p.lda + k, nv, p.a_vec);
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
           const int k = idx / (BM / 4), c = (idx % (BM / 4)) * 4;
           const int row = m0 + c;
           if (FAST) {
-            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long)(k0 + k) * p.lda + row);
+            ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long)(k0 + k) * p.lda + (ALIGNED ? row : min(row, p.M - 4)));
           } else {
             const int nv = (k0 + k) < kend ? max(0, min(4, p.M - row)) : 0;
             ra[i] = ld4(p.A + (long)(k0 + k) * p.lda + row, nv, p.a_vec);
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
           const int r = idx / KQ, c = (idx % KQ) * 4;
           const int col = n0 + r, k = k0 + c;
           if (FAST) {
-            rb[i] = *reinterpret_cast<const f32x4*>(p.B + (long)col * p.ldb + k);
+            rb[i] = *reinterpret_cast<const f32x4*>(p.B + (long)(ALIGNED ? col : min(col, p.N - 1)) * p.ldb + k);
           } else {
             const int nv = col < p.N ? max(0, min(4, kend - k)) : 0;
             rb[i] = ld4(p.B + (long)col * p.ldb + k, nv, p.b_vec);
@@ -131,7 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
           const int k = idx / (BN / 4), c = (idx % (BN / 4)) * 4;
           const int col = n0 + c;
           if (FAST) {
-            rb[i] = *reinterpret_cast<const f32x4*>(p.B + (long)(k0 + k) * p.ldb + col);
+            rb[i] = *reinterpret_cast<const f32x4*>(p.B + (long)(k0 + k) * p.ldb + (ALIGNED ? col : min(col, p.N - 4)));
           } else {
             const int nv = (k0 + k) < kend ? max(0, min(4, p.N - col)) : 0;
             rb[i] = ld4(p.B + (long)(k0 + k) * p.ldb + col, nv, p.b_vec);
@@ -223,12 +234,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + li;
-      if (!FAST && col >= p.N) continue;
+      if (!ALIGNED && col >= p.N) continue;
       const float bv = (!split && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (!FAST && row >= p.M) continue;
+        if (!ALIGNED && row >= p.M) continue;
         float v = acc[i][j][r] + bv;
         if (!split) {
           if (p.epi == EPI_GELU) {
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, h = lane >> 5;
 
-  const int bid = blockIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
   const int kbeg = blockIdx.z * p.k_chunk;
@@ -516,18 +527,18 @@ static int launch_dma(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t 
   return MTVAF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, bool FAST>
+template <int BM, int BN, int WM, int WN, int BK, bool FAST, bool ALIGNED = false>
 static int launch_l(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   constexpr int KC_LD = BK + 4;
   const int asz = la ? BK * BM : BM * KC_LD, bsz = lb ? BK * BN : BN * KC_LD;
   const size_t smem = (size_t)2 * (asz + bsz) * sizeof(float);
   dim3 block(WM * WN * 64);
   if (la == 0 && lb == 0)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, false, false, FAST>), grid, block, smem, st, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, false, false, FAST, ALIGNED>), grid, block, smem, st, a);
   else if (la == 0 && lb == 1)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, false, true, FAST>), grid, block, smem, st, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, false, true, FAST, ALIGNED>), grid, block, smem, st, a);
   else if (la == 1 && lb == 1)
-    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, true, true, FAST>), grid, block, smem, st, a);
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, true, true, FAST, ALIGNED>), grid, block, smem, st, a);
   else if (!FAST)  // KM x KC is not produced by the path; only the checked kernel carries it
     hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, BK, true, false, false>), grid, block, smem, st, a);
   else
@@ -537,9 +548,11 @@ static int launch_l(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st
 }
 
 template <int BM, int BN, int WM, int WN, int BK>
-static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, bool fast, hipStream_t st) {
-  if (fast && !(la == 1 && lb == 0)) return launch_l<BM, BN, WM, WN, BK, true>(a, la, lb, grid, st);
-  return launch_l<BM, BN, WM, WN, BK, false>(a, la, lb, grid, st);
+static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, int mode, hipStream_t st) {
+  // mode 2: k-aligned + whole tiles, 1: k-aligned with clamped ragged rows, 0: fully checked
+  if (mode == 2 && !(la == 1 && lb == 0)) return launch_l<BM, BN, WM, WN, BK, true, true>(a, la, lb, grid, st);
+  if (mode >= 1 && !(la == 1 && lb == 0)) return launch_l<BM, BN, WM, WN, BK, true, false>(a, la, lb, grid, st);
+  return launch_l<BM, BN, WM, WN, BK, false, false>(a, la, lb, grid, st);
 }
 
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
@@ -696,8 +709,12 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
   const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
   a.tiles_n = (int)cdiv(N, bn);
   dim3 grid((unsigned)(cdiv(M, bm) * a.tiles_n), 1, (unsigned)splits);
-  const bool fast = (M % bm == 0) && (N % bn == 0) && (K % bk == 0) && a.a_vec && a.b_vec && (kc % bk == 0);
-  if (cfg >= kFirstDma && !(fast && !(layout_a == 1 && layout_b == 0))) {
+  // KM operands are loaded as float4 along the row index: a clamped tail needs M (N) % 4 == 0
+  const bool fast = (K % bk == 0) && (kc % bk == 0) && a.a_vec && a.b_vec && (layout_a == 0 || M % 4 == 0) &&
+                    (layout_b == 0 || N % 4 == 0) && M >= 4 && N >= 4;
+  const bool aligned = fast && (M % bm == 0) && (N % bn == 0);
+  const int mode = aligned ? 2 : (fast ? 1 : 0);
+  if (cfg >= kFirstDma && !(aligned && !(layout_a == 1 && layout_b == 0))) {
     if (cfg_forced) return MTVAF_ERR_SHAPE;
     static const int staged_twin[3] = {6, 5, 8};  // same tile, register-staged kernel (handles any alignment)
     cfg = staged_twin[cfg - kFirstDma];
@@ -705,7 +722,7 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
   ProfRec* pr = nullptr;
   if (g_prof && g_prof_n < g_prof_cap) {
     pr = &g_prof[g_prof_n++];
-    const int key[8] = {cfg, layout_a, layout_b, fast ? 1 : 0, M, N, K, splits};
+    const int key[8] = {cfg, layout_a, layout_b, mode, M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
     hipEventRecord(pr->e0, stream);
   }
@@ -714,15 +731,15 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;
     case 10: rc = launch_dma<128, 128, 2, 2>(a, layout_a, layout_b, grid, stream); break;
     case 11: rc = launch_dma<128, 192, 2, 2>(a, layout_a, layout_b, grid, stream); break;
-    case 0: rc = launch_cfg<128, 128, 2, 2, 16>(a, layout_a, layout_b, grid, fast, stream); break;
-    case 1: rc = launch_cfg<128, 96, 4, 1, 16>(a, layout_a, layout_b, grid, fast, stream); break;
-    case 2: rc = launch_cfg<128, 288, 4, 1, 16>(a, layout_a, layout_b, grid, fast, stream); break;
-    case 3: rc = launch_cfg<64, 64, 2, 2, 16>(a, layout_a, layout_b, grid, fast, stream); break;
-    case 4: rc = launch_cfg<128, 64, 4, 1, 16>(a, layout_a, layout_b, grid, fast, stream); break;
-    case 5: rc = launch_cfg<128, 128, 2, 2, 32>(a, layout_a, layout_b, grid, fast, stream); break;
-    case 6: rc = launch_cfg<128, 96, 4, 1, 32>(a, layout_a, layout_b, grid, fast, stream); break;
-    case 7: rc = launch_cfg<128, 192, 2, 2, 16>(a, layout_a, layout_b, grid, fast, stream); break;
-    default: rc = launch_cfg<128, 192, 2, 2, 32>(a, layout_a, layout_b, grid, fast, stream); break;
+    case 0: rc = launch_cfg<128, 128, 2, 2, 16>(a, layout_a, layout_b, grid, mode, stream); break;
+    case 1: rc = launch_cfg<128, 96, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
+    case 2: rc = launch_cfg<128, 288, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
+    case 3: rc = launch_cfg<64, 64, 2, 2, 16>(a, layout_a, layout_b, grid, mode, stream); break;
+    case 4: rc = launch_cfg<128, 64, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
+    case 5: rc = launch_cfg<128, 128, 2, 2, 32>(a, layout_a, layout_b, grid, mode, stream); break;
+    case 6: rc = launch_cfg<128, 96, 4, 1, 32>(a, layout_a, layout_b, grid, mode, stream); break;
+    case 7: rc = launch_cfg<128, 192, 2, 2, 16>(a, layout_a, layout_b, grid, mode, stream); break;
+    default: rc = launch_cfg<128, 192, 2, 2, 32>(a, layout_a, layout_b, grid, mode, stream); break;
   }
   if (pr) hipEventRecord(pr->e1, stream);
   if (rc != MTVAF_OK) return rc;

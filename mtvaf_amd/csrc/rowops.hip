@@ -237,6 +237,41 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
   }
 }
 
+// Same reduction for NP stacked partial rows [rows][NP][H] -> NP separate outputs in ONE launch
+// (LayerNorm backward: dgamma, dbeta, dense-bias gradient, token-type rows).  grid = ceil(NP*H / 32).
+struct OutPtrs { float* p[4]; };
+__global__ __launch_bounds__(256) void colsum_final_multi_kernel(const float* __restrict__ x, int rows, int H, int NP,
+                                                                OutPtrs outs, int accumulate) {
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int cols = NP * H;
+  const long ld = cols;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int r = rg;
+    for (; r + 24 < rows; r += 32) {
+      s0 += x[(long)r * ld + c];
+      s1 += x[(long)(r + 8) * ld + c];
+      s2 += x[(long)(r + 16) * ld + c];
+      s3 += x[(long)(r + 24) * ld + c];
+    }
+    for (; r < rows; r += 8) s0 += x[(long)r * ld + c];
+  }
+  red[rg][cl] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float* out = outs.p[c / H];
+    if (!out) return;
+    float s = red[0][cl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += red[i][cl];
+    const int cc = c % H;
+    if (accumulate) s += out[cc];
+    out[cc] = s;
+  }
+}
+
 // stage 1 of a tall column sum: partial[chunk][c] = sum over this chunk's rows
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int cols, long ld,
                                                             float* __restrict__ partial, int rows_per_chunk) {
@@ -366,12 +401,9 @@ int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res
                      nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
                      offset);
   MTVAF_LAUNCH_CHECK();
-  const int cb = (H + 31) / 32;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part, g, H, (long)3 * H, dgamma, accumulate);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + H, g, H, (long)3 * H, dbeta, accumulate);
-  if (dbias_x)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + 2 * H, g, H, (long)3 * H, dbias_x,
-                       accumulate);
+  OutPtrs outs{{dgamma, dbeta, dbias_x, nullptr}};
+  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((3 * H + 31) / 32), dim3(256), 0, st, part, g, H, 3, outs,
+                     accumulate);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -394,12 +426,9 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
   hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(g), dim3(256), 0, st, dout, nullptr, nullptr, ids, type_ids, pos_ids,
                      word, pos, type, gamma, mean, rstd, dz_ws, nullptr, 0, part, M, S, H, p_drop, seed, offset);
   MTVAF_LAUNCH_CHECK();
-  const int cb = (H + 31) / 32;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part, g, H, (long)4 * H, dgamma, accumulate);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + H, g, H, (long)4 * H, dbeta, accumulate);
-  for (int t = 0; t < type_vocab; ++t)
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, part + (2 + t) * H, g, H, (long)4 * H,
-                       dtype + (long)t * H, accumulate);
+  OutPtrs outs{{dgamma, dbeta, dtype, type_vocab > 1 ? dtype + H : nullptr}};
+  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((4 * H + 31) / 32), dim3(256), 0, st, part, g, H, 4, outs,
+                     accumulate);
   if (!accumulate) {
     hipError_t e = hipMemsetAsync(dword, 0, (size_t)vocab * H * sizeof(float), st);
     if (e != hipSuccess) return (int)e;

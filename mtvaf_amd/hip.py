@@ -141,7 +141,8 @@ def kernel_symbol(cfg, la, lb, fast):
     b = lambda x: "true" if x else "false"
     if cfg >= 9:
         return f"gemm_f32_dma_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {b(la)}, {b(lb)}>"
-    return f"gemm_f32_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {dims[4]}, {b(la)}, {b(lb)}, {b(fast)}>"
+    return (f"gemm_f32_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {dims[4]}, {b(la)}, {b(lb)}, "
+            f"{b(fast >= 1)}, {b(fast == 2)}>")
 TILE_NAMES = {0: "128x128x16", 1: "128x96x16", 2: "128x288x16", 3: "64x64x16", 4: "128x64x16", 5: "128x128x32",
               6: "128x96x32", 7: "128x192x16", 8: "128x192x32", 9: "128x96x32dma", 10: "128x128x32dma",
               11: "128x192x32dma"}
