@@ -32,6 +32,7 @@ struct GemmArgs {
   long slab_stride;
   int epi, a_vec, b_vec, accumulate;
   int tiles_n;
+  int wide;  // wide (LDS-transposed, dwordx4) epilogue allowed: ldc/ldaux % 4 == 0, 16-B aligned C/aux/bias
 };
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so
@@ -55,6 +56,54 @@ __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int nvalid, bo
     if (nvalid > 3) v.w = p[3];
   }
   return v;
+}
+
+// Wide epilogue for whole tiles: the accumulator tile is transposed through LDS (free after the main loop)
+// so that every lane applies the epilogue to 4 consecutive columns and stores ONE dwordx4 (the MFMA C
+// layout would give 16 dword stores per 32x32 block: the store tail is issue-bound, not bandwidth-bound).
+// Requires ldc / ldaux / n0 multiples of 4 and 16-byte aligned C / aux / bias (checked by the launcher).
+template <int BM, int BN, int WM, int WN, int TM, int TN, int NT>
+__device__ __forceinline__ void epilogue_wide(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
+                                              int wm, int wn, int li, int h, int tid) {
+  constexpr int LDE = BN + 4;
+  __syncthreads();  // every wave is done reading the operand tiles
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        smem[row * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
+      }
+  __syncthreads();
+  float* C = p.C + (long)blockIdx.z * p.slab_stride;
+  const bool split = gridDim.z > 1;
+  constexpr int C4 = BN / 4;
+#pragma unroll 2
+  for (int idx = tid; idx < BM * C4; idx += NT) {
+    const int r = idx / C4, c = (idx % C4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
+    const long row = m0 + r;
+    const int col = n0 + c;
+    if (!split) {
+      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+      if (p.epi == EPI_GELU) {
+        *reinterpret_cast<f32x4*>(p.aux + row * p.ldaux + col) = v;
+        v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+      } else if (p.epi == EPI_TANH) {
+        v = f32x4{tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w)};
+      } else if (p.epi == EPI_DGELU) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+        v = f32x4{v.x * gelu_erf_grad(a.x), v.y * gelu_erf_grad(a.y), v.z * gelu_erf_grad(a.z), v.w * gelu_erf_grad(a.w)};
+      } else if (p.epi == EPI_DTANH) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+        v = v * (1.f - t * t);
+      }
+      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * p.ldc + col);
+    }
+    *reinterpret_cast<f32x4*>(C + row * p.ldc + col) = v;
+  }
 }
 
 // FAST: every k-chunk a multiple of BK and 16-byte aligned operands (M, N multiples of 4 for KM operands):
@@ -227,6 +276,12 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------
+  if constexpr (ALIGNED && (2 * (A_SZ + B_SZ) >= BM * (BN + 4))) {
+    if (p.wide) {
+      epilogue_wide<BM, BN, WM, WN, TM, TN, NT>(p, acc, smem, m0, n0, wm, wn, li, h, tid);
+      return;
+    }
+  }
   float* C = p.C + (long)blockIdx.z * p.slab_stride;
   const bool split = gridDim.z > 1;
 #pragma unroll
@@ -449,6 +504,10 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
     st_l = st_l == NSTAGE - 1 ? 0 : st_l + 1;
   }
 
+  if (p.wide) {
+    epilogue_wide<BM, BN, WM, WN, TM, TN, NW * 64>(p, acc, smem, m0, n0, wm, wn, li, h, tid);
+    return;
+  }
   float* C = p.C + (long)blockIdx.z * p.slab_stride;
   const bool split = gridDim.z > 1;
 #pragma unroll
@@ -714,6 +773,9 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
                     (layout_b == 0 || N % 4 == 0) && M >= 4 && N >= 4;
   const bool aligned = fast && (M % bm == 0) && (N % bn == 0);
   const int mode = aligned ? 2 : (fast ? 1 : 0);
+  a.wide = aligned && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) &&
+           (!aux || ((ldaux % 4 == 0) && (((uintptr_t)aux & 15) == 0))) && (!bias || (((uintptr_t)bias & 15) == 0)) &&
+           (a.slab_stride % 4 == 0);
   if (cfg >= kFirstDma && !(aligned && !(layout_a == 1 && layout_b == 0))) {
     if (cfg_forced) return MTVAF_ERR_SHAPE;
     static const int staged_twin[3] = {6, 5, 8};  // same tile, register-staged kernel (handles any alignment)

@@ -251,3 +251,70 @@ def test_training_reduces_loss_and_dropout_is_live():
     e1 = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss
     e2 = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss
     assert float(e1) == float(e2)
+
+
+def test_long_sequence_config5_shape_vs_oracle():
+    """BASELINE config-5 geometry (S = 512, P = 36) at B = 2: several key/query tiles, prefix + ragged lengths."""
+    cfg = P.EncCfg(vocab_size=2000, hidden=768, heads=12, inter=3072, layers=2, max_pos=512)
+    B, S, Pn = 2, 512, 36
+    sde = P.encoder_params(cfg, 21, std=0.03)
+    m = build_encoder(cfg)
+    m.load_state_dict(sde, strict=False)
+    m.to(DEV).train()
+    ids, mask, tt, _ = P.text_batch(cfg, 22, B, S, lengths=[512, 301], lo_id=5)
+    pkv = P.prefix_kv(23, cfg.layers, B, cfg.heads, Pn, std=0.5)
+    full = torch.cat([torch.ones(B, Pn, dtype=mask.dtype), mask], 1)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sde.items()}
+    ohs = O.bert_model(sdg, ids, full, tt, pkv, cfg.layers, cfg.heads, cfg.eps)
+    gw = torch.randn(B, S, cfg.hidden, generator=torch.Generator().manual_seed(5))
+    (ohs[-1] * gw).sum().backward()
+    gp = [(k.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)) for k, v in pkv]
+    out = m(input_ids=ids.to(DEV), attention_mask=full.to(DEV), token_type_ids=tt.to(DEV), past_key_values=gp,
+            output_hidden_states=True)
+    close(out["last_hidden_state"], ohs[-1], name="S512 last hidden")
+    (out["last_hidden_state"] * gw.to(DEV)).sum().backward()
+    named = dict(m.named_parameters())
+    for n in ("encoder.layer.0.attention.self.key.weight", "encoder.layer.1.output.dense.weight",
+              "embeddings.position_embeddings.weight", "encoder.layer.0.attention.output.LayerNorm.weight"):
+        close(named[n].grad, sdg[n].grad, rtol=3e-3, name=n)
+
+
+def test_roberta_base_dims_and_single_sentence():
+    """RoBERTa-base geometry (vocab 50265, 514 positions, eps 1e-5, pad id 1) with B = 1 and a short sequence."""
+    cfg = P.EncCfg(vocab_size=50265, hidden=768, heads=12, inter=3072, layers=2, max_pos=514, type_vocab=1, eps=1e-5,
+                   roberta=True, pad_idx=1)
+    sde = P.encoder_params(cfg, 31, std=0.03)
+    m = build_encoder(cfg)
+    m.load_state_dict(sde, strict=False)
+    m.to(DEV).eval()
+    ids = torch.tensor([[0, 713, 16, 1, 10, 1296, 2, 0, 0, 0, 0]])  # a <pad>=1 inside, zeros (= <s>) as the dataset pads
+    mask = torch.tensor([[1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0]])
+    tt = torch.zeros_like(ids)
+    ohs = O.bert_model(sde, ids, mask, tt, None, cfg.layers, cfg.heads, cfg.eps, roberta=True, pad_idx=1)
+    out = m(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), token_type_ids=tt.to(DEV), output_hidden_states=True)
+    close(out["hidden_states"][0], ohs[0], name="roberta embeddings")
+    close(out["last_hidden_state"], ohs[-1], name="roberta last hidden")
+    emb = m.get_embedding_output(ids.to(DEV), tt.to(DEV))
+    seq, pooled = m.get_bert_output(emb, attention_mask=mask.to(DEV))
+    close(seq, ohs[-1], name="get_bert_output")
+    close(pooled, O.bert_pooler(sde, ohs[-1]), name="pooler")
+
+
+def test_backward_is_deterministic_and_eval_has_no_grad_overhead():
+    cfg = P.EncCfg(vocab_size=300, hidden=128, heads=2, inter=256, layers=2, max_pos=64)
+    m = build_tvnet2(cfg, make_args(use_prefix=False), sde=P.encoder_params(cfg, 1), sdh=P.head_params(cfg, 2))
+    m.eval()
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 3, 6, 40, lo_id=5))
+    grads = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss.backward()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    for n in grads[0]:
+        if "word_embeddings" in n:
+            continue  # scatter-add with float atomics: order-dependent in the last bits
+        assert torch.equal(grads[0][n], grads[1][n]), n
+    with torch.no_grad():
+        out = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels)
+    assert out.loss.grad_fn is None and len(out.logits) == 6
+    assert [len(t) for t in out.logits] == mask.sum(1).tolist()
