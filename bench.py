@@ -111,6 +111,20 @@ def cpu_baseline(S, P, seconds_budget=20.0):
                       f"encoder+fc+CRF (prompt generator excluded)"}
 
 
+def pmc_traffic(symbol):
+    """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/pmc_gemm.json,
+    written by tools/pmc_to_json.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane
+    streams, plus WRITE_SIZE).  None when no profile of this kernel is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_gemm.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        rec = json.load(open(path)).get(symbol)
+        return None if rec is None else rec["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -191,6 +205,28 @@ def main():
     per_gpu = value / world
     ftrain = 3 * f_fwd(S, P)
 
+    fwd_bwd_only = None
+    if opt is not None:
+        # secondary figure: the same K steps without the optimizer update (the metric's literal "fwd+bwd")
+        def step_nb():
+            out = model(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None,
+                        images=feats, aux_imgs=aux)
+            out.loss.backward()
+            for p_ in model.parameters():
+                p_.grad = None
+        step_nb()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step_nb()
+        barrier()
+        dt1 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt1], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt1 = float(t)
+        fwd_bwd_only = {"value": round(world * B * a.steps / dt1, 2), "ms_per_step": round(1e3 * dt1 / a.steps, 3)}
+
     res = {"metric": "training sentences/sec (fwd+bwd)", "value": round(value, 2), "unit": "sentences/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
@@ -202,7 +238,7 @@ def main():
                       "parallelism": f"dp{world}" + (" (RCCL all-reduce overlapped with backward)" if world > 1 else "")},
            "loss": round(loss_val, 4),
            "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS["fp32"] * 1e12), 4),
-           "flop_per_sentence_train": ftrain}
+           "flop_per_sentence_train": ftrain, "fwd_bwd_without_optimizer": fwd_bwd_only}
 
     # ---- roofline of the dominant kernel (fp32 MFMA GEMM), measured live with HIP events recorded by the
     # library on the launch stream, directly around each main GEMM kernel of 3 further identical steps ----
@@ -233,7 +269,7 @@ def main():
         ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": None, "kernel": sym,
+            "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": pmc_traffic(sym), "kernel": sym,
             "avg_launch_us": round(avg_us, 1), "launches_per_step": cnt // NPROF,
             "flops_per_launch_avg": fl / cnt,
             "all_gemm_kernels": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
