@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--aux", type=int, default=8, help="aux crops: prefix slots = 4*(1+aux)")
     ap.add_argument("--full-length", action="store_true", help="all sequences at full length (worst case)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
+                    help="GEMM arithmetic: fp32 (BASELINE config 2, default) or bf16 compute with fp32 accumulation (configs 3-4)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -156,6 +158,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(device))
     from mtvaf_amd import hip
     hip.lib()
+    hip.set_compute_dtype(a.dtype)
 
     B, S, P = a.batch, a.seq, 4 * (1 + a.aux)
     model, cfg = build_model(device)
@@ -229,7 +232,8 @@ def main():
 
     res = {"metric": "training sentences/sec (fwd+bwd)", "value": round(value, 2), "unit": "sentences/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype if a.dtype == "fp32" else "bf16 MFMA / fp32 accumulate+storage",
+           "data": "synthetic",
            "config": {"workload": f"TVNetSAModel2 BERT-base random-init, fwd+bwd{'' if a.no_optimizer else '+AdamW(torch fused)'}, "
                                   f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
                                   f"images through the prompt generator), train mode (dropout live), "

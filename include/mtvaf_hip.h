@@ -66,6 +66,13 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
                    int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
                    mtvaf_stream_t stream);
 
+/* bf16-compute variant for the mixed-precision configurations: identical contract (fp32 buffers), operands are
+ * rounded to bf16 while staged and multiplied on the bf16 MFMA with fp32 accumulation. */
+int mtvaf_gemm_bf16(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                    int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                    mtvaf_stream_t stream);
+
 /* ---- fused prefix self-attention ---------------------------------------------------------------------
  * replaces BertSelfAttention.forward's prefix concat + scores + mask + softmax + dropout + PV + head merge
  * (modeling_bert.py:282-286, 303, 320-337; modeling_roberta.py:218-222) and its backward.

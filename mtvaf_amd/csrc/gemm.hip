@@ -13,98 +13,10 @@
 // feeds the MFMA with a k-permuted fragment (step s, lane half h <-> k = 8*kb + 4*h + s) so that a
 // KC operand is fetched with one ds_read_b128 per four MFMAs.  A and B use the same permutation,
 // so the sum over k is unchanged.
-#include "common.h"
+#include "gemm_common.h"
 #include <cstdlib>
 
 namespace mtvaf {
-
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_TANH = 2, EPI_DGELU = 3, EPI_DTANH = 4 };
-
-struct GemmArgs {
-  const float* A;
-  const float* B;
-  float* C;
-  const float* bias;
-  float* aux;
-  int M, N, K;
-  int lda, ldb, ldc, ldaux;
-  int k_chunk;
-  long slab_stride;
-  int epi, a_vec, b_vec, accumulate;
-  int tiles_n;
-  int wide;  // wide (LDS-transposed, dwordx4) epilogue allowed: ldc/ldaux % 4 == 0, 16-B aligned C/aux/bias
-};
-
-// XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so
-// consecutive blockIdx values never share an L2.  This bijective remap gives each XCD a CONTIGUOUS run of
-// tiles (whole rows of the tile grid), so an A row-panel is fetched by one XCD only and the B panels it is
-// multiplied with stay hot in that XCD's L2.  Placement is a speed hint only -- results never depend on it.
-__device__ __forceinline__ int xcd_remap(int bid, int nb) {
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int q = nb >> 3, r = nb & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-__device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int nvalid, bool vec) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (nvalid >= 4 && vec) {
-    v = *reinterpret_cast<const f32x4*>(p);
-  } else {
-    if (nvalid > 0) v.x = p[0];
-    if (nvalid > 1) v.y = p[1];
-    if (nvalid > 2) v.z = p[2];
-    if (nvalid > 3) v.w = p[3];
-  }
-  return v;
-}
-
-// Wide epilogue for whole tiles: the accumulator tile is transposed through LDS (free after the main loop)
-// so that every lane applies the epilogue to 4 consecutive columns and stores ONE dwordx4 (the MFMA C
-// layout would give 16 dword stores per 32x32 block: the store tail is issue-bound, not bandwidth-bound).
-// Requires ldc / ldaux / n0 multiples of 4 and 16-byte aligned C / aux / bias (checked by the launcher).
-template <int BM, int BN, int WM, int WN, int TM, int TN, int NT>
-__device__ __forceinline__ void epilogue_wide(const GemmArgs& p, f32x16 (&acc)[TM][TN], float* smem, int m0, int n0,
-                                              int wm, int wn, int li, int h, int tid) {
-  constexpr int LDE = BN + 4;
-  __syncthreads();  // every wave is done reading the operand tiles
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        smem[row * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
-      }
-  __syncthreads();
-  float* C = p.C + (long)blockIdx.z * p.slab_stride;
-  const bool split = gridDim.z > 1;
-  constexpr int C4 = BN / 4;
-#pragma unroll 2
-  for (int idx = tid; idx < BM * C4; idx += NT) {
-    const int r = idx / C4, c = (idx % C4) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
-    const long row = m0 + r;
-    const int col = n0 + c;
-    if (!split) {
-      if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-      if (p.epi == EPI_GELU) {
-        *reinterpret_cast<f32x4*>(p.aux + row * p.ldaux + col) = v;
-        v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
-      } else if (p.epi == EPI_TANH) {
-        v = f32x4{tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w)};
-      } else if (p.epi == EPI_DGELU) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
-        v = f32x4{v.x * gelu_erf_grad(a.x), v.y * gelu_erf_grad(a.y), v.z * gelu_erf_grad(a.z), v.w * gelu_erf_grad(a.w)};
-      } else if (p.epi == EPI_DTANH) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
-        v = v * (1.f - t * t);
-      }
-      if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * p.ldc + col);
-    }
-    *reinterpret_cast<f32x4*>(C + row * p.ldc + col) = v;
-  }
-}
 
 // FAST: every k-chunk a multiple of BK and 16-byte aligned operands (M, N multiples of 4 for KM operands):
 // the main loop has no bounds checks or scalar tails -- rows beyond M / N are CLAMPED to the last valid row
@@ -614,6 +526,8 @@ static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, int mode, hi
   return launch_l<BM, BN, WM, WN, BK, false, false>(a, la, lb, grid, st);
 }
 
+int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, bool aligned, hipStream_t st);  // gemm_bf16.hip
+
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
 // ---- optional launch profiler (bench.py roofline): HIP events recorded on the launch stream directly
@@ -626,7 +540,8 @@ static int g_prof_cap = 0, g_prof_n = 0;
 // Cost model (units: fp32 MFMA cycles of one CU).  The MFMA pipe of a CU is shared by its resident
 // blocks, so time ~ rounds over the 256 CUs x work per tile / efficiency of that tile shape (calibrated
 // with tools/gemm_sweep.py on MI355X at M = 4096), plus, for split-K, the slab write + ordered reduce.
-static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi, int* cfg_out, int* splits_out) {
+static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi, int* cfg_out, int* splits_out,
+                   int compute = 0) {
   //                                  128x128 128x96 128x288 64x64 128x64 128x128x32 128x96x32 128x192 128x192x32
   static const double eff_base[kNumCfgs] = {0.80, 0.86, 0.72, 0.45, 0.80, 0.70, 1.00, 0.92, 0.78,
                                             1.08, 0.90, 0.80};  // 9..11: LDS-DMA pipeline
@@ -648,7 +563,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
   int bc = 0, bs = 1;
   for (int c = 0; c < kNumCfgs; ++c) {
     if (eff[c] <= 0.0) continue;
-    const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = kCfgs[c].bk;
+    if (compute == 1 && !(c == 6 || c == 5 || c == 3)) continue;  // bf16 kernels exist for 128x96, 128x128, 64x64
+    const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute == 1 ? 32 : kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
     const int max_s = allow_split ? 16 : 1;
     for (int s = 1; s <= max_s; ++s) {
@@ -732,16 +648,24 @@ int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi
 // epi: 0 none, 1 bias+GELU (pre-activation stored to aux), 2 bias+tanh, 3 dGELU (multiply by
 // gelu'(aux)), 4 dtanh (multiply by 1-aux^2).  accumulate: C += result.  allow_split: permit a
 // deterministic split-K (slabs in workspace + ordered reduction); cfg/splits < 0 = heuristic.
-int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                   int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
-                   int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
-                   hipStream_t stream) {
+static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb,
+                         float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
+                         int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                         hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_SHAPE;
+  if (compute == 1) {
+    // the bf16 kernels need k-aligned, vector-loadable operands; anything else runs the fp32 kernels
+    const bool ok = (K % 32 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
+                    (((uintptr_t)B & 15) == 0) && (layout_a == 0 || M % 4 == 0) && (layout_b == 0 || N % 4 == 0) &&
+                    M >= 4 && N >= 4 && !(layout_a == 1 && layout_b == 0);
+    if (!ok) compute = 0;
+    if (compute == 1 && !(cfg == 6 || cfg == 5 || cfg == 3)) cfg = -1;
+  }
   if (!A || !B || !C) return MTVAF_ERR_ARG;
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
   if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1) return MTVAF_ERR_ARG;
   int c_auto, s_auto;
-  choose(M, N, K, allow_split && epi == EPI_NONE, layout_a, layout_b, epi, &c_auto, &s_auto);
+  choose(M, N, K, allow_split && epi == EPI_NONE, layout_a, layout_b, epi, &c_auto, &s_auto, compute);
   const bool cfg_forced = cfg >= 0 && cfg < kNumCfgs;
   if (!cfg_forced) cfg = c_auto;
   if (splits <= 0) splits = s_auto;
@@ -756,7 +680,7 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
   a.epi = epi; a.accumulate = accumulate;
   a.a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
   a.b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
-  const int bk = kCfgs[cfg].bk;
+  const int bk = compute == 1 ? 32 : kCfgs[cfg].bk;
   int kc = (int)cdiv(cdiv(K, splits), bk) * bk;
   splits = (int)cdiv(K, kc);
   a.k_chunk = kc;
@@ -784,11 +708,14 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
   ProfRec* pr = nullptr;
   if (g_prof && g_prof_n < g_prof_cap) {
     pr = &g_prof[g_prof_n++];
-    const int key[8] = {cfg, layout_a, layout_b, mode, M, N, K, splits};
+    const int key[8] = {compute == 1 ? 100 + cfg : cfg, layout_a, layout_b, mode, M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
     hipEventRecord(pr->e0, stream);
   }
   int rc;
+  if (compute == 1) {
+    rc = launch_gemm_bf16(cfg == 6 ? 0 : (cfg == 5 ? 1 : 2), a, layout_a, layout_b, grid, aligned, stream);
+  } else
   switch (cfg) {
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;
     case 10: rc = launch_dma<128, 128, 2, 2>(a, layout_a, layout_b, grid, stream); break;
@@ -813,6 +740,25 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
     MTVAF_LAUNCH_CHECK();
   }
   return MTVAF_OK;
+}
+
+int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                   int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                   int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                   hipStream_t stream) {
+  return gemm_dispatch(0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
+                       allow_split, workspace, workspace_bytes, cfg, splits, stream);
+}
+
+// Same contract as mtvaf_gemm_f32 (fp32 operands and results in memory), but the products run on the bf16
+// MFMA with fp32 accumulation: operands are rounded to bf16 (RNE) while tiles are staged.  Shapes the bf16
+// kernels cannot take (K % 32 != 0, unaligned operands) silently use the fp32 kernels.
+int mtvaf_gemm_bf16(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                    int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                    int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                    hipStream_t stream) {
+  return gemm_dispatch(1, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
+                       allow_split, workspace, workspace_bytes, cfg, splits, stream);
 }
 
 }  // extern "C"

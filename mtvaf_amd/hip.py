@@ -27,6 +27,7 @@ _SIGS = {
     "mtvaf_prof_stop": (c_int, [P, P, P, I]),
     "mtvaf_gemm_f32_plan": (c_int, [I, I, I, I, I, I, I, P, P]),
     "mtvaf_gemm_f32": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
+    "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_ln_bwd_workspace_bytes": (SZ, [I, I]),
@@ -139,6 +140,9 @@ def kernel_symbol(cfg, la, lb, fast):
             4: (128, 64, 4, 1, 16), 5: (128, 128, 2, 2, 32), 6: (128, 96, 4, 1, 32), 7: (128, 192, 2, 2, 16),
             8: (128, 192, 2, 2, 32), 9: (128, 96, 4, 1), 10: (128, 128, 2, 2), 11: (128, 192, 2, 2)}[cfg]
     b = lambda x: "true" if x else "false"
+    if cfg >= 100:
+        d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
+        return f"gemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(fast == 2)}>"
     if cfg >= 9:
         return f"gemm_f32_dma_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {b(la)}, {b(lb)}>"
     return (f"gemm_f32_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {dims[4]}, {b(la)}, {b(lb)}, "
@@ -157,12 +161,22 @@ def gemm_plan(M, N, K, allow_split, layout_a=0, layout_b=0, epi=0):
 
 KC, KM = 0, 1
 EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH = 0, 1, 2, 3, 4
+# GEMM arithmetic: "fp32" (v_mfma_f32_32x32x2_f32) or "bf16" (operands rounded to bf16 while staged, fp32
+# accumulation; buffers stay fp32).  Set per call or process-wide through set_compute_dtype().
+COMPUTE = "fp32"
+
+
+def set_compute_dtype(dtype: str):
+    global COMPUTE
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError(dtype)
+    COMPUTE = dtype
 
 
 def gemm(a: torch.Tensor, layout_a: int, b: torch.Tensor, layout_b: int, out: torch.Tensor, M: int, N: int, K: int,
          bias: Optional[torch.Tensor] = None, epi: int = EPI_NONE, aux: Optional[torch.Tensor] = None,
          accumulate: bool = False, allow_split: bool = False, lda: Optional[int] = None, ldb: Optional[int] = None,
-         ldc: Optional[int] = None, cfg: int = -1, splits: int = -1):
+         ldc: Optional[int] = None, cfg: int = -1, splits: int = -1, compute: Optional[str] = None):
     """out[M,N] = opA[M,K] . opB[K,N] (+bias, epilogue).  KC: reduction index contiguous; KM: k-major."""
     _f32(a, b, out, bias, aux)
     lda = a.stride(0) if lda is None else lda
@@ -176,9 +190,10 @@ def gemm(a: torch.Tensor, layout_a: int, b: torch.Tensor, layout_b: int, out: to
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _ck(lib().mtvaf_gemm_f32(layout_a, layout_b, _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, _p(bias), epi, _p(aux),
-                             aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws), wsb,
-                             cfg, splits, _st()), "mtvaf_gemm_f32")
+    fn = lib().mtvaf_gemm_bf16 if (compute or COMPUTE) == "bf16" else lib().mtvaf_gemm_f32
+    _ck(fn(layout_a, layout_b, _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, _p(bias), epi, _p(aux),
+           aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws), wsb, cfg, splits, _st()),
+        "mtvaf_gemm")
     if prof is not None:
         e1.record()
         prof.append(((layout_a, layout_b, M, N, K, epi, int(allow_split)), e0, e1))

@@ -318,3 +318,41 @@ def test_backward_is_deterministic_and_eval_has_no_grad_overhead():
         out = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels)
     assert out.loss.grad_fn is None and len(out.logits) == 6
     assert [len(t) for t in out.logits] == mask.sum(1).tolist()
+
+
+def test_bf16_compute_mode_tracks_the_fp32_oracle():
+    """BASELINE configs 3-4 arithmetic (bf16 MFMA, fp32 accumulation / storage / statistics) against the fp32
+    oracle at BERT-base width: bf16 operand rounding (2^-9 relative) bounds the deviation."""
+    from mtvaf_amd import hip
+    cfg = P.EncCfg(vocab_size=3000, hidden=768, heads=12, inter=3072, layers=4, max_pos=128)
+    B, S, Pn = 4, 64, 16
+    sde, sdh = P.encoder_params(cfg, 7, std=0.03), P.head_params(cfg, 8)
+    m = build_tvnet2(cfg, make_args(use_prefix=False), sde=sde, sdh=sdh)
+    m.eval()
+    ids, mask, tt, labels = P.text_batch(cfg, 9, B, S, lo_id=100)
+    labels[:, 0] = 9
+    pkv = P.prefix_kv(10, cfg.layers, B, cfg.heads, Pn, std=0.5)
+    sd = {**{"bert." + k: v.clone().requires_grad_(True) for k, v in sde.items()}, **sdh}
+    oloss, oem, otags, ohs = O.tvnet2_forward(sd, ids, mask, tt, labels, pkv, cfg.layers, cfg.heads, cfg.eps)
+    oloss.backward()
+    full = torch.cat([torch.ones(B, Pn, dtype=mask.dtype), mask], 1).to(DEV)
+    gp = [(k.to(DEV), v.to(DEV)) for k, v in pkv]
+    hip.set_compute_dtype("bf16")
+    try:
+        bo = m.bert(input_ids=ids.to(DEV), attention_mask=full, token_type_ids=tt.to(DEV), past_key_values=gp)
+        from mtvaf_amd import engine
+        em = engine.LinearFunction.apply(bo["last_hidden_state"], m.fc.weight, m.fc.bias, False)
+        mask_u8 = mask.to(DEV).to(torch.uint8)
+        loss = -m.crf(em, labels.to(DEV), mask=mask_u8, reduction="mean")
+        loss.backward()
+        tags = m.crf.decode(em, mask_u8)
+    finally:
+        hip.set_compute_dtype("fp32")
+    rel = float((bo["last_hidden_state"].cpu() - ohs[-1]).norm() / ohs[-1].norm())
+    assert rel < 2e-2, rel
+    assert abs(float(loss) - float(oloss)) <= 2e-2 * abs(float(oloss)), (float(loss), float(oloss))
+    agree = sum(a == b for ta, tb in zip(tags, otags) for a, b in zip(ta, tb)) / sum(len(t) for t in otags)
+    assert agree > 0.9, agree
+    g = m.bert.encoder.layer[1].intermediate.dense.weight.grad.cpu()
+    go = sd["bert.encoder.layer.1.intermediate.dense.weight"].grad
+    assert float((g - go).norm() / go.norm()) < 5e-2

@@ -476,3 +476,49 @@ def test_gemm_dma_pipeline(hip, cfg):
     close(out, F.gelu(pre), name="dma gelu")
     with pytest.raises(RuntimeError):
         hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M - 1, N, K, cfg=cfg)  # unaligned shape is refused
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16-compute GEMM (mixed-precision configurations): fp32 buffers, bf16 MFMA, fp32 accumulation
+# ---------------------------------------------------------------------------------------------
+def _bf16_round(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("cfg", [-1, 6, 5, 3])
+def test_gemm_bf16_compute(hip, cfg):
+    """Exact model of the kernel: operands rounded to bf16 (RNE), products and sums in >= fp32."""
+    for (M, N, K) in [(256, 192, 96), (130, 100, 64), (512, 768, 768)]:
+        x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+        out = torch.empty(M, N, device=DEV)
+        hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, bias=b.to(DEV), cfg=cfg, compute="bf16")
+        ref = _bf16_round(x) @ _bf16_round(w).t() + b.double()
+        close(out, ref, rtol=2e-5, name=f"bf16 nt {M}x{N}x{K}")
+        # and it stays within bf16 rounding of the fp32 result
+        close(out, F.linear(x.double(), w.double(), b.double()), rtol=2e-2, name="bf16 vs fp32")
+    M, N, K = 384, 288, 160
+    dy, w = rnd(M, K, seed=4), rnd(K, N, seed=5)
+    out = rnd(M, N, seed=6).to(DEV)
+    ref = out.cpu().double() + _bf16_round(dy) @ _bf16_round(w)
+    hip.gemm(dy.to(DEV), hip.KC, w.to(DEV), hip.KM, out, M, N, K, accumulate=True, cfg=cfg, compute="bf16")
+    close(out, ref, rtol=2e-5, name="bf16 nn+acc")
+    for (M, N, K, splits) in [(256, 192, 2048, 4), (100, 60, 64, 1), (768, 768, 4096, -1)]:
+        dy, x = rnd(K, M, seed=7), rnd(K, N, seed=8)
+        out = torch.empty(M, N, device=DEV)
+        hip.gemm(dy.to(DEV), hip.KM, x.to(DEV), hip.KM, out, M, N, K, allow_split=True, cfg=cfg, splits=splits,
+                 compute="bf16")
+        close(out, _bf16_round(dy).t() @ _bf16_round(x), rtol=5e-5, name=f"bf16 tn {M}x{N}x{K}")
+    # epilogue + unaligned K falls back to the fp32 kernels (exact fp32 result)
+    M, N, K = 128, 96, 72
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    out = torch.empty(M, N, device=DEV)
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, compute="bf16")
+    close(out, x.double() @ w.double().t(), name="bf16 request on K%32!=0 -> fp32 kernels")
+    M, N, K = 128, 192, 64
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+    pre = _bf16_round(x) @ _bf16_round(w).t() + b.double()
+    out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, bias=b.to(DEV), epi=hip.EPI_GELU, aux=aux, cfg=cfg,
+             compute="bf16")
+    close(aux, pre, rtol=2e-5, name="bf16 gelu-pre")
+    close(out, F.gelu(pre), rtol=1e-4, name="bf16 gelu")

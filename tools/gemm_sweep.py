@@ -29,6 +29,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--M", type=int, default=4096)
     ap.add_argument("--cfgs", default="0,1,2,4,5,6,7,8")
+    ap.add_argument("--compute", default="fp32")
     ap.add_argument("--zeros", action="store_true", help="zero operands (DVFS check: MI355X_MICROARCH.md give-back)")
     a = ap.parse_args()
     M, H, I = a.M, 768, 3072
@@ -56,7 +57,7 @@ def main():
             for s in ([1] if not split else [1, 2, 3, 4, 6, 8, 16]):
                 try:
                     us = time_call(lambda: hip.gemm(A, la, B, lb, C, m, n, k, bias=bias, epi=epi, aux=aux,
-                                                    allow_split=bool(split), cfg=cfg, splits=s))
+                                                    allow_split=bool(split), cfg=cfg, splits=s, compute=a.compute))
                 except RuntimeError as e:
                     continue
                 tf = 2.0 * m * n * k / us / 1e6
