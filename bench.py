@@ -29,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3}  # MI355X dense fp32 MFMA peak (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 LABELS = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
 
 
@@ -57,11 +57,16 @@ def synthetic_batch(B, S, n_aux, vocab, seed, device, full_length=False):
     return tuple(t.to(device) for t in (ids, mask, tt, labels, feats, aux))
 
 
-def build_model(device):
-    from transformers import BertConfig
+def build_model(device, arch="bert", max_pos=512):
+    from transformers import BertConfig, RobertaConfig
     from mtvaf_amd.models.bert_model import TVNetSAModel2
-    cfg = BertConfig()  # bert-base-uncased architecture, hidden/attention dropout 0.1
-    args = types.SimpleNamespace(bert_name="bert-base-uncased", bert_config=cfg, use_prefix=True, vao=False,
+    if arch == "roberta":  # roberta-base architecture (BASELINE config 3)
+        cfg = RobertaConfig(vocab_size=50265, max_position_embeddings=max(514, max_pos + 2), type_vocab_size=1,
+                            layer_norm_eps=1e-5, pad_token_id=1)
+    else:
+        cfg = BertConfig(max_position_embeddings=max(512, max_pos))  # bert-base-uncased, dropout 0.1
+    args = types.SimpleNamespace(bert_name="roberta-base" if arch == "roberta" else "bert-base-uncased",
+                                 bert_config=cfg, use_prefix=True, vao=False,
                                  noauxloss=True, use_probe=False, n_gpu=1, alpha=0.0, prefix_len=4, prefix_dim=768,
                                  device=device, resnet_root=None, use_152=False)
     torch.manual_seed(1234)
@@ -138,6 +143,7 @@ def main():
     ap.add_argument("--seq", type=int, default=128)
     ap.add_argument("--aux", type=int, default=8, help="aux crops: prefix slots = 4*(1+aux)")
     ap.add_argument("--full-length", action="store_true", help="all sequences at full length (worst case)")
+    ap.add_argument("--model", default="bert", choices=["bert", "roberta"], help="encoder architecture (base size)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="GEMM arithmetic: fp32 (BASELINE config 2, default) or bf16 compute with fp32 accumulation (configs 3-4)")
     ap.add_argument("--no-optimizer", action="store_true")
@@ -161,7 +167,7 @@ def main():
     hip.set_compute_dtype(a.dtype)
 
     B, S, P = a.batch, a.seq, 4 * (1 + a.aux)
-    model, cfg = build_model(device)
+    model, cfg = build_model(device, a.model, S)
     model.train()
     sync = None
     if world > 1:
@@ -234,14 +240,14 @@ def main():
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype if a.dtype == "fp32" else "bf16 MFMA / fp32 accumulate+storage",
            "data": "synthetic",
-           "config": {"workload": f"TVNetSAModel2 BERT-base random-init, fwd+bwd{'' if a.no_optimizer else '+AdamW(torch fused)'}, "
+           "config": {"workload": f"TVNetSAModel2 {'RoBERTa' if a.model == 'roberta' else 'BERT'}-base random-init, fwd+bwd{'' if a.no_optimizer else '+AdamW(torch fused)'}, "
                                   f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
                                   f"images through the prompt generator), train mode (dropout live), "
                                   f"{'full-length' if a.full_length else 'ragged 16..S'} sequences",
                       "global_batch": B * world, "seq_len": S, "prefix": P,
                       "parallelism": f"dp{world}" + (" (RCCL all-reduce overlapped with backward)" if world > 1 else "")},
            "loss": round(loss_val, 4),
-           "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS["fp32"] * 1e12), 4),
+           "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
            "flop_per_sentence_train": ftrain, "fwd_bwd_without_optimizer": fwd_bwd_only}
 
     # ---- roofline of the dominant kernel (fp32 MFMA GEMM), measured live with HIP events recorded by the
@@ -272,12 +278,12 @@ def main():
         avg_us = 1e3 * ms / cnt
         ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
         res["roofline"] = {
-            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_TFLOPS["fp32"], 4), "traffic": pmc_traffic(sym), "kernel": sym,
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": pmc_traffic(sym), "kernel": sym,
             "avg_launch_us": round(avg_us, 1), "launches_per_step": cnt // NPROF,
             "flops_per_launch_avg": fl / cnt,
             "all_gemm_kernels": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                 "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS["fp32"], 4)},
+                                 "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4)},
             "per_kernel": [{"kernel": s_, "launches_per_step": c_ // NPROF, "avg_us": round(1e3 * m_ / c_, 1),
                             "tflops": round(f_ / (m_ * 1e-3) / 1e12, 1)}
                            for s_, (m_, c_, f_) in sorted(by_sym.items(), key=lambda kv: -kv[1][0])[:8]],
