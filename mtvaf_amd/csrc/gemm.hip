@@ -381,28 +381,33 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
   };
-  // One basic block per k-tile.  An MFMA only occupies the issue port for a few cycles of its 64-cycle
+  // One straight-line body per k-tile.  An MFMA only occupies the issue port for a few cycles of its 64-cycle
   // pass, but the wave issues in order: a burst of LDS reads or DMA pieces between two MFMA groups leaves the
-  // matrix pipe idle.  sched_group_barrier therefore interleaves ONE non-MFMA instruction group behind each
-  // MFMA: the reads of k-blocks 1-2 ride behind the MFMAs of k-block 0, the DMA pieces of tile kt+2 behind
-  // k-block 1, the reads of k-block 3 behind k-block 2 (three fragment sets in registers).
+  // matrix pipe idle.  sched_group_barrier therefore puts ONE non-MFMA instruction group behind each MFMA:
+  // the reads of k-blocks 1-2 ride behind the MFMAs of k-block 0, the DMA pieces of tile kt+2 behind k-block
+  // 1, the reads of k-block 3 behind k-block 2.  The wait + barrier that publishes tile kt+1 sits BEFORE the
+  // last MFMA group, and the first fragments of tile kt+1 are read behind that group -- no LDS latency is
+  // exposed after the barrier.  (WAR: the stage of tile kt is next written by the DMA of tile kt+3, issued one
+  // iteration later behind k-block 0; every wave has drained its reads of tile kt (lgkmcnt(0)) before the
+  // barrier it must pass first.)
   constexpr int NMF = TM * TN * 4;                                    // MFMAs per k-block
   constexpr int NRD = (A_KM ? 4 : 1) * TM + (B_KM ? 4 : 1) * TN;      // ds_read instructions per k-block
   constexpr int R12 = (2 * NRD + NMF - 1) / NMF, R3 = (NRD + NMF - 1) / NMF;
-  auto compute = [&](int stage, auto do_issue, int issue_stage) {
+  f32x4 fa0[TM], fb0[TN];  // k-block 0 fragments of the tile about to be computed (loop-carried)
+
+  // PHASE 2: steady (issue tile kt+2, publish kt+1); 1: second-to-last (publish kt+1, all DMA landed); 0: last
+  auto tile_body = [&](auto phase_tag, int stage, int next_stage, int issue_stage) {
+    constexpr int PHASE = decltype(phase_tag)::value;
     const float* a = smem + stage * STAGE;
     const float* b = a + A_SZ;
-    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN], fa2[TM], fb2[TN];
-    load_frags(a, b, 0, fa0, fb0);
+    f32x4 fa1[TM], fb1[TN], fa2[TM], fb2[TN], fa3[TM], fb3[TN], fan[TM], fbn[TN];
     load_frags(a, b, 1, fa1, fb1);
     load_frags(a, b, 2, fa2, fb2);
     mfma_group(fa0, fb0);
-    if constexpr (decltype(do_issue)::value) issue(issue_stage);
-    load_frags(a, b, 3, fa0, fb0);
+    if constexpr (PHASE == 2) issue(issue_stage);
+    load_frags(a, b, 3, fa3, fb3);
     mfma_group(fa1, fb1);
     mfma_group(fa2, fb2);
-    mfma_group(fa0, fb0);
-    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);  // reads of k-block 0 first
 #pragma unroll
     for (int i = 0; i < NMF; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -411,40 +416,62 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
 #pragma unroll
     for (int i = 0; i < NMF; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (decltype(do_issue)::value) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (PHASE == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
 #pragma unroll
     for (int i = 0; i < NMF; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, R3, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PHASE >= 1) {
+      if constexpr (PHASE == 2) wait_vmcnt<IA + IB>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const float* an = smem + next_stage * STAGE;
+      load_frags(an, an + A_SZ, 0, fan, fbn);
+    }
+    mfma_group(fa3, fb3);
+    if constexpr (PHASE >= 1) {
+#pragma unroll
+      for (int i = 0; i < NMF; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, R3, 1);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa0[i] = fan[i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb0[j] = fbn[j];
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   issue(0);
-  if (nk > 1) issue(1);
-  int st_c = 0, st_l = 2;  // stage computed this iteration / stage loaded (tile kt+2)
-  auto advance = [&]() {
-    st_c = st_c == NSTAGE - 1 ? 0 : st_c + 1;
-    st_l = st_l == NSTAGE - 1 ? 0 : st_l + 1;
-  };
-  int kt = 0;
-  for (; kt + 2 < nk; ++kt) {  // steady state: tile kt+2 is issued inside the MFMA stream of tile kt
+  if (nk > 1) {
+    issue(1);
     wait_vmcnt<IA + IB>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    compute(st_c, std::true_type{}, st_l);
-    asm volatile("" ::: "memory");
-    advance();
+  } else {
+    wait_vmcnt<0>();
   }
-  for (; kt < nk; ++kt) {      // drain: nothing left to issue
-    if (kt + 1 < nk) wait_vmcnt<IA + IB>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    compute(st_c, std::false_type{}, st_l);
-    asm volatile("" ::: "memory");
-    advance();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  load_frags(smem, smem + A_SZ, 0, fa0, fb0);
+  int st_c = 0;
+  auto nxt = [](int st) { return st == NSTAGE - 1 ? 0 : st + 1; };
+  int kt = 0;
+  for (; kt + 2 < nk; ++kt) {
+    const int s1 = nxt(st_c);
+    tile_body(std::integral_constant<int, 2>{}, st_c, s1, nxt(s1));
+    st_c = s1;
   }
+  if (kt + 1 < nk) {
+    const int s1 = nxt(st_c);
+    tile_body(std::integral_constant<int, 1>{}, st_c, s1, 0);
+    st_c = s1;
+    ++kt;
+  }
+  if (kt < nk) tile_body(std::integral_constant<int, 0>{}, st_c, 0, 0);
 
   if (p.wide) {
     epilogue_wide<BM, BN, WM, WN, TM, TN, NW * 64>(p, acc, smem, m0, n0, wm, wn, li, h, tid);
@@ -574,19 +601,17 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
                    int compute = 0) {
   //                                  128x128 128x96 128x288 64x64 128x64 128x128x32 128x96x32 128x192 128x192x32
   static const double eff_base[kNumCfgs] = {0.80, 0.86, 0.72, 0.45, 0.80, 0.70, 1.00, 0.92, 0.78,
-                                            1.15, 1.00, 0.85};  // 9..11: LDS-DMA pipeline
+                                            1.18, 1.00, 0.85};  // 9..11: LDS-DMA pipeline
   double eff[kNumCfgs];
-  const bool km_km = (la == 1 && lb == 1);
   for (int c = 0; c < kNumCfgs; ++c) {
     eff[c] = eff_base[c];
     if (c >= kFirstDma) {
       const bool aligned = (M % kCfgs[c].bm == 0) && (N % kCfgs[c].bn == 0) && (K % 32 == 0);
       if (!aligned || (la == 1 && lb == 0)) eff[c] = 0.0;  // KM x KC never occurs on the path
-      if (km_km) eff[c] *= 0.97;                            // k-major fragments: 4 ds_read_b32 instead of one b128
       // one 84-KB block per CU cannot overlap a GELU-class epilogue with the next tile's main loop (measured:
       // tools/gemm_sweep.py): the 128x128 DMA tile amortises it best forward, the staged kernel backward
-      if (epi == EPI_GELU) eff[c] *= (c == 10 ? 1.12 : 0.92);
-      if (epi == EPI_DGELU) eff[c] *= (c == 10 ? 0.97 : 0.80);
+      if (epi == EPI_GELU) eff[c] *= (c == 10 ? 1.10 : 0.90);
+      if (epi == EPI_DGELU) eff[c] *= (c == 10 ? 1.02 : 0.85);
     }
   }
   double best = 1e300;
