@@ -185,7 +185,7 @@ def test_gradsync_single_rank_rccl_on_gpu():
                                      device="cuda", resnet_root=None, use_152=False)
         labels_list = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
         torch.manual_seed(0)
-        m = TVNetSAModel2(labels_list, None, args).to("cuda").train()
+        m = TVNetSAModel2(labels_list, None, args).to("cuda").eval()  # head dropout (p = 0.1) off: deterministic
         ids, mask, tt, labels = (t.to("cuda") for t in P.text_batch(P.EncCfg(vocab_size=500), 3, 8, 32, lo_id=5))
         m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss.backward()
         ref = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
