@@ -509,20 +509,31 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
   }
 }
 
-// dst[r][c] (ld ldd) = (accumulate ? dst : 0) + sum_z slabs[z][r][c] (+ bias[c])
+// dst[r][c] (ld ldd) = (accumulate ? dst : 0) + epi(sum_z slabs[z][r][c] + bias[c]);  epi: none, tanh, or
+// multiply by 1 - aux^2 (the two element-wise epilogues that may follow a split product)
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long slab_stride, float* dst,
-                                     int rows, int cols, int ldd, const float* bias, int accumulate) {
+                                     int rows, int cols, int ldd, const float* bias, int accumulate, int epi,
+                                     const float* __restrict__ aux, int ldaux) {
   const long n = (long)rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols), c = (int)(i % cols);
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += slabs[z * slab_stride + i];
     if (bias) s += bias[c];
+    if (epi == EPI_TANH) {
+      s = tanhf(s);
+    } else if (epi == EPI_DTANH) {
+      const float t = aux[(long)r * ldaux + c];
+      s *= (1.f - t * t);
+    }
     float* d = dst + (long)r * ldd + c;
     if (accumulate) s += *d;
     *d = s;
   }
 }
+
+// epilogues that commute with the ordered slab reduction (applied by splitk_reduce_kernel)
+static inline bool splittable(int epi) { return epi == EPI_NONE || epi == EPI_TANH || epi == EPI_DTANH; }
 
 struct TileCfg { int bm, bn, bk; };
 static const TileCfg kCfgs[] = {{128, 128, 16}, {128, 96, 16}, {128, 288, 16}, {64, 64, 16}, {128, 64, 16},
@@ -695,7 +706,7 @@ int mtvaf_prof_stop(int* n_out, int* keys, float* ms, int max_records) {
 int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi, int allow_split, int* cfg,
                         int* splits) {
   if (M <= 0 || N <= 0 || K <= 0 || !cfg || !splits) return MTVAF_ERR_ARG;
-  choose(M, N, K, allow_split && epi == EPI_NONE, layout_a, layout_b, epi, cfg, splits);
+  choose(M, N, K, allow_split && splittable(epi), layout_a, layout_b, epi, cfg, splits);
   return MTVAF_OK;
 }
 
@@ -720,11 +731,11 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
   if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1) return MTVAF_ERR_ARG;
   int c_auto, s_auto;
-  choose(M, N, K, allow_split && epi == EPI_NONE, layout_a, layout_b, epi, &c_auto, &s_auto, compute);
+  choose(M, N, K, allow_split && splittable(epi), layout_a, layout_b, epi, &c_auto, &s_auto, compute);
   const bool cfg_forced = cfg >= 0 && cfg < kNumCfgs;
   if (!cfg_forced) cfg = c_auto;
   if (splits <= 0) splits = s_auto;
-  if (!(allow_split && epi == EPI_NONE)) splits = 1;
+  if (!(allow_split && splittable(epi))) splits = 1;
   if (splits > 1 && (size_t)splits * M * N * sizeof(float) > workspace_bytes) {
     splits = (int)(workspace_bytes / ((size_t)M * N * sizeof(float)));
     if (splits < 1) splits = 1;
@@ -791,7 +802,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     const long n = (long)M * N;
     int blocks = (int)std::min<long>(cdiv(n, 256), 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, splits,
-                       (long)M * N, C, M, N, ldc, bias, accumulate);
+                       (long)M * N, C, M, N, ldc, bias, accumulate, epi, (const float*)aux, ldaux);
     MTVAF_LAUNCH_CHECK();
   }
   return MTVAF_OK;

@@ -102,6 +102,7 @@ class TVNetSAModel2(nn.Module):
             self.bert = enc_cls(bert_config)
         else:
             self.bert = enc_cls.from_pretrained(args.bert_name)
+        self.bert.skip_pooler = True  # pooler_output is unused on this path
         hidden = self.bert.config.hidden_size
         self.num_labels = len(label_list) + 1
 

@@ -421,7 +421,9 @@ class BertModel(nn.Module):
         enc = self.encoder(emb, attention_mask=ext, past_key_values=past_key_values,
                            output_hidden_states=output_hidden_states, return_dict=True)
         seq = enc.last_hidden_state
-        pooled = self.pooler(seq) if self.pooler is not None else None
+        # the pooler output is consumed only by the span model's DualGCN head; TVNetSAModel2 never reads it
+        # (models/bert_model.py:496-506) and sets `skip_pooler` so the [B,H]x[H,H] product is not launched
+        pooled = self.pooler(seq) if (self.pooler is not None and not getattr(self, "skip_pooler", False)) else None
         if not return_dict:
             return (seq, pooled) + ((enc.hidden_states,) if enc.hidden_states is not None else ())
         return BaseModelOutputWithPoolingAndCrossAttentions(last_hidden_state=seq, pooler_output=pooled,

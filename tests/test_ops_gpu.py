@@ -522,3 +522,23 @@ def test_gemm_bf16_compute(hip, cfg):
              compute="bf16")
     close(aux, pre, rtol=2e-5, name="bf16 gelu-pre")
     close(out, F.gelu(pre), rtol=1e-4, name="bf16 gelu")
+
+
+def test_gemm_splitk_with_tanh_epilogues(hip):
+    """Few output tiles + long K (the prompt generator's shapes): the split-K path applies bias+tanh / dtanh in
+    the ordered slab reduction."""
+    M, N, K = 288, 800, 3840
+    x, w, b = rnd(M, K, seed=1, scale=0.1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    out = torch.empty(M, N, device=DEV)
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, bias=b.to(DEV), epi=hip.EPI_TANH, allow_split=True,
+             splits=4)
+    close(out, torch.tanh(F.linear(x.double(), w.double(), b.double())), rtol=3e-4, name="split tanh")
+    t = torch.tanh(rnd(M, N, seed=5))
+    hip.gemm(x.to(DEV), hip.KC, w.to(DEV), hip.KC, out, M, N, K, epi=hip.EPI_DTANH, aux=t.to(DEV), allow_split=True,
+             splits=3)
+    close(out, F.linear(x.double(), w.double()) * (1 - t.double() ** 2), rtol=3e-4, name="split dtanh")
+    out2 = torch.empty(48, 288, device=DEV).t()  # non-contiguous guard is the wrapper's job: use contiguous
+    lg = torch.empty(288, 48, device=DEV)
+    xs, ws, bs = rnd(288, 6144, seed=7, scale=0.1), rnd(48, 6144, seed=8, scale=0.1), rnd(48, seed=9)
+    hip.linear_fwd(xs.to(DEV), ws.to(DEV), bs.to(DEV), lg)
+    close(lg, F.linear(xs.double(), ws.double(), bs.double()), rtol=3e-4, name="auto split skinny")
