@@ -85,6 +85,7 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, int ld,
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[KT * LDT];
   __shared__ __attribute__((aligned(16))) float Vs[KT * LDT];
+  __shared__ __attribute__((aligned(16))) float Ms[KT];  // additive mask of the tile's keys (NEG_BIG beyond T)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -109,6 +110,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     __syncthreads();
     stage_kv(Ks, a, b, h, t0, 1);
     stage_kv(Vs, a, b, h, t0, 2);
+    if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? a.addmask[(long)b * T + t0 + threadIdx.x] : NEG_BIG;
     __syncthreads();
     f32x4 s[4];
     float tmax = NEG_BIG;
@@ -124,12 +126,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) s[j] = MFMA16(kf[t], qreg[db][t], s[j]);
       }
-      const int key0 = t0 + 16 * j + 4 * g;
+      const f32x4 mv = *reinterpret_cast<const f32x4*>(Ms + 16 * j + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = key0 + r;
-        const float mv = key < T ? a.addmask[(long)b * T + key] : 0.f;
-        s[j][r] = key < T ? s[j][r] * a.scale + mv : NEG_BIG;
+        s[j][r] = mv[r] > -1.0e29f ? s[j][r] * a.scale + mv[r] : NEG_BIG;
         tmax = fmaxf(tmax, s[j][r]);
       }
     }
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[KT * LDT];
   __shared__ __attribute__((aligned(16))) float Vs[KT * LDT];
+  __shared__ __attribute__((aligned(16))) float Ms[KT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -215,6 +216,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
     __syncthreads();
     stage_kv(Ks, a, b, h, t0, 1);
     stage_kv(Vs, a, b, h, t0, 2);
+    if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? a.addmask[(long)b * T + t0 + threadIdx.x] : NEG_BIG;
     __syncthreads();
     const int nsub = min(4, (T - t0 + 15) >> 4);
 #pragma unroll
@@ -232,12 +234,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
         }
       }
       const int key0 = t0 + 16 * j + 4 * g;
+      const f32x4 mv = *reinterpret_cast<const f32x4*>(Ms + 16 * j + 4 * g);
       f32x4 ds;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = key0 + r;
         float p = 0.f;
-        if (key < T) p = __expf(s[r] * a.scale + a.addmask[(long)b * T + key] - lse);
+        if (mv[r] > -1.0e29f) p = __expf(s[r] * a.scale + mv[r] - lse);
         float dpe = dp[r];
         if (a.p_drop > 0.f) dpe = attn_dropout_keep(a.drop_key, drow, (uint32_t)key, a.drop_thr) ? dpe * inv_keep : 0.f;
         ds[r] = p * (dpe - dl) * a.scale;
