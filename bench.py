@@ -188,6 +188,7 @@ def main():
         else:
             for p in model.parameters():
                 p.grad = None
+        assert len(out.logits) == B  # the trainer reads the decoded tags after the update (modules/train.py:627-647)
         return out
 
     def barrier():
@@ -223,6 +224,7 @@ def main():
             out.loss.backward()
             for p_ in model.parameters():
                 p_.grad = None
+            assert len(out.logits) == B
         step_nb()
         barrier()
         t1 = time.perf_counter()

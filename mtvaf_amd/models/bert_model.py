@@ -151,7 +151,8 @@ class TVNetSAModel2(nn.Module):
         sequence_output = engine.dropout(bert_output["last_hidden_state"], self.dropout.p, self.training)
         emissions = engine.LinearFunction.apply(sequence_output, self.fc.weight, self.fc.bias, False)
         mask_u8 = attention_mask.to(torch.uint8)
-        logits = self.crf.decode(emissions, mask_u8)
+        # Viterbi paths: device kernel + async packed copy; the list materialises on first use (no mid-step sync)
+        logits = self.crf.decode_deferred(emissions, mask_u8)
         loss = None
         if labels is not None:
             loss = -1 * self.crf(emissions, labels, mask=mask_u8, reduction="mean")

@@ -14,6 +14,57 @@ from torch import nn
 from .. import engine, hip
 
 
+class DeferredTags(list):
+    """``List[List[int]]`` of Viterbi paths whose device->host copy has been ENQUEUED but not waited for.
+
+    The reference's ``crf.decode`` returns Python lists, which forces a host sync in the middle of every training
+    step (models/bert_model.py:511).  This list subclass carries the packed
+    [B, S+1] int32 result (tags | length) in pinned host memory plus the copy's event and fills itself on first
+    use (indexing, iteration, len, comparison, repr ...), i.e. where the trainer builds y_pred after
+    ``loss.backward()`` (modules/train.py:627-647).  Values are identical to an eager ``decode``."""
+
+    def __init__(self, packed_host: torch.Tensor, event, S: int):
+        super().__init__()
+        self._packed, self._event, self._S = packed_host, event, S
+
+    def _fill(self):
+        if self._packed is not None:
+            if self._event is not None:
+                self._event.synchronize()
+            packed, S = self._packed, self._S
+            self._packed = None
+            super().extend(row[:n].tolist() for row, n in zip(packed[:, :S], packed[:, S].tolist()))
+        return self
+
+    def __getitem__(self, i):
+        self._fill()
+        return super().__getitem__(i)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def __eq__(self, other):
+        self._fill()
+        return list(self) == (list(other) if isinstance(other, list) else other)
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._fill()
+        return super().__repr__()
+
+    def __reduce__(self):
+        return (list, (list(self),))
+
+
 class CRF(nn.Module):
     def __init__(self, num_tags: int, batch_first: bool = False) -> None:
         if num_tags <= 0:
@@ -74,6 +125,17 @@ class CRF(nn.Module):
         hip.crf_viterbi(em, mask, self.start_transitions.data, self.end_transitions.data, self.transitions.data, tags,
                         lens)
         return tags, lens
+
+    def decode_deferred(self, emissions, mask: Optional[torch.Tensor] = None) -> DeferredTags:
+        """Viterbi on device + asynchronous packed copy to pinned host memory; no host sync here."""
+        tags, lens = self.decode_packed(emissions, mask)
+        S = tags.shape[1]
+        packed = torch.cat([tags, lens[:, None]], dim=1)
+        host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+        host.copy_(packed, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return DeferredTags(host, ev, S)
 
     def decode(self, emissions, mask: Optional[torch.Tensor] = None) -> List[List[int]]:
         tags, lens = self.decode_packed(emissions, mask)

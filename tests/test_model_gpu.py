@@ -356,3 +356,23 @@ def test_bf16_compute_mode_tracks_the_fp32_oracle():
     g = m.bert.encoder.layer[1].intermediate.dense.weight.grad.cpu()
     go = sd["bert.encoder.layer.1.intermediate.dense.weight"].grad
     assert float((g - go).norm() / go.norm()) < 5e-2
+
+
+def test_deferred_tags_behave_like_the_eager_list():
+    cfg = P.EncCfg(vocab_size=300, hidden=128, heads=2, inter=256, layers=2, max_pos=64)
+    m = build_tvnet2(cfg, make_args(use_prefix=False), sde=P.encoder_params(cfg, 1), sdh=P.head_params(cfg, 2))
+    m.eval()
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 3, 6, 40, lo_id=5))
+    out = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels)
+    from mtvaf_amd.modules.crf import DeferredTags
+    assert isinstance(out.logits, list) and isinstance(out.logits, DeferredTags)
+    em_hook = {}
+    h = m.fc.register_forward_hook(lambda *a: None)
+    h.remove()
+    bo = m.bert(input_ids=ids, attention_mask=mask, token_type_ids=tt)
+    em = torch.nn.functional.linear(bo["last_hidden_state"], m.fc.weight, m.fc.bias)
+    eager = m.crf.decode(em, mask.to(torch.uint8))
+    assert len(out.logits) == 6 and out.logits == eager and list(out.logits) == eager
+    assert out.logits[2][1] == eager[2][1] and [len(t) for t in out.logits] == mask.sum(1).tolist()
+    import copy, json
+    assert json.loads(json.dumps(out.logits)) == eager and copy.deepcopy(out.logits) == eager
