@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model: torch.nn.Module, process_group=None, force: bool = False):
+    def __init__(self, model: torch.nn.Module, process_group=None, force: bool = False, big_numel: int = 1 << 20):
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised process group (backend 'nccl' = RCCL on ROCm)")
         self.model = model
@@ -36,14 +36,19 @@ class GradSync:
         self._armed = False
         self.enabled = True
         self.force = force  # run the collectives even with world_size == 1 (single-GPU test of the N > 1 path)
+        # Large non-encoder gradients (94 MB word table, encoder_conv weights) are reduced the moment autograd has
+        # accumulated them, so e.g. the word-table all-reduce overlaps the prompt generator's backward instead of
+        # sitting in the un-overlapped tail bucket.
+        self._early_done = set()
+        for p in model.parameters():
+            if id(p) not in self._enc_param_ids and p.requires_grad and p.numel() >= big_numel:
+                p.register_post_accumulate_grad_hook(self._param_ready)
 
     # -- called from inside EncoderFunction.backward, newest layer first ---------------------------------
     def _layer_done(self, li: int, flat_grad: Optional[torch.Tensor]):
         if not self.enabled or (self.world == 1 and not self.force):
             return
-        if not self._armed:
-            self._armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+        self._arm()
         if flat_grad is None:  # gradient-accumulation fallback: reduce the .grad tensors at the end
             self._slow_layers.append(li)
             return
@@ -57,11 +62,33 @@ class GradSync:
             dist.all_reduce(flat_grad, group=self.group)
             flat_grad.mul_(1.0 / self.world)
 
+    def _arm(self):
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+
+    def _param_ready(self, p):
+        if not self.enabled or (self.world == 1 and not self.force) or p.grad is None:
+            return
+        self._arm()
+        g = p.grad
+        if self._comm is None:
+            self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
+        else:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(ev)
+                dist.all_reduce(g, group=self.group)
+                g.mul_(1.0 / self.world)
+        self._early_done.add(id(p))
+
     # -- runs once when the autograd pass is complete ---------------------------------------------------------
     def _finish(self):
         self._armed = False
         rest = [p for p in self.model.parameters()
-                if p.grad is not None and (id(p) not in self._enc_param_ids)]
+                if p.grad is not None and (id(p) not in self._enc_param_ids) and (id(p) not in self._early_done)]
+        self._early_done = set()
         # a layer whose gradients autograd copied instead of adopting (its .grad does not alias the flat
         # buffer that was reduced) is reduced again from its .grad tensors -- correctness never depends on
         # the zero-copy fast path

@@ -105,9 +105,10 @@ class _FakeModel(torch.nn.Module):
         super().__init__()
         self.encoder = _FakeEncoder()
         self.head = torch.nn.Linear(4, 1)
+        self.table = torch.nn.Parameter(torch.ones(64, 8))  # "large" parameter: reduced early by its own hook
 
     def forward(self, x):
-        return self.encoder(x) + self.head(x[:4]).sum()
+        return self.encoder(x) + self.head(x[:4]).sum() + (self.table * x).sum()
 
 
 def _worker(rank, world, port, q):
@@ -117,7 +118,8 @@ def _worker(rank, world, port, q):
     from mtvaf_amd.parallel import GradSync
     torch.manual_seed(0)
     m = _FakeModel()
-    sync = GradSync(m)
+    sync = GradSync(m, big_numel=256)
+    assert len(sync._early_done) == 0
     x = torch.arange(8, dtype=torch.float32) * (rank + 1)
     res = {}
     # fast path: .grad is None -> flat buffers adopted and all-reduced per layer
