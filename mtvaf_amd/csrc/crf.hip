@@ -14,23 +14,39 @@ constexpr int CMAX = 16;
 constexpr float NEG = -1.0e30f;
 
 __device__ __forceinline__ float lse2(float m, float s) { return m + __logf(s); }
+// broadcast lane `i` (compile-time constant) of x to the whole wave: v_readlane_b32 into an SGPR instead of a
+// ds_bpermute round trip through the LDS crossbar -- the tag recursions do 16-32 of these per time step
+__device__ __forceinline__ float bcast(float x, int i) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i));
+}
 
 // ---------------------------------------------------------------------------------------------
 // forward: alpha[b,t,:] (after step t), logZ[b], llh[b] = score(gold) - logZ
 // ---------------------------------------------------------------------------------------------
+// The recursion over S is serial, so every global load inside it would expose its full latency once per
+// step: the per-sequence operands (emissions S x C, mask, tags, and alpha in the backward) are therefore
+// staged in LDS first (dynamic LDS: S*C floats [+ S*C alpha] + S ints + S bytes).
 __global__ __launch_bounds__(64) void crf_fwd_kernel(const float* __restrict__ em, const int64_t* __restrict__ tags,
                                                     const uint8_t* __restrict__ mask, const float* __restrict__ start,
                                                     const float* __restrict__ end, const float* __restrict__ trans,
                                                     float* __restrict__ alpha_ws, float* __restrict__ logz,
                                                     float* __restrict__ llh, int S, int C) {
+  extern __shared__ __attribute__((aligned(16))) float crf_lds[];
+  float* e = crf_lds;                                   // [S*C]
+  int* tg = reinterpret_cast<int*>(e + S * C);          // [S]
+  uint8_t* mk = reinterpret_cast<uint8_t*>(tg + S);     // [S]
   const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < S * C; i += 64) e[i] = em[(long)b * S * C + i];
+  for (int i = lane; i < S; i += 64) {
+    tg[i] = (int)tags[(long)b * S + i];
+    mk[i] = mask[(long)b * S + i];
+  }
+  __syncthreads();
   const bool act = lane < C;
   const int j = act ? lane : 0;
   float tcol[CMAX];
 #pragma unroll
   for (int i = 0; i < CMAX; ++i) tcol[i] = (i < C) ? trans[i * C + j] : 0.f;
-  const float* e = em + (long)b * S * C;
-  const uint8_t* mk = mask + (long)b * S;
   float alpha = act ? start[j] + e[j] : NEG;
   if (act && alpha_ws) alpha_ws[((long)b * S) * C + j] = alpha;
   for (int t = 1; t < S; ++t) {
@@ -38,7 +54,7 @@ __global__ __launch_bounds__(64) void crf_fwd_kernel(const float* __restrict__ e
     float m = NEG;
 #pragma unroll
     for (int i = 0; i < CMAX; ++i) {
-      const float ai = __shfl(alpha, i, 64);
+      const float ai = bcast(alpha, i);
       v[i] = (i < C) ? ai + tcol[i] : NEG;
       m = fmaxf(m, v[i]);
     }
@@ -53,7 +69,6 @@ __global__ __launch_bounds__(64) void crf_fwd_kernel(const float* __restrict__ e
   const float m = wave_max(fin);
   const float z = lse2(m, wave_sum(act ? __expf(fin - m) : 0.f));
   // gold path score, lanes stride over t
-  const int64_t* tg = tags + (long)b * S;
   float sc = 0.f;
   int cnt = 0;
   for (int t = lane; t < S; t += 64) {
@@ -88,7 +103,21 @@ __global__ __launch_bounds__(64) void crf_bwd_kernel(const float* __restrict__ e
                                                     const float* __restrict__ logz, const float* __restrict__ gout,
                                                     float* __restrict__ dem, float* __restrict__ partial, int B, int S,
                                                     int C) {
+  extern __shared__ __attribute__((aligned(16))) float crf_lds[];
+  float* e = crf_lds;                                   // [S*C]
+  float* al = e + S * C;                                // [S*C]
+  int* tg = reinterpret_cast<int*>(al + S * C);         // [S]
+  uint8_t* mk = reinterpret_cast<uint8_t*>(tg + S);     // [S]
   const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < S * C; i += 64) {
+    e[i] = em[(long)b * S * C + i];
+    al[i] = alpha_ws[(long)b * S * C + i];
+  }
+  for (int i = lane; i < S; i += 64) {
+    tg[i] = (int)tags[(long)b * S + i];
+    mk[i] = mask[(long)b * S + i];
+  }
+  __syncthreads();
   const bool act = lane < C;
   const int j = act ? lane : 0;
   const float g = (gout ? *gout : 1.f) / B;
@@ -99,10 +128,6 @@ __global__ __launch_bounds__(64) void crf_bwd_kernel(const float* __restrict__ e
     trow[i] = (i < C) ? trans[j * C + i] : 0.f;   // trans[lane][i]
     eacc[i] = 0.f;
   }
-  const float* e = em + (long)b * S * C;
-  const uint8_t* mk = mask + (long)b * S;
-  const int64_t* tg = tags + (long)b * S;
-  const float* al = alpha_ws + (long)b * S * C;
   float* de = dem + (long)b * S * C;
   const float z = logz[b];
   int cnt = 0;
@@ -127,7 +152,7 @@ __global__ __launch_bounds__(64) void crf_bwd_kernel(const float* __restrict__ e
     const int gi = (int)tg[t - 1], gj = (int)tg[t];
 #pragma unroll
     for (int i = 0; i < CMAX; ++i) {
-      const float ai = __shfl(aprev, i, 64);
+      const float ai = bcast(aprev, i);
       if (i < C && act) eacc[i] += __expf(ai + tcol[i] + eb - z) - ((i == gi && j == gj) ? 1.f : 0.f);
     }
     // beta_{t-1}[lane] = lse_k(trans[lane][k] + emit[t][k] + beta_t[k])
@@ -135,7 +160,7 @@ __global__ __launch_bounds__(64) void crf_bwd_kernel(const float* __restrict__ e
     float m = NEG;
 #pragma unroll
     for (int k = 0; k < CMAX; ++k) {
-      const float ebk = __shfl(eb, k, 64);
+      const float ebk = bcast(eb, k);
       v[k] = (k < C) ? trow[k] + ebk : NEG;
       m = fmaxf(m, v[k]);
     }
@@ -177,15 +202,19 @@ __global__ __launch_bounds__(64) void crf_viterbi_kernel(const float* __restrict
                                                         const float* __restrict__ start, const float* __restrict__ end,
                                                         const float* __restrict__ trans, int32_t* __restrict__ tags_out,
                                                         int32_t* __restrict__ lens_out, int S, int C) {
-  extern __shared__ uint8_t bp[];  // [S][CMAX]
+  extern __shared__ __attribute__((aligned(16))) float crf_lds[];
+  float* e = crf_lds;                                   // [S*C]
+  uint8_t* mk = reinterpret_cast<uint8_t*>(e + S * C);  // [S]
+  uint8_t* bp = mk + ((S + 15) & ~15);                  // [S][CMAX] back-pointers
   const int b = blockIdx.x, lane = threadIdx.x;
+  for (int i = lane; i < S * C; i += 64) e[i] = em[(long)b * S * C + i];
+  for (int i = lane; i < S; i += 64) mk[i] = mask[(long)b * S + i];
+  __syncthreads();
   const bool act = lane < C;
   const int j = act ? lane : 0;
   float tcol[CMAX];
 #pragma unroll
   for (int i = 0; i < CMAX; ++i) tcol[i] = (i < C) ? trans[i * C + j] : 0.f;
-  const float* e = em + (long)b * S * C;
-  const uint8_t* mk = mask + (long)b * S;
   float score = act ? start[j] + e[j] : NEG;
   int cnt = 0;
   for (int t = lane; t < S; t += 64) cnt += mk[t] ? 1 : 0;
@@ -196,7 +225,7 @@ __global__ __launch_bounds__(64) void crf_viterbi_kernel(const float* __restrict
     int bi = 0;
 #pragma unroll
     for (int i = 0; i < CMAX; ++i) {
-      const float v = __shfl(score, i, 64) + tcol[i];
+      const float v = bcast(score, i) + tcol[i];
       if (i < C && v > best) { best = v; bi = i; }
     }
     if (act) bp[t * CMAX + j] = (uint8_t)bi;
@@ -244,8 +273,10 @@ int mtvaf_crf_nll_fwd(const float* emissions, const int64_t* tags, const uint8_t
   float* alpha = (float*)workspace;
   float* logz = alpha + (size_t)B * S * C;
   float* llh = logz + B;
-  hipLaunchKernelGGL(crf_fwd_kernel, dim3(B), dim3(64), 0, st, emissions, tags, mask, start, end, trans, alpha, logz, llh,
-                     S, C);
+  const size_t lds_f = (size_t)S * C * sizeof(float) + (size_t)S * sizeof(int) + (size_t)S;
+  if (lds_f > 64 * 1024) return MTVAF_ERR_SHAPE;  // S * C <= ~16000 (S = 512, C = 11 uses 25 KB)
+  hipLaunchKernelGGL(crf_fwd_kernel, dim3(B), dim3(64), lds_f, st, emissions, tags, mask, start, end, trans, alpha, logz,
+                     llh, S, C);
   hipLaunchKernelGGL(crf_loss_kernel, dim3(1), dim3(64), 0, st, llh, loss, B);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
@@ -262,7 +293,9 @@ int mtvaf_crf_nll_bwd(const float* grad_out, const float* emissions, const int64
   float* alpha = (float*)workspace;
   float* logz = alpha + (size_t)B * S * C;
   float* partial = logz + 2 * B;
-  hipLaunchKernelGGL(crf_bwd_kernel, dim3(B), dim3(64), 0, st, emissions, tags, mask, end, trans, alpha, logz, grad_out,
+  const size_t lds_b = (size_t)2 * S * C * sizeof(float) + (size_t)S * sizeof(int) + (size_t)S;
+  if (lds_b > 64 * 1024) return MTVAF_ERR_SHAPE;  // S * C <= ~8000 (S = 512, C = 11 uses 48 KB)
+  hipLaunchKernelGGL(crf_bwd_kernel, dim3(B), dim3(64), lds_b, st, emissions, tags, mask, end, trans, alpha, logz, grad_out,
                      demissions, partial, B, S, C);
   const int n = 2 * C + C * C;
   hipLaunchKernelGGL(crf_param_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, grad_out, B, C, dstart,
@@ -274,9 +307,11 @@ int mtvaf_crf_nll_bwd(const float* grad_out, const float* emissions, const int64
 // tags_out [B,S] int32 (best path, -1 padded), lens_out [B] int32.
 int mtvaf_crf_viterbi(const float* emissions, const uint8_t* mask, const float* start, const float* end,
                       const float* trans, int32_t* tags_out, int32_t* lens_out, int B, int S, int C, hipStream_t st) {
-  if (B <= 0 || S <= 0 || C <= 0 || C > CMAX || S > 4096) return MTVAF_ERR_SHAPE;
-  hipLaunchKernelGGL(crf_viterbi_kernel, dim3(B), dim3(64), (size_t)S * CMAX, st, emissions, mask, start, end, trans,
-                     tags_out, lens_out, S, C);
+  if (B <= 0 || S <= 0 || C <= 0 || C > CMAX) return MTVAF_ERR_SHAPE;
+  if ((size_t)S * C * sizeof(float) + (size_t)S * (CMAX + 2) > 64 * 1024) return MTVAF_ERR_SHAPE;
+  const size_t lds_v = (size_t)S * C * sizeof(float) + (size_t)((S + 15) & ~15) + (size_t)S * CMAX;
+  hipLaunchKernelGGL(crf_viterbi_kernel, dim3(B), dim3(64), lds_v, st, emissions, mask, start, end, trans, tags_out,
+                     lens_out, S, C);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
