@@ -162,6 +162,40 @@ int mtvaf_kl_logsoftmax_bwd(const float* grad_out, float gscale, const float* lo
 int mtvaf_mean_l_fwd(const float* enc, float* out, long n, int L, int W4, mtvaf_stream_t stream);
 int mtvaf_mean_l_bwd(const float* dmean, float* denc, long n, int L, int W4, mtvaf_stream_t stream);
 
+/* ---- span model heads: TVNetSAModel.classification + the loss of TVNetSAModel.forward --------------------------
+ * Replaces models/bert_model.py:140-179 (flatten_emb_by_sentence, get_span_representation,
+ * get_self_att_representation), :181-190 (distant_cross_entropy), :288-303 (CrossEntropyLoss on the span logits).
+ * mask [B,S] u8, span_starts/ends [B,M] int64 (token offsets inside each sentence), seq [B*S,H] fp32 (H % 4 == 0,
+ * H <= 1024).  `index` is a device int32 block of mtvaf_span_index_ints(B,S,M) entries that mtvaf_span_index fills
+ * (valid-token compaction, per-span offsets/widths, text length and JR = widest span, clamped to S) -- the sizes
+ * the reference reads back to the host stay on the device.  pooled [B*M,H], stats [B*M,2].
+ * Contract: 0 <= span_starts, span widths <= S (wider spans are clamped; the reference would index past S only
+ * for spans that leave the sentence). */
+size_t mtvaf_span_index_ints(int B, int S, int M);
+int mtvaf_span_index(const uint8_t* mask, const int64_t* span_starts, const int64_t* span_ends, int* index, int B,
+                     int S, int M, mtvaf_stream_t stream);
+int mtvaf_span_pool_fwd(const float* seq, const float* w_unary, const float* b_unary, const int* index,
+                        float* pooled, float* stats, int B, int S, int M, int H, mtvaf_stream_t stream);
+size_t mtvaf_span_pool_bwd_workspace_bytes(int B, int S, int M, int H);
+/* dseq [B*S,H] overwritten (deterministic, no atomics); *dw_part_out [B*M,H] / *db_part_out [B*M] point into the
+ * workspace: their column sums (mtvaf_colsum) are the unary_affine weight / bias gradients. */
+int mtvaf_span_pool_bwd(const float* dpooled, const float* pooled, const float* stats, const float* seq,
+                        const float* w_unary, const float* b_unary, const int* index, float* dseq,
+                        float** dw_part_out, float** db_part_out, int B, int S, int M, int H, void* ws,
+                        size_t ws_bytes, mtvaf_stream_t stream);
+/* loss (+)= scale * -mean_b( sum_s pos log_softmax(logits)_s / sum_s pos );  logits element (b,s) at
+ * logits[(b*S+s)*ld] (the start / end logits are the two columns of the binary_affine output, ld = 2);
+ * positions [B,S] fp32 multi-hot; row_ws [B,3] is kept for the backward. */
+int mtvaf_distant_ce_fwd(const float* logits, int ld, const float* positions, float* loss, float* row_ws, int B,
+                         int S, float scale, int accumulate, mtvaf_stream_t stream);
+int mtvaf_distant_ce_bwd(const float* grad_out, float scale, const float* logits, int ld, const float* positions,
+                         const float* row_ws, float* dlogits, int ldd, int B, int S, mtvaf_stream_t stream);
+/* mean cross entropy over rows with label != -100 (C <= 64); ws2 [2] is kept for the backward. */
+int mtvaf_ce_fwd(const float* logits, const int64_t* labels, float* loss, float* ws2, int N, int C,
+                 mtvaf_stream_t stream);
+int mtvaf_ce_bwd(const float* grad_out, const float* logits, const int64_t* labels, const float* ws2,
+                 float* dlogits, int N, int C, mtvaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

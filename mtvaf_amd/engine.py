@@ -393,3 +393,75 @@ class KLFunction(torch.autograd.Function):
         hip._ck(hip.lib().mtvaf_kl_logsoftmax_bwd(hip._p(g), 1.0, hip._p(z), hip._p(t), hip._p(dz), B, N, hip._st()),
                 "mtvaf_kl_logsoftmax_bwd")
         return dz, None
+
+
+# -------------------------------------------------------------------------------------------------
+# span model heads (TVNetSAModel): reference models/bert_model.py:147-190, 288-305, 363-369
+# -------------------------------------------------------------------------------------------------
+class SpanPoolFunction(torch.autograd.Function):
+    """get_span_representation + unary_affine + get_self_att_representation fused (bert_model.py:364-369):
+    pooled[b*M+m] = sum_r softmax_r(score) x_r over the span's tokens.  `index` comes from hip.span_index."""
+
+    @staticmethod
+    def forward(ctx, seq, w_unary, b_unary, index, M):
+        B, S, H = seq.shape
+        x = seq.contiguous()
+        pooled, stats = _empty(B * M, H, like=x), _empty(B * M, 2, like=x)
+        hip.span_pool_fwd(x, w_unary, b_unary, index, pooled, stats, B, S, M)
+        ctx.stash = (x, w_unary, b_unary, index, pooled, stats, M)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, w_unary, b_unary, index, pooled, stats, M = ctx.stash
+        B, S, H = x.shape
+        dseq = torch.empty_like(x)
+        dw, db = torch.empty_like(w_unary), torch.empty_like(b_unary)
+        hip.span_pool_bwd(dpooled.contiguous(), pooled, stats, x, w_unary, b_unary, index, dseq, dw.view(-1), db, B, S, M)
+        return dseq, dw, db, None, None
+
+
+class DistantCEPairFunction(torch.autograd.Function):
+    """(distant_cross_entropy(start_logits, start_positions) + distant_cross_entropy(end_logits, end_positions)) / 2
+    (bert_model.py:298-300) on the [B,S,2] binary_affine output -- the two logit sets are its columns."""
+
+    @staticmethod
+    def forward(ctx, ae_logits, start_positions, end_positions):
+        B, S, two = ae_logits.shape
+        assert two == 2
+        z = ae_logits.contiguous()
+        sp, ep = start_positions.contiguous().float(), end_positions.contiguous().float()
+        loss, ws = _empty(1, like=z), _empty(2, B, 3, like=z)
+        hip.distant_ce_fwd(z, 2, sp, loss, ws[0], B, S, 0.5, False)
+        hip.distant_ce_fwd(z[..., 1:], 2, ep, loss, ws[1], B, S, 0.5, True)
+        ctx.stash = (z, sp, ep, ws)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        z, sp, ep, ws = ctx.stash
+        B, S, _ = z.shape
+        g = gout.contiguous().view(1).float()
+        dz = torch.empty_like(z)
+        hip.distant_ce_bwd(g, 0.5, z, 2, sp, ws[0], dz, 2, B, S)
+        hip.distant_ce_bwd(g, 0.5, z[..., 1:], 2, ep, ws[1], dz[..., 1:], 2, B, S)
+        return dz, None, None
+
+
+class CrossEntropyFunction(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean over rows whose label != -100) -> 0-dim tensor."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        z, lab = logits.contiguous(), labels.contiguous().long()
+        loss, ws2 = _empty(1, like=z), _empty(2, like=z)
+        hip.ce_fwd(z, lab, loss, ws2)
+        ctx.stash = (z, lab, ws2)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        z, lab, ws2 = ctx.stash
+        dz = torch.empty_like(z)
+        hip.ce_bwd(gout.contiguous().view(1).float(), z, lab, ws2, dz)
+        return dz, None

@@ -53,6 +53,15 @@ _SIGS = {
     "mtvaf_kl_logsoftmax_bwd": (c_int, [P, F, P, P, P, I, I, P]),
     "mtvaf_mean_l_fwd": (c_int, [P, P, L, I, I, P]),
     "mtvaf_mean_l_bwd": (c_int, [P, P, L, I, I, P]),
+    "mtvaf_span_index_ints": (SZ, [I, I, I]),
+    "mtvaf_span_index": (c_int, [P, P, P, P, I, I, I, P]),
+    "mtvaf_span_pool_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, P]),
+    "mtvaf_span_pool_bwd_workspace_bytes": (SZ, [I, I, I, I]),
+    "mtvaf_span_pool_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, SZ, P]),
+    "mtvaf_distant_ce_fwd": (c_int, [P, I, P, P, P, I, I, F, I, P]),
+    "mtvaf_distant_ce_bwd": (c_int, [P, F, P, I, P, P, P, I, I, I, P]),
+    "mtvaf_ce_fwd": (c_int, [P, P, P, P, I, I, P]),
+    "mtvaf_ce_bwd": (c_int, [P, P, P, P, P, I, I, P]),
 }
 
 _lib = None
@@ -312,3 +321,53 @@ def crf_viterbi(em, mask_u8, start, end, trans, tags_out, lens_out):
     B, S, C = em.shape
     _ck(lib().mtvaf_crf_viterbi(_p(em), _p(mask_u8), _p(start), _p(end), _p(trans), _p(tags_out), _p(lens_out), B, S, C,
                                 _st()), "mtvaf_crf_viterbi")
+
+
+# ---- span model heads (csrc/span.hip) -----------------------------------------------------------------------------
+def span_index(mask_u8, span_starts, span_ends):
+    B, S = mask_u8.shape
+    M = span_starts.shape[1]
+    index = torch.empty(lib().mtvaf_span_index_ints(B, S, M), dtype=torch.int32, device=mask_u8.device)
+    _ck(lib().mtvaf_span_index(_p(mask_u8), _p(span_starts), _p(span_ends), _p(index), B, S, M, _st()), "mtvaf_span_index")
+    return index
+
+
+def span_pool_fwd(seq, w_unary, b_unary, index, pooled, stats, B, S, M):
+    H = seq.shape[-1]
+    _ck(lib().mtvaf_span_pool_fwd(_p(seq), _p(w_unary), _p(b_unary), _p(index), _p(pooled), _p(stats), B, S, M, H, _st()),
+        "mtvaf_span_pool_fwd")
+
+
+def span_pool_bwd(dpooled, pooled, stats, seq, w_unary, b_unary, index, dseq, dw, db, B, S, M):
+    """dseq overwritten; dw [H] and db [1] = column sums of the per-span partials (deterministic)."""
+    H = seq.shape[-1]
+    wsb = lib().mtvaf_span_pool_bwd_workspace_bytes(B, S, M, H)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=seq.device)  # private: the colsum below uses the shared one
+    dwp, dbp = ctypes.c_void_p(), ctypes.c_void_p()
+    _ck(lib().mtvaf_span_pool_bwd(_p(dpooled), _p(pooled), _p(stats), _p(seq), _p(w_unary), _p(b_unary), _p(index), _p(dseq),
+                                  ctypes.byref(dwp), ctypes.byref(dbp), B, S, M, H, _p(ws), wsb, _st()), "mtvaf_span_pool_bwd")
+    off_w = (dwp.value - ws.data_ptr()) // 4
+    off_b = (dbp.value - ws.data_ptr()) // 4
+    NS = B * M
+    colsum(ws[off_w:off_w + NS * H].view(NS, H), dw)
+    colsum(ws[off_b:off_b + NS].view(NS, 1), db)
+
+
+def distant_ce_fwd(logits, ld, positions, loss, row_ws, B, S, scale, accumulate):
+    _ck(lib().mtvaf_distant_ce_fwd(_p(logits), ld, _p(positions), _p(loss), _p(row_ws), B, S, float(scale), int(accumulate),
+                                   _st()), "mtvaf_distant_ce_fwd")
+
+
+def distant_ce_bwd(gout, scale, logits, ld, positions, row_ws, dlogits, ldd, B, S):
+    _ck(lib().mtvaf_distant_ce_bwd(_p(gout), float(scale), _p(logits), ld, _p(positions), _p(row_ws), _p(dlogits), ldd, B, S,
+                                   _st()), "mtvaf_distant_ce_bwd")
+
+
+def ce_fwd(logits, labels, loss, ws2):
+    N, C = logits.shape
+    _ck(lib().mtvaf_ce_fwd(_p(logits), _p(labels), _p(loss), _p(ws2), N, C, _st()), "mtvaf_ce_fwd")
+
+
+def ce_bwd(gout, logits, labels, ws2, dlogits):
+    N, C = logits.shape
+    _ck(lib().mtvaf_ce_bwd(_p(gout), _p(logits), _p(labels), _p(ws2), _p(dlogits), N, C, _st()), "mtvaf_ce_bwd")

@@ -1,4 +1,4 @@
-"""TVNetSAModel2 -- the live MTVAF task model (BERT/RoBERTa + visual prefix + CRF tagger), MI355X-native.
+"""TVNetSAModel2 (CRF tagger, the live model) and TVNetSAModel (span variant) -- the MTVAF task models (BERT/RoBERTa + visual prefix + CRF tagger), MI355X-native.
 
 Drop-in for the reference's ``models/bert_model.py::TVNetSAModel2`` (:416-588): same constructor
 ``(label_list, tokenizer, args, type_num=None, use_weight=False)``, same ``forward`` signature and
@@ -216,3 +216,154 @@ class TVNetSAModel2(nn.Module):
         proj_params = [p for m in self.projectors for p in (m.weight, m.bias)]
         pkv = engine.PromptFunction.apply(enc, pp.w, pp.b, NL, *proj_params)
         return PrefixKV(pkv, cfg.num_attention_heads, hidden // cfg.num_attention_heads), img_tag_loss, aux_img_tag_loss
+
+
+
+# ====================================================================================================
+def flatten(x):
+    """reference: models/bert_model.py:113-124"""
+    if x.dim() == 2:
+        return x.reshape(x.shape[0] * x.shape[1])
+    if x.dim() == 3:
+        return x.reshape(x.shape[0] * x.shape[1], x.shape[2])
+    raise Exception()
+
+
+def reconstruct(x, ref):
+    """reference: models/bert_model.py:127-138"""
+    if x.dim() == 1:
+        return x.view(ref.shape[0], ref.shape[1])
+    if x.dim() == 2:
+        return x.view(ref.shape[0], ref.shape[1], x.shape[1])
+    raise Exception()
+
+
+class TVNetSAModel(nn.Module):
+    """Span-extraction variant (reference models/bert_model.py:192-414): the same prefix-fused encoder, a
+    start/end extraction head (``binary_affine``) trained with distant cross entropy, and a span classifier
+    (gather the span's tokens -> ``unary_affine`` self-attention pooling -> ``dense``+tanh -> ``classifier``).
+    Same constructor, ``forward`` / ``extraction`` / ``classification`` / ``get_visual_prompt`` signatures and
+    parameter names as the reference, so ``modules/train.py::SATrainer`` drives it unchanged.
+
+    The reference reads the widest span (``JR``) and the valid-token count back to the host inside
+    ``get_span_representation`` (:160-165); here they stay in a device-side index block
+    (``mtvaf_span_index``), so a training step of this model has no host sync either.
+
+    Not built (out of scope): the GCN branches (``gcn_layer_number`` / ``num_layers`` > 0,
+    whose modules are missing from the reference checkout), the structural probe, and cutoff augmentation
+    (``augument=True`` needs ``apex`` and an import chain that does not resolve in the reference)."""
+
+    def __init__(self, label_list, tokenizer, args, type_num=None, use_weight=False):
+        super().__init__()
+        self.args = args
+        self.type_num = type_num
+        self.tokenizer = tokenizer
+        self.prefix_dim = _arg(args, "prefix_dim", 768)
+        self.prefix_len = _arg(args, "prefix_len", 4)
+        enc_cls = RobertaModel if "roberta" in args.bert_name else BertModel
+        bert_config = _arg(args, "bert_config", None)
+        self.bert = enc_cls(bert_config) if bert_config is not None else enc_cls.from_pretrained(args.bert_name)
+        self.bert.skip_pooler = True  # pooler_output only feeds the (unbuilt) GCN branch (:349)
+        hidden = self.bert.config.hidden_size
+        self.dense = nn.Linear(hidden, hidden)
+        self.activation = nn.Tanh()
+        self.unary_affine = nn.Linear(hidden, 1)
+        self.binary_affine = nn.Linear(hidden, 2)
+        self.num_labels = len(label_list) + 1
+        self.classifier = nn.Linear(hidden, 4)
+        if _arg(args, "use_prefix"):
+            small = _arg(args, "use_34") or _arg(args, "use_18")
+            self.feat_dim = 960 if small else 3840
+            if _arg(args, "resnet_root", None) is not None:
+                self.image_model = ImageModel(use_152=_arg(args, "use_152"), use_101=_arg(args, "use_101"),
+                                              use_34=_arg(args, "use_34"), use_18=_arg(args, "use_18"),
+                                              resnet_root=args.resnet_root)
+            else:
+                self.image_model = None
+            self.encoder_conv = nn.Sequential(nn.Linear(self.feat_dim, 800), nn.Tanh(), nn.Linear(800, 4 * 2 * hidden))
+            self.projectors = nn.ModuleList([nn.Linear(4 * hidden * 2, 4)
+                                             for _ in range(self.bert.config.num_hidden_layers)])
+            self._packed_proj: Optional[_PackedLinears] = None
+        self.fc = nn.Linear(hidden, self.num_labels)  # unused by forward, kept: it is in the reference's state_dict
+        self.dropout = nn.Dropout(0.1)
+        if _arg(args, "gcn_layer_number", 0) > 0 or _arg(args, "num_layers", 0) > 0:
+            raise NotImplementedError("the GCN branches are outside the accelerated path (their modules are not in "
+                                      "the reference checkout either: models/bert_model.py:233-237)")
+        if _arg(args, "use_probe"):
+            raise NotImplementedError("the structural probe (probes/) is off the hot path and its import chain is "
+                                      "broken in the reference (models/bert_model.py:238-245)")
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, start_positions=None,
+                end_positions=None, span_starts=None, span_ends=None, polarity_labels=None, label_masks=None,
+                images=None, aux_imgs=None, valid_ids=None, adjacency_matrix=None, output_attention=False,
+                augument=False, labels=None, adj_matrix=None, src_mask=None, aspect_mask=None, polaritys=None):
+        """reference: models/bert_model.py:246-321 (use_probe / GCN branches excluded)."""
+        bsz = input_ids.size(0)
+        if _arg(self.args, "use_prefix"):
+            prefix_guids = self.get_visual_prompt(images, aux_imgs)
+            prefix_len = prefix_guids[0][0].shape[2]
+            prefix_mask = torch.ones((bsz, prefix_len), device=attention_mask.device, dtype=attention_mask.dtype)
+            prompt_attention_mask = torch.cat((prefix_mask, attention_mask), dim=1)
+        else:
+            prefix_guids = None
+            prompt_attention_mask = attention_mask
+        ae_logits, sequence_output = self._extract(prompt_attention_mask, input_ids, prefix_guids, token_type_ids,
+                                                   augument)
+        logits, ac_logits = self.classification(attention_mask=attention_mask, span_starts=span_starts,
+                                                span_ends=span_ends, sequence_input=sequence_output)
+        flat_polarity_labels = flatten(polarity_labels)
+        flat_label_masks = flatten(label_masks).to(dtype=ac_logits.dtype)
+        # :298-300  (start_loss + end_loss) / 2, both distant cross entropies in one node
+        ae_loss = engine.DistantCEPairFunction.apply(ae_logits, start_positions, end_positions)
+        ac_loss = engine.CrossEntropyFunction.apply(ac_logits, flat_polarity_labels)
+        ac_loss = torch.sum(flat_label_masks * ac_loss) / flat_label_masks.sum()  # :303, the reference's scalar quirk
+        return TokenClassifierOutput(loss=ae_loss + ac_loss, logits=logits)
+
+    def _extract(self, prompt_attention_mask, input_ids, prefix_guids, token_type_ids, augument=False):
+        if augument:
+            raise NotImplementedError("cutoff augmentation (models/bert_model.py:333-343) is outside the accelerated path")
+        bert_output = self.bert(input_ids=input_ids, attention_mask=prompt_attention_mask,
+                                token_type_ids=token_type_ids, past_key_values=prefix_guids, output_attentions=True,
+                                output_hidden_states=True, return_dict=True)
+        sequence_output = engine.dropout(bert_output["last_hidden_state"], self.dropout.p, self.training)
+        ae_logits = engine.LinearFunction.apply(sequence_output, self.binary_affine.weight, self.binary_affine.bias, False)
+        return ae_logits, sequence_output
+
+    def extraction(self, prompt_attention_mask, input_ids, prefix_guids, token_type_ids, augument=False, labels=None,
+                   adj_matrix=None, src_mask=None, aspect_mask=None):
+        """reference: models/bert_model.py:323-361 -> (start_logits [B,S], end_logits [B,S], sequence_output)."""
+        ae_logits, sequence_output = self._extract(prompt_attention_mask, input_ids, prefix_guids, token_type_ids, augument)
+        return ae_logits[..., 0], ae_logits[..., 1], sequence_output
+
+    def classification(self, span_starts, span_ends, sequence_input, attention_mask):
+        """reference: models/bert_model.py:363-376 -> (logits [B,M,4], ac_logits [B*M,4])."""
+        M = span_starts.shape[1]
+        index = engine.hip.span_index(attention_mask.to(torch.uint8).contiguous(), span_starts.contiguous().long(),
+                                      span_ends.contiguous().long())
+        pooled = engine.SpanPoolFunction.apply(sequence_input, self.unary_affine.weight, self.unary_affine.bias, index, M)
+        pooled = engine.LinearFunction.apply(pooled, self.dense.weight, self.dense.bias, True)
+        pooled = engine.dropout(pooled, self.dropout.p, self.training)
+        ac_logits = engine.LinearFunction.apply(pooled, self.classifier.weight, self.classifier.bias, False)
+        return reconstruct(ac_logits, span_starts), ac_logits
+
+    # ------------------------------------------------------------------------------------------------
+    _region_features = TVNetSAModel2._region_features
+
+    def get_visual_prompt(self, images, aux_imgs):
+        """reference: models/bert_model.py:379-414 -> list of num_layers (K, V) [B,NH,P,64]."""
+        feats, aux = self._region_features(images, aux_imgs)
+        bsz, L, Fd = feats.shape
+        cfg = self.bert.config
+        hidden = cfg.hidden_size
+        NI = 1 + len(aux)
+        x = torch.stack([feats] + aux).reshape(NI * bsz * L, Fd)
+        e0, e2 = self.encoder_conv[0], self.encoder_conv[2]
+        t = engine.LinearFunction.apply(x, e0.weight, e0.bias, True)
+        enc = engine.LinearFunction.apply(t, e2.weight, e2.bias, False).view(NI, bsz, L, 8 * hidden)
+        if self._packed_proj is None or not self._packed_proj.valid(self.projectors):
+            self._packed_proj = _PackedLinears(self.projectors)
+        pp = self._packed_proj
+        proj_params = [p for m in self.projectors for p in (m.weight, m.bias)]
+        pkv = engine.PromptFunction.apply(enc, pp.w, pp.b, len(self.projectors), *proj_params)
+        return PrefixKV(pkv, cfg.num_attention_heads, hidden // cfg.num_attention_heads)

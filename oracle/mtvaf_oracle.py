@@ -315,3 +315,61 @@ def tvnet2_forward(sd: Dict[str, Tensor], input_ids: Tensor, attention_mask: Ten
         loss = -1 * crf_log_likelihood(emissions, labels, attention_mask.byte(), *crf, reduction="mean")  # :521
         loss = loss + alpha * img_tag_loss  # :530
     return loss, emissions, tags, hs
+
+
+# --------------------------------------------------------------------------------------
+# Span model TVNetSAModel (models/bert_model.py:113-376): extraction + classification heads
+# --------------------------------------------------------------------------------------
+def span_representation(span_starts: Tensor, span_ends: Tensor, inp: Tensor, input_mask: Tensor):
+    """get_span_representation models/bert_model.py:147-170.  Spans index the FLATTENED list of valid tokens
+    (flatten_emb_by_sentence :140-145); JR = widest span of the batch; positions beyond a span's width are
+    masked, indices beyond the text are clipped to the last token."""
+    input_mask = input_mask.to(dtype=span_starts.dtype)
+    input_len = torch.sum(input_mask, dim=-1)
+    word_offset = torch.cumsum(input_len, dim=0) - input_len
+    s_off = (span_starts + word_offset.unsqueeze(1)).view(-1)
+    e_off = (span_ends + word_offset.unsqueeze(1)).view(-1)
+    width = e_off - s_off + 1
+    JR = int(torch.max(width))
+    B, S, H = inp.shape
+    ctx = inp.reshape(B * S, H)[input_mask.reshape(B * S).nonzero().squeeze(-1), :]
+    text_length = ctx.shape[0]
+    idx = torch.arange(JR).unsqueeze(0) + s_off.unsqueeze(1)
+    idx = torch.min(idx, (text_length - 1) * torch.ones_like(idx))
+    emb = ctx[idx, :]
+    span_mask = torch.arange(JR) < width.unsqueeze(-1)
+    return emb, span_mask
+
+
+def self_att_representation(inp: Tensor, score: Tensor, mask: Tensor) -> Tensor:
+    """get_self_att_representation models/bert_model.py:172-179."""
+    score = score + (1.0 - mask.to(score.dtype)) * -10000.0
+    prob = torch.softmax(score, dim=-1).unsqueeze(-1)
+    return torch.sum(prob * inp, dim=1)
+
+
+def distant_cross_entropy(logits: Tensor, positions: Tensor) -> Tensor:
+    """distant_cross_entropy models/bert_model.py:181-190 (mask=None branch, the one the model uses :298-299)."""
+    logp = torch.log_softmax(logits, dim=-1)
+    pos = positions.to(logp.dtype)
+    return -1 * torch.mean(torch.sum(pos * logp, dim=-1) / torch.sum(pos, dim=-1))
+
+
+def tvnet1_heads(sd: Dict[str, Tensor], sequence_output: Tensor, attention_mask: Tensor, span_starts: Tensor,
+                 span_ends: Tensor, start_positions: Tensor, end_positions: Tensor, polarity_labels: Tensor,
+                 label_masks: Tensor):
+    """TVNetSAModel.extraction (:351-354) + classification (:363-376) + the loss of forward (:288-305), given the
+    (dropped-out) encoder output.  Returns (tot_loss, logits [B,M,4], start_logits, end_logits)."""
+    ae = F.linear(sequence_output, sd["binary_affine.weight"], sd["binary_affine.bias"])
+    start_logits, end_logits = ae[..., 0], ae[..., 1]
+    emb, smask = span_representation(span_starts, span_ends, sequence_output, attention_mask)
+    score = F.linear(emb, sd["unary_affine.weight"], sd["unary_affine.bias"]).squeeze(-1)
+    pooled = self_att_representation(emb, score, smask)
+    pooled = torch.tanh(F.linear(pooled, sd["dense.weight"], sd["dense.bias"]))
+    ac_logits = F.linear(pooled, sd["classifier.weight"], sd["classifier.bias"])
+    B, M = span_starts.shape
+    ae_loss = (distant_cross_entropy(start_logits, start_positions) + distant_cross_entropy(end_logits, end_positions)) / 2
+    ac_loss = F.cross_entropy(ac_logits, polarity_labels.reshape(-1))
+    flat_masks = label_masks.reshape(-1).to(ac_logits.dtype)
+    ac_loss = torch.sum(flat_masks * ac_loss) / flat_masks.sum()  # reference quirk (:302-303): a scalar times the mask
+    return ae_loss + ac_loss, ac_logits.view(B, M, -1), start_logits, end_logits

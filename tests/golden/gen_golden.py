@@ -324,6 +324,47 @@ def gen_tvnet2(name, seed, B, S, n_aux):
     print(f"[golden] {name}: ok loss={float(out.loss):.5f}")
 
 
+def gen_tvnet1(name, seed, B, S, M):
+    """TVNetSAModel (span variant) extraction/classification heads + loss on top of the tiny reference encoder."""
+    import torch.nn as nn
+    from models.bert_model import TVNetSAModel
+    cfg = P.TINY_BERT_L8
+    lengths = [S, S - 5, 6][:B]
+    sde = P.encoder_params(cfg, seed)
+    ids, mask, tt, _ = P.text_batch(cfg, seed + 1, B, S, lengths)
+    starts, ends, spos, epos, pol, lm = P.span_batch(cfg, seed + 2, B, S, M, lengths)
+    sdh = P.span_head_params(cfg, seed + 3)
+    args = types.SimpleNamespace(use_prefix=False, use_probe=False, num_layers=0, gcn_layer_number=0, n_gpu=1, device="cpu")
+    s = types.SimpleNamespace(args=args)
+    s.bert = ref_encoder(cfg, sde)
+    s.dense, s.activation = nn.Linear(cfg.hidden, cfg.hidden), nn.Tanh()
+    s.unary_affine, s.binary_affine = nn.Linear(cfg.hidden, 1), nn.Linear(cfg.hidden, 2)
+    s.classifier, s.dropout = nn.Linear(cfg.hidden, 4), nn.Dropout(0.0)
+    holder = nn.Module()
+    holder.dense, holder.unary_affine, holder.binary_affine, holder.classifier = s.dense, s.unary_affine, s.binary_affine, s.classifier
+    holder.load_state_dict(sdh)
+    s.extraction = types.MethodType(TVNetSAModel.extraction, s)
+    s.classification = types.MethodType(TVNetSAModel.classification, s)
+    out = TVNetSAModel.forward(s, input_ids=ids, attention_mask=mask, token_type_ids=tt, start_positions=spos,
+                               end_positions=epos, span_starts=starts, span_ends=ends, polarity_labels=pol, label_masks=lm)
+    st, en, seq = s.extraction(mask, ids, None, tt)
+    out.loss.backward()
+    named = dict(holder.named_parameters())
+    fx = {"seed": seed, "B": B, "S": S, "M": M, "lengths": np.array(lengths), "loss": np.float32(float(out.loss)),
+          "logits": t2n(out.logits), "start_logits": t2n(st), "end_logits": t2n(en),
+          "g_dense_w": t2n(named["dense.weight"].grad), "g_unary_w": t2n(named["unary_affine.weight"].grad),
+          "g_unary_b": t2n(named["unary_affine.bias"].grad), "g_binary_w": t2n(named["binary_affine.weight"].grad),
+          "g_cls_b": t2n(named["classifier.bias"].grad),
+          "g_o1_w": t2n(dict(s.bert.named_parameters())[f"encoder.layer.{cfg.layers - 1}.output.dense.weight"].grad)}
+    # oracle cross-check
+    hs = O.bert_model(sde, ids, mask, tt, None, cfg.layers, cfg.heads, cfg.eps)
+    oloss, ologits, ost, oen = O.tvnet1_heads(sdh, hs[-1], mask, starts, ends, spos, epos, pol, lm)
+    assert abs(float(oloss) - float(out.loss)) < 1e-5 * max(1.0, abs(float(out.loss))), (float(oloss), float(out.loss))
+    assert (ologits - out.logits).abs().max().item() < 2e-5
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+    print(f"[golden] {name}: ok loss={float(out.loss):.5f}")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -342,6 +383,7 @@ def main():
     gen_prompt("prompt_novao", 400, B=2, n_aux=3, vao=False)
     gen_prompt("prompt_vao", 410, B=2, n_aux=3, vao=True)
     gen_tvnet2("tvnet2_base_B2S16", 500, B=2, S=16, n_aux=3)
+    gen_tvnet1("tvnet1_tiny_B3S16", 600, B=3, S=16, M=5)
 
 
 if __name__ == "__main__":

@@ -29,6 +29,7 @@ class EncCfg:
 
 
 TINY_BERT = EncCfg()
+TINY_BERT_L8 = EncCfg(layers=8)  # the span model reads hidden_states[7] (bert_model.py:331): needs >= 7 layers
 TINY_ROBERTA = EncCfg(type_vocab=1, eps=1e-5, roberta=True, pad_idx=1, max_pos=66)
 BASE_BERT = EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=12, max_pos=512)
 BASE_ROBERTA = EncCfg(vocab_size=50265, hidden=768, heads=12, inter=3072, layers=12, max_pos=514,
@@ -132,3 +133,35 @@ def prefix_kv(seed: int, layers: int, B: int, heads: int, P: int, D: int = 64, s
         return None
     rng = np.random.default_rng(seed)
     return [(_normal(rng, (B, heads, P, D), std), _normal(rng, (B, heads, P, D), std)) for _ in range(layers)]
+
+
+def span_batch(cfg, seed, B, S, M, lengths):
+    """Synthetic span supervision: M candidate spans per sentence inside the valid tokens, multi-hot start/end
+    positions (distant supervision), polarity labels 0..3, a few masked (padding) span slots."""
+    rng = np.random.default_rng(seed)
+    starts = np.zeros((B, M), dtype=np.int64)
+    ends = np.zeros((B, M), dtype=np.int64)
+    spos = np.zeros((B, S), dtype=np.int64)
+    epos = np.zeros((B, S), dtype=np.int64)
+    for b, L in enumerate(lengths):
+        for m in range(M):
+            a = int(rng.integers(1, max(2, L - 1)))
+            w = int(rng.integers(1, 5))
+            starts[b, m], ends[b, m] = a, min(L - 1, a + w - 1)
+        for _ in range(2):
+            a = int(rng.integers(1, L))
+            spos[b, a] = 1
+            epos[b, min(L - 1, a + int(rng.integers(0, 3)))] = 1
+    pol = rng.integers(0, 4, size=(B, M)).astype(np.int64)
+    lm = (rng.random((B, M)) > 0.3).astype(np.int64)
+    lm[:, 0] = 1
+    return tuple(torch.from_numpy(x) for x in (starts, ends, spos, epos, pol, lm))
+
+
+def span_head_params(cfg, seed):
+    rng = np.random.default_rng(seed)
+    H = cfg.hidden
+    n = lambda shape, std: torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(std))
+    return {"dense.weight": n((H, H), 0.05), "dense.bias": n((H,), 0.02), "unary_affine.weight": n((1, H), 0.1),
+            "unary_affine.bias": n((1,), 0.02), "binary_affine.weight": n((2, H), 0.1), "binary_affine.bias": n((2,), 0.02),
+            "classifier.weight": n((4, H), 0.1), "classifier.bias": n((4,), 0.02)}

@@ -132,3 +132,30 @@ def test_tvnet2_end_to_end_base_dims():
     np.testing.assert_allclose(float(loss), float(fx["loss"]), rtol=1e-5)
     exp = [[int(t) for t in row if t >= 0] for row in fx["tags"]]
     assert tags == exp
+
+
+def test_span_model_heads_golden():
+    """TVNetSAModel (span variant) heads + loss on the 8-layer tiny encoder vs the fixture captured from the
+    reference class (models/bert_model.py:246-376)."""
+    fx = load("tvnet1_tiny_B3S16")
+    cfg = P.TINY_BERT_L8
+    seed, B, S, M = int(fx["seed"]), int(fx["B"]), int(fx["S"]), int(fx["M"])
+    lengths = [int(x) for x in fx["lengths"]]
+    sde = {k: v.clone().requires_grad_(True) for k, v in P.encoder_params(cfg, seed).items()}
+    sdh = {k: v.clone().requires_grad_(True) for k, v in P.span_head_params(cfg, seed + 3).items()}
+    ids, mask, tt, _ = P.text_batch(cfg, seed + 1, B, S, lengths)
+    starts, ends, spos, epos, pol, lm = P.span_batch(cfg, seed + 2, B, S, M, lengths)
+    hs = O.bert_model(sde, ids, mask, tt, None, cfg.layers, cfg.heads, cfg.eps)
+    loss, logits, st, en = O.tvnet1_heads(sdh, hs[-1], mask, starts, ends, spos, epos, pol, lm)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-5 * abs(float(fx["loss"]))
+    np.testing.assert_allclose(logits.detach().numpy(), fx["logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(st.detach().numpy(), fx["start_logits"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(en.detach().numpy(), fx["end_logits"], rtol=1e-4, atol=2e-5)
+    loss.backward()
+    for k, pn in {"g_dense_w": "dense.weight", "g_unary_w": "unary_affine.weight", "g_unary_b": "unary_affine.bias",
+                  "g_binary_w": "binary_affine.weight", "g_cls_b": "classifier.bias"}.items():
+        ref = fx[k]
+        np.testing.assert_allclose(sdh[pn].grad.numpy(), ref, rtol=2e-3, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    ref = fx["g_o1_w"]
+    np.testing.assert_allclose(sde[f"encoder.layer.{cfg.layers - 1}.output.dense.weight"].grad.numpy(), ref, rtol=2e-3,
+                               atol=2e-5 * max(1.0, np.abs(ref).max()))
