@@ -258,9 +258,9 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
-__global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p) {
-  constexpr int BK = 32, NSTAGE = 3;
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE = 3>
+__global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma_kernel(GemmArgs p) {
+  constexpr int BK = 32;
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int A_SZ = BM * BK, B_SZ = BN * BK, STAGE = A_SZ + B_SZ;  // floats
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
   f32x4 fa0[TM], fb0[TN];  // k-block 0 fragments of the tile about to be computed (loop-carried)
 
   // PHASE 2: steady (issue tile kt+2, publish kt+1); 1: second-to-last (publish kt+1, all DMA landed); 0: last
+  // PHASE 3 (2-stage ring, two blocks per CU): issue tile kt+1 into the stage tile kt-1 left, publish it
   auto tile_body = [&](auto phase_tag, int stage, int next_stage, int issue_stage) {
     constexpr int PHASE = decltype(phase_tag)::value;
     const float* a = smem + stage * STAGE;
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
     load_frags(a, b, 1, fa1, fb1);
     load_frags(a, b, 2, fa2, fb2);
     mfma_group(fa0, fb0);
-    if constexpr (PHASE == 2) issue(issue_stage);
+    if constexpr (PHASE >= 2) issue(issue_stage);  // (issuing the 2-stage ring's DMA one k-block earlier measured 3 % slower)
     load_frags(a, b, 3, fa3, fb3);
     mfma_group(fa1, fb1);
     mfma_group(fa2, fb2);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
 #pragma unroll
     for (int i = 0; i < NMF; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if (PHASE == 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (PHASE >= 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
     }
 #pragma unroll
     for (int i = 0; i < NMF; ++i) {
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
   };
 
   issue(0);
-  if (nk > 1) {
+  if (NSTAGE == 3 && nk > 1) {
     issue(1);
     wait_vmcnt<IA + IB>();
   } else {
@@ -460,16 +461,24 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void gemm_f32_dma_kernel(GemmArgs p
   int st_c = 0;
   auto nxt = [](int st) { return st == NSTAGE - 1 ? 0 : st + 1; };
   int kt = 0;
-  for (; kt + 2 < nk; ++kt) {
-    const int s1 = nxt(st_c);
-    tile_body(std::integral_constant<int, 2>{}, st_c, s1, nxt(s1));
-    st_c = s1;
-  }
-  if (kt + 1 < nk) {
-    const int s1 = nxt(st_c);
-    tile_body(std::integral_constant<int, 1>{}, st_c, s1, 0);
-    st_c = s1;
-    ++kt;
+  if constexpr (NSTAGE == 3) {
+    for (; kt + 2 < nk; ++kt) {
+      const int s1 = nxt(st_c);
+      tile_body(std::integral_constant<int, 2>{}, st_c, s1, nxt(s1));
+      st_c = s1;
+    }
+    if (kt + 1 < nk) {
+      const int s1 = nxt(st_c);
+      tile_body(std::integral_constant<int, 1>{}, st_c, s1, 0);
+      st_c = s1;
+      ++kt;
+    }
+  } else {
+    for (; kt + 1 < nk; ++kt) {
+      const int s1 = nxt(st_c);
+      tile_body(std::integral_constant<int, 3>{}, st_c, s1, s1);
+      st_c = s1;
+    }
   }
   if (kt < nk) tile_body(std::integral_constant<int, 0>{}, st_c, 0, 0);
 
@@ -538,17 +547,19 @@ static inline bool splittable(int epi) { return epi == EPI_NONE || epi == EPI_TA
 struct TileCfg { int bm, bn, bk; };
 static const TileCfg kCfgs[] = {{128, 128, 16}, {128, 96, 16}, {128, 288, 16}, {64, 64, 16}, {128, 64, 16},
                                 {128, 128, 32}, {128, 96, 32}, {128, 192, 16}, {128, 192, 32},
-                                {128, 96, 32}, {128, 128, 32}, {128, 192, 32}};  // 9..11: LDS-DMA pipeline (FAST only)
-constexpr int kNumCfgs = 12;
+                                {128, 96, 32}, {128, 128, 32}, {128, 192, 32},   // 9..11: LDS-DMA pipeline (FAST only)
+                                {128, 96, 32}, {128, 128, 32}};  // 12..13: 2-stage LDS-DMA ring, two blocks per CU
+constexpr int kNumCfgs = 14;
 constexpr int kFirstDma = 9;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
 static int launch_dma(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
-  const size_t smem = (size_t)3 * (BM + BN) * 32 * sizeof(float);
+  size_t smem = (size_t)NSTAGE * (BM + BN) * 32 * sizeof(float);
+  if (smem < (size_t)BM * (BN + 4) * sizeof(float)) smem = (size_t)BM * (BN + 4) * sizeof(float);  // wide epilogue image
   dim3 block(WM * WN * 64);
 #define MTVAF_DMA_LAUNCH(AK, BKM)                                                                                   \
   do {                                                                                                               \
-    auto kern = gemm_f32_dma_kernel<BM, BN, WM, WN, AK, BKM>;                                                        \
+    auto kern = gemm_f32_dma_kernel<BM, BN, WM, WN, AK, BKM, NSTAGE>;                                                      \
     static bool attr_set = false;                                                                                    \
     if (smem > 64 * 1024 && !attr_set) {                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
@@ -612,7 +623,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
                    int compute = 0) {
   //                                  128x128 128x96 128x288 64x64 128x64 128x128x32 128x96x32 128x192 128x192x32
   static const double eff_base[kNumCfgs] = {0.80, 0.86, 0.72, 0.45, 0.80, 0.70, 1.00, 0.92, 0.78,
-                                            1.18, 1.00, 0.85};  // 9..11: LDS-DMA pipeline
+                                            1.18, 1.00, 0.85,   // 9..11: LDS-DMA pipeline
+                                            1.18, 1.00};        // 12..13: same tiles, 2-stage ring, two blocks per CU
   double eff[kNumCfgs];
   for (int c = 0; c < kNumCfgs; ++c) {
     eff[c] = eff_base[c];
@@ -621,8 +633,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       if (!aligned || (la == 1 && lb == 0)) eff[c] = 0.0;  // KM x KC never occurs on the path
       // one 84-KB block per CU cannot overlap a GELU-class epilogue with the next tile's main loop (measured:
       // tools/gemm_sweep.py): the 128x128 DMA tile amortises it best forward, the staged kernel backward
-      if (epi == EPI_GELU) eff[c] *= (c == 10 ? 1.10 : 0.90);
-      if (epi == EPI_DGELU) eff[c] *= (c == 10 ? 1.02 : 0.85);
+      if (epi == EPI_GELU) eff[c] *= ((c == 10 || c == 13) ? 1.10 : 0.90);
+      if (epi == EPI_DGELU) eff[c] *= ((c == 10 || c == 13) ? 1.02 : 0.85);
     }
   }
   double best = 1e300;
@@ -638,7 +650,10 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       const long rounds = cdiv(tiles * s, 256);
       const double kc = (double)cdiv(cdiv(K, s), bk) * bk;
       // per tile: (bm*bn*kc*2 flop) / (256 flop/clk/CU) cycles at 100 %
-      double cost = (double)rounds * bm * bn * kc / 128.0 / eff[c];
+      // two co-resident blocks hide each other's prologue / epilogue / barrier stalls once every CU holds two
+      // (measured +8..9 % at >= 2 tiles per CU, -3..5 % with a single tile per CU: the 2-stage ring is shallower)
+      const double occ2 = c >= 12 ? (tiles * s >= 512 ? 1.08 : 0.95) : 1.0;
+      double cost = (double)rounds * bm * bn * kc / 128.0 / (eff[c] * occ2);
       cost += 3000.0;  // fill/drain + launch
       if (s > 1) {
         // slabs: s*M*N floats written then read once (plus the final write) at ~4 TB/s ~ 1.7 KB/clk chip-wide
@@ -768,7 +783,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
            (a.slab_stride % 4 == 0);
   if (cfg >= kFirstDma && !(aligned && !(layout_a == 1 && layout_b == 0))) {
     if (cfg_forced) return MTVAF_ERR_SHAPE;
-    static const int staged_twin[3] = {6, 5, 8};  // same tile, register-staged kernel (handles any alignment)
+    static const int staged_twin[5] = {6, 5, 8, 6, 5};  // same tile, register-staged kernel (handles any alignment)
     cfg = staged_twin[cfg - kFirstDma];
   }
   ProfRec* pr = nullptr;
@@ -786,6 +801,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;
     case 10: rc = launch_dma<128, 128, 2, 2>(a, layout_a, layout_b, grid, stream); break;
     case 11: rc = launch_dma<128, 192, 2, 2>(a, layout_a, layout_b, grid, stream); break;
+    case 12: rc = launch_dma<128, 96, 4, 1, 2>(a, layout_a, layout_b, grid, stream); break;
+    case 13: rc = launch_dma<128, 128, 2, 2, 2>(a, layout_a, layout_b, grid, stream); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 16>(a, layout_a, layout_b, grid, mode, stream); break;
     case 1: rc = launch_cfg<128, 96, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
     case 2: rc = launch_cfg<128, 288, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
