@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="GEMM arithmetic: fp32 (BASELINE config 2, default) or bf16 compute with fp32 accumulation (configs 3-4)")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--optimizer", default="all", choices=["all", "reference"],
+                    help="all: fused AdamW over every parameter; reference: the three name-matched groups + linear "
+                         "warm-up schedule of modules/train.py:894-926 (mtvaf_amd.optim)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -173,8 +176,14 @@ def main():
     if world > 1:
         from mtvaf_amd.parallel import GradSync
         sync = GradSync(model)
-    opt = None if a.no_optimizer else torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5,
-                                                        weight_decay=1e-2, fused=True)
+    sched = None
+    if a.no_optimizer:
+        opt = None
+    elif a.optimizer == "reference":
+        from mtvaf_amd.optim import build_optimizer
+        opt, sched = build_optimizer(model, types.SimpleNamespace(lr=3e-5, warmup_ratio=0.01, use_prefix=True), 100000)
+    else:
+        opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, fused=True)
     batch = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, a.full_length)
     ids, mask, tt, labels, feats, aux = batch
 
@@ -184,6 +193,8 @@ def main():
         out.loss.backward()
         if opt is not None:
             opt.step()
+            if sched is not None:
+                sched.step()
             opt.zero_grad(set_to_none=True)
         else:
             for p in model.parameters():

@@ -133,6 +133,7 @@ class EncoderFunction(torch.autograd.Function):
             outs.append(h2.view(B, S, H))
             x = h2
         ctx.stash = (saved, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
+        ctx.set_materialize_grads(False)  # unused hidden states arrive as None, not as [B,S,H] zero fills + adds
         return tuple(outs)
 
     @staticmethod

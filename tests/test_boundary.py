@@ -97,3 +97,27 @@ def test_span_model_parameter_names_and_surface():
     with pytest.raises(RuntimeError):  # no GPU here: the product path must refuse, not fall back
         ids = torch.ones(1, 4, dtype=torch.long)
         m.extraction(torch.ones(1, 4, dtype=torch.long), ids, None, torch.zeros_like(ids))
+
+
+def test_reference_optimizer_groups_and_schedule():
+    """mtvaf_amd.optim mirrors modules/train.py:887-926: groups by name, lr 5e-2 for crf/fc, projectors in no
+    group (reference quirk), linear warm-up schedule equal to transformers' implementation."""
+    from transformers import get_linear_schedule_with_warmup
+    from mtvaf_amd.optim import build_optimizer, reference_param_groups
+    m = tiny_model()
+    groups = reference_param_groups(m, 3e-5)
+    assert [len(g["params"]) for g in groups] == [5 + 16 * 2 + 2, 4, 5]
+    assert [g["lr"] for g in groups] == [3e-5, 3e-5, 5e-2] and all(g["weight_decay"] == 1e-2 for g in groups)
+    in_groups = {id(p) for g in groups for p in g["params"]}
+    named = dict(m.named_parameters())
+    assert id(named["projectors.0.weight"]) not in in_groups and id(named["img_classifier.bias"]) not in in_groups
+    args = types.SimpleNamespace(lr=3e-5, warmup_ratio=0.01, use_prefix=True)
+    opt, sched = build_optimizer(m, args, train_num_steps=250)
+    ref_opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=3e-5)
+    ref = get_linear_schedule_with_warmup(ref_opt, num_warmup_steps=0.01 * 250, num_training_steps=250)
+    for _ in range(20):
+        assert abs(sched.get_last_lr()[0] - ref.get_last_lr()[0]) < 1e-12
+        assert abs(sched.get_last_lr()[2] / 5e-2 - ref.get_last_lr()[0] / 3e-5) < 1e-9
+        opt.step(); sched.step(); ref_opt.step(); ref.step()
+    one = reference_param_groups(tiny_model(use_prefix=False), 1e-5, use_prefix=False)
+    assert len(one) == 1 and len(one[0]["params"]) == len(list(tiny_model(use_prefix=False).parameters()))
