@@ -196,6 +196,12 @@ int mtvaf_ce_fwd(const float* logits, const int64_t* labels, float* loss, float*
 int mtvaf_ce_bwd(const float* grad_out, const float* logits, const int64_t* labels, const float* ws2,
                  float* dlogits, int N, int C, mtvaf_stream_t stream);
 
+/* Cutoff augmentation on the embedding output (modules/augument.py:99-159): out = x * row_keep[b,s] * col_keep[b,:]
+ * (either mask may be NULL); x/out [B,S,H] fp32, row_keep [B*S], col_keep [B,H].  Self-adjoint: the backward is the
+ * same call on the gradient. */
+int mtvaf_mask_mul(const float* x, const float* row_keep, const float* col_keep, float* out, int B, int S, int H,
+                   mtvaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

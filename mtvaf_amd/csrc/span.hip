@@ -10,6 +10,7 @@
 // .item(), nonzero()); here both live in a small device-side `meta` block so the step has no host sync.
 // All kernels are HBM/latency-bound row operations: one wave64 per span / token / row, float4 accesses.
 #include "common.h"
+#include <algorithm>
 
 namespace mtvaf {
 
@@ -317,6 +318,22 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ g
   }
 }
 
+// Cutoff augmentation (modules/augument.py:99-159): out[b,s,:] = x[b,s,:] * row_keep[b,s] * col_keep[b,:]
+// (span / token cutoff zero whole token rows, dim cutoff zeroes embedding dimensions per sample).  Its own
+// backward: the same product applied to the incoming gradient.
+__global__ __launch_bounds__(256) void mask_mul_kernel(const float* __restrict__ x, const float* __restrict__ row_keep,
+                                                      const float* __restrict__ col_keep, float* __restrict__ out,
+                                                      long n4, int S, int H4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const long row = i / H4;
+    const int c = (int)(i % H4);
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    if (row_keep) v *= row_keep[row];
+    if (col_keep) v *= reinterpret_cast<const f32x4*>(col_keep)[(row / S) * H4 + c];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+  }
+}
+
 }  // namespace mtvaf
 
 using namespace mtvaf;
@@ -416,6 +433,16 @@ int mtvaf_ce_bwd(const float* grad_out, const float* logits, const int64_t* labe
                  int C, hipStream_t st) {
   if (N <= 0 || C <= 0 || C > 64) return MTVAF_ERR_SHAPE;
   hipLaunchKernelGGL(ce_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, grad_out, logits, labels, ws2, dlogits, N, C);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+int mtvaf_mask_mul(const float* x, const float* row_keep, const float* col_keep, float* out, int B, int S, int H,
+                   hipStream_t st) {
+  if (B <= 0 || S <= 0 || H <= 0 || H % 4) return MTVAF_ERR_SHAPE;
+  const long n4 = (long)B * S * (H / 4);
+  hipLaunchKernelGGL(mask_mul_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 4096)), dim3(256), 0, st, x, row_keep,
+                     col_keep, out, n4, S, H / 4);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

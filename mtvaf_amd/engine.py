@@ -466,3 +466,19 @@ class CrossEntropyFunction(torch.autograd.Function):
         dz = torch.empty_like(z)
         hip.ce_bwd(gout.contiguous().view(1).float(), z, lab, ws2, dz)
         return dz, None
+
+
+class MaskMulFunction(torch.autograd.Function):
+    """Cutoff augmentation apply (modules/augument.py:99-159): x * row_keep[b,s] * col_keep[b,:]."""
+
+    @staticmethod
+    def forward(ctx, x, row_keep, col_keep):
+        xc = x.contiguous()
+        ctx.stash = (row_keep, col_keep)
+        return hip.mask_mul(xc, row_keep, col_keep, torch.empty_like(xc))
+
+    @staticmethod
+    def backward(ctx, dy):
+        row_keep, col_keep = ctx.stash
+        dyc = dy.contiguous()
+        return hip.mask_mul(dyc, row_keep, col_keep, torch.empty_like(dyc)), None, None

@@ -62,6 +62,7 @@ _SIGS = {
     "mtvaf_distant_ce_bwd": (c_int, [P, F, P, I, P, P, P, I, I, I, P]),
     "mtvaf_ce_fwd": (c_int, [P, P, P, P, I, I, P]),
     "mtvaf_ce_bwd": (c_int, [P, P, P, P, P, I, I, P]),
+    "mtvaf_mask_mul": (c_int, [P, P, P, P, I, I, I, P]),
 }
 
 _lib = None
@@ -372,3 +373,9 @@ def ce_fwd(logits, labels, loss, ws2):
 def ce_bwd(gout, logits, labels, ws2, dlogits):
     N, C = logits.shape
     _ck(lib().mtvaf_ce_bwd(_p(gout), _p(logits), _p(labels), _p(ws2), _p(dlogits), N, C, _st()), "mtvaf_ce_bwd")
+
+
+def mask_mul(x, row_keep, col_keep, out):
+    B, S, H = x.shape
+    _ck(lib().mtvaf_mask_mul(_p(x), _p(row_keep), _p(col_keep), _p(out), B, S, H, _st()), "mtvaf_mask_mul")
+    return out

@@ -249,9 +249,9 @@ class TVNetSAModel(nn.Module):
     ``get_span_representation`` (:160-165); here they stay in a device-side index block
     (``mtvaf_span_index``), so a training step of this model has no host sync either.
 
+    ``augument=True`` runs the cutoff augmentation of ``modules/augument.py`` (``mtvaf_amd.modules.augument``).
     Not built (out of scope): the GCN branches (``gcn_layer_number`` / ``num_layers`` > 0,
-    whose modules are missing from the reference checkout), the structural probe, and cutoff augmentation
-    (``augument=True`` needs ``apex`` and an import chain that does not resolve in the reference)."""
+    whose modules are missing from the reference checkout) and the structural probe."""
 
     def __init__(self, label_list, tokenizer, args, type_num=None, use_weight=False):
         super().__init__()
@@ -322,11 +322,17 @@ class TVNetSAModel(nn.Module):
 
     def _extract(self, prompt_attention_mask, input_ids, prefix_guids, token_type_ids, augument=False):
         if augument:
-            raise NotImplementedError("cutoff augmentation (models/bert_model.py:333-343) is outside the accelerated path")
-        bert_output = self.bert(input_ids=input_ids, attention_mask=prompt_attention_mask,
-                                token_type_ids=token_type_ids, past_key_values=prefix_guids, output_attentions=True,
-                                output_hidden_states=True, return_dict=True)
-        sequence_output = engine.dropout(bert_output["last_hidden_state"], self.dropout.p, self.training)
+            # :333-343 -- the cut input replaces the plain pass (the reference still runs the plain encoder first
+            # and throws its output away; only hidden_states[7] of it feeds the unbuilt probe)
+            from ..modules.augument import Cutoff
+            cutoff = Cutoff(input_ids=input_ids, token_type_ids=token_type_ids, attention_masks=prompt_attention_mask,
+                            prefix_guids=prefix_guids, args=self.args, model=self.bert)
+            last_hidden = cutoff._training_step_with_cutoff(self.args.aug_type)[0]
+        else:
+            last_hidden = self.bert(input_ids=input_ids, attention_mask=prompt_attention_mask,
+                                    token_type_ids=token_type_ids, past_key_values=prefix_guids, output_attentions=True,
+                                    output_hidden_states=True, return_dict=True)["last_hidden_state"]
+        sequence_output = engine.dropout(last_hidden, self.dropout.p, self.training)
         ae_logits = engine.LinearFunction.apply(sequence_output, self.binary_affine.weight, self.binary_affine.bias, False)
         return ae_logits, sequence_output
 

@@ -441,4 +441,5 @@ class BertModel(nn.Module):
         ext = self.get_extended_attention_mask(attention_mask)
         enc = self.encoder(embedding_output, attention_mask=ext, past_key_values=past_key_values, return_dict=True)
         seq = enc.last_hidden_state
-        return (seq, self.pooler(seq))
+        pooled = self.pooler(seq) if (self.pooler is not None and not getattr(self, "skip_pooler", False)) else None
+        return (seq, pooled)

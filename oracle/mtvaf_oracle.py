@@ -373,3 +373,42 @@ def tvnet1_heads(sd: Dict[str, Tensor], sequence_output: Tensor, attention_mask:
     flat_masks = label_masks.reshape(-1).to(ac_logits.dtype)
     ac_loss = torch.sum(flat_masks * ac_loss) / flat_masks.sum()  # reference quirk (:302-303): a scalar times the mask
     return ae_loss + ac_loss, ac_logits.view(B, M, -1), start_logits, end_logits
+
+
+# --------------------------------------------------------------------------------------
+# Cutoff augmentation (modules/augument.py:99-159), with the random draws passed in
+# --------------------------------------------------------------------------------------
+def cutoff_span(embeds: Tensor, masks: Tensor, input_lens: Tensor, ratio: float, u: Tensor):
+    """generate_span_cutoff_embedding :99-117; ``u[i]`` stands for the reference's ``torch.rand(1)`` of sample i."""
+    out_e, out_m = [], []
+    for i in range(embeds.shape[0]):
+        cutoff_length = int(input_lens[i] * ratio)
+        start = int(u[i] * (input_lens[i] - cutoff_length))
+        out_e.append(torch.cat((embeds[i][:start], torch.zeros([cutoff_length, embeds.shape[-1]], dtype=torch.float),
+                                embeds[i][start + cutoff_length:]), dim=0))
+        out_m.append(torch.cat((masks[i][:start], torch.zeros([cutoff_length], dtype=torch.long),
+                                masks[i][start + cutoff_length:]), dim=0))
+    return torch.stack(out_e, dim=0), torch.stack(out_m, dim=0)
+
+
+def cutoff_token(embeds: Tensor, masks: Tensor, zero_index: Sequence[Tensor]):
+    """generate_token_cutoff_embedding :120-141; ``zero_index[i]`` stands for ``torch.randint(len_i, (cutoff_length,))``."""
+    out_e, out_m = [], []
+    for i in range(embeds.shape[0]):
+        tmp_mask = torch.ones(embeds[i].shape[0])
+        for ind in zero_index[i]:
+            tmp_mask[ind] = 0
+        out_e.append(torch.mul(tmp_mask[:, None], embeds[i]))
+        out_m.append(torch.mul(tmp_mask, masks[i]).type(torch.int64))
+    return torch.stack(out_e, dim=0), torch.stack(out_m, dim=0)
+
+
+def cutoff_dim(embeds: Tensor, masks: Tensor, zero_index: Sequence[Tensor]):
+    """generate_dim_cutoff_embedding :144-159."""
+    out_e = []
+    for i in range(embeds.shape[0]):
+        tmp_mask = torch.ones(embeds[i].shape[1])
+        for ind in zero_index[i]:
+            tmp_mask[ind] = 0.0
+        out_e.append(torch.mul(tmp_mask, embeds[i]))
+    return torch.stack(out_e, dim=0), masks
