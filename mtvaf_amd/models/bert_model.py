@@ -32,20 +32,19 @@ def _arg(args, name, default=False):
 
 class ImageModel(nn.Module):
     """Frozen ResNet pyramid front-end (reference: models/bert_model.py:63-111).  It is UPSTREAM of the
-    accelerated path and runs in plain torch/torchvision when raw images are
-    fed; pre-extracted region features bypass it (see ``TVNetSAModel2.get_visual_prompt``)."""
+    accelerated path and runs in plain torch (MIOpen convolutions) on the trunks of
+    ``mtvaf_amd/models/resnet.py`` (torchvision's architecture and state_dict names; torchvision itself is not
+    required).  ``resnet_root`` holds the reference's ``resnetNN.pth`` files; ``resnet_root="random"`` skips the
+    load (synthetic runs).  Pre-extracted region features bypass it (``TVNetSAModel2.get_visual_prompt``,
+    ``mtvaf_amd.features``)."""
 
     def __init__(self, use_152=False, use_101=False, use_34=False, use_18=False, resnet_root=None):
         super().__init__()
-        try:
-            from torchvision.models import resnet18, resnet34, resnet50, resnet101, resnet152
-        except ImportError as e:  # pragma: no cover - torchvision is absent in the build container
-            raise ImportError("raw-image input needs torchvision for the frozen ResNet front-end; feed "
-                              "pre-extracted region features [B,3840,2,2] instead") from e
+        from .resnet import resnet18, resnet34, resnet50, resnet101, resnet152
         name, ctor = (("resnet152", resnet152) if use_152 else ("resnet101", resnet101) if use_101 else
                       ("resnet34", resnet34) if use_34 else ("resnet18", resnet18) if use_18 else ("resnet50", resnet50))
         self.resnet = ctor()
-        if resnet_root is not None:
+        if resnet_root is not None and resnet_root != "random":
             self.resnet.load_state_dict(torch.load(f"{resnet_root}/{name}.pth", map_location="cpu"))
 
     def forward(self, x, aux_imgs=None):

@@ -1,0 +1,69 @@
+"""Frozen visual front-end (row f1): the ResNet trunks match torchvision's published layouts, the pyramid
+pooling follows ImageModel.get_resnet_prompt, and cached region features reproduce the raw-image prefix."""
+import types
+
+import pytest
+import torch
+
+
+def test_resnet_trunks_have_torchvision_layout():
+    from mtvaf_amd.models import resnet as R
+    # published torchvision parameter counts
+    counts = {"resnet18": 11_689_512, "resnet34": 21_797_672, "resnet50": 25_557_032, "resnet101": 44_549_160,
+              "resnet152": 60_192_808}
+    for name, n in counts.items():
+        m = getattr(R, name)()
+        assert sum(p.numel() for p in m.parameters()) == n, name
+        assert [k for k, _ in m.named_children()] == ["conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3",
+                                                      "layer4", "avgpool", "fc"]
+    sd = R.resnet50().state_dict()
+    for k in ("conv1.weight", "bn1.running_mean", "layer1.0.downsample.0.weight", "layer1.0.downsample.1.bias",
+              "layer3.5.conv3.weight", "layer4.2.bn3.num_batches_tracked", "fc.bias"):
+        assert k in sd, k
+    assert tuple(sd["layer2.0.conv2.weight"].shape) == (128, 128, 3, 3) and R.resnet50().layer2[0].conv2.stride == (2, 2)
+
+
+def test_pyramid_pooling_and_feature_cache_cpu():
+    from mtvaf_amd.features import RegionFeatureCache
+    from mtvaf_amd.models.bert_model import ImageModel
+    torch.manual_seed(0)
+    im = ImageModel(use_18=True, resnet_root="random")
+    x = torch.randn(2, 3, 64, 64)
+    aux = torch.randn(2, 3, 3, 64, 64)
+    im.eval()
+    pyr, aux_pyr = im(x, aux)
+    assert [tuple(p.shape) for p in pyr] == [(2, 64, 2, 2), (2, 128, 2, 2), (2, 256, 2, 2), (2, 512, 2, 2)]
+    assert len(aux_pyr) == 3 and tuple(aux_pyr[0][3].shape) == (2, 512, 2, 2)
+    # layer1 output is 16x16 at 64x64 input: kernel 8 -> the pooled cell is the mean of an 8x8 quadrant
+    h = im.resnet.layer1(im.resnet.maxpool(im.resnet.relu(im.resnet.bn1(im.resnet.conv1(x)))))
+    assert torch.allclose(pyr[0][:, :, 0, 1], h[:, :, :8, 8:].mean((2, 3)), atol=1e-6)
+    cache = RegionFeatureCache(im)
+    im.train()
+    feats, fa = cache.extract(x, aux)
+    assert im.training and tuple(feats.shape) == (2, 960, 2, 2) and tuple(fa.shape) == (2, 3, 960, 2, 2)
+    assert torch.equal(feats, torch.cat(pyr, 1)) and torch.equal(fa[:, 1], torch.cat(aux_pyr[1], 1))
+    cache.add(["a", "b"], x, aux)
+    f2, a2 = cache.batch(["b", "a"], "cpu")
+    assert torch.equal(f2[0], feats[1]) and torch.equal(a2[1], fa[0])
+
+
+@pytest.mark.gpu
+def test_cached_features_reproduce_raw_image_prefix():
+    from test_model_gpu import DEV, LABELS, hf_config, make_args
+    import params as P
+    from mtvaf_amd.features import RegionFeatureCache
+    from mtvaf_amd.models.bert_model import TVNetSAModel2
+    cfg = P.EncCfg(vocab_size=64, hidden=768, heads=12, inter=128, layers=12, max_pos=32)
+    args = make_args(resnet_root="random")
+    args.bert_config = hf_config(cfg)
+    torch.manual_seed(0)
+    m = TVNetSAModel2(LABELS, None, args).to(DEV).eval()
+    x = torch.randn(2, 3, 64, 64, device=DEV)
+    aux = torch.randn(2, 3, 3, 64, 64, device=DEV)
+    raw, _, _ = m.get_visual_prompt(x, aux, None)
+    feats, fa = RegionFeatureCache(m.image_model).extract(x, aux)
+    assert tuple(feats.shape) == (2, 3840, 2, 2)
+    cached, _, _ = m.get_visual_prompt(feats, fa, None)
+    for (k1, v1), (k2, v2) in zip(raw, cached):
+        assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert tuple(raw[0][0].shape) == (2, 12, 16, 64)
