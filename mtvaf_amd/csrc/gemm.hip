@@ -651,7 +651,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       const double kc = (double)cdiv(cdiv(K, s), bk) * bk;
       // per tile: (bm*bn*kc*2 flop) / (256 flop/clk/CU) cycles at 100 %
       // two co-resident blocks hide each other's prologue / epilogue / barrier stalls once every CU holds two
-      // (measured +8..9 % at >= 2 tiles per CU, -3..5 % with a single tile per CU: the 2-stage ring is shallower)
+      // (measured +8..9 % at >= 2 tiles per CU, -3..5 % with a single tile per CU: the 2-stage ring is shallower;
+      // preferring it there anyway for its smaller footprint measured 0.5 % slower on the whole step)
       const double occ2 = c >= 12 ? (tiles * s >= 512 ? 1.08 : 0.95) : 1.0;
       double cost = (double)rounds * bm * bn * kc / 128.0 / (eff[c] * occ2);
       cost += 3000.0;  // fill/drain + launch

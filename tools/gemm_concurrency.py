@@ -1,22 +1,31 @@
-"""Do two co-resident GEMM kernels per CU (2 waves/SIMD) raise MFMA utilisation?  Runs the dX (LDS-DMA kernel,
-84 KB LDS) and dW (register-staged kernel, 64.5 KB LDS) products of one FFN layer serially on one stream and
-concurrently on two streams."""
+"""Do two co-resident GEMM kernels per CU raise MFMA utilisation?  Runs the dX and dW products of one encoder
+layer (FFN-2, FFN-1, attention-output, QKV) serially on one stream and concurrently on two streams (dW on the
+side stream), with the planner's tiles and with the 2-stage LDS-DMA tiles (57-67 KB LDS: two different kernels
+fit on one CU)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mtvaf_amd import hip
 dev = "cuda"
 M, H, I = 4096, 768, 3072
-dy = torch.randn(M, H, device=dev); w2 = torch.randn(H, I, device=dev); act = torch.randn(M, I, device=dev)
-dpre = torch.empty(M, I, device=dev); dw2 = torch.empty(H, I, device=dev)
-dpre_in = torch.randn(M, I, device=dev); w1 = torch.randn(I, H, device=dev); h1 = torch.randn(M, H, device=dev)
-dh1 = torch.empty(M, H, device=dev); dw1 = torch.empty(I, H, device=dev)
+g = torch.Generator(device=dev).manual_seed(0)
+R = lambda *s: torch.randn(*s, device=dev, generator=g)
+# (dy [M,N], w [N,K], x [M,K]) per linear: N = out features, K = in features
+lin = {"ffn2": (R(M, H), R(H, I), R(M, I)), "ffn1": (R(M, I), R(I, H), R(M, H)), "ao": (R(M, H), R(H, H), R(M, H)),
+       "qkv": (R(M, 3 * H), R(3 * H, H), R(M, H))}
+outs = {k: (torch.empty_like(x), torch.empty_like(w)) for k, (dy, w, x) in lin.items()}
 s2 = torch.cuda.Stream()
-ws2 = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+ws2 = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 
-def dx_a(): hip.linear_bwd_input(dy, w2, dpre)            # [M,I] = dy[M,H] . w2[H,I]   (K = 768)
-def dw_a(): hip.linear_bwd_weight(dy, act, dw2)           # [H,I] = dy^T act            (K = 4096, split)
-def dx_b(): hip.linear_bwd_input(dpre_in, w1, dh1)        # [M,H] = dpre[M,I] . w1[I,H] (K = 3072)
-def dw_b(): hip.linear_bwd_weight(dpre_in, h1, dw1)       # [I,H]
+
+def dx(k, cfg):
+    dy, w, x = lin[k]
+    hip.gemm(dy, hip.KC, w, hip.KM, outs[k][0], M, w.shape[1], w.shape[0], cfg=cfg)
+
+
+def dw(k, cfg, splits):
+    dy, w, x = lin[k]
+    hip.gemm(dy, hip.KM, x, hip.KM, outs[k][1], w.shape[0], w.shape[1], M, allow_split=True, cfg=cfg, splits=splits)
+
 
 def timeit(fn, iters=20):
     for _ in range(3): fn()
@@ -27,20 +36,32 @@ def timeit(fn, iters=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
 
-def serial(): dx_a(); dw_a(); dx_b(); dw_b()
 
-def concurrent():
-    main = torch.cuda.current_stream()
-    s2.wait_stream(main)
-    with torch.cuda.stream(s2):
-        # side stream needs its own split-K workspace
-        old = hip._ws.get(0); hip._ws[0] = ws2
-        dw_a(); dw_b()
-        hip._ws[0] = old
-    dx_a(); dx_b()
-    main.wait_stream(s2)
+def run(plan, concurrent):
+    """plan: {name: (dx cfg, dw cfg, dw splits)}"""
+    def fn():
+        main = torch.cuda.current_stream()
+        for k in ("ffn2", "ffn1", "ao", "qkv"):
+            cx, cw, sw = plan[k]
+            if concurrent:
+                s2.wait_stream(main)
+                with torch.cuda.stream(s2):
+                    old = hip._ws.get(0); hip._ws[0] = ws2
+                    dw(k, cw, sw)
+                    hip._ws[0] = old
+                dx(k, cx)
+            else:
+                dx(k, cx); dw(k, cw, sw)
+        if concurrent:
+            main.wait_stream(s2)
+    return fn
 
-fl = 2.0 * M * H * I * 4
-ts, tc = timeit(serial), timeit(concurrent)
-print(f"serial     : {ts:8.1f} us  {fl/ts/1e6:6.1f} TF")
-print(f"concurrent : {tc:8.1f} us  {fl/tc/1e6:6.1f} TF   speed-up {ts/tc:.3f}x")
+
+fl = sum(2.0 * M * w.numel() * 2 for _, w, _ in lin.values())
+auto = {k: (-1, -1, -1) for k in lin}
+two = {"ffn2": (13, 12, 4), "ffn1": (12, 12, 4), "ao": (12, 12, 4), "qkv": (12, 12, 6)}
+two_b = {"ffn2": (13, 12, 2), "ffn1": (12, 12, 2), "ao": (12, 12, 4), "qkv": (12, 12, 3)}
+for name, plan, conc in (("serial auto", auto, False), ("concurrent auto", auto, True), ("serial 2-stage", two, False),
+                         ("concurrent 2-stage", two, True), ("concurrent 2-stage, fewer splits", two_b, True)):
+    t = timeit(run(plan, conc))
+    print(f"{name:34s}: {t:8.1f} us per layer-backward GEMM set  {fl / t / 1e6:6.1f} TF", flush=True)
