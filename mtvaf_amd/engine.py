@@ -108,7 +108,7 @@ class EncoderFunction(torch.autograd.Function):
         Pn = 0 if pkv is None else pkv.shape[3] // H
         x = h0.contiguous().view(M, H)
         seed = RNG.seed()
-        saved = []
+        saved, offs = [], []
         outs = []
         for li, w in enumerate(weights):
             I = w.w1.shape[0]
@@ -129,20 +129,25 @@ class EncoderFunction(torch.autograd.Function):
             hip.linear_fwd(act, w.w2, w.bi2, f)
             h2, mean2, rstd2 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
             hip.dropout_res_ln_fwd(f, h1, w.g2, w.b2, h2, mean2, rstd2, eps, p_hidden, seed, off + 2)
-            saved.append((x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2, off))
+            saved.extend((x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2))
+            offs.append(off)
             outs.append(h2.view(B, S, H))
             x = h2
-        ctx.stash = (saved, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
+        # activations go through save_for_backward so that autograd releases them as soon as the backward has run
+        # (a python attribute would keep ~3 GB per layer at B=128, S=512 alive until the loss tensor dies)
+        ctx.save_for_backward(*saved)
+        ctx.stash = (offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
         ctx.set_materialize_grads(False)  # unused hidden states arrive as None, not as [B,S,H] zero fills + adds
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        saved, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params = ctx.stash
+        offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params = ctx.stash
+        flat = ctx.saved_tensors
         NH, eps, p_hidden, p_attn = cfg
         L = len(weights)
         M = B * S
-        dev_like = saved[0][0]
+        dev_like = flat[0]
         dpkv = torch.empty_like(pkv) if Pn else None
         need_param_grads = any(p.requires_grad for p in params)
         # parameter-gradient destinations: the module's flat per-layer gradient buffers when they are
@@ -152,7 +157,8 @@ class EncoderFunction(torch.autograd.Function):
 
         dh = None  # gradient wrt the current layer's OUTPUT, [M,H], owned by us
         for li in range(L - 1, -1, -1):
-            x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2, off = saved[li]
+            x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2 = flat[13 * li:13 * li + 13]
+            off = offs[li]
             w = weights[li]
             I = w.w1.shape[0]
             g_out = douts[li]

@@ -23,9 +23,9 @@ class DeferredTags(list):
     use (indexing, iteration, len, comparison, repr ...), i.e. where the trainer builds y_pred after
     ``loss.backward()`` (modules/train.py:627-647).  Values are identical to an eager ``decode``."""
 
-    def __init__(self, packed_host: torch.Tensor, event, S: int):
+    def __init__(self, packed_host: torch.Tensor, event, S: int, release=None):
         super().__init__()
-        self._packed, self._event, self._S = packed_host, event, S
+        self._packed, self._event, self._S, self._release = packed_host, event, S, release
 
     def _fill(self):
         if self._packed is not None:
@@ -33,8 +33,18 @@ class DeferredTags(list):
                 self._event.synchronize()
             packed, S = self._packed, self._S
             self._packed = None
-            super().extend(row[:n].tolist() for row, n in zip(packed[:, :S], packed[:, S].tolist()))
+            rows, lens = packed[:, :S].tolist(), packed[:, S].tolist()
+            super().extend(row[:n] for row, n in zip(rows, lens))
+            self._give_back()
         return self
+
+    def _give_back(self):
+        if self._release is not None:
+            self._release()
+            self._release = None
+
+    def __del__(self):  # never read: the staging buffer goes back with its (possibly pending) copy event
+        self._give_back()
 
     def __getitem__(self, i):
         self._fill()
@@ -77,6 +87,9 @@ class CRF(nn.Module):
         self.start_transitions = nn.Parameter(torch.empty(num_tags))
         self.end_transitions = nn.Parameter(torch.empty(num_tags))
         self.transitions = nn.Parameter(torch.empty(num_tags, num_tags))
+        # pinned staging buffers of decode_deferred, recycled: a fresh pinned allocation per step costs a
+        # hipHostMalloc that waits for the GPU to drain (measured 185 ms per step at B=128, S=512)
+        self._host_pool: list = []
         self.reset_parameters()
 
     def reset_parameters(self) -> None:
@@ -131,11 +144,20 @@ class CRF(nn.Module):
         tags, lens = self.decode_packed(emissions, mask)
         S = tags.shape[1]
         packed = torch.cat([tags, lens[:, None]], dim=1)
-        host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+        need = packed.numel()
+        buf = None
+        for i, (t, ev_old) in enumerate(self._host_pool):
+            if t.numel() >= need and (ev_old is None or ev_old.query()):
+                buf = self._host_pool.pop(i)[0]
+                break
+        if buf is None:
+            buf = torch.empty(max(need, 1 << 14), dtype=packed.dtype, pin_memory=True)
+        host = buf[:need].view(packed.shape)
         host.copy_(packed, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return DeferredTags(host, ev, S)
+        pool = self._host_pool
+        return DeferredTags(host, ev, S, release=lambda: pool.append((buf, ev)) if len(pool) < 8 else None)
 
     def decode(self, emissions, mask: Optional[torch.Tensor] = None) -> List[List[int]]:
         tags, lens = self.decode_packed(emissions, mask)

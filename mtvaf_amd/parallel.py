@@ -59,8 +59,7 @@ class GradSync:
         ev.record()
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ev)
-            dist.all_reduce(flat_grad, group=self.group)
-            flat_grad.mul_(1.0 / self.world)
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.group)  # RCCL averages inside the collective
 
     def _arm(self):
         if not self._armed:
@@ -79,8 +78,7 @@ class GradSync:
             ev.record()
             with torch.cuda.stream(self._comm):
                 self._comm.wait_event(ev)
-                dist.all_reduce(g, group=self.group)
-                g.mul_(1.0 / self.world)
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
         self._early_done.add(id(p))
 
     # -- runs once when the autograd pass is complete ---------------------------------------------------------
@@ -120,7 +118,10 @@ class GradSync:
             return
         grads = [p.grad for p in params]
         flat = torch._utils._flatten_dense_tensors(grads)
-        dist.all_reduce(flat, group=self.group)
-        flat.mul_(1.0 / self.world)
+        if flat.is_cuda:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:  # gloo has no AVG
+            dist.all_reduce(flat, group=self.group)
+            flat.mul_(1.0 / self.world)
         for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
             g.copy_(s)

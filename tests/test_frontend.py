@@ -64,6 +64,6 @@ def test_cached_features_reproduce_raw_image_prefix():
     feats, fa = RegionFeatureCache(m.image_model).extract(x, aux)
     assert tuple(feats.shape) == (2, 3840, 2, 2)
     cached, _, _ = m.get_visual_prompt(feats, fa, None)
-    for (k1, v1), (k2, v2) in zip(raw, cached):
-        assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    for (k1, v1), (k2, v2) in zip(raw, cached):  # MIOpen may pick different conv algorithms between the two passes
+        assert torch.allclose(k1, k2, rtol=1e-4, atol=1e-5) and torch.allclose(v1, v2, rtol=1e-4, atol=1e-5)
     assert tuple(raw[0][0].shape) == (2, 12, 16, 64)
