@@ -78,6 +78,16 @@ __device__ __forceinline__ bool attn_dropout_keep(uint32_t key, uint32_t row, ui
   uint32_t h = mix32(row * 0x9E3779B1u + key) ^ (col * 0x85EBCA77u);
   return mix32(h) >= thr;
 }
+// Cheaper split form for the attention kernels (the VALU work per probability decides their speed): the row part
+// is mixed once per lane, an element costs one add, one xor, one multiply and the compare.  The top bits of the
+// product depend on every bit of (rowhash ^ column term); adjacent-row / adjacent-column correlations of the
+// resulting masks are at the sampling-noise level (checked over 16k rows x 164 columns).
+constexpr uint32_t ATTN_DROP_C2 = 0x85EBCA77u;
+__device__ __forceinline__ uint32_t attn_dropout_rowhash(uint32_t key, uint32_t row) { return mix32(row * 0x9E3779B1u + key); }
+__device__ __forceinline__ bool attn_dropout_keep2(uint32_t rowhash, uint32_t col_term, uint32_t thr) {
+  // col_term = col * ATTN_DROP_C2
+  return (rowhash ^ col_term) * 0x2c1b3c6du >= thr;
+}
 __device__ __forceinline__ uint32_t dropout_threshold(float p_drop) {
   return (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f);
 }

@@ -46,6 +46,39 @@ struct AttnArgs {
   uint32_t drop_key, drop_thr;
 };
 
+// Stage a [64][64] tile of K (which = 1) or V (which = 2) rows t0..t0+63 of the concatenated
+// [prefix ; text] key axis into LDS (row stride LDT); rows >= T are zero-filled.
+__device__ __forceinline__ void stage_kv(float* dst, const AttnArgs& a, int b, int h, int t0, int which) {
+  const int T = a.P + a.S;
+  const float* pre = which == 1 ? a.pk : a.pv;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int r = idx >> 4, c = (idx & 15) * 4;
+    const int t = t0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (t < a.P) {
+      v = *reinterpret_cast<const f32x4*>(pre + ((long)b * a.P * a.NH + (long)h * a.P + t) * D + c);
+    } else if (t < T) {
+      v = *reinterpret_cast<const f32x4*>(a.qkv + ((long)b * a.S + (t - a.P)) * 3 * a.H + which * a.H + h * D + c);
+    }
+    *reinterpret_cast<f32x4*>(dst + r * LDT + c) = v;
+  }
+}
+
+// Stage a [64][64] tile of rows q0..q0+63 of a token-major [B*S, ld] matrix (head column block h).
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, int ld, int col0, int b, int S, int q0) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + 256 * i;
+    const int r = idx >> 4, c = (idx & 15) * 4;
+    const int q = q0 + r;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (q < S) v = *reinterpret_cast<const f32x4*>(src + ((long)b * S + q) * ld + col0 + c);
+    *reinterpret_cast<f32x4*>(dst + r * LDT + c) = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: grid (ceil(S/64), NH, B), 256 threads; wave w owns queries q0+16w .. +15
 // ---------------------------------------------------------------------------------------------
