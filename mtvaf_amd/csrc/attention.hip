@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int T = a.P + a.S;
   const int key = blockIdx.x * 64 + wave * 16 + lk;
   const bool kok = key < T;
+  const bool wave_live = (int)(blockIdx.x * 64 + wave * 16) < T;
   const int keyc = min(key, T - 1);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   // keys beyond T: mask -1e30 makes their probabilities exactly 0
@@ -373,7 +374,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
       rh_s[threadIdx.x] = attn_dropout_rowhash(a.drop_key, row_base + (uint32_t)qq);
     }
     __syncthreads();
-    const int nsub = min(4, (a.S - q0 + 15) >> 4);
+    // a wave whose 16 keys all lie beyond T (last key tile) only takes part in the staging and the barriers
+    const int nsub = wave_live ? min(4, (a.S - q0 + 15) >> 4) : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nsub) {
