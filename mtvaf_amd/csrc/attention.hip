@@ -302,7 +302,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // dpk/dpv -- the gradient that flows on to the prompt generator); loops over query tiles.
 // grid (ceil(T/64), NH, B)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs a) {
+// 4 waves per SIMD (<= 128 VGPRs): ceil(T/64)*NH*B = 1152 blocks at bs 32 need 4 resident blocks per CU to stay near one round
+__global__ __launch_bounds__(256, 4) void attn_bwd_dkv_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Qs[KT * LDT];
   __shared__ __attribute__((aligned(16))) float dOs[KT * LDT];
   __shared__ __attribute__((aligned(16))) float lse_s[KT];   // lse * log2(e); +1e30 for rows beyond S
