@@ -269,11 +269,20 @@ def main():
         if sync is not None:
             sync.enabled = False
         NPROF = 3
+        # kernels are timed one at a time: the weight-gradient stream (mtvaf_amd.engine.DW_SIDE_STREAM), which co-runs
+        # the dW products with the dX chain in the timed region above, is serialised for these profiled steps --
+        # a duration measured while two kernels share the CUs says nothing about either kernel
+        from mtvaf_amd import engine as _engine
+        side_was = _engine.DW_SIDE_STREAM
+        _engine.DW_SIDE_STREAM = False
+        step()
+        torch.cuda.synchronize()
         hip.prof_start(8192)
         for _ in range(NPROF):
             step()
         torch.cuda.synchronize()
         recs = hip.prof_stop(8192)
+        _engine.DW_SIDE_STREAM = side_was
         by_sym, by_shape = {}, {}
         for k, ms in recs:
             sym = hip.kernel_symbol(k["cfg"], k["la"], k["lb"], k["fast"])
@@ -294,6 +303,8 @@ def main():
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
             "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": pmc_traffic(sym), "kernel": sym,
             "avg_launch_us": round(avg_us, 1), "launches_per_step": cnt // NPROF,
+            "measured": "HIP events around each main GEMM kernel, 3 steps with the weight-gradient side stream serialised "
+                        "(MTVAF_DW_STREAM=0) so that every kernel is timed alone",
             "flops_per_launch_avg": fl / cnt,
             "all_gemm_kernels": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
                                  "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS[a.dtype], 4)},

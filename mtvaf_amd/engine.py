@@ -13,6 +13,7 @@ nothing but the C-ABI kernels for arithmetic; torch is used for buffer allocatio
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -91,6 +92,21 @@ class LayerWeights:
 N_LAYER_PARAMS = 16  # q.w q.b k.w k.b v.w v.b ao.w ao.b ln1.w ln1.b i.w i.b o.w o.b ln2.w ln2.b
 
 
+# Weight-gradient products (and the bias column sums) of the encoder backward depend only on tensors the dX chain has
+# already produced, so they run on a side stream and fill the bubbles of the chain's non-GEMM kernels (attention
+# backward, LayerNorm backward, split-K reductions) and the head / tail of its GEMMs.  MTVAF_DW_STREAM=0 serialises.
+DW_SIDE_STREAM = os.environ.get("MTVAF_DW_STREAM", "1") != "0"
+_side_streams = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = torch.device(device).index or 0
+    st = _side_streams.get(key)
+    if st is None:
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class EncoderFunction(torch.autograd.Function):
     """All encoder layers in one autograd node.
 
@@ -155,6 +171,22 @@ class EncoderFunction(torch.autograd.Function):
         gviews = grad_sink.acquire(params) if grad_sink is not None else None
         pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
 
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev_like.device) if (DW_SIDE_STREAM and need_param_grads) else None
+
+        def on_side(reads, fn):
+            """Run `fn` (weight-gradient kernels that only read `reads`) behind everything enqueued so far."""
+            if side is None:
+                fn()
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                fn()
+            for t in reads:  # temporaries freed before the join below: the allocator must wait for the side stream
+                t.record_stream(side)
+
         dh = None  # gradient wrt the current layer's OUTPUT, [M,H], owned by us
         for li in range(L - 1, -1, -1):
             x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2 = flat[13 * li:13 * li + 13]
@@ -184,25 +216,32 @@ class EncoderFunction(torch.autograd.Function):
             df, dh1 = _empty(M, H, like=dev_like), _empty(M, H, like=dev_like)
             hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, df, dh1, False, G[14], G[15], False, p_hidden, seed,
                                    off + 2, dbias_x=G[13])
-            hip.linear_bwd_weight(df, act, G[12])
+            on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12]))
             dpre = _empty(M, I, like=dev_like)
             hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
-            hip.colsum(dpre, G[11])
-            hip.linear_bwd_weight(dpre, h1, G[10])
+
+            def ffn1_grads():
+                hip.colsum(dpre, G[11])
+                hip.linear_bwd_weight(dpre, h1, G[10])
+            on_side((dpre,), ffn1_grads)
             hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
             # ---- attention block ----
-            da, dh0 = df, dh  # reuse buffers
+            da = df if side is None else _empty(M, H, like=dev_like)  # df is still being read on the side stream
+            dh0 = dh  # reuse
             hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
                                    off + 1, dbias_x=G[7])
-            hip.linear_bwd_weight(da, cx, G[6])
+            on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6]))
             dctx = dh1
             hip.linear_bwd_input(da, w.wo, dctx)
             dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
             hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
                                 delta, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, B, S, Pn, NH,
                                 p_attn, seed, off)
-            hip.colsum(dqkv, dbqkv)
-            hip.linear_bwd_weight(dqkv, x, dwqkv)
+
+            def qkv_grads():
+                hip.colsum(dqkv, dbqkv)
+                hip.linear_bwd_weight(dqkv, x, dwqkv)
+            on_side((dqkv,), qkv_grads)
             hip.linear_bwd_input(dqkv, w.wqkv, dh0, accumulate=True)
             dh = dh0
             if gviews is None:
@@ -210,7 +249,16 @@ class EncoderFunction(torch.autograd.Function):
                 G[1], G[3], G[5] = dbqkv[:H], dbqkv[H:2 * H], dbqkv[2 * H:]
             pgrads[base:base + N_LAYER_PARAMS] = G
             if grad_sink is not None:
-                grad_sink.layer_done(li)
+                if side is not None and grad_sink.on_layer_done is not None:
+                    # the hook (GradSync) orders its all-reduce behind the CURRENT stream: on the side stream that
+                    # is behind this layer's last weight-gradient kernel, which itself waited for everything the
+                    # main stream had produced up to the attention backward (incl. the LayerNorm gradients)
+                    with torch.cuda.stream(side):
+                        grad_sink.layer_done(li)
+                else:
+                    grad_sink.layer_done(li)
+        if side is not None:
+            main.wait_stream(side)  # join: gradients (and every buffer the side stream read) are settled from here on
         dh0_out = dh.view(B, S, H) if dh is not None else None
         if not need_param_grads:
             pgrads = [None] * len(params)

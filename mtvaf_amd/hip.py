@@ -115,7 +115,9 @@ _ws = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    key = (torch.device(device).index or 0)
+    """Scratch for split-K slabs / column-sum partials, one buffer per (device, stream): kernels launched on a side
+    stream (the weight-gradient products of the encoder backward) must not share slabs with the main stream."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
