@@ -194,14 +194,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // ---------------------------------------------------------------------------------------------
 // backward, query side: dQ (and delta = rowsum(dO.O)); same decomposition as the forward.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float Ks[KT * LDT];  // read as row fragments AND as columns
-  __shared__ __attribute__((aligned(16))) float Vs[KT * LDK];  // row fragments only
-  __shared__ __attribute__((aligned(16))) float Ms[KT];
+// Ks [KT*LDT]: read as row fragments AND as columns; Vs [KT*LDK]: row fragments only; Ms [KT]
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, float* Ks, float* Vs, float* Ms) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 64 + wave * 16 + lq;
+  const int q = qtile * 64 + wave * 16 + lq;
   const int T = a.P + a.S;
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
@@ -302,20 +300,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // dpk/dpv -- the gradient that flows on to the prompt generator); loops over query tiles.
 // grid (ceil(T/64), NH, B)
 // ---------------------------------------------------------------------------------------------
-// 4 waves per SIMD (<= 128 VGPRs): ceil(T/64)*NH*B = 1152 blocks at bs 32 need 4 resident blocks per CU to stay near one round
-__global__ __launch_bounds__(256, 4) void attn_bwd_dkv_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float Qs[KT * LDT];
-  __shared__ __attribute__((aligned(16))) float dOs[KT * LDT];
-  __shared__ __attribute__((aligned(16))) float lse_s[KT];   // lse * log2(e); +1e30 for rows beyond S
-  __shared__ __attribute__((aligned(16))) float del_s[KT];
-  __shared__ __attribute__((aligned(16))) uint32_t rh_s[KT];  // dropout row hashes of the tile's queries
+// Qs, dOs [KT*LDT]; lse_s [KT] = lse * log2(e) (+1e30 for rows beyond S); del_s [KT] = rowsum(dO.O), computed here
+// from the staged dO tile and the matching O rows so that this side does not depend on the query side (both run in
+// one launch); rh_s [KT] = dropout row hashes of the tile's queries.
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, float* Qs, float* dOs, float* lse_s,
+                                                  float* del_s, uint32_t* rh_s) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lk = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int T = a.P + a.S;
-  const int key = blockIdx.x * 64 + wave * 16 + lk;
+  const int key = ktile * 64 + wave * 16 + lk;
   const bool kok = key < T;
-  const bool wave_live = (int)(blockIdx.x * 64 + wave * 16) < T;
+  const bool wave_live = (int)(ktile * 64 + wave * 16) < T;
   const int keyc = min(key, T - 1);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   // keys beyond T: mask -1e30 makes their probabilities exactly 0
@@ -345,6 +341,7 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dkv_kernel(AttnArgs a) {
   const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
   const float* qsrc = a.qkv + (long)b * a.S * 3 * a.H + h * D + c4;
   const float* dosrc = a.dctx + (long)b * a.S * a.H + h * D + c4;
+  const float* osrc = a.ctx + (long)b * a.S * a.H + h * D + c4;
   const float* qfrag = Qs + lk * LDT + 4 * g;
   const float* ofrag = dOs + lk * LDT + 4 * g;
   const float* qcol = Qs + 4 * g * LDT + lk;
@@ -353,25 +350,34 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dkv_kernel(AttnArgs a) {
 
   for (int q0 = 0; q0 < a.S; q0 += KT) {
     f32x4 qr[4], orr[4];
+    float dsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int qq = min(q0 + r0 + 16 * i, a.S - 1);
       qr[i] = *reinterpret_cast<const f32x4*>(qsrc + (long)qq * 3 * a.H);
       orr[i] = *reinterpret_cast<const f32x4*>(dosrc + (long)qq * a.H);
+      const f32x4 o = *reinterpret_cast<const f32x4*>(osrc + (long)qq * a.H);
+      dsum[i] = o.x * orr[i].x + o.y * orr[i].y + o.z * orr[i].z + o.w * orr[i].w;
     }
-    float lreg = 1.0e30f, dreg = 0.f;
-    if (threadIdx.x < KT) {
-      const int qq = min(q0 + (int)threadIdx.x, a.S - 1);
-      lreg = a.lse[((long)b * a.NH + h) * a.S + qq] * LOG2E;
-      dreg = a.delta[((long)b * a.NH + h) * a.S + qq];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // the 16 threads of a row are 16 consecutive lanes
+      dsum[i] += __shfl_xor(dsum[i], 1, 64);
+      dsum[i] += __shfl_xor(dsum[i], 2, 64);
+      dsum[i] += __shfl_xor(dsum[i], 4, 64);
+      dsum[i] += __shfl_xor(dsum[i], 8, 64);
     }
+    float lreg = 1.0e30f;
+    if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, a.S - 1)] * LOG2E;
     __syncthreads();
     kv_store<LDT>(Qs, qr);
     kv_store<LDT>(dOs, orr);
+    if ((threadIdx.x & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) del_s[r0 + 16 * i] = dsum[i];
+    }
     if (threadIdx.x < KT) {
       const int qq = q0 + threadIdx.x;
       lse_s[threadIdx.x] = qq < a.S ? lreg : 1.0e30f;
-      del_s[threadIdx.x] = dreg;
       rh_s[threadIdx.x] = attn_dropout_rowhash(a.drop_key, row_base + (uint32_t)qq);
     }
     __syncthreads();
@@ -439,6 +445,20 @@ __global__ __launch_bounds__(256, 4) void attn_bwd_dkv_kernel(AttnArgs a) {
   }
 }
 
+// One launch for the whole attention backward: blocks [0, nq) of x are query tiles (dQ), the rest key tiles
+// (dK, dV).  The two sides are independent (the key side recomputes delta), so they share the machine -- each is
+// VALU / issue bound at ~40 % MFMA utilisation on its own -- and need neither atomics nor a second stream.
+__global__ __launch_bounds__(256, 4) void attn_bwd_kernel(AttnArgs a, int nq) {
+  __shared__ __attribute__((aligned(16))) float tile0[KT * LDK];
+  __shared__ __attribute__((aligned(16))) float tile1[KT * LDK];
+  __shared__ __attribute__((aligned(16))) float small[3 * KT];
+  if ((int)blockIdx.x < nq) {
+    attn_bwd_dq_body(a, blockIdx.x, tile0, tile1, small);
+  } else {
+    attn_bwd_dkv_body(a, blockIdx.x - nq, tile0, tile1, small, small + KT, reinterpret_cast<uint32_t*>(small + 2 * KT));
+  }
+}
+
 static int check(const AttnArgs& a) {
   if (a.B <= 0 || a.S <= 0 || a.P < 0 || a.NH <= 0 || a.H != a.NH * D) return MTVAF_ERR_SHAPE;
   if ((long)a.B * a.NH * a.S >= (1L << 32)) return MTVAF_ERR_SHAPE;
@@ -494,8 +514,8 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
   int rc = check(a);
   if (rc) return rc;
   if (P > 0 && (!dpk || !dpv)) return MTVAF_ERR_ARG;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((S + 63) / 64, NH, B), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((P + S + 63) / 64, NH, B), dim3(256), 0, st, a);
+  const int nq = (S + 63) / 64;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nq + (P + S + 63) / 64, NH, B), dim3(256), 0, st, a, nq);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
