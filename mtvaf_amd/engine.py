@@ -172,7 +172,8 @@ class EncoderFunction(torch.autograd.Function):
         pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
 
         main = torch.cuda.current_stream()
-        side = _side_stream(dev_like.device) if (DW_SIDE_STREAM and need_param_grads) else None
+        # (small batches are host-bound: the extra events / stream switches cost more than the overlap returns)
+        side = _side_stream(dev_like.device) if (DW_SIDE_STREAM and need_param_grads and M >= 1024) else None
 
         def on_side(reads, fn):
             """Run `fn` (weight-gradient kernels that only read `reads`) behind everything enqueued so far."""

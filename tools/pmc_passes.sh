@@ -2,6 +2,8 @@
 # PMC passes for the bench (one counter group per run; rocprofv3 --pmc must not be mixed with sys traces).
 # usage: tools/pmc_passes.sh <outdir-under-gpurun_out>
 export TMPDIR=/tmp
+# per-kernel counters are only meaningful when kernels run one at a time: serialise the weight-gradient stream
+export MTVAF_DW_STREAM=0
 R=$PWD
 OUT=$R/gpurun_out/${1:-pmc}
 ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline"
