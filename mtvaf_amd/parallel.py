@@ -27,6 +27,8 @@ class GradSync:
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        # RCCL averages inside the collective; gloo (CPU tests, and the 2-rank-on-one-GPU test) has no AVG
+        self._avg_op = dist.get_backend(process_group) == "nccl"
         self.encoder = model.bert.encoder if hasattr(model, "bert") else model.encoder
         self.encoder.grad_sink.on_layer_done = self._layer_done
         self._enc_param_ids = {id(p) for l in self.encoder.layer for p in l.ordered_params()}
@@ -59,7 +61,14 @@ class GradSync:
         ev.record()
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ev)
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.AVG, group=self.group)  # RCCL averages inside the collective
+            self._allreduce_mean(flat_grad)
+
+    def _allreduce_mean(self, t: torch.Tensor):
+        if self._avg_op:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(t, group=self.group)
+            t.mul_(1.0 / self.world)
 
     def _arm(self):
         if not self._armed:
@@ -78,7 +87,7 @@ class GradSync:
             ev.record()
             with torch.cuda.stream(self._comm):
                 self._comm.wait_event(ev)
-                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+                self._allreduce_mean(g)
         self._early_done.add(id(p))
 
     # -- runs once when the autograd pass is complete ---------------------------------------------------------
@@ -118,10 +127,6 @@ class GradSync:
             return
         grads = [p.grad for p in params]
         flat = torch._utils._flatten_dense_tensors(grads)
-        if flat.is_cuda:
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:  # gloo has no AVG
-            dist.all_reduce(flat, group=self.group)
-            flat.mul_(1.0 / self.world)
+        self._allreduce_mean(flat)
         for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
             g.copy_(s)

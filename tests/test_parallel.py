@@ -205,3 +205,68 @@ def test_gradsync_single_rank_rccl_on_gpu():
         assert st.grad.data_ptr() <= g.data_ptr() < st.grad.data_ptr() + st.grad.numel() * 4
     finally:
         dist.destroy_process_group()
+
+
+def _gpu_worker(rank, world, port, q):
+    """Two ranks on ONE MI355X over gloo (RCCL refuses two ranks per device): the real model, the encoder's
+    weight-gradient side stream (M = 1024), the per-layer hooks, the early word-table hook and the tail bucket."""
+    import types
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import params as P
+        from transformers import BertConfig
+        from mtvaf_amd.models.bert_model import TVNetSAModel2
+        from mtvaf_amd.parallel import GradSync
+        torch.cuda.set_device(0)
+        cfg = BertConfig(vocab_size=3000, hidden_size=128, num_hidden_layers=3, num_attention_heads=2,
+                         intermediate_size=256, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0)
+        args = types.SimpleNamespace(bert_name="bert-base-uncased", bert_config=cfg, use_prefix=False, vao=False,
+                                     noauxloss=True, use_probe=False, n_gpu=1, alpha=0.0, prefix_len=4, prefix_dim=768,
+                                     device="cuda", resnet_root=None, use_152=False)
+        labels_list = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
+        torch.manual_seed(0)
+        m = TVNetSAModel2(labels_list, None, args).to("cuda").eval()
+        batches = [tuple(t.to("cuda") for t in P.text_batch(P.EncCfg(vocab_size=3000), 11 + r, 16, 64, lo_id=5))
+                   for r in range(world)]
+
+        def grads(batch):
+            ids, mask, tt, labels = batch
+            m.zero_grad(set_to_none=True)
+            m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss.backward()
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+
+        local = [grads(b) for b in batches]                       # no sync installed yet
+        want = {n: sum(g[n] for g in local) / world for n in local[0]}
+        sync = GradSync(m, big_numel=1 << 16)                      # the 3000x128 word table takes the early hook
+        got = grads(batches[rank])
+        worst = 0.0
+        for n, w in want.items():
+            err = float((got[n] - w).abs().max()) / (float(w.abs().max()) + 1e-12)
+            worst = max(worst, err)
+        aliased = m.bert.encoder._stores[1].grad is not None
+        q.put((rank, worst, aliased, len(want)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gradsync_two_ranks_real_model_one_gpu():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, worst, aliased, n in out:
+        assert n > 50 and aliased
+        assert worst < 2e-4, f"rank {rank}: synced gradients differ from the mean of the per-rank gradients by {worst:.2e}"
