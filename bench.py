@@ -160,11 +160,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # Launcher smoke test on a 1-GPU box: MTVAF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 over gloo (RCCL refuses
+    # two ranks per device).  It exercises rendezvous, GradSync, barriers and the rank-0 JSON line -- not a measurement.
+    one_dev = os.environ.get("MTVAF_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
     from mtvaf_amd import hip
     hip.lib()
     hip.set_compute_dtype(a.dtype)
