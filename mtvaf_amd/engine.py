@@ -103,7 +103,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
     key = torch.device(device).index or 0
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device=device)
+        st = _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("MTVAF_DW_PRIORITY", "0")))
     return st
 
 
