@@ -150,8 +150,18 @@ class TVNetSAModel2(nn.Module):
         sequence_output = engine.dropout(bert_output["last_hidden_state"], self.dropout.p, self.training)
         emissions = engine.LinearFunction.apply(sequence_output, self.fc.weight, self.fc.bias, False)
         mask_u8 = attention_mask.to(torch.uint8)
-        # Viterbi paths: device kernel + async packed copy; the list materialises on first use (no mid-step sync)
-        logits = self.crf.decode_deferred(emissions, mask_u8)
+        # Viterbi paths: device kernel + async packed copy; the list materialises on first use (no mid-step sync).
+        # One wavefront per sentence is all the parallelism Viterbi and the CRF forward algorithm have, so the two
+        # run side by side (second stream) instead of back to back.
+        if emissions.is_cuda and engine.DW_SIDE_STREAM:
+            main, side = torch.cuda.current_stream(), engine._side_stream(emissions.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                logits = self.crf.decode_deferred(emissions.detach(), mask_u8)
+            emissions.record_stream(side)
+            mask_u8.record_stream(side)
+        else:
+            logits = self.crf.decode_deferred(emissions, mask_u8)
         loss = None
         if labels is not None:
             loss = -1 * self.crf(emissions, labels, mask=mask_u8, reduction="mean")
