@@ -448,7 +448,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
 // One launch for the whole attention backward: blocks [0, nq) of x are query tiles (dQ), the rest key tiles
 // (dK, dV).  The two sides are independent (the key side recomputes delta), so they share the machine -- each is
 // VALU / issue bound at ~40 % MFMA utilisation on its own -- and need neither atomics nor a second stream.
-__global__ __launch_bounds__(256, 4) void attn_bwd_kernel(AttnArgs a, int nq) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_kernel(AttnArgs a, int nq) {  // 4 per SIMD spills 10 VGPRs
+
   __shared__ __attribute__((aligned(16))) float tile0[KT * LDK];
   __shared__ __attribute__((aligned(16))) float tile1[KT * LDK];
   __shared__ __attribute__((aligned(16))) float small[3 * KT];

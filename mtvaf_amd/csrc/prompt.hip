@@ -58,8 +58,9 @@ __global__ void gate_bwd_kernel(const float* __restrict__ logits, const float* _
 }
 
 // one block per (img, b, l); thread t handles columns 4t..4t+3 of the W-wide split
+// (launch bound stated: with the default 1024-thread assumption the unrolled layer loop spilled 144 VGPRs to scratch)
 template <int NL>
-__global__ void prompt_mix_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ gate,
+__global__ __launch_bounds__(384) void prompt_mix_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ gate,
                                       float* __restrict__ pkv, int NI, int B, int L, int W) {
   __shared__ float gs[NL * 4];
   const int blk = blockIdx.x;
@@ -73,10 +74,12 @@ __global__ void prompt_mix_fwd_kernel(const float* __restrict__ enc, const float
     const f32x4 s0 = *reinterpret_cast<const f32x4*>(e + c), s1 = *reinterpret_cast<const f32x4*>(e + W + c),
                 s2 = *reinterpret_cast<const f32x4*>(e + 2 * W + c), s3 = *reinterpret_cast<const f32x4*>(e + 3 * W + c);
     const int kv = c >= hid ? 1 : 0, cc = c - kv * hid;
+    float* dst = pkv + ((long)kv * B + b) * P * hid + (long)slot * hid + cc;
+    const long lstride = 2L * B * P * hid;  // one layer of [2, B, P*hid]
 #pragma unroll
     for (int idx = 0; idx < NL; ++idx) {
       const f32x4 v = s0 * gs[idx * 4] + s1 * gs[idx * 4 + 1] + s2 * gs[idx * 4 + 2] + s3 * gs[idx * 4 + 3];
-      *reinterpret_cast<f32x4*>(pkv + (((long)idx * 2 + kv) * B + b) * P * hid + (long)slot * hid + cc) = v;
+      *reinterpret_cast<f32x4*>(dst + idx * lstride) = v;
     }
   }
 }
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void prompt_mix_bwd_gate_kernel(const float* _
 
 // Pass B: denc[n][l][k*W+c] = sum_idx gate[n][idx][k] * dpkv[idx][..][c] + dsm[n][l*W+c]/4
 template <int NL>
-__global__ void prompt_mix_bwd_enc_kernel(const float* __restrict__ gate, const float* __restrict__ dpkv,
+__global__ __launch_bounds__(384) void prompt_mix_bwd_enc_kernel(const float* __restrict__ gate, const float* __restrict__ dpkv,
                                           const float* __restrict__ dsm, float* __restrict__ denc, int NI, int B, int L,
                                           int W) {
   __shared__ float gs[NL * 4];
@@ -141,9 +144,11 @@ __global__ void prompt_mix_bwd_enc_kernel(const float* __restrict__ gate, const 
     const f32x4 m = *reinterpret_cast<const f32x4*>(dsm + n * L * W + (long)l * W + c) * 0.25f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) o[k] = m;
+    const float* src = dpkv + ((long)kv * B + b) * P * hid + (long)slot * hid + cc;
+    const long lstride = 2L * B * P * hid;
 #pragma unroll
     for (int idx = 0; idx < NL; ++idx) {
-      const f32x4 d = *reinterpret_cast<const f32x4*>(dpkv + (((long)idx * 2 + kv) * B + b) * P * hid + (long)slot * hid + cc);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(src + idx * lstride);
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k] += d * gs[idx * 4 + k];
     }
@@ -248,7 +253,7 @@ int mtvaf_gate_fwd(const float* logits, float* gate, long ngroups, hipStream_t s
 int mtvaf_prompt_mix_fwd(const float* enc, const float* gate, float* pkv, int NI, int B, int L, int W, int NL,
                          hipStream_t st) {
   if (W % 8 || NI <= 0 || B <= 0 || L <= 0) return MTVAF_ERR_SHAPE;
-  dim3 grid(NI * B * L), block(256);
+  dim3 grid(NI * B * L), block(W / 4 <= 384 && (W / 4) % 64 == 0 ? W / 4 : 256);
   if (NL == 12) hipLaunchKernelGGL((prompt_mix_fwd_kernel<12>), grid, block, 0, st, enc, gate, pkv, NI, B, L, W);
   else if (NL == 2) hipLaunchKernelGGL((prompt_mix_fwd_kernel<2>), grid, block, 0, st, enc, gate, pkv, NI, B, L, W);
   else return MTVAF_ERR_SHAPE;
@@ -275,7 +280,7 @@ int mtvaf_prompt_mix_bwd_gate(const float* enc, const float* dpkv, const float* 
 int mtvaf_prompt_mix_bwd_enc(const float* gate, const float* dpkv, const float* dsm, float* denc, int NI, int B, int L,
                              int W, int NL, hipStream_t st) {
   if (W % 8 || NI <= 0 || B <= 0 || L <= 0) return MTVAF_ERR_SHAPE;
-  dim3 grid(NI * B * L), block(256);
+  dim3 grid(NI * B * L), block(W / 4 <= 384 && (W / 4) % 64 == 0 ? W / 4 : 256);
   if (NL == 12) hipLaunchKernelGGL((prompt_mix_bwd_enc_kernel<12>), grid, block, 0, st, gate, dpkv, dsm, denc, NI, B, L, W);
   else if (NL == 2) hipLaunchKernelGGL((prompt_mix_bwd_enc_kernel<2>), grid, block, 0, st, gate, dpkv, dsm, denc, NI, B, L, W);
   else return MTVAF_ERR_SHAPE;
