@@ -118,7 +118,7 @@ class EncoderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, *params):
         B, S, H = h0.shape
-        NH, eps, p_hidden, p_attn = cfg
+        NH, eps, p_hidden, p_attn, pkv_ready = cfg
         L = len(weights)
         M = B * S
         Pn = 0 if pkv is None else pkv.shape[3] // H
@@ -134,6 +134,10 @@ class EncoderFunction(torch.autograd.Function):
             cx, lse = _empty(M, H, like=x), _empty(B, NH, S, like=x)
             pk = pkv[li, 0] if Pn else None
             pv = pkv[li, 1] if Pn else None
+            if li == 0 and Pn and pkv_ready is not None:  # prefix produced on the second stream (prompt generator)
+                cur = torch.cuda.current_stream()
+                cur.wait_event(pkv_ready)
+                pkv.record_stream(cur)
             hip.prefix_attn_fwd(qkv, pk, pv, addmask, cx, lse, B, S, Pn, NH, p_attn, seed, off)
             a = _empty(M, H, like=x)
             hip.linear_fwd(cx, w.wo, w.bo, a)
@@ -160,7 +164,7 @@ class EncoderFunction(torch.autograd.Function):
     def backward(ctx, *douts):
         offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params = ctx.stash
         flat = ctx.saved_tensors
-        NH, eps, p_hidden, p_attn = cfg
+        NH, eps, p_hidden, p_attn = cfg[:4]
         L = len(weights)
         M = B * S
         dev_like = flat[0]

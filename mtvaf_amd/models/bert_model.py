@@ -30,6 +30,30 @@ def _arg(args, name, default=False):
     return getattr(args, name, default)
 
 
+def _on_second_stream(fn, inputs, join=False):
+    """Run the prompt generator (small, low-occupancy GEMMs and mixing kernels) on the engine's second stream so it
+    overlaps the embeddings and the first QKV product; the encoder waits for the prefix right before its first
+    attention kernel (``PrefixKV.ready_event``).  Autograd runs the generator's backward on the same stream, next to
+    the embeddings' backward.  Small batches / CPU tensors / MTVAF_DW_STREAM=0: plain call."""
+    ts = [t for t in inputs if isinstance(t, torch.Tensor)]
+    if not (engine.DW_SIDE_STREAM and ts and ts[0].is_cuda and ts[0].shape[0] >= 8):
+        return fn()
+    main, side = torch.cuda.current_stream(), engine._side_stream(ts[0].device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn()
+        ev = torch.cuda.Event()
+        ev.record(side)
+    for t in ts:
+        t.record_stream(side)
+    pkv = out[0] if isinstance(out, tuple) else out
+    if join or not isinstance(pkv, PrefixKV):
+        main.wait_event(ev)
+    else:
+        pkv.ready_event = ev
+    return out
+
+
 class ImageModel(nn.Module):
     """Frozen ResNet pyramid front-end (reference: models/bert_model.py:63-111).  It is UPSTREAM of the
     accelerated path and runs in plain torch (MIOpen convolutions) on the trunks of
@@ -136,7 +160,9 @@ class TVNetSAModel2(nn.Module):
         bsz = input_ids.size(0)
         img_tag_loss = 0
         if _arg(self.args, "use_prefix"):
-            prefix_guids, img_tag_loss, aux_img_tag_loss = self.get_visual_prompt(images, aux_imgs, imagelabel)
+            prefix_guids, img_tag_loss, aux_img_tag_loss = _on_second_stream(
+                lambda: self.get_visual_prompt(images, aux_imgs, imagelabel), (images, aux_imgs, imagelabel),
+                join=_arg(self.args, "vao"))  # the VAO losses are consumed on the main stream right away
             img_tag_loss = img_tag_loss if _arg(self.args, "noauxloss") else img_tag_loss + sum(aux_img_tag_loss)
             prefix_len = prefix_guids[0][0].shape[2]
             prefix_mask = torch.ones((bsz, prefix_len), device=attention_mask.device, dtype=attention_mask.dtype)
@@ -310,7 +336,7 @@ class TVNetSAModel(nn.Module):
         """reference: models/bert_model.py:246-321 (use_probe / GCN branches excluded)."""
         bsz = input_ids.size(0)
         if _arg(self.args, "use_prefix"):
-            prefix_guids = self.get_visual_prompt(images, aux_imgs)
+            prefix_guids = _on_second_stream(lambda: self.get_visual_prompt(images, aux_imgs), (images, aux_imgs))
             prefix_len = prefix_guids[0][0].shape[2]
             prefix_mask = torch.ones((bsz, prefix_len), device=attention_mask.device, dtype=attention_mask.dtype)
             prompt_attention_mask = torch.cat((prefix_mask, attention_mask), dim=1)

@@ -250,7 +250,7 @@ class BertEncoder(nn.Module):
             raise ValueError(f"attention mask covers {addmask.shape[1]} keys, expected prefix {Pn} + text {S}")
         tr = self.training
         ecfg = (cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob if tr else 0.0,
-                cfg.attention_probs_dropout_prob if tr else 0.0)
+                cfg.attention_probs_dropout_prob if tr else 0.0, getattr(past_key_values, "ready_event", None))
         params = [p for l in self.layer for p in l.ordered_params()]
         outs = engine.EncoderFunction.apply(hidden_states, pkv, addmask, ecfg, [st.weights for st in stores],
                                             sink if torch.is_grad_enabled() else None, *params)
@@ -272,6 +272,9 @@ class PrefixKV(list):
         super().__init__((flat[i, 0].view(B, num_heads, P, head_dim), flat[i, 1].view(B, num_heads, P, head_dim))
                          for i in range(L))
         self.flat = flat
+        # set when the prompt generator ran on a second stream: the encoder waits for it right before the first
+        # attention kernel instead of at its entry (the embeddings and the layer-0 QKV product do not need the prefix)
+        self.ready_event = None
 
 
 def pack_prefix(past_key_values, B: int, H: int) -> Optional[torch.Tensor]:
