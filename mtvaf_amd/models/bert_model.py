@@ -36,7 +36,7 @@ def _on_second_stream(fn, inputs, join=False):
     attention kernel (``PrefixKV.ready_event``).  Autograd runs the generator's backward on the same stream, next to
     the embeddings' backward.  Small batches / CPU tensors / MTVAF_DW_STREAM=0: plain call."""
     ts = [t for t in inputs if isinstance(t, torch.Tensor)]
-    if not (engine.DW_SIDE_STREAM and ts and ts[0].is_cuda and ts[0].shape[0] >= 8):
+    if not (engine.DW_SIDE_STREAM and ts and ts[0].is_cuda and ts[0].shape[0] >= 8):  # small batches are host-bound
         return fn()
     main, side = torch.cuda.current_stream(), engine._side_stream(ts[0].device)
     side.wait_stream(main)
@@ -179,7 +179,7 @@ class TVNetSAModel2(nn.Module):
         # Viterbi paths: device kernel + async packed copy; the list materialises on first use (no mid-step sync).
         # One wavefront per sentence is all the parallelism Viterbi and the CRF forward algorithm have, so the two
         # run side by side (second stream) instead of back to back.
-        if emissions.is_cuda and engine.DW_SIDE_STREAM:
+        if emissions.is_cuda and engine.DW_SIDE_STREAM and emissions.shape[0] * emissions.shape[1] >= 1024:  # host-bound below
             main, side = torch.cuda.current_stream(), engine._side_stream(emissions.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
