@@ -92,7 +92,14 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _st():
+    """hipStream_t of torch's current stream on the current device (one C call: torch.cuda.current_stream() builds a
+    Stream object and costs ~8 us, which adds up over ~130 launches per step in the launch-bound configurations)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -117,7 +124,7 @@ _ws = {}
 def workspace(nbytes: int, device) -> torch.Tensor:
     """Scratch for split-K slabs / column-sum partials, one buffer per (device, stream): kernels launched on a side
     stream (the weight-gradient products of the encoder backward) must not share slabs with the main stream."""
-    key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream if torch.cuda.is_available() else 0)
+    key = (torch.device(device).index or 0, _st() if _lib is not None else 0)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
