@@ -124,11 +124,19 @@ class BertLayer(nn.Module):
         self.output = BertOutput(config)
 
     def ordered_params(self) -> List[nn.Parameter]:
+        # nn.Module attribute lookups are slow (16 parameters x 12 layers x 2 per step add up in the launch-bound
+        # configurations): the Parameter objects are cached and the cache is dropped if the first / last one is replaced
+        c = self.__dict__.get("_ordered")
+        if c is not None and c[0] is self.attention.self.query._parameters["weight"] and \
+                c[15] is self.output.LayerNorm._parameters["bias"]:
+            return c
         a, s = self.attention, self.attention.self
-        return [s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias,
-                a.output.dense.weight, a.output.dense.bias, a.output.LayerNorm.weight, a.output.LayerNorm.bias,
-                self.intermediate.dense.weight, self.intermediate.dense.bias,
-                self.output.dense.weight, self.output.dense.bias, self.output.LayerNorm.weight, self.output.LayerNorm.bias]
+        c = [s.query.weight, s.query.bias, s.key.weight, s.key.bias, s.value.weight, s.value.bias,
+             a.output.dense.weight, a.output.dense.bias, a.output.LayerNorm.weight, a.output.LayerNorm.bias,
+             self.intermediate.dense.weight, self.intermediate.dense.bias,
+             self.output.dense.weight, self.output.dense.bias, self.output.LayerNorm.weight, self.output.LayerNorm.bias]
+        self.__dict__["_ordered"] = c
+        return c
 
 
 class _LayerStore:
