@@ -202,6 +202,17 @@ int mtvaf_ce_bwd(const float* grad_out, const float* logits, const int64_t* labe
 int mtvaf_mask_mul(const float* x, const float* row_keep, const float* col_keep, float* out, int B, int S, int H,
                    mtvaf_stream_t stream);
 
+/* bf16-OPERAND GEMM (mixed-precision configurations): C[M,N] fp32 = A[M,K] . B[N,K]^T with A, B stored as bf16
+ * (K contiguous), fp32 accumulation, the epilogues / deterministic split-K of mtvaf_gemm_f32.  Aligned shapes only
+ * (M % 128, N % 96 or 128, K % 64, 16-byte aligned operands): MTVAF_ERR_SHAPE / _ALIGN otherwise and the caller
+ * uses mtvaf_gemm_bf16.  mtvaf_cast_bf16 prepares operands: a row-major and / or a transposed bf16 copy of an fp32
+ * matrix (new functionality: the reference has no mixed precision). */
+int mtvaf_gemm_bf16kc(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                      const float* bias, int epi, float* aux, int ldaux, int accumulate, int allow_split,
+                      void* workspace, size_t workspace_bytes, int tile, int splits, mtvaf_stream_t stream);
+int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int ldt, int R, int C,
+                    mtvaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

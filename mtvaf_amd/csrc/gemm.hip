@@ -607,6 +607,17 @@ static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, int mode, hi
 
 int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, bool aligned, hipStream_t st);  // gemm_bf16.hip
 
+// ordered split-K slab reduction (+ bias / tanh / dtanh epilogue), shared with gemm_bf16kc.hip
+int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
+                         int epi, const float* aux, int ldaux, hipStream_t stream) {
+  const long n = (long)M * N;
+  const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, splits, n, C, M, N, ldc, bias,
+                     accumulate, epi, aux, ldaux);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 
 // ---- optional launch profiler (bench.py roofline): HIP events recorded on the launch stream directly

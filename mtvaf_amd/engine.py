@@ -89,6 +89,36 @@ class LayerWeights:
     __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2")
 
 
+def _bf16(*shape, like: torch.Tensor):
+    return torch.empty(shape, device=like.device, dtype=torch.bfloat16)
+
+
+def _cast(x, transposed=False, both=False):
+    """fp32 [R,C] -> bf16 row-major copy, transposed copy, or (row-major, transposed)."""
+    R, C = x.shape
+    out = _bf16(R, C, like=x) if (both or not transposed) else None
+    out_t = _bf16(C, R, like=x) if (both or transposed) else None
+    hip.cast_bf16(x, out=out, out_t=out_t)
+    return (out, out_t) if both else (out_t if transposed else out)
+
+
+def _weights_bf16(w: LayerWeights):
+    """bf16 shadows (row-major for the forward products, transposed for dX) of a layer's four weight matrices.  They
+    are rebuilt in every forward pass (85 M parameters: ~0.2 ms per step) and handed to the backward pass: the fp32
+    masters are updated in place by the optimizer through Parameter objects whose version counters the kernel-side
+    views do not share, so there is nothing cheap and reliable to key a cache on."""
+    return tuple(_cast(t, both=True) for t in (w.wqkv, w.wo, w.w1, w.w2))
+
+
+BF16_OPERANDS = os.environ.get("MTVAF_BF16_OPERANDS", "1") != "0"  # 0: fp32-operand bf16 kernels only (gemm_bf16.hip)
+
+
+def _bf16_ok(M, H, I):
+    """bf16-operand kernels need whole 128-row / 96- or 128-column tiles and 64-deep k-tiles."""
+    return (hip.COMPUTE == "bf16" and BF16_OPERANDS and M % 128 == 0 and H % 384 == 0 and I % 384 == 0 and
+            (3 * H) % 128 == 0)
+
+
 N_LAYER_PARAMS = 16  # q.w q.b k.w k.b v.w v.b ao.w ao.b ln1.w ln1.b i.w i.b o.w o.b ln2.w ln2.b
 
 
@@ -126,11 +156,17 @@ class EncoderFunction(torch.autograd.Function):
         seed = RNG.seed()
         saved, offs = [], []
         outs = []
+        use_h = _bf16_ok(M, H, weights[0].w1.shape[0]) if L else False
+        wh = [_weights_bf16(w) for w in weights] if use_h else None
         for li, w in enumerate(weights):
             I = w.w1.shape[0]
             off = RNG.next(3)
             qkv = _empty(M, 3 * H, like=x)
-            hip.linear_fwd(x, w.wqkv, w.bqkv, qkv)
+            if use_h:  # mixed precision: bf16 operands prepared once per use, fp32 accumulation / results / statistics
+                (wqkv_h, _), (wo_h, _), (w1_h, _), (w2_h, _) = wh[li]
+                hip.gemm_bf16kc(_cast(x), wqkv_h, qkv, bias=w.bqkv)
+            else:
+                hip.linear_fwd(x, w.wqkv, w.bqkv, qkv)
             cx, lse = _empty(M, H, like=x), _empty(B, NH, S, like=x)
             pk = pkv[li, 0] if Pn else None
             pv = pkv[li, 1] if Pn else None
@@ -140,13 +176,20 @@ class EncoderFunction(torch.autograd.Function):
                 pkv.record_stream(cur)
             hip.prefix_attn_fwd(qkv, pk, pv, addmask, cx, lse, B, S, Pn, NH, p_attn, seed, off)
             a = _empty(M, H, like=x)
-            hip.linear_fwd(cx, w.wo, w.bo, a)
+            if use_h:
+                hip.gemm_bf16kc(_cast(cx), wo_h, a, bias=w.bo)
+            else:
+                hip.linear_fwd(cx, w.wo, w.bo, a)
             h1, mean1, rstd1 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
             hip.dropout_res_ln_fwd(a, x, w.g1, w.b1, h1, mean1, rstd1, eps, p_hidden, seed, off + 1)
             pre, act = _empty(M, I, like=x), _empty(M, I, like=x)
-            hip.linear_fwd(h1, w.w1, w.bi1, act, epi=hip.EPI_GELU, aux=pre)
             f = _empty(M, H, like=x)
-            hip.linear_fwd(act, w.w2, w.bi2, f)
+            if use_h:
+                hip.gemm_bf16kc(_cast(h1), w1_h, act, bias=w.bi1, epi=hip.EPI_GELU, aux=pre)
+                hip.gemm_bf16kc(_cast(act), w2_h, f, bias=w.bi2)
+            else:
+                hip.linear_fwd(h1, w.w1, w.bi1, act, epi=hip.EPI_GELU, aux=pre)
+                hip.linear_fwd(act, w.w2, w.bi2, f)
             h2, mean2, rstd2 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
             hip.dropout_res_ln_fwd(f, h1, w.g2, w.b2, h2, mean2, rstd2, eps, p_hidden, seed, off + 2)
             saved.extend((x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2))
@@ -157,6 +200,7 @@ class EncoderFunction(torch.autograd.Function):
         # (a python attribute would keep ~3 GB per layer at B=128, S=512 alive until the loss tensor dies)
         ctx.save_for_backward(*saved)
         ctx.stash = (offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
+        ctx.wh = wh
         ctx.set_materialize_grads(False)  # unused hidden states arrive as None, not as [B,S,H] zero fills + adds
         return tuple(outs)
 
@@ -175,6 +219,8 @@ class EncoderFunction(torch.autograd.Function):
         gviews = grad_sink.acquire(params) if grad_sink is not None else None
         pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
 
+        wh = ctx.wh
+        use_h = wh is not None
         main = torch.cuda.current_stream()
         # (small batches are host-bound: the extra events / stream switches cost more than the overlap returns)
         side = _side_stream(dev_like.device) if (DW_SIDE_STREAM and need_param_grads and M >= 1024) else None
@@ -221,33 +267,61 @@ class EncoderFunction(torch.autograd.Function):
             df, dh1 = _empty(M, H, like=dev_like), _empty(M, H, like=dev_like)
             hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, df, dh1, False, G[14], G[15], False, p_hidden, seed,
                                    off + 2, dbias_x=G[13])
-            on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12]))
             dpre = _empty(M, I, like=dev_like)
-            hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
+            if use_h:
+                # dX = dY . W with the transposed bf16 weight shadow; dW = dY^T . X with both operands cast transposed
+                (_, wqkvT_h), (_, woT_h), (_, w1T_h), (_, w2T_h) = wh[li]
+                df_h, dfT_h = _cast(df, both=True)
+                on_side((dfT_h,), lambda: hip.gemm_bf16kc(dfT_h, _cast(act, transposed=True), G[12], allow_split=True))
+                hip.gemm_bf16kc(df_h, w2T_h, dpre, epi=hip.EPI_DGELU, aux=pre)
+                dpre_h, dpreT_h = _cast(dpre, both=True)
 
-            def ffn1_grads():
-                hip.colsum(dpre, G[11])
-                hip.linear_bwd_weight(dpre, h1, G[10])
-            on_side((dpre,), ffn1_grads)
-            hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
+                def ffn1_grads():
+                    hip.colsum(dpre, G[11])
+                    hip.gemm_bf16kc(dpreT_h, _cast(h1, transposed=True), G[10], allow_split=True)
+                on_side((dpre, dpreT_h), ffn1_grads)
+                hip.gemm_bf16kc(dpre_h, w1T_h, dh1, accumulate=True)
+            else:
+                on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12]))
+                hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
+
+                def ffn1_grads():
+                    hip.colsum(dpre, G[11])
+                    hip.linear_bwd_weight(dpre, h1, G[10])
+                on_side((dpre,), ffn1_grads)
+                hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
             # ---- attention block ----
             da = df if side is None else _empty(M, H, like=dev_like)  # df is still being read on the side stream
             dh0 = dh  # reuse
             hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
                                    off + 1, dbias_x=G[7])
-            on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6]))
             dctx = dh1
-            hip.linear_bwd_input(da, w.wo, dctx)
+            if use_h:
+                da_h, daT_h = _cast(da, both=True)
+                on_side((daT_h,), lambda: hip.gemm_bf16kc(daT_h, _cast(cx, transposed=True), G[6], allow_split=True))
+                hip.gemm_bf16kc(da_h, woT_h, dctx)
+            else:
+                on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6]))
+                hip.linear_bwd_input(da, w.wo, dctx)
             dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
             hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
                                 delta, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, B, S, Pn, NH,
                                 p_attn, seed, off)
 
-            def qkv_grads():
-                hip.colsum(dqkv, dbqkv)
-                hip.linear_bwd_weight(dqkv, x, dwqkv)
-            on_side((dqkv,), qkv_grads)
-            hip.linear_bwd_input(dqkv, w.wqkv, dh0, accumulate=True)
+            if use_h:
+                dqkv_h, dqkvT_h = _cast(dqkv, both=True)
+
+                def qkv_grads():
+                    hip.colsum(dqkv, dbqkv)
+                    hip.gemm_bf16kc(dqkvT_h, _cast(x, transposed=True), dwqkv, allow_split=True)
+                on_side((dqkv, dqkvT_h), qkv_grads)
+                hip.gemm_bf16kc(dqkv_h, wqkvT_h, dh0, accumulate=True)
+            else:
+                def qkv_grads():
+                    hip.colsum(dqkv, dbqkv)
+                    hip.linear_bwd_weight(dqkv, x, dwqkv)
+                on_side((dqkv,), qkv_grads)
+                hip.linear_bwd_input(dqkv, w.wqkv, dh0, accumulate=True)
             dh = dh0
             if gviews is None:
                 G[0], G[2], G[4] = dwqkv[:H], dwqkv[H:2 * H], dwqkv[2 * H:]

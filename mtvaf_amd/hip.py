@@ -63,6 +63,8 @@ _SIGS = {
     "mtvaf_ce_fwd": (c_int, [P, P, P, P, I, I, P]),
     "mtvaf_ce_bwd": (c_int, [P, P, P, P, P, I, I, P]),
     "mtvaf_mask_mul": (c_int, [P, P, P, P, I, I, I, P]),
+    "mtvaf_gemm_bf16kc": (c_int, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
+    "mtvaf_cast_bf16": (c_int, [P, I, P, I, P, I, I, I, P]),
 }
 
 _lib = None
@@ -387,4 +389,26 @@ def ce_bwd(gout, logits, labels, ws2, dlogits):
 def mask_mul(x, row_keep, col_keep, out):
     B, S, H = x.shape
     _ck(lib().mtvaf_mask_mul(_p(x), _p(row_keep), _p(col_keep), _p(out), B, S, H, _st()), "mtvaf_mask_mul")
+    return out
+
+
+# ---- bf16-operand GEMM (csrc/gemm_bf16kc.hip) ---------------------------------------------------------------------
+def cast_bf16(x, out=None, out_t=None):
+    """x [R,C] fp32 -> out [R,C] bf16 and / or out_t [C,R] bf16 (either may be None)."""
+    R, C = x.shape
+    _ck(lib().mtvaf_cast_bf16(_p(x), x.stride(0), _p(out), out.stride(0) if out is not None else 0, _p(out_t),
+                              out_t.stride(0) if out_t is not None else 0, R, C, _st()), "mtvaf_cast_bf16")
+
+
+def gemm_bf16kc(a, b, out, bias=None, epi=EPI_NONE, aux=None, accumulate=False, allow_split=False, tile=0, splits=-1):
+    """out[M,N] fp32 = a[M,K] . b[N,K]^T, a / b bf16 with K contiguous (aligned shapes only; raises otherwise)."""
+    M, K = a.shape
+    N = b.shape[0]
+    ws, wsb = None, 0
+    if allow_split:
+        wsb = 8 * M * N * 4
+        ws = workspace(wsb, out.device)
+    _ck(lib().mtvaf_gemm_bf16kc(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), epi,
+                                _p(aux), aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws),
+                                wsb, tile, splits, _st()), "mtvaf_gemm_bf16kc")
     return out

@@ -358,6 +358,46 @@ def test_bf16_compute_mode_tracks_the_fp32_oracle():
     assert float((g - go).norm() / go.norm()) < 5e-2
 
 
+def test_bf16_operand_path_matches_the_fp32_operand_bf16_kernels():
+    """Same arithmetic model (operands rounded to bf16, fp32 accumulation), two implementations: the bf16-operand
+    DMA kernels fed by cast / transpose passes vs the kernels that round fp32 tiles while staging them.  Loss and
+    every encoder gradient must agree to accumulation-order noise."""
+    from mtvaf_amd import engine, hip
+    cfg = P.EncCfg(vocab_size=3000, hidden=768, heads=12, inter=3072, layers=3, max_pos=128)
+    B, S, Pn = 4, 128, 36
+    m = build_tvnet2(cfg, make_args(use_prefix=False), sde=P.encoder_params(cfg, 17, std=0.03), sdh=P.head_params(cfg, 18))
+    m.eval()
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 19, B, S, lo_id=100))
+    labels[:, 0] = 9
+    gp = [(k.to(DEV), v.to(DEV)) for k, v in P.prefix_kv(20, cfg.layers, B, cfg.heads, Pn, std=0.5)]
+    full = torch.cat([torch.ones(B, Pn, dtype=mask.dtype, device=DEV), mask], 1)
+    res = {}
+    hip.set_compute_dtype("bf16")
+    was = engine.BF16_OPERANDS
+    try:
+        for flag in (True, False):
+            engine.BF16_OPERANDS = flag
+            m.zero_grad(set_to_none=True)
+            hs = m.bert(input_ids=ids, attention_mask=full, token_type_ids=tt, past_key_values=gp)["last_hidden_state"]
+            em = torch.nn.functional.linear(hs, m.fc.weight, m.fc.bias)
+            loss = -m.crf(em, labels, mask=mask.to(torch.uint8), reduction="mean")
+            loss.backward()
+            res[flag] = (float(loss), hs.detach().clone(), {n: p.grad.clone() for n, p in m.bert.named_parameters()
+                                                            if p.grad is not None})
+    finally:
+        engine.BF16_OPERANDS = was
+        hip.set_compute_dtype("fp32")
+    # a 1e-6 difference upstream flips individual bf16 roundings downstream (2^-9 each), so the two runs agree to a
+    # few 1e-3 in norm, not element by element; a wrong operand or transpose would be an O(1) error
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    assert abs(res[True][0] - res[False][0]) <= 1e-3 * abs(res[False][0])
+    assert rel(res[True][1], res[False][1]) < 5e-3
+    assert len(res[True][2]) == len(res[False][2]) > 40
+    for n, g in res[False][2].items():
+        if float(g.abs().max()) > 1e-6:   # (the key bias has a true gradient of 0: pure rounding noise)
+            assert rel(res[True][2][n], g) < 2e-2, (n, rel(res[True][2][n], g))
+
+
 def test_deferred_tags_behave_like_the_eager_list():
     cfg = P.EncCfg(vocab_size=300, hidden=128, heads=2, inter=256, layers=2, max_pos=64)
     m = build_tvnet2(cfg, make_args(use_prefix=False), sde=P.encoder_params(cfg, 1), sdh=P.head_params(cfg, 2))

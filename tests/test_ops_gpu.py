@@ -542,3 +542,38 @@ def test_gemm_splitk_with_tanh_epilogues(hip):
     xs, ws, bs = rnd(288, 6144, seed=7, scale=0.1), rnd(48, 6144, seed=8, scale=0.1), rnd(48, seed=9)
     hip.linear_fwd(xs.to(DEV), ws.to(DEV), bs.to(DEV), lg)
     close(lg, F.linear(xs.double(), ws.double(), bs.double()), rtol=3e-4, name="auto split skinny")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 96, 64), (256, 384, 192), (512, 768, 768), (384, 128, 4096)])
+def test_gemm_bf16_operands(hip, M, N, K):
+    """bf16-OPERAND kernel (gemm_bf16kc.hip): exact model = fp32/fp64 products of the bf16-rounded operands; every
+    epilogue, accumulate, forced tiles and split-K; the cast kernel (row-major + transposed copies) is exact."""
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    xh, xt = torch.empty(M, K, dtype=torch.bfloat16, device=DEV), torch.empty(K, M, dtype=torch.bfloat16, device=DEV)
+    hip.cast_bf16(x.to(DEV), out=xh, out_t=xt)
+    assert torch.equal(xh.cpu(), x.to(torch.bfloat16)) and torch.equal(xt.cpu(), x.t().contiguous().to(torch.bfloat16))
+    wh = w.to(torch.bfloat16).to(DEV)
+    ref = xh.double().cpu() @ wh.double().cpu().t()
+    out = torch.empty(M, N, device=DEV)
+    for tile in ([0] + ([1] if N % 96 == 0 else []) + ([2] if N % 128 == 0 else [])):
+        hip.gemm_bf16kc(xh, wh, out, bias=b.to(DEV), tile=tile)
+        close(out, ref + b.double(), rtol=2e-5, name=f"bias tile {tile}")
+    aux = torch.empty(M, N, device=DEV)
+    hip.gemm_bf16kc(xh, wh, out, bias=b.to(DEV), epi=hip.EPI_GELU, aux=aux)
+    close(aux, ref + b.double(), rtol=2e-5, name="pre")
+    close(out, F.gelu((ref + b.double())), rtol=2e-5, atol=2e-6 * float(ref.abs().max()), name="gelu")
+    pre = rnd(M, N, seed=5)
+    hip.gemm_bf16kc(xh, wh, out, epi=hip.EPI_DGELU, aux=pre.to(DEV))
+    pd = pre.double().requires_grad_(True)
+    F.gelu(pd).sum().backward()
+    close(out, ref * pd.grad, rtol=3e-5, atol=3e-6 * float(ref.abs().max()), name="dgelu")
+    acc0 = rnd(M, N, seed=6)
+    out.copy_(acc0)
+    hip.gemm_bf16kc(xh, wh, out, accumulate=True)
+    close(out, ref + acc0.double(), rtol=2e-5, name="accumulate")
+    if K >= 512:
+        for s in (2, 3):
+            hip.gemm_bf16kc(xh, wh, out, allow_split=True, splits=s)
+            close(out, ref, rtol=2e-5, name=f"split {s}")
+    with pytest.raises(RuntimeError):
+        hip.gemm_bf16kc(xh[:100], wh, out[:100])  # ragged M: the caller must use the fp32-operand kernels
