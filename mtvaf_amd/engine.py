@@ -86,7 +86,7 @@ class EmbeddingsFunction(torch.autograd.Function):
 # -------------------------------------------------------------------------------------------------
 class LayerWeights:
     """Device pointers of one encoder layer in kernel-ready (QKV-packed) form."""
-    __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2")
+    __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2", "wparams", "_h")
 
 
 def _bf16(*shape, like: torch.Tensor):
@@ -103,13 +103,28 @@ def _cast(x, transposed=False, both=False):
 
 
 def _weights_bf16(w: LayerWeights):
-    """bf16 shadows (row-major for the forward products, transposed for dX) of a layer's four weight matrices.  They
-    are rebuilt in every forward pass (85 M parameters: ~0.2 ms per step) and handed to the backward pass: the fp32
-    masters are updated in place by the optimizer through Parameter objects whose version counters the kernel-side
-    views do not share, so there is nothing cheap and reliable to key a cache on."""
-    return tuple(_cast(t, both=True) for t in (w.wqkv, w.wo, w.w1, w.w2))
+    """bf16 shadows (row-major for the forward products, transposed for dX) of a layer's four weight matrices.
+    Rebuilt when the masters may have changed: after ANY torch optimizer step (global post-step hook -- the fused
+    optimizers update parameters without moving their version counters) or when a weight Parameter's version
+    counter has moved (load_state_dict, in-place updates through the Parameter).  Writes through ``.data`` are
+    invisible to both: MTVAF_BF16_WCACHE=0 rebuilds in every forward pass (85 M parameters, ~0.3 ms per step)."""
+    ver = (_OPT_EPOCH[0],) + tuple(p._version for p in w.wparams) if (BF16_WCACHE and getattr(w, "wparams", None)) else None
+    c = getattr(w, "_h", None)
+    if ver is None or c is None or c[0] != ver:
+        c = (ver, tuple(_cast(t, both=True) for t in (w.wqkv, w.wo, w.w1, w.w2)))
+        if ver is not None:
+            w._h = c
+    return c[1]
 
 
+_OPT_EPOCH = [0]
+try:  # every optimizer step invalidates the bf16 weight shadows
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(lambda opt, args, kwargs: _OPT_EPOCH.__setitem__(0, _OPT_EPOCH[0] + 1))
+    _HAVE_OPT_HOOK = True
+except Exception:  # pragma: no cover - very old torch: never cache
+    _HAVE_OPT_HOOK = False
+BF16_WCACHE = os.environ.get("MTVAF_BF16_WCACHE", "1") != "0" and _HAVE_OPT_HOOK
 BF16_OPERANDS = os.environ.get("MTVAF_BF16_OPERANDS", "1") != "0"  # 0: fp32-operand bf16 kernels only (gemm_bf16.hip)
 
 
@@ -154,7 +169,7 @@ class EncoderFunction(torch.autograd.Function):
         Pn = 0 if pkv is None else pkv.shape[3] // H
         x = h0.contiguous().view(M, H)
         seed = RNG.seed()
-        saved, offs = [], []
+        saved, offs, saved_t = [], [], []
         outs = []
         use_h = _bf16_ok(M, H, weights[0].w1.shape[0]) if L else False
         wh = [_weights_bf16(w) for w in weights] if use_h else None
@@ -164,7 +179,8 @@ class EncoderFunction(torch.autograd.Function):
             qkv = _empty(M, 3 * H, like=x)
             if use_h:  # mixed precision: bf16 operands prepared once per use, fp32 accumulation / results / statistics
                 (wqkv_h, _), (wo_h, _), (w1_h, _), (w2_h, _) = wh[li]
-                hip.gemm_bf16kc(_cast(x), wqkv_h, qkv, bias=w.bqkv)
+                x_h, xT_h = _cast(x, both=True)  # the transposed copies are the B operands of the dW products
+                hip.gemm_bf16kc(x_h, wqkv_h, qkv, bias=w.bqkv)
             else:
                 hip.linear_fwd(x, w.wqkv, w.bqkv, qkv)
             cx, lse = _empty(M, H, like=x), _empty(B, NH, S, like=x)
@@ -177,7 +193,8 @@ class EncoderFunction(torch.autograd.Function):
             hip.prefix_attn_fwd(qkv, pk, pv, addmask, cx, lse, B, S, Pn, NH, p_attn, seed, off)
             a = _empty(M, H, like=x)
             if use_h:
-                hip.gemm_bf16kc(_cast(cx), wo_h, a, bias=w.bo)
+                cx_h, cxT_h = _cast(cx, both=True)
+                hip.gemm_bf16kc(cx_h, wo_h, a, bias=w.bo)
             else:
                 hip.linear_fwd(cx, w.wo, w.bo, a)
             h1, mean1, rstd1 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
@@ -185,8 +202,11 @@ class EncoderFunction(torch.autograd.Function):
             pre, act = _empty(M, I, like=x), _empty(M, I, like=x)
             f = _empty(M, H, like=x)
             if use_h:
-                hip.gemm_bf16kc(_cast(h1), w1_h, act, bias=w.bi1, epi=hip.EPI_GELU, aux=pre)
-                hip.gemm_bf16kc(_cast(act), w2_h, f, bias=w.bi2)
+                h1_h, h1T_h = _cast(h1, both=True)
+                hip.gemm_bf16kc(h1_h, w1_h, act, bias=w.bi1, epi=hip.EPI_GELU, aux=pre)
+                act_h, actT_h = _cast(act, both=True)
+                hip.gemm_bf16kc(act_h, w2_h, f, bias=w.bi2)
+                saved_t.extend((xT_h, cxT_h, h1T_h, actT_h))
             else:
                 hip.linear_fwd(h1, w.w1, w.bi1, act, epi=hip.EPI_GELU, aux=pre)
                 hip.linear_fwd(act, w.w2, w.bi2, f)
@@ -198,7 +218,7 @@ class EncoderFunction(torch.autograd.Function):
             x = h2
         # activations go through save_for_backward so that autograd releases them as soon as the backward has run
         # (a python attribute would keep ~3 GB per layer at B=128, S=512 alive until the loss tensor dies)
-        ctx.save_for_backward(*saved)
+        ctx.save_for_backward(*saved, *saved_t)
         ctx.stash = (offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
         ctx.wh = wh
         ctx.set_materialize_grads(False)  # unused hidden states arrive as None, not as [B,S,H] zero fills + adds
@@ -221,6 +241,7 @@ class EncoderFunction(torch.autograd.Function):
 
         wh = ctx.wh
         use_h = wh is not None
+        flat_t = flat[13 * L:]  # bf16 transposed activation copies (4 per layer) in mixed-precision mode
         main = torch.cuda.current_stream()
         # (small batches are host-bound: the extra events / stream switches cost more than the overlap returns)
         side = _side_stream(dev_like.device) if (DW_SIDE_STREAM and need_param_grads and M >= 1024) else None
@@ -272,13 +293,14 @@ class EncoderFunction(torch.autograd.Function):
                 # dX = dY . W with the transposed bf16 weight shadow; dW = dY^T . X with both operands cast transposed
                 (_, wqkvT_h), (_, woT_h), (_, w1T_h), (_, w2T_h) = wh[li]
                 df_h, dfT_h = _cast(df, both=True)
-                on_side((dfT_h,), lambda: hip.gemm_bf16kc(dfT_h, _cast(act, transposed=True), G[12], allow_split=True))
+                xT_h, cxT_h, h1T_h, actT_h = flat_t[4 * li:4 * li + 4]
+                on_side((dfT_h,), lambda: hip.gemm_bf16kc(dfT_h, actT_h, G[12], allow_split=True))
                 hip.gemm_bf16kc(df_h, w2T_h, dpre, epi=hip.EPI_DGELU, aux=pre)
                 dpre_h, dpreT_h = _cast(dpre, both=True)
 
                 def ffn1_grads():
                     hip.colsum(dpre, G[11])
-                    hip.gemm_bf16kc(dpreT_h, _cast(h1, transposed=True), G[10], allow_split=True)
+                    hip.gemm_bf16kc(dpreT_h, h1T_h, G[10], allow_split=True)
                 on_side((dpre, dpreT_h), ffn1_grads)
                 hip.gemm_bf16kc(dpre_h, w1T_h, dh1, accumulate=True)
             else:
@@ -298,7 +320,7 @@ class EncoderFunction(torch.autograd.Function):
             dctx = dh1
             if use_h:
                 da_h, daT_h = _cast(da, both=True)
-                on_side((daT_h,), lambda: hip.gemm_bf16kc(daT_h, _cast(cx, transposed=True), G[6], allow_split=True))
+                on_side((daT_h,), lambda: hip.gemm_bf16kc(daT_h, cxT_h, G[6], allow_split=True))
                 hip.gemm_bf16kc(da_h, woT_h, dctx)
             else:
                 on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6]))
@@ -313,7 +335,7 @@ class EncoderFunction(torch.autograd.Function):
 
                 def qkv_grads():
                     hip.colsum(dqkv, dbqkv)
-                    hip.gemm_bf16kc(dqkvT_h, _cast(x, transposed=True), dwqkv, allow_split=True)
+                    hip.gemm_bf16kc(dqkvT_h, xT_h, dwqkv, allow_split=True)
                 on_side((dqkv, dqkvT_h), qkv_grads)
                 hip.gemm_bf16kc(dqkv_h, wqkvT_h, dh0, accumulate=True)
             else:

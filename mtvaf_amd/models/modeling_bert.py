@@ -168,6 +168,8 @@ class _LayerStore:
         w.wqkv = self.flat[:3 * H * H].view(3 * H, H)
         w.bqkv = self.flat[3 * H * H:3 * H * H + 3 * H]
         (w.wo, w.bo, w.g1, w.b1, w.w1, w.bi1, w.w2, w.bi2, w.g2, w.b2) = [p.data for p in ps[6:]]
+        w.wparams = (ps[0], ps[2], ps[4], ps[6], ps[10], ps[12])  # the weight matrices' Parameters (version counters)
+        w._h = None
         self.weights = w
         self.shapes = [p.shape for p in ps]
 
