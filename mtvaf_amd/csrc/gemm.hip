@@ -627,6 +627,19 @@ struct ProfRec { hipEvent_t e0, e1; int key[8]; };
 static ProfRec* g_prof = nullptr;
 static int g_prof_cap = 0, g_prof_n = 0;
 
+// begin / end of a profiled launch for the other GEMM translation units (gemm_bf16kc.hip): returns a record index
+// or -1 when the profiler is off
+int prof_begin(const int key[8], hipStream_t stream) {
+  if (!g_prof || g_prof_n >= g_prof_cap) return -1;
+  const int i = g_prof_n++;
+  for (int j = 0; j < 8; ++j) g_prof[i].key[j] = key[j];
+  (void)hipEventRecord(g_prof[i].e0, stream);
+  return i;
+}
+void prof_end(int i, hipStream_t stream) {
+  if (i >= 0 && g_prof) (void)hipEventRecord(g_prof[i].e1, stream);
+}
+
 // Cost model (units: fp32 MFMA cycles of one CU).  The MFMA pipe of a CU is shared by its resident
 // blocks, so time ~ rounds over the 256 CUs x work per tile / efficiency of that tile shape (calibrated
 // with tools/gemm_sweep.py on MI355X at M = 4096), plus, for split-K, the slab write + ordered reduce.

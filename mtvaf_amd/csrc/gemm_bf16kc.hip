@@ -19,6 +19,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
                          int epi, const float* aux, int ldaux, hipStream_t stream);  // gemm.hip
+int prof_begin(const int key[8], hipStream_t stream);                                // gemm.hip (launch profiler)
+void prof_end(int rec, hipStream_t stream);
 
 __device__ __forceinline__ void glds16b(const void* src, void* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -230,7 +232,10 @@ int mtvaf_gemm_bf16kc(const void* A, int lda, const void* B, int ldb, float* C, 
   a.tiles_n = N / bn;
   a.wide = 1;
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
+  const int key[8] = {bn == 96 ? 200 : 201, 0, 0, 2, M, N, K, splits};
+  const int rec = prof_begin(key, stream);
   int rc = bn == 96 ? launch_kc<128, 96, 4, 1>(h, grid, stream) : launch_kc<128, 128, 2, 2>(h, grid, stream);
+  prof_end(rec, stream);
   if (rc != MTVAF_OK) return rc;
   if (splits > 1) return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
   return MTVAF_OK;

@@ -162,6 +162,8 @@ def kernel_symbol(cfg, la, lb, fast):
             8: (128, 192, 2, 2, 32), 9: (128, 96, 4, 1), 10: (128, 128, 2, 2), 11: (128, 192, 2, 2),
             12: (128, 96, 4, 1), 13: (128, 128, 2, 2)}.get(cfg)
     b = lambda x: "true" if x else "false"
+    if cfg >= 200:
+        return "gemm_bf16kc_kernel<128, 96, 4, 1>" if cfg == 200 else "gemm_bf16kc_kernel<128, 128, 2, 2>"
     if cfg >= 100:
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
         return f"gemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(fast == 2)}>"
