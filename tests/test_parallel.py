@@ -221,22 +221,29 @@ def _gpu_worker(rank, world, port, q):
         from mtvaf_amd.models.bert_model import TVNetSAModel2
         from mtvaf_amd.parallel import GradSync
         torch.cuda.set_device(0)
-        cfg = BertConfig(vocab_size=3000, hidden_size=128, num_hidden_layers=3, num_attention_heads=2,
+        cfg = BertConfig(vocab_size=3000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
                          intermediate_size=256, max_position_embeddings=64, hidden_dropout_prob=0.0,
                          attention_probs_dropout_prob=0.0)
-        args = types.SimpleNamespace(bert_name="bert-base-uncased", bert_config=cfg, use_prefix=False, vao=False,
+        # with the visual prefix: the prompt generator runs on the second stream (forward AND backward), its
+        # encoder_conv weights take the early all-reduce hook from there
+        args = types.SimpleNamespace(bert_name="bert-base-uncased", bert_config=cfg, use_prefix=True, vao=False,
                                      noauxloss=True, use_probe=False, n_gpu=1, alpha=0.0, prefix_len=4, prefix_dim=768,
                                      device="cuda", resnet_root=None, use_152=False)
         labels_list = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
         torch.manual_seed(0)
         m = TVNetSAModel2(labels_list, None, args).to("cuda").eval()
-        batches = [tuple(t.to("cuda") for t in P.text_batch(P.EncCfg(vocab_size=3000), 11 + r, 16, 64, lo_id=5))
-                   for r in range(world)]
+        batches = []
+        for r in range(world):
+            g = torch.Generator().manual_seed(100 + r)
+            feats = torch.randn(16, 3840, 2, 2, generator=g).abs().to("cuda")
+            aux = torch.randn(16, 3, 3840, 2, 2, generator=g).abs().to("cuda")
+            batches.append(tuple(t.to("cuda") for t in P.text_batch(P.EncCfg(vocab_size=3000), 11 + r, 16, 64, lo_id=5))
+                           + (feats, aux))
 
         def grads(batch):
-            ids, mask, tt, labels = batch
+            ids, mask, tt, labels, feats, aux = batch
             m.zero_grad(set_to_none=True)
-            m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss.backward()
+            m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux).loss.backward()
             torch.cuda.synchronize()
             return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
 
@@ -268,5 +275,5 @@ def test_gradsync_two_ranks_real_model_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank, worst, aliased, n in out:
-        assert n > 50 and aliased
+        assert n >= 40 and aliased
         assert worst < 2e-4, f"rank {rank}: synced gradients differ from the mean of the per-rank gradients by {worst:.2e}"
