@@ -73,10 +73,11 @@ def build_model(device, arch="bert", max_pos=512):
     return TVNetSAModel2(LABELS, None, args).to(device), cfg
 
 
-def cpu_baseline(S, P, seconds_budget=20.0):
-    """The reference algorithm on the host cores: the CPU oracle (a line-by-line restatement of the
-    reference modules, proven equal to them by tests/test_oracle_golden.py) doing fwd+bwd on a bounded
-    sample of the same workload."""
+def cpu_baseline(B, S, n_aux, seconds_budget=60.0, min_steps=3):
+    """The reference algorithm on the host cores: the CPU oracle (a line-by-line restatement of the reference modules,
+    proven equal to them by tests/test_oracle_golden.py) doing fwd+bwd of the SAME workload as the GPU line: the full
+    batch, prompt generator (`O.visual_prompt`, 1 + n_aux region-feature images) -> encoder -> fc -> CRF decode + NLL.
+    Median of >= `min_steps` steps within the time budget."""
     from oracle import mtvaf_oracle as O
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import params as PR
@@ -86,48 +87,54 @@ def cpu_baseline(S, P, seconds_budget=20.0):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
-    log(f"cpu baseline on {cores} threads")
+    log(f"cpu baseline on {cores} threads: B={B} S={S} aux={n_aux}")
     cfg = PR.BASE_BERT
-    Bc = 8
     sd = {**{"bert." + k: v.requires_grad_(True) for k, v in PR.encoder_params(cfg, 1, std=0.02).items()},
-          **{k: v.requires_grad_(True) for k, v in PR.head_params(cfg, 2).items()}}
-    ids, mask, tt, labels = PR.text_batch(cfg, 3, Bc, S, lo_id=1000)
+          **{k: v.requires_grad_(True) for k, v in PR.head_params(cfg, 2).items()},
+          **{k: v.requires_grad_(True) for k, v in PR.prompt_params(5).items()}}
+    ids, mask, tt, labels = PR.text_batch(cfg, 3, B, S, lo_id=1000)
     labels[:, 0] = 9
-    pkv = PR.prefix_kv(4, cfg.layers, Bc, cfg.heads, P, std=0.02)
+    g = torch.Generator().manual_seed(7)
+    feats = torch.randn(B, 4, 3840, generator=g).abs()
+    aux = [torch.randn(B, 4, 3840, generator=g).abs() for _ in range(n_aux)]
 
     def step():
+        pkv, _, _ = O.visual_prompt(sd, feats, aux, num_layers=cfg.layers, num_heads=cfg.heads)
         loss, _, _, _ = O.tvnet2_forward(sd, ids, mask, tt, labels, pkv, cfg.layers, cfg.heads, cfg.eps)
         loss.backward()
         for v in sd.values():
             v.grad = None
 
-    tw = time.perf_counter()
-    step()
-    tw = time.perf_counter() - tw
-    log(f"cpu baseline warm-up step: {tw:.2f}s")
-    t0 = time.perf_counter()
-    n = 0
-    while n < 1 or (time.perf_counter() - t0 + tw < seconds_budget and n < 12):
+    t_all = time.perf_counter()
+    step()  # warm-up (thread pool, allocator)
+    times = []
+    while len(times) < min_steps or (time.perf_counter() - t_all < seconds_budget and len(times) < 9):
+        t0 = time.perf_counter()
         step()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(Bc * n / dt, 3), "unit": "sentences/s", "cores": cores, "kind": "port",
-            "sample": f"{n} fwd+bwd steps of B={Bc}, S={S}, P={P} BERT-base fp32 on torch CPU ({cores} threads), "
-                      f"encoder+fc+CRF (prompt generator excluded)"}
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {"value": round(B / med, 3), "unit": "sentences/s", "cores": cores, "kind": "port",
+            "sample": f"median of {len(times)} fwd+bwd steps of the bench workload itself (B={B}, S={S}, P={4 * (1 + n_aux)}: "
+                      f"prompt generator + BERT-base encoder + fc + CRF decode/NLL, fp32) on torch CPU, {cores} threads",
+            "seconds_per_step": round(med, 3)}
 
 
 def pmc_traffic(symbol):
-    """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/pmc_gemm.json,
-    written by tools/pmc_to_json.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane
-    streams, plus WRITE_SIZE).  None when no profile of this kernel is committed."""
+    """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/pmc_gemm.json, written by
+    tools/pmc_to_json.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams, plus
+    WRITE_SIZE).  -> (bytes or None, provenance string): the counters come from a separate profiled run of this same
+    command, not from the run that prints the line."""
     path = os.path.join(ROOT, "profiles", "pmc_gemm.json")
     if not os.path.exists(path):
-        return None
+        return None, None
     try:
-        rec = json.load(open(path)).get(symbol)
-        return None if rec is None else rec["traffic_bytes_per_launch"]
+        d = json.load(open(path))
+        rec = d.get(symbol)
+        if rec is None:
+            return None, None
+        return rec["traffic_bytes_per_launch"], d.get("_source", "profiles/pmc_gemm.json (rocprofv3 --pmc passes, committed)")
     except Exception:
-        return None
+        return None, None
 
 
 def log(msg):
@@ -147,9 +154,10 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="GEMM arithmetic: fp32 (BASELINE config 2, default) or bf16 compute with fp32 accumulation (configs 3-4)")
     ap.add_argument("--no-optimizer", action="store_true")
-    ap.add_argument("--optimizer", default="all", choices=["all", "reference"],
-                    help="all: fused AdamW over every parameter; reference: the three name-matched groups + linear "
-                         "warm-up schedule of modules/train.py:894-926 (mtvaf_amd.optim)")
+    ap.add_argument("--optimizer", default="all", choices=["all", "reference", "torch"],
+                    help="all: mtvaf_amd.optim.AdamW (HIP kernels, per-layer updates enqueued inside the backward pass) over "
+                         "every parameter; reference: the same optimizer on the three name-matched groups + linear warm-up "
+                         "schedule of modules/train.py:894-926; torch: torch.optim.AdamW(fused=True) after the backward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -158,6 +166,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N > 1 with `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # Launcher smoke test on a 1-GPU box: MTVAF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 over gloo (RCCL refuses
@@ -189,9 +200,14 @@ def main():
         opt = None
     elif a.optimizer == "reference":
         from mtvaf_amd.optim import build_optimizer
-        opt, sched = build_optimizer(model, types.SimpleNamespace(lr=3e-5, warmup_ratio=0.01, use_prefix=True), 100000)
-    else:
+        opt, sched = build_optimizer(model, types.SimpleNamespace(lr=3e-5, warmup_ratio=0.01, use_prefix=True,
+                                                                  grad_sync=sync), 100000)
+    elif a.optimizer == "torch":
         opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, fused=True)
+    else:
+        from mtvaf_amd.optim import AdamW
+        opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model,
+                    overlap=True, grad_sync=sync)
     batch = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, a.full_length)
     ids, mask, tt, labels, feats, aux = batch
 
@@ -219,11 +235,18 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
+    # per-step HIP events on the main stream (no host sync inside the timed region): the median step is reported next to
+    # the bracketed wall-clock figure, which stays `value` (the driver's contract)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         out = step()
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    med_ms = statistics.median(step_ms)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -244,6 +267,8 @@ def main():
             for p_ in model.parameters():
                 p_.grad = None
             assert len(out.logits) == B
+        if hasattr(opt, "suspended"):
+            opt.suspended = True  # no step() follows these backward passes
         step_nb()
         barrier()
         t1 = time.perf_counter()
@@ -256,17 +281,20 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt1 = float(t)
         fwd_bwd_only = {"value": round(world * B * a.steps / dt1, 2), "ms_per_step": round(1e3 * dt1 / a.steps, 3)}
+        if hasattr(opt, "suspended"):
+            opt.suspended = False
 
     res = {"metric": "training sentences/sec (fwd+bwd)", "value": round(value, 2), "unit": "sentences/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype if a.dtype == "fp32" else "bf16 MFMA / fp32 accumulate+storage",
            "data": "synthetic",
-           "config": {"workload": f"TVNetSAModel2 {'RoBERTa' if a.model == 'roberta' else 'BERT'}-base random-init, fwd+bwd{'' if a.no_optimizer else '+AdamW(torch fused)'}, "
+           "config": {"workload": f"TVNetSAModel2 {'RoBERTa' if a.model == 'roberta' else 'BERT'}-base random-init, fwd+bwd{'' if a.no_optimizer else {'torch': '+AdamW(torch fused)'}.get(a.optimizer, '+AdamW(HIP, overlapped with backward)')}, "
                                   f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
                                   f"images through the prompt generator), train mode (dropout live), "
                                   f"{'full-length' if a.full_length else 'ragged 16..S'} sequences",
                       "global_batch": B * world, "seq_len": S, "prefix": P,
                       "parallelism": f"dp{world}" + (" (RCCL all-reduce overlapped with backward)" if world > 1 else "")},
+           "median_ms_per_step": round(med_ms, 3), "value_median": round(world * B / (med_ms * 1e-3), 2),
            "loss": round(loss_val, 4),
            "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
            "flop_per_sentence_train": ftrain, "fwd_bwd_without_optimizer": fwd_bwd_only}
@@ -307,9 +335,10 @@ def main():
         sym, (ms, cnt, fl) = max(by_sym.items(), key=lambda kv: kv[1][0])
         avg_us = 1e3 * ms / cnt
         ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
+        traffic, traffic_src = pmc_traffic(sym)
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": pmc_traffic(sym), "kernel": sym,
+            "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": sym,
             "avg_launch_us": round(avg_us, 1), "launches_per_step": cnt // NPROF,
             "measured": "HIP events around each main GEMM kernel, 3 steps with the weight-gradient side stream serialised "
                         "(MTVAF_DW_STREAM=0) so that every kernel is timed alone",
@@ -326,7 +355,9 @@ def main():
     if rank == 0:
         log("roofline pass done")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(S, P)
+        res["cpu_baseline"] = cpu_baseline(B, S, a.aux)
+        if (B, S, a.aux) == (32, 128, 8):  # second entry: the reference's own CPU-runnable configuration (configs[0])
+            res["cpu_baseline_c1"] = cpu_baseline(4, 64, 3, seconds_budget=15.0)
         log("cpu baseline done")
     if world > 1:
         dist.barrier()

@@ -213,6 +213,28 @@ int mtvaf_gemm_bf16kc(const void* A, int lda, const void* B, int ldb, float* C, 
 int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int ldt, int R, int C,
                     mtvaf_stream_t stream);
 
+/* ---- optimizer step ------------------------------------------------------------
+ * AdamW exactly as torch.optim.AdamW, which the reference trainer builds (modules/train.py:887-926) and steps
+ * (:621-625): decoupled weight decay, bias corrections passed in (bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t)).
+ * mtvaf_adamw updates ONE flat fp32 tensor (an encoder layer's parameter buffer: all 16 parameters of a layer in one
+ * launch, enqueued behind that layer's gradient all-reduce so the update overlaps the rest of the backward pass) and
+ * optionally writes the updated parameters rounded to bf16 (the GEMM operand shadow of the bf16 compute mode).
+ * mtvaf_adamw_multi updates `count` tensors of one parameter group per launch (host arrays of device pointers). */
+int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, mtvaf_stream_t stream);
+int mtvaf_adamw_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
+                      const long* n, float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
+                      float bc2_sqrt, float grad_scale, mtvaf_stream_t stream);
+
+/* ---- bf16 gradient wire format of the data-parallel exchange (mtvaf_amd/parallel.py; new functionality, the
+ * reference never synchronises gradients: MTVAF_training.py:305-309).  pack: dst[i] = bf16(src[i]), zero padding up to
+ * npad (npad % 8 == 0); reduce: out[c] = bf16(scale * sum_r recv[r*chunk + c]) with fp32 accumulation in rank order;
+ * unpack: dst[i] = float(src[i]).  The collectives themselves (all_to_all, all_gather: RCCL over xGMI) are issued
+ * through torch.distributed -- the section 8(b) proposal of mtvaf_rccl_* entry points is not built, see INTEGRATION.md. */
+int mtvaf_grad_pack_bf16(const float* src, void* dst, long n, long npad, mtvaf_stream_t stream);
+int mtvaf_grad_reduce_bf16(const void* recv, void* out, int world, long chunk, float scale, mtvaf_stream_t stream);
+int mtvaf_grad_unpack_bf16(const void* src, float* dst, long n, mtvaf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

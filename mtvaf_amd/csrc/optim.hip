@@ -1,0 +1,219 @@
+// AdamW update (reference modules/train.py:894-926 builds torch.optim.AdamW groups and
+// :621-625 steps them) and the bf16 gradient wire format of mtvaf_amd/parallel.py.  All kernels are HBM-bound
+// streams: 16 bytes per lane per access, grid sized to a few waves per SIMD.
+//
+//   AdamW, per element (decoupled weight decay, bias-corrected, as torch.optim.AdamW):
+//     p  -= lr * wd * p
+//     m   = m + (1 - b1) * (g - m)
+//     v   = b2 * v + (1 - b2) * g * g
+//     p  -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+//   7 fp32 streams per parameter (read p, g, m, v; write p, m, v) = 28 B; an optional bf16 copy of the new
+//   parameter (the GEMM operand shadow of the bf16 compute mode) adds 2 B.
+#include "common.h"
+
+namespace mtvaf {
+
+struct AdamHyper {
+  float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale;
+};
+
+__device__ __forceinline__ void adamw1(float& p, float g, float& m, float& v, const AdamHyper& h) {
+  g *= h.grad_scale;
+  p -= h.lr * h.wd * p;
+  m += (1.f - h.beta1) * (g - m);
+  v = h.beta2 * v + (1.f - h.beta2) * g * g;
+  const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
+  p -= (h.lr / h.bc1) * (m / denom);
+}
+
+__device__ __forceinline__ void adamw_span(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                           float* __restrict__ v, __bf16* __restrict__ ph, long n, long i0, long stride,
+                                           const AdamHyper& h) {
+  // vector body: 4 floats per lane per iteration when every base is 16-byte aligned (views into packed parameter
+  // storage may not be), scalar otherwise and for the tail
+  const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (!ph || ((uintptr_t)ph & 7) == 0);
+  const long n4 = vec ? (n >> 2) : 0;
+  for (long i = i0; i < n4; i += stride) {
+    f32x4 P = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 G = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 M = reinterpret_cast<f32x4*>(m)[i];
+    f32x4 V = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float pj = P[j], mj = M[j], vj = V[j];
+      adamw1(pj, G[j], mj, vj, h);
+      P[j] = pj; M[j] = mj; V[j] = vj;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = P;
+    reinterpret_cast<f32x4*>(m)[i] = M;
+    reinterpret_cast<f32x4*>(v)[i] = V;
+    if (ph) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 o = {(__bf16)P.x, (__bf16)P.y, (__bf16)P.z, (__bf16)P.w};
+      reinterpret_cast<bf16x4*>(ph)[i] = o;
+    }
+  }
+  for (long i = (n4 << 2) + i0; i < n; i += stride) {
+    float P = p[i], M = m[i], V = v[i];
+    adamw1(P, g[i], M, V, h);
+    p[i] = P; m[i] = M; v[i] = V;
+    if (ph) ph[i] = (__bf16)P;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, __bf16* ph, long n,
+                                                    AdamHyper h) {
+  adamw_span(p, g, m, v, ph, n, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256, h);
+}
+
+// several tensors of one parameter group in one launch: blockIdx.x -> (tensor, block within tensor) through a prefix table
+constexpr int ADAM_MAXT = 48;
+struct AdamMulti {
+  float* p[ADAM_MAXT];
+  const float* g[ADAM_MAXT];
+  float* m[ADAM_MAXT];
+  float* v[ADAM_MAXT];
+  long n[ADAM_MAXT];
+  int blk0[ADAM_MAXT + 1];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamMulti t, AdamHyper h) {
+  int k = 0;
+  const int b = blockIdx.x;
+  while (k + 1 < t.count && b >= t.blk0[k + 1]) ++k;
+  const int nb = t.blk0[k + 1] - t.blk0[k];
+  adamw_span(t.p[k], t.g[k], t.m[k], t.v[k], nullptr, t.n[k], (long)(b - t.blk0[k]) * 256 + threadIdx.x, (long)nb * 256, h);
+}
+
+// ---- bf16 gradient wire format ------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// dst[i] = bf16(src[i]) for i < n, 0 for n <= i < npad   (npad % 8 == 0)
+__global__ __launch_bounds__(256) void grad_pack_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n, long npad) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i8 = (long)blockIdx.x * 256 + threadIdx.x; i8 < (npad >> 3); i8 += stride) {
+    const long i = i8 << 3;
+    bf16x8 o;
+    if (i + 8 <= n) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + i), b = *reinterpret_cast<const f32x4*>(src + i + 4);
+      o = bf16x8{(__bf16)a.x, (__bf16)a.y, (__bf16)a.z, (__bf16)a.w, (__bf16)b.x, (__bf16)b.y, (__bf16)b.z, (__bf16)b.w};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (i + j < n) ? (__bf16)src[i + j] : (__bf16)0.f;
+    }
+    *reinterpret_cast<bf16x8*>(dst + i) = o;
+  }
+}
+
+// out[c] = bf16(scale * sum_{r < W} float(recv[r * chunk + c]))  -- fp32 accumulation in rank order (deterministic)
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const __bf16* __restrict__ recv, __bf16* __restrict__ out, int W,
+                                                         long chunk, float scale) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i8 = (long)blockIdx.x * 256 + threadIdx.x; i8 < (chunk >> 3); i8 += stride) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < W; ++r) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(recv + (long)r * chunk + (i8 << 3));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)x[j];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)(acc[j] * scale);
+    *reinterpret_cast<bf16x8*>(out + (i8 << 3)) = o;
+  }
+}
+
+// dst[i] = float(src[i]) for i < n
+__global__ __launch_bounds__(256) void grad_unpack_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i8 = (long)blockIdx.x * 256 + threadIdx.x; (i8 << 3) < n; i8 += stride) {
+    const long i = i8 << 3;
+    const bf16x8 x = *reinterpret_cast<const bf16x8*>(src + i);
+    if (i + 8 <= n) {
+      *reinterpret_cast<f32x4*>(dst + i) = f32x4{(float)x[0], (float)x[1], (float)x[2], (float)x[3]};
+      *reinterpret_cast<f32x4*>(dst + i + 4) = f32x4{(float)x[4], (float)x[5], (float)x[6], (float)x[7]};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (i + j < n) dst[i + j] = (float)x[j];
+    }
+  }
+}
+
+static inline int stream_grid(long work_items) {
+  long b = (work_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 256 * 8 ? 256 * 8 : b));  // up to 8 blocks per CU: enough loads in flight for HBM
+}
+
+}  // namespace mtvaf
+
+using namespace mtvaf;
+
+extern "C" {
+
+// One flat tensor (an encoder layer's parameter buffer).  bias corrections are passed in: bc1 = 1 - beta1^t,
+// bc2_sqrt = sqrt(1 - beta2^t).  p_bf16 (optional) receives the updated parameter rounded to bf16.
+int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+                float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, hipStream_t stream) {
+  if (!p || !g || !m || !v || n <= 0) return MTVAF_ERR_ARG;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 3) return MTVAF_ERR_ALIGN;
+  AdamHyper h{lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale};
+  hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, stream, p, g, m, v,
+                     static_cast<__bf16*>(p_bf16), n, h);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+// `count` tensors sharing one set of hyper-parameters (a torch parameter group); host arrays of device pointers.
+int mtvaf_adamw_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long* n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
+                      float grad_scale, hipStream_t stream) {
+  if (count < 0 || (count && (!p || !g || !m || !v || !n))) return MTVAF_ERR_ARG;
+  AdamHyper h{lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale};
+  for (int base = 0; base < count; base += ADAM_MAXT) {
+    AdamMulti t;
+    t.count = count - base < ADAM_MAXT ? count - base : ADAM_MAXT;
+    int blocks = 0;
+    for (int k = 0; k < t.count; ++k) {
+      const int i = base + k;
+      if (!p[i] || !g[i] || !m[i] || !v[i] || n[i] <= 0) return MTVAF_ERR_ARG;
+      if (((uintptr_t)p[i] | (uintptr_t)g[i] | (uintptr_t)m[i] | (uintptr_t)v[i]) & 3) return MTVAF_ERR_ALIGN;
+      t.p[k] = p[i]; t.g[k] = g[i]; t.m[k] = m[i]; t.v[k] = v[i]; t.n[k] = n[i];
+      t.blk0[k] = blocks;
+      long b = ((n[i] + 3) / 4 + 255) / 256;
+      blocks += (int)(b > 1024 ? 1024 : b);
+    }
+    t.blk0[t.count] = blocks;
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3(blocks), dim3(256), 0, stream, t, h);
+    MTVAF_LAUNCH_CHECK();
+  }
+  return MTVAF_OK;
+}
+
+int mtvaf_grad_pack_bf16(const float* src, void* dst, long n, long npad, hipStream_t stream) {
+  if (!src || !dst || n <= 0 || npad < n || (npad & 7)) return MTVAF_ERR_ARG;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return MTVAF_ERR_ALIGN;
+  hipLaunchKernelGGL(grad_pack_kernel, dim3(stream_grid(npad / 8)), dim3(256), 0, stream, src, static_cast<__bf16*>(dst), n, npad);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+int mtvaf_grad_reduce_bf16(const void* recv, void* out, int world, long chunk, float scale, hipStream_t stream) {
+  if (!recv || !out || world <= 0 || chunk <= 0 || (chunk & 7)) return MTVAF_ERR_ARG;
+  if (((uintptr_t)recv | (uintptr_t)out) & 15) return MTVAF_ERR_ALIGN;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(stream_grid(chunk / 8)), dim3(256), 0, stream, static_cast<const __bf16*>(recv),
+                     static_cast<__bf16*>(out), world, chunk, scale);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+int mtvaf_grad_unpack_bf16(const void* src, float* dst, long n, hipStream_t stream) {
+  if (!src || !dst || n <= 0) return MTVAF_ERR_ARG;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return MTVAF_ERR_ALIGN;
+  hipLaunchKernelGGL(grad_unpack_kernel, dim3(stream_grid((n + 7) / 8)), dim3(256), 0, stream, static_cast<const __bf16*>(src), dst, n);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+}  // extern "C"

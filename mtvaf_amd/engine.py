@@ -26,11 +26,19 @@ from . import hip
 
 
 class _Rng:
+    """seed: torch.initial_seed() (so torch.manual_seed() controls the dropout masks) xor a per-stream constant.
+    Under data parallelism every rank must draw different masks for its (site, row) elements even when the launcher
+    seeds all ranks alike: ``mtvaf_amd.parallel.GradSync`` calls ``set_stream(rank)``."""
+
     def __init__(self):
         self.offset = 0
+        self.stream = 0
+
+    def set_stream(self, stream: int):
+        self.stream = int(stream)
 
     def seed(self) -> int:
-        return int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        return (int(torch.initial_seed()) ^ (self.stream * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
 
     def next(self, n: int = 1) -> int:
         o = self.offset
@@ -221,6 +229,8 @@ class EncoderFunction(torch.autograd.Function):
         ctx.save_for_backward(*saved, *saved_t)
         ctx.stash = (offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
         ctx.wh = wh
+        if grad_sink is not None:
+            grad_sink.node_created()
         ctx.set_materialize_grads(False)  # unused hidden states arrive as None, not as [B,S,H] zero fills + adds
         return tuple(outs)
 
@@ -354,6 +364,12 @@ class EncoderFunction(torch.autograd.Function):
                     # the hook (GradSync) orders its all-reduce behind the CURRENT stream: on the side stream that
                     # is behind this layer's last weight-gradient kernel, which itself waited for everything the
                     # main stream had produced up to the attention backward (incl. the LayerNorm gradients)
+                    if grad_sink.settle_params:
+                        # an optimizer update hangs off the hook: it must also be behind the layer's LAST product that
+                        # reads the weights (dX of the QKV projection, enqueued on the main stream just above)
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        side.wait_event(ev)
                     with torch.cuda.stream(side):
                         grad_sink.layer_done(li)
                 else:

@@ -65,6 +65,11 @@ _SIGS = {
     "mtvaf_mask_mul": (c_int, [P, P, P, P, I, I, I, P]),
     "mtvaf_gemm_bf16kc": (c_int, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_cast_bf16": (c_int, [P, I, P, I, P, I, I, I, P]),
+    "mtvaf_adamw": (c_int, [P, P, P, P, L, F, F, F, F, F, F, F, F, P, P]),
+    "mtvaf_adamw_multi": (c_int, [I, P, P, P, P, P, F, F, F, F, F, F, F, F, P]),
+    "mtvaf_grad_pack_bf16": (c_int, [P, P, L, L, P]),
+    "mtvaf_grad_reduce_bf16": (c_int, [P, P, I, L, F, P]),
+    "mtvaf_grad_unpack_bf16": (c_int, [P, P, L, P]),
 }
 
 _lib = None
@@ -414,3 +419,36 @@ def gemm_bf16kc(a, b, out, bias=None, epi=EPI_NONE, aux=None, accumulate=False, 
                                 _p(aux), aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws),
                                 wsb, tile, splits, _st()), "mtvaf_gemm_bf16kc")
     return out
+
+
+# ---- optimizer / gradient wire format (csrc/optim.hip) ------------------------------------------------------------
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, p_bf16=None):
+    """In-place AdamW update of one flat fp32 tensor (torch.optim.AdamW semantics); `step` is the 1-based step count."""
+    n = p.numel()
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    _ck(lib().mtvaf_adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, bc1, bc2 ** 0.5, grad_scale,
+                          _p(p_bf16), _st()), "mtvaf_adamw")
+
+
+def adamw_multi(ps, gs, ms, vs, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    """One launch per 48 tensors of a parameter group sharing hyper-parameters and step count."""
+    k = len(ps)
+    if k == 0:
+        return
+    arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+    ns = (ctypes.c_long * k)(*[t.numel() for t in ps])
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    _ck(lib().mtvaf_adamw_multi(k, arr(ps), arr(gs), arr(ms), arr(vs), ns, lr, beta1, beta2, eps, weight_decay, bc1,
+                                bc2 ** 0.5, grad_scale, _st()), "mtvaf_adamw_multi")
+
+
+def grad_pack_bf16(src, dst, n, npad):
+    _ck(lib().mtvaf_grad_pack_bf16(_p(src), _p(dst), n, npad, _st()), "mtvaf_grad_pack_bf16")
+
+
+def grad_reduce_bf16(recv, out, world, chunk, scale):
+    _ck(lib().mtvaf_grad_reduce_bf16(_p(recv), _p(out), world, chunk, scale, _st()), "mtvaf_grad_reduce_bf16")
+
+
+def grad_unpack_bf16(src, dst, n):
+    _ck(lib().mtvaf_grad_unpack_bf16(_p(src), _p(dst), n, _st()), "mtvaf_grad_unpack_bf16")

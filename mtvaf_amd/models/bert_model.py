@@ -184,14 +184,21 @@ class TVNetSAModel2(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 logits = self.crf.decode_deferred(emissions.detach(), mask_u8)
+                decoded = torch.cuda.Event()
+                decoded.record(side)
             emissions.record_stream(side)
             mask_u8.record_stream(side)
         else:
             logits = self.crf.decode_deferred(emissions, mask_u8)
+            decoded = None
         loss = None
         if labels is not None:
             loss = -1 * self.crf(emissions, labels, mask=mask_u8, reduction="mean")
             loss = loss + _arg(self.args, "alpha", 0.0) * img_tag_loss
+        if decoded is not None:
+            # the decode reads the CRF parameters: whatever follows on the main stream (optimizer.step() updates them in
+            # place) is ordered behind it here, not only by the join inside the encoder backward (frozen encoders skip it)
+            torch.cuda.current_stream().wait_event(decoded)
         return TokenClassifierOutput(loss=loss, logits=logits)
 
     # ------------------------------------------------------------------------------------------------

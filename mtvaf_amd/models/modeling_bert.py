@@ -189,18 +189,39 @@ class _LayerStore:
 class GradSink:
     """Hands the encoder backward its parameter-gradient destinations.
 
-    Fast path (every ``param.grad is None``, i.e. after ``zero_grad(set_to_none=True)``): kernels write
-    into the per-layer flat gradient buffers and autograd adopts the returned views without a copy, so
-    a data-parallel hook can all-reduce one contiguous buffer per layer as soon as it is produced.
-    Otherwise fresh tensors are returned and autograd accumulates them (gradient accumulation)."""
+    Fast path (every ``param.grad is None``, i.e. after ``zero_grad(set_to_none=True)``, and exactly ONE encoder
+    node in the autograd pass): kernels write into the per-layer flat gradient buffers and autograd adopts the
+    returned views without a copy, so a data-parallel hook can all-reduce one contiguous buffer per layer as soon
+    as it is produced.  Otherwise fresh tensors are returned and autograd accumulates them (gradient accumulation).
+
+    Two encoder nodes under one ``loss.backward()`` (the reference's cutoff flow runs ``model(...)`` and
+    ``model(..., augument=True)`` and backpropagates the summed loss, modules/train.py:414-455) both see
+    ``param.grad is None`` -- AccumulateGrad only runs once both edges have arrived -- so the flat buffer must not be
+    handed to both: the second node would overwrite the views already sitting in autograd's input buffer.  Nodes are
+    therefore counted when they are created (``node_created``) and the flat buffers are used only while a single one
+    is outstanding; the count is cleared when the backward pass that consumed them ends."""
 
     def __init__(self, stores: List[_LayerStore]):
         self.stores = stores
         self.on_layer_done = None  # callable(layer_index, flat_grad_tensor) or None
         self.fast = False
+        self.settle_params = False  # set by an optimizer that updates parameters from the hook (mtvaf_amd.optim.AdamW)
+        self.live_nodes = 0
+        self._reset_armed = False
+
+    def node_created(self):
+        self.live_nodes += 1
+
+    def _pass_done(self):
+        self.live_nodes = 0
+        self._reset_armed = False
 
     def acquire(self, params):
-        self.fast = all(p.grad is None for p in params if p.requires_grad) and all(p.requires_grad for p in params)
+        if not self._reset_armed:  # (always called from inside a backward pass)
+            self._reset_armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._pass_done)
+        self.fast = (self.live_nodes <= 1 and all(p.requires_grad for p in params)
+                     and all(p.grad is None for p in params))
         if not self.fast:
             return None
         views = []
@@ -229,10 +250,11 @@ class BertEncoder(nn.Module):
 
     def _prepare(self):
         if self._stores is None or not all(st.valid(l) for st, l in zip(self._stores, self.layer)):
-            hook = self._sink.on_layer_done if self._sink is not None else None
+            old = self._sink
             self._stores = [_LayerStore(l) for l in self.layer]
             self._sink = GradSink(self._stores)
-            self._sink.on_layer_done = hook
+            if old is not None:
+                self._sink.on_layer_done, self._sink.settle_params = old.on_layer_done, old.settle_params
         return self._stores, self._sink
 
     @property

@@ -1,21 +1,163 @@
 """Optimizer / LR schedule of the reference trainers, for the drop-in models.
 
+``AdamW`` below is the hand-written optimizer of the path: torch.optim.AdamW semantics on the HIP kernels of
+``csrc/optim.hip`` -- ONE launch per encoder layer over the layer's flat parameter / gradient / moment buffers, one
+multi-tensor launch per 48 remaining tensors -- and, with ``overlap=True``, the per-layer updates are enqueued from
+inside the backward pass (behind the layer's gradient all-reduce on the communication stream under ``GradSync``, behind
+its weight-gradient kernels on the second stream otherwise), so the HBM-bound update runs next to the MFMA-bound rest of
+the backward pass instead of after it.
+
 ``modules/train.py::SATrainer2.multiModal_before_train`` (:894-926) builds three AdamW parameter groups by
 NAME (encoder ``bert*`` at ``args.lr``; ``encoder_conv*`` / ``gates*`` at ``args.lr``; ``crf*`` / ``fc*`` at
 5e-2; weight decay 1e-2 everywhere), freezes ``image_model*`` and attaches a linear warm-up / linear decay
 schedule; ``bert_before_train`` (:887-892) is the text-only variant (one group, all parameters).  The same
-grouping is reproduced here on top of torch's fused multi-tensor AdamW (one launch per ~25 tensors, already at
-the HBM roofline: 7 fp32 streams per parameter), so a step of the reference trainer
-costs what ``bench.py`` measures.
+grouping is reproduced here (``reference_param_groups`` / ``build_optimizer``) on top of ``AdamW`` below, so a step of
+the reference trainer costs what ``bench.py`` measures.
 
 Reference quirk kept on purpose: ``projectors.*``, ``img_classifier.*`` and ``aux_img_classifier.*`` match no
 group (the second group looks for the long-gone ``gates``), so the reference never updates them.
 """
 from __future__ import annotations
 
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
+
+from . import hip
+
+
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW (decoupled weight decay, bias correction, no amsgrad) on the gfx950 kernels.
+
+    ``attach(model)`` (or ``model=`` at construction) lets the optimizer see the encoder's per-layer flat buffers
+    (``BertEncoder._stores``): a layer whose 16 parameters sit in one parameter group is updated by ONE launch.
+
+    ``overlap=True``: layers are updated from inside ``loss.backward()`` as soon as their gradients are final (after
+    the all-reduce under data parallelism).  Contract: every backward pass is followed by exactly one ``step()`` before
+    the next backward (the reference trainer's flow with gradient_accumulation_steps = 1, modules/train.py:620-625);
+    a second backward without a ``step()`` raises.  ``step()`` then only updates what is left (embeddings, heads,
+    prompt generator) and layers that could not take the fast path."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 model: Optional[torch.nn.Module] = None, overlap: bool = False, grad_sync=None):
+        if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
+            raise ValueError("invalid AdamW hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.overlap = overlap
+        self._encoder = None
+        self._layer_group: Dict[int, Optional[dict]] = {}
+        self._early = set()
+        self.suspended = False    # True: the backward hook does nothing (backward passes that are not followed by step())
+        self._bf16_shadow = None  # callable(layer_index) -> flat bf16 shadow tensor or None (bf16 compute mode)
+        if model is not None:
+            self.attach(model, grad_sync)
+
+    # -- wiring -----------------------------------------------------------------------------------------------
+    def attach(self, model: torch.nn.Module, grad_sync=None):
+        enc = getattr(getattr(model, "bert", model), "encoder", None)
+        if enc is None or not hasattr(enc, "grad_sink"):
+            raise ValueError("AdamW.attach needs a mtvaf_amd model (TVNetSAModel2 / TVNetSAModel / BertModel)")
+        self._encoder = enc
+        self._map_layers()
+        if self.overlap:
+            sink = enc.grad_sink
+            sink.settle_params = True  # the hook's stream must also be behind the layer's last dX product (engine.py)
+            if grad_sync is not None:
+                grad_sync.after_layer_reduced = self._early_layer_update
+            else:
+                sink.on_layer_done = lambda li, flat: self._early_layer_update(li) if flat is not None else None
+        return self
+
+    def _map_layers(self):
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        self._layer_group = {}
+        for li, layer in enumerate(self._encoder.layer):
+            gs = {id(group_of.get(id(p))) for p in layer.ordered_params()}
+            g0 = group_of.get(id(layer.ordered_params()[0]))
+            self._layer_group[li] = g0 if (len(gs) == 1 and g0 is not None) else None
+
+    def _layer_state(self, li: int, store):
+        """Flat moment buffers of layer li; the per-parameter state entries are views of them."""
+        key = ("layer", li)
+        st = self.__dict__.setdefault("_flat_state", {}).get(key)
+        if st is None or st["m"].numel() != store.flat.numel() or st["m"].device != store.flat.device:
+            st = {"m": torch.zeros_like(store.flat), "v": torch.zeros_like(store.flat), "step": 0}
+            self._flat_state[key] = st
+            for i, p in enumerate(self._encoder.layer[li].ordered_params()):
+                off, n = store.offsets[i], p.numel()
+                ps = self.state[p]
+                ps["exp_avg"] = st["m"][off:off + n].view(p.shape)
+                ps["exp_avg_sq"] = st["v"][off:off + n].view(p.shape)
+                ps["step"] = st["step"]
+        return st
+
+    def _update_layer_flat(self, li: int, group: dict, store):
+        st = self._layer_state(li, store)
+        st["step"] += 1
+        for p in self._encoder.layer[li].ordered_params():
+            self.state[p]["step"] = st["step"]
+        b1, b2 = group["betas"]
+        shadow = self._bf16_shadow(li) if self._bf16_shadow is not None else None
+        hip.adamw(store.flat, store.grad, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                  st["step"], p_bf16=shadow)
+
+    def _early_layer_update(self, li: int):
+        """Called from inside the backward pass (current stream: the one the layer's gradients are final on)."""
+        group = self._layer_group.get(li)
+        stores = self._encoder._stores
+        if self.suspended or group is None or stores is None or stores[li].grad is None:
+            return
+        if li in self._early:
+            raise RuntimeError("mtvaf_amd.optim.AdamW(overlap=True): a second backward pass ran before optimizer.step()")
+        self._update_layer_flat(li, group, stores[li])
+        self._early.add(li)
+
+    # -- the step ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        done = set()
+        enc = self._encoder
+        if enc is not None and enc._stores is not None:
+            if len(self._layer_group) != len(enc.layer):
+                self._map_layers()
+            for li, layer in enumerate(enc.layer):
+                ps = layer.ordered_params()
+                if li in self._early:
+                    done.update(id(p) for p in ps)
+                    continue
+                group, store = self._layer_group.get(li), enc._stores[li]
+                if group is None or store.grad is None or not store.valid(layer):
+                    continue
+                lo = store.grad.data_ptr()
+                if all(p.grad is not None and p.grad.data_ptr() == lo + 4 * store.offsets[i] and p.grad.is_contiguous()
+                       for i, p in enumerate(ps)):
+                    self._update_layer_flat(li, group, store)
+                    done.update(id(p) for p in ps)
+        self._early = set()
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            buckets: Dict[int, list] = {}
+            for p in group["params"]:
+                if p.grad is None or id(p) in done:
+                    continue
+                if p.grad.is_sparse or p.dtype != torch.float32 or not p.is_cuda:
+                    raise RuntimeError("mtvaf_amd.optim.AdamW updates dense fp32 parameters on the MI355X only")
+                stt = self.state[p]
+                if "exp_avg" not in stt:
+                    stt["exp_avg"], stt["exp_avg_sq"], stt["step"] = torch.zeros_like(p), torch.zeros_like(p), 0
+                stt["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                if not p.is_contiguous():
+                    raise RuntimeError("non-contiguous parameter")
+                buckets.setdefault(stt["step"], []).append((p, g, stt["exp_avg"], stt["exp_avg_sq"]))
+            for step_no, items in buckets.items():
+                hip.adamw_multi([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
+                                float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step_no)
+        return loss
 
 
 def reference_param_groups(model: torch.nn.Module, lr: float, use_prefix: bool = True) -> List[Dict]:
@@ -52,6 +194,10 @@ def build_optimizer(model: torch.nn.Module, args, train_num_steps: int):
             if "image_model" in n:
                 p.requires_grad = False
     on_gpu = any(p.is_cuda for g in groups for p in g["params"])
-    opt = torch.optim.AdamW(groups, lr=args.lr, fused=True) if on_gpu else torch.optim.AdamW(groups, lr=args.lr)
+    if on_gpu:  # the path's own optimizer kernels; overlap: the reference trainer steps after every backward (:620-625)
+        opt = AdamW(groups, lr=args.lr, model=model, overlap=bool(getattr(args, "overlap_optimizer", True)),
+                    grad_sync=getattr(args, "grad_sync", None))
+    else:
+        opt = torch.optim.AdamW(groups, lr=args.lr)
     sched = linear_schedule_with_warmup(opt, getattr(args, "warmup_ratio", 0.01) * train_num_steps, train_num_steps)
     return opt, sched

@@ -1,4 +1,4 @@
-"""Data-parallel gradient synchronisation: one process per GPU, RCCL all-reduce over xGMI.
+"""Data-parallel gradient synchronisation: one process per GPU, RCCL collectives over xGMI.
 
 The reference never wraps its model in DistributedDataParallel (MTVAF_training.py:305-309 initialises a
 process group and a DistributedSampler and stops there), so this is new functionality whose semantic
@@ -8,9 +8,25 @@ gradients are averaged (sum / world_size).
 Design for the 8-GPU xGMI mesh: the encoder backward (``engine.EncoderFunction``) writes each layer's
 parameter gradients into ONE contiguous fp32 buffer (28 MB for BERT-base) and reports it through
 ``GradSink.on_layer_done`` as soon as that layer's kernels are enqueued, layer 11 first.  This hook
-launches the all-reduce of that buffer on a side stream, so communication overlaps the remaining
-backward; everything else (embeddings, head, prompt generator: ~125 MB, dominated by the 94 MB word
-table) is reduced in one flat bucket when autograd finishes.  No gradient is copied on the fast path.
+launches the all-reduce of that buffer on a communication stream, so communication overlaps the remaining
+backward; large parameters outside the encoder (94 MB word table, ``encoder_conv``) are reduced the moment
+autograd has accumulated them; the small rest goes through ONE persistent flat bucket when autograd
+finishes.  No gradient is copied on the fast path.
+
+Two wire formats:
+
+* fp32 (default in fp32 compute mode): RCCL ``all_reduce(AVG)`` of the flat buffer in place.
+* bf16 (``compress="bf16"``, default in bf16 compute mode -- BASELINE configs 3-4): a direct exchange shaped for the
+  fully connected xGMI mesh instead of a ring: every rank packs its fp32 gradients to bf16, ``all_to_all`` sends
+  chunk r to rank r over the dedicated link, each rank sums the ``world`` chunks it received IN FP32 (rank order,
+  deterministic), scales by 1/world, rounds ONCE to bf16 and ``all_gather``s the reduced chunk; the result is
+  unpacked into the fp32 gradient buffer.  Half the bytes of the fp32 ring on every link, one rounding per phase
+  instead of one per ring hop, and every rank ends with bit-identical gradients.  Pack / reduce / unpack are HIP
+  kernels (``csrc/comm.hip``) on the communication stream.
+
+Dropout under data parallelism: ``engine.RNG`` derives its seed from ``torch.initial_seed()``; launchers that seed
+every rank alike would make all ranks draw the same masks for the same (site, row).  GradSync therefore folds the
+rank into the dropout seed (``engine.RNG.set_stream(rank)``) unless ``seed_per_rank=False``.
 """
 from __future__ import annotations
 
@@ -21,23 +37,34 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, model: torch.nn.Module, process_group=None, force: bool = False, big_numel: int = 1 << 20):
+    def __init__(self, model: torch.nn.Module, process_group=None, force: bool = False, big_numel: int = 1 << 20,
+                 compress: Optional[str] = "auto", seed_per_rank: bool = True):
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised process group (backend 'nccl' = RCCL on ROCm)")
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group)
+        self.rank = dist.get_rank(process_group)
         # RCCL averages inside the collective; gloo (CPU tests, and the 2-rank-on-one-GPU test) has no AVG
         self._avg_op = dist.get_backend(process_group) == "nccl"
+        if compress == "auto":
+            from . import hip
+            compress = "bf16" if hip.COMPUTE == "bf16" else None
+        if compress not in (None, "bf16"):
+            raise ValueError(f"compress must be None, 'bf16' or 'auto', got {compress!r}")
+        self.compress = compress
         self.encoder = model.bert.encoder if hasattr(model, "bert") else model.encoder
         self.encoder.grad_sink.on_layer_done = self._layer_done
         self._enc_param_ids = {id(p) for l in self.encoder.layer for p in l.ordered_params()}
         self._comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending: List = []
         self._slow_layers: List[int] = []
+        self._fast_layers: List[int] = []
         self._armed = False
         self.enabled = True
         self.force = force  # run the collectives even with world_size == 1 (single-GPU test of the N > 1 path)
+        self._bufs = {}     # persistent staging: tail bucket, bf16 send / receive / shard
+        self.after_layer_reduced = None  # callable(layer_index) run on the comm stream behind a layer's all-reduce
         # Large non-encoder gradients (94 MB word table, encoder_conv weights) are reduced the moment autograd has
         # accumulated them, so e.g. the word-table all-reduce overlaps the prompt generator's backward instead of
         # sitting in the un-overlapped tail bucket.
@@ -45,6 +72,50 @@ class GradSync:
         for p in model.parameters():
             if id(p) not in self._enc_param_ids and p.requires_grad and p.numel() >= big_numel:
                 p.register_post_accumulate_grad_hook(self._param_ready)
+        if seed_per_rank:
+            from . import engine
+            engine.RNG.set_stream(self.rank)
+
+    # -- wire formats ------------------------------------------------------------------------------------------
+    def _buf(self, name: str, numel: int, dtype, device) -> torch.Tensor:
+        b = self._bufs.get(name)
+        if b is None or b.numel() < numel or b.device != device:
+            b = self._bufs[name] = torch.zeros(numel, dtype=dtype, device=device)
+        return b
+
+    def _allreduce_mean(self, t: torch.Tensor):
+        """In-place mean over the ranks of the flat fp32 tensor `t` (enqueued on the current stream)."""
+        if self.compress == "bf16":
+            return self._allreduce_mean_bf16(t)
+        if self._avg_op:
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(t, group=self.group)
+            t.mul_(1.0 / self.world)
+
+    def _allreduce_mean_bf16(self, t: torch.Tensor):
+        W, n = self.world, t.numel()
+        chunk = ((n + W - 1) // W + 7) // 8 * 8  # 16-byte aligned chunks
+        send = self._buf("send", W * chunk, torch.bfloat16, t.device)[:W * chunk]
+        recv = self._buf("recv", W * chunk, torch.bfloat16, t.device)[:W * chunk]
+        shard = self._buf("shard", chunk, torch.bfloat16, t.device)[:chunk]
+        flat = t.view(-1)
+        if t.is_cuda:
+            from . import hip
+            hip.grad_pack_bf16(flat, send, n, W * chunk)
+        else:  # gloo / CPU: protocol test harness only
+            send[:n].copy_(flat)
+            send[n:].zero_()
+        dist.all_to_all_single(recv, send, group=self.group)
+        if t.is_cuda:
+            hip.grad_reduce_bf16(recv, shard, W, chunk, 1.0 / W)
+        else:
+            shard.copy_(recv.view(W, chunk).float().sum(0).mul_(1.0 / W))
+        dist.all_gather_into_tensor(send, shard, group=self.group)
+        if t.is_cuda:
+            hip.grad_unpack_bf16(send, flat, n)
+        else:
+            flat.copy_(send[:n])
 
     # -- called from inside EncoderFunction.backward, newest layer first ---------------------------------
     def _layer_done(self, li: int, flat_grad: Optional[torch.Tensor]):
@@ -54,21 +125,22 @@ class GradSync:
         if flat_grad is None:  # gradient-accumulation fallback: reduce the .grad tensors at the end
             self._slow_layers.append(li)
             return
+        self._fast_layers.append(li)
         if self._comm is None:  # CPU / gloo (tests)
-            self._pending.append((dist.all_reduce(flat_grad, group=self.group, async_op=True), flat_grad))
+            if self.compress is None:
+                self._pending.append((dist.all_reduce(flat_grad, group=self.group, async_op=True), flat_grad))
+            else:
+                self._allreduce_mean(flat_grad)
+            if self.after_layer_reduced is not None:
+                self._pending.append((None, li))
             return
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ev)
             self._allreduce_mean(flat_grad)
-
-    def _allreduce_mean(self, t: torch.Tensor):
-        if self._avg_op:
-            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(t, group=self.group)
-            t.mul_(1.0 / self.world)
+            if self.after_layer_reduced is not None:
+                self.after_layer_reduced(li)
 
     def _arm(self):
         if not self._armed:
@@ -81,7 +153,10 @@ class GradSync:
         self._arm()
         g = p.grad
         if self._comm is None:
-            self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
+            if self.compress is None:
+                self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
+            else:
+                self._allreduce_mean(g)
         else:
             ev = torch.cuda.Event()
             ev.record()
@@ -96,37 +171,59 @@ class GradSync:
         rest = [p for p in self.model.parameters()
                 if p.grad is not None and (id(p) not in self._enc_param_ids) and (id(p) not in self._early_done)]
         self._early_done = set()
-        # a layer whose gradients autograd copied instead of adopting (its .grad does not alias the flat
-        # buffer that was reduced) is reduced again from its .grad tensors -- correctness never depends on
-        # the zero-copy fast path
+        # A layer whose flat buffer was all-reduced but whose .grad tensors do NOT alias it (autograd cloned the returned
+        # views instead of adopting them, e.g. because a tensor hook kept a reference): the clone ran on the main stream
+        # while the ring was still writing partial sums into the flat buffer, so the .grad values may be torn.  They
+        # are NOT reduced again; once the communication stream has been joined the (correctly reduced) flat buffer is
+        # copied over them.  The fast path is only taken when every .grad was None and a single encoder node was in the
+        # pass, so .grad holds nothing but that clone.
         stores = getattr(self.encoder, "_stores", None) or []
-        for li, st in enumerate(stores):
-            if li in self._slow_layers or st.grad is None:
-                continue
-            g = self.encoder.layer[li].intermediate.dense.weight.grad
-            lo = st.grad.data_ptr()
-            if g is not None and not (lo <= g.data_ptr() < lo + st.grad.numel() * 4):
-                self._slow_layers.append(li)
+        copied = []
+        for li in self._fast_layers:
+            st = stores[li]
+            lo, hi = st.grad.data_ptr(), st.grad.data_ptr() + st.grad.numel() * st.grad.element_size()
+            ps = self.encoder.layer[li].ordered_params()
+            if any(p.grad is not None and not (lo <= p.grad.data_ptr() < hi) for p in ps):
+                copied.append(li)
         for li in self._slow_layers:
             rest.extend(p for p in self.encoder.layer[li].ordered_params() if p.grad is not None)
-        self._slow_layers = []
+        self._slow_layers, self._fast_layers = [], []
         if self._comm is not None:
             self._comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm):
                 self._reduce_bucket(rest)
             torch.cuda.current_stream().wait_stream(self._comm)
         else:
+            hooks = []
             for work, buf in self._pending:
+                if work is None:
+                    hooks.append(buf)
+                    continue
                 work.wait()
                 buf.mul_(1.0 / self.world)
             self._pending = []
+            for li in hooks:
+                self.after_layer_reduced(li)
             self._reduce_bucket(rest)
+        for li in copied:
+            views = stores[li].grad_views()
+            with torch.no_grad():
+                for p, v in zip(self.encoder.layer[li].ordered_params(), views):
+                    if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                        p.grad.copy_(v)
 
     def _reduce_bucket(self, params):
+        """The small non-encoder rest (position / type tables, LayerNorms, fc, crf, projectors ...: ~3 MB) through one
+        PERSISTENT flat buffer: a gather (torch.cat into the buffer), the collective, a multi-tensor scatter back."""
         if not params:
             return
         grads = [p.grad for p in params]
-        flat = torch._utils._flatten_dense_tensors(grads)
+        n = sum(g.numel() for g in grads)
+        flat = self._buf("tail", n, torch.float32, grads[0].device)[:n]
+        torch.cat([g.reshape(-1) for g in grads], out=flat)
         self._allreduce_mean(flat)
-        for g, s in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-            g.copy_(s)
+        views, off = [], 0
+        for g in grads:
+            views.append(flat[off:off + g.numel()].view(g.shape))
+            off += g.numel()
+        torch._foreach_copy_(grads, views)

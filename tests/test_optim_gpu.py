@@ -1,0 +1,133 @@
+"""mtvaf_amd.optim.AdamW (csrc/optim.hip) against torch.optim.AdamW on the reference trainer's three parameter groups
+(modules/train.py:894-926), and the in-backward (overlap=True) schedule against the plain one."""
+import copy
+import types
+
+import pytest
+import torch
+
+import params as P
+from test_model_gpu import DEV, LABELS, _prompt_inputs, hf_config, make_args
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(layers=3, dropout=0.0):
+    from mtvaf_amd.models.bert_model import TVNetSAModel2
+    cfg = P.EncCfg(vocab_size=600, hidden=128, heads=2, inter=256, layers=layers, max_pos=64)
+    args = make_args(alpha=0.0)
+    args.bert_config = hf_config(cfg, dropout=dropout)
+    torch.manual_seed(11)
+    return TVNetSAModel2(LABELS, None, args).to(DEV), cfg
+
+
+def _batch(cfg, B=16, S=64, seed=5):
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, seed, B, S, lo_id=5))
+    feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(seed + 1, B, 3))
+    return dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+
+
+def test_adamw_kernels_match_torch_adamw_on_the_reference_groups():
+    from mtvaf_amd.optim import AdamW, linear_schedule_with_warmup, reference_param_groups
+    m, cfg = _model()
+    m.eval()
+    m2 = copy.deepcopy(m)
+    ours = AdamW(reference_param_groups(m, 3e-3), model=m)
+    ref = torch.optim.AdamW(reference_param_groups(m2, 3e-3))
+    s1 = linear_schedule_with_warmup(ours, 2, 10)
+    s2 = linear_schedule_with_warmup(ref, 2, 10)
+    batch = _batch(cfg)
+    n1, n2 = dict(m.named_parameters()), dict(m2.named_parameters())
+    for it in range(4):
+        # both optimizers are fed the SAME gradient sequence (computed once, by m): a parameter whose true gradient is
+        # zero (the key bias) has a rounding-noise gradient and Adam turns its sign into a full +-lr step, so two
+        # independently evolving models would not stay comparable at 1e-6
+        m(**batch).loss.backward()
+        for n, p in n1.items():
+            n2[n].grad = None if p.grad is None else p.grad.clone()
+        for opt, sch in ((ours, s1), (ref, s2)):
+            opt.step()
+            sch.step()
+        ours.zero_grad(set_to_none=True)
+    for n, p in n1.items():
+        torch.testing.assert_close(p, n2[n], rtol=1e-6, atol=1e-7, msg=n)
+    # the layer-flat path was taken (one launch per layer) and its state is exposed per parameter
+    w = m.bert.encoder.layer[1].intermediate.dense.weight
+    st = ours.state[w]
+    flat = ours._flat_state[("layer", 1)]
+    assert st["exp_avg"].data_ptr() >= flat["m"].data_ptr() and st["step"] == 4 == flat["step"]
+    torch.testing.assert_close(st["exp_avg"], ref.state[n2["bert.encoder.layer.1.intermediate.dense.weight"]]["exp_avg"],
+                               rtol=1e-5, atol=1e-8)
+    # reference quirk: projectors are in no group and never move
+    assert "projectors.0.weight" in n1 and ours.state.get(n1["projectors.0.weight"], {}) == {}
+
+
+
+def test_overlap_update_inside_backward_equals_the_plain_schedule():
+    """overlap=True enqueues each layer's update from the backward hook (second stream, M >= 1024); parameters after
+    3 steps must equal the plain step() schedule, in train mode with dropout (same seeds)."""
+    from mtvaf_amd import engine
+    from mtvaf_amd.optim import AdamW, reference_param_groups
+    outs = []
+    for overlap in (False, True):
+        m, cfg = _model(dropout=0.1)
+        m.train()
+        opt = AdamW(reference_param_groups(m, 1e-3), model=m, overlap=overlap)
+        batch = _batch(cfg)
+        engine.RNG.offset = 0
+        torch.manual_seed(3)
+        losses = []
+        for it in range(3):
+            out = m(**batch)
+            out.loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            losses.append(float(out.loss))
+        torch.cuda.synchronize()
+        outs.append((losses, {n: p.detach().clone() for n, p in m.named_parameters()}))
+        if overlap:
+            assert m.bert.encoder.grad_sink.settle_params
+    # (the word-table gradient is a float-atomic scatter-add: order-dependent in the last bits, so the two runs are
+    # compared to rounding noise, not bit for bit; the key bias has a pure-noise gradient whose SIGN Adam amplifies to a
+    # full +-lr step -- it does not influence the function, softmax is invariant to it)
+    torch.testing.assert_close(torch.tensor(outs[0][0]), torch.tensor(outs[1][0]), rtol=1e-5, atol=0)
+    for n, p in outs[0][1].items():
+        if "key.bias" in n:
+            continue
+        torch.testing.assert_close(p, outs[1][1][n], rtol=0, atol=5e-6, msg=n)
+
+
+def test_overlap_contract_violation_raises():
+    from mtvaf_amd.optim import AdamW
+    m, cfg = _model(layers=2)
+    m.eval()
+    opt = AdamW(m.parameters(), lr=1e-3, model=m, overlap=True)
+    batch = _batch(cfg)
+    m(**batch).loss.backward()
+    m.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError, match="second backward"):
+        m(**batch).loss.backward()
+    opt.step()
+
+
+def test_grad_wire_format_kernels():
+    """pack / reduce / unpack of the bf16 gradient exchange against torch arithmetic (bit-exact: RNE casts, fp32 sums
+    in rank order)."""
+    from mtvaf_amd import hip
+    g = torch.Generator(device="cpu").manual_seed(0)
+    n, W = 100003, 4
+    src = (torch.randn(n, generator=g) * 3).to(DEV)
+    chunk = ((n + W - 1) // W + 7) // 8 * 8
+    send = torch.full((W * chunk,), 7.0, dtype=torch.bfloat16, device=DEV)
+    hip.grad_pack_bf16(src, send, n, W * chunk)
+    assert torch.equal(send[:n], src.to(torch.bfloat16)) and not send[n:].any()
+    recv = (torch.randn(W * chunk, generator=g)).to(torch.bfloat16).to(DEV)
+    shard = torch.empty(chunk, dtype=torch.bfloat16, device=DEV)
+    hip.grad_reduce_bf16(recv, shard, W, chunk, 1.0 / W)
+    acc = torch.zeros(chunk, device=DEV)
+    for r in range(W):
+        acc += recv[r * chunk:(r + 1) * chunk].float()
+    assert torch.equal(shard, (acc * (1.0 / W)).to(torch.bfloat16))
+    dst = torch.zeros(n, device=DEV)
+    hip.grad_unpack_bf16(send, dst, n)
+    assert torch.equal(dst, send[:n].float())

@@ -166,6 +166,93 @@ def test_gradsync_two_ranks_gloo():
         torch.testing.assert_close(torch.tensor(a), torch.tensor(b))
 
 
+class _HeadsModel(torch.nn.Module):
+    """Stand-in with the section 8(e) gotchas: a parameter that NEVER receives a gradient (`pooler`, as bert.pooler.* on
+    the TVNetSAModel2 path) and optional heads that only contribute when `vao` is on."""
+
+    def __init__(self, vao):
+        super().__init__()
+        self.encoder = _FakeEncoder(L=4, n=8)
+        self.pooler = torch.nn.Linear(8, 8)          # never used in forward
+        self.head = torch.nn.Linear(4, 1)
+        self.vao_heads = torch.nn.ModuleList([torch.nn.Linear(8, 3) for _ in range(2)])
+        self.table = torch.nn.Parameter(torch.ones(64, 8))
+        self.vao = vao
+
+    def forward(self, x):
+        y = self.encoder(x) + self.head(x[:4]).sum() + (self.table * x).sum()
+        if self.vao:
+            y = y + sum(h(x).pow(2).sum() for h in self.vao_heads)
+        return y
+
+
+def _worker4(rank, world, port, q, mode):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtvaf_amd.parallel import GradSync
+    torch.manual_seed(0)
+    m = _HeadsModel(vao=(mode != "novao"))
+    sync = GradSync(m, big_numel=256, compress="bf16" if mode == "bf16" else None)
+    keep = []
+    if mode == "copy":  # a tensor hook that keeps the incoming gradient alive: AccumulateGrad must CLONE the flat view
+        m.encoder.layer[2].intermediate.dense.weight.register_hook(lambda g: keep.append(g))
+    reduced = []
+    sync.after_layer_reduced = reduced.append
+    x = torch.arange(8, dtype=torch.float32) * (rank + 1) * 0.25
+    opt = torch.optim.SGD(m.parameters(), lr=0.01)
+    m(x).backward()
+    res = {"none": sorted(n for n, p in m.named_parameters() if p.grad is None),
+           "aliased": m.encoder.layer[2].intermediate.dense.weight.grad.data_ptr() == m.encoder._stores[2].grad.data_ptr(),
+           "reduced": sorted(reduced)}
+    opt.step()
+    res["weights"] = {n: p.detach().tolist() for n, p in m.named_parameters()}  # (lists: tensors would travel by fd)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["vao", "novao", "copy", "bf16"])
+def test_gradsync_four_ranks_heterogeneous_grads_gloo(mode):
+    """world_size 4, the REAL GradSync: parameters without gradients (pooler always; VAO heads when off) are left out of
+    every bucket identically on all ranks; the post-step weights equal a single-process step on the mean gradient (the
+    'concatenated global batch' oracle); `copy` forces autograd to clone a layer's flat views (the reduced flat buffer
+    must win over the possibly torn clone); `bf16` runs the all_to_all / fp32-sum / all_gather exchange."""
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker4, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ref = _HeadsModel(vao=(mode != "novao"))
+    grads = []
+    for r in range(world):
+        ref.zero_grad(set_to_none=True)
+        ref(torch.arange(8, dtype=torch.float32) * (r + 1) * 0.25).backward()
+        grads.append({n: (None if p.grad is None else p.grad.clone()) for n, p in ref.named_parameters()})
+    want = {}
+    for n, p in ref.named_parameters():
+        g = None if grads[0][n] is None else sum(gr[n] for gr in grads) / world
+        want[n] = p.detach() if g is None else p.detach() - 0.01 * g
+    none_expected = sorted(n for n in want if grads[0][n] is None)
+    assert any(n.startswith("pooler") for n in none_expected)
+    assert (mode == "novao") == any(n.startswith("vao_heads") for n in none_expected)
+    tol = dict(rtol=2e-2, atol=1e-3) if mode == "bf16" else dict(rtol=1e-6, atol=1e-6)
+    for r in range(world):
+        assert out[r]["none"] == none_expected
+        assert out[r]["reduced"] == [0, 1, 2, 3]
+        assert out[r]["aliased"] == (mode != "copy")
+        for n, w in want.items():
+            torch.testing.assert_close(torch.tensor(out[r]["weights"][n]), w, msg=f"{mode} rank {r} {n}", **tol)
+        for n in want:  # every rank ends with the same weights, bit for bit
+            assert out[r]["weights"][n] == out[0]["weights"][n], n
+
+
 @pytest.mark.gpu
 def test_gradsync_single_rank_rccl_on_gpu():
     """1-rank RCCL group with force=True: the real encoder's layer hooks, side stream, events and the
@@ -203,6 +290,51 @@ def test_gradsync_single_rank_rccl_on_gpu():
         st = m.bert.encoder._stores[1]
         g = m.bert.encoder.layer[1].intermediate.dense.weight.grad
         assert st.grad.data_ptr() <= g.data_ptr() < st.grad.data_ptr() + st.grad.numel() * 4
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_gradsync_bf16_exchange_and_overlapped_adamw_single_rank_rccl():
+    """1-rank RCCL group, force=True, compress='bf16': pack -> all_to_all -> fp32 reduce -> all_gather -> unpack on the
+    communication stream (HIP kernels + RCCL), with the AdamW layer updates hanging off the per-layer hook.  With one
+    rank the exchange is a bf16 round trip of the gradient: the result must equal an update from bf16-rounded grads."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import params as P
+    from transformers import BertConfig
+    from mtvaf_amd.models.bert_model import TVNetSAModel2
+    from mtvaf_amd.optim import AdamW
+    from mtvaf_amd.parallel import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        cfg = BertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=3, num_attention_heads=2,
+                         intermediate_size=256, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0)
+        args = types.SimpleNamespace(bert_name="bert-base-uncased", bert_config=cfg, use_prefix=False, vao=False,
+                                     noauxloss=True, use_probe=False, n_gpu=1, alpha=0.0, prefix_len=4, prefix_dim=768,
+                                     device="cuda", resnet_root=None, use_152=False)
+        labels_list = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
+        ids, mask, tt, labels = (t.to("cuda") for t in P.text_batch(P.EncCfg(vocab_size=500), 3, 32, 32, lo_id=5))
+        res = []
+        for use_sync in (False, True):
+            torch.manual_seed(0)
+            m = TVNetSAModel2(labels_list, None, args).to("cuda").eval()
+            sync = GradSync(m, force=True, compress="bf16", seed_per_rank=False) if use_sync else None
+            opt = AdamW(m.parameters(), lr=1e-3, model=m, overlap=use_sync, grad_sync=sync)
+            m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss.backward()
+            if not use_sync:  # oracle of the 1-rank exchange: every gradient rounded to bf16 once
+                for p in m.parameters():
+                    if p.grad is not None:
+                        p.grad.copy_(p.grad.to(torch.bfloat16).float())
+            opt.step()
+            torch.cuda.synchronize()
+            res.append({n: p.detach().clone() for n, p in m.named_parameters()})
+        for n, p in res[0].items():
+            if "word_embeddings" in n or "key.bias" in n:
+                continue  # float-atomic scatter-add / pure-noise gradient whose sign Adam amplifies
+            torch.testing.assert_close(res[1][n], p, rtol=0, atol=2e-6, msg=n)
     finally:
         dist.destroy_process_group()
 
