@@ -232,6 +232,19 @@ __global__ void mean_l_bwd_kernel(const float* __restrict__ dmean, float* __rest
 
 using namespace mtvaf;
 
+// the mixing kernels unroll over the encoder depth: 12 (base), 24 (large) and the small depths the tests use
+#define MTVAF_NL_DISPATCH(NLV, LAUNCH)            \
+  switch (NLV) {                                  \
+    case 2: LAUNCH(2); break;                     \
+    case 3: LAUNCH(3); break;                     \
+    case 4: LAUNCH(4); break;                     \
+    case 6: LAUNCH(6); break;                     \
+    case 8: LAUNCH(8); break;                     \
+    case 12: LAUNCH(12); break;                   \
+    case 24: LAUNCH(24); break;                   \
+    default: return MTVAF_ERR_SHAPE;              \
+  }
+
 extern "C" {
 
 int mtvaf_split_mean(const float* enc, float* sm, long rows, int W, hipStream_t st) {
@@ -249,14 +262,14 @@ int mtvaf_gate_fwd(const float* logits, float* gate, long ngroups, hipStream_t s
   return MTVAF_OK;
 }
 
-// enc [NI,B,L,4W] + gate [NI*B, NL*4] -> pkv [NL,2,B,(NI*L)*(W/2)].  NL must be 12 or 2 (test config).
+// enc [NI,B,L,4W] + gate [NI*B, NL*4] -> pkv [NL,2,B,(NI*L)*(W/2)].  NL in {2,3,4,6,8,12,24}.
 int mtvaf_prompt_mix_fwd(const float* enc, const float* gate, float* pkv, int NI, int B, int L, int W, int NL,
                          hipStream_t st) {
   if (W % 8 || NI <= 0 || B <= 0 || L <= 0) return MTVAF_ERR_SHAPE;
   dim3 grid(NI * B * L), block(W / 4 <= 384 && (W / 4) % 64 == 0 ? W / 4 : 256);
-  if (NL == 12) hipLaunchKernelGGL((prompt_mix_fwd_kernel<12>), grid, block, 0, st, enc, gate, pkv, NI, B, L, W);
-  else if (NL == 2) hipLaunchKernelGGL((prompt_mix_fwd_kernel<2>), grid, block, 0, st, enc, gate, pkv, NI, B, L, W);
-  else return MTVAF_ERR_SHAPE;
+#define MTVAF_L(N_) hipLaunchKernelGGL((prompt_mix_fwd_kernel<N_>), grid, block, 0, st, enc, gate, pkv, NI, B, L, W)
+  MTVAF_NL_DISPATCH(NL, MTVAF_L)
+#undef MTVAF_L
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -266,9 +279,9 @@ int mtvaf_prompt_mix_bwd_gate(const float* enc, const float* dpkv, const float* 
                               float* dgate_part, float* dlogits, int NI, int B, int L, int W, int NL, hipStream_t st) {
   if (W % 8 || NI <= 0 || B <= 0 || L <= 0) return MTVAF_ERR_SHAPE;
   dim3 grid(NI * B * L), block(256);
-  if (NL == 12) hipLaunchKernelGGL((prompt_mix_bwd_gate_kernel<12>), grid, block, 0, st, enc, dpkv, dgate_part, NI, B, L, W);
-  else if (NL == 2) hipLaunchKernelGGL((prompt_mix_bwd_gate_kernel<2>), grid, block, 0, st, enc, dpkv, dgate_part, NI, B, L, W);
-  else return MTVAF_ERR_SHAPE;
+#define MTVAF_L(N_) hipLaunchKernelGGL((prompt_mix_bwd_gate_kernel<N_>), grid, block, 0, st, enc, dpkv, dgate_part, NI, B, L, W)
+  MTVAF_NL_DISPATCH(NL, MTVAF_L)
+#undef MTVAF_L
   const long n = (long)NI * B;
   hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)((n * NL + 255) / 256)), dim3(256), 0, st, logits, gate, dgate_part,
                      dlogits, n, NL, L);
@@ -281,9 +294,9 @@ int mtvaf_prompt_mix_bwd_enc(const float* gate, const float* dpkv, const float* 
                              int W, int NL, hipStream_t st) {
   if (W % 8 || NI <= 0 || B <= 0 || L <= 0) return MTVAF_ERR_SHAPE;
   dim3 grid(NI * B * L), block(W / 4 <= 384 && (W / 4) % 64 == 0 ? W / 4 : 256);
-  if (NL == 12) hipLaunchKernelGGL((prompt_mix_bwd_enc_kernel<12>), grid, block, 0, st, gate, dpkv, dsm, denc, NI, B, L, W);
-  else if (NL == 2) hipLaunchKernelGGL((prompt_mix_bwd_enc_kernel<2>), grid, block, 0, st, gate, dpkv, dsm, denc, NI, B, L, W);
-  else return MTVAF_ERR_SHAPE;
+#define MTVAF_L(N_) hipLaunchKernelGGL((prompt_mix_bwd_enc_kernel<N_>), grid, block, 0, st, gate, dpkv, dsm, denc, NI, B, L, W)
+  MTVAF_NL_DISPATCH(NL, MTVAF_L)
+#undef MTVAF_L
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

@@ -378,25 +378,29 @@ class BertModel(nn.Module):
 
     @classmethod
     def from_pretrained(cls, name_or_path, *model_args, **kwargs):
-        """Loads ``config.json`` + ``pytorch_model.bin`` / ``model.safetensors`` from a local directory
-        (there is no hub access on the target machines).  Keys may carry the ``bert.`` / ``roberta.``
-        prefix of task checkpoints.  With ``MTVAF_RANDOM_INIT=1`` a missing checkpoint yields a
-        random-init model of the named architecture (synthetic benchmarks)."""
+        """``BertModel.from_pretrained(args.bert_name)`` as the reference calls it (models/bert_model.py:425-429): a local
+        directory, or a hub NAME (``bert-base-uncased``, ``roberta-base`` ...) resolved through the local Hugging Face
+        cache (``HF_HUB_CACHE`` / ``~/.cache/huggingface/hub``, or ``cache_dir=``) without network access -- the target
+        machines have none, so a name that is not cached raises.  Loads ``config.json`` + ``model.safetensors`` /
+        ``pytorch_model.bin``; keys may carry the ``bert.`` / ``roberta.`` prefix of task checkpoints.  With
+        ``MTVAF_RANDOM_INIT=1`` a missing checkpoint yields a random-init model of the named architecture (synthetic
+        benchmarks)."""
         config = kwargs.pop("config", None)
-        if os.path.isdir(str(name_or_path)):
+        path = cls._resolve_checkpoint_dir(str(name_or_path), kwargs.pop("cache_dir", None))
+        if path is not None:
             if config is None:
-                config = cls.config_class.from_pretrained(name_or_path)
+                config = cls.config_class.from_pretrained(path)
             model = cls(config, *model_args)
             sd = None
-            st = os.path.join(name_or_path, "model.safetensors")
-            pt = os.path.join(name_or_path, "pytorch_model.bin")
+            st = os.path.join(path, "model.safetensors")
+            pt = os.path.join(path, "pytorch_model.bin")
             if os.path.exists(st):
                 from safetensors.torch import load_file
                 sd = load_file(st)
             elif os.path.exists(pt):
                 sd = torch.load(pt, map_location="cpu")
             if sd is None:
-                raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {name_or_path}")
+                raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
             model.load_reference_state_dict(sd)
             return model
         if os.environ.get("MTVAF_RANDOM_INIT", "0") == "1":
@@ -404,8 +408,19 @@ class BertModel(nn.Module):
                 config = cls.default_config(str(name_or_path))
             return cls(config, *model_args)
         raise FileNotFoundError(
-            f"{name_or_path!r} is not a local checkpoint directory (no hub access); set MTVAF_RANDOM_INIT=1 "
-            "for a random-init model of that architecture")
+            f"{name_or_path!r} is neither a local checkpoint directory nor a model in the local Hugging Face cache (no hub "
+            "access here); set MTVAF_RANDOM_INIT=1 for a random-init model of that architecture")
+
+    @staticmethod
+    def _resolve_checkpoint_dir(name: str, cache_dir=None) -> Optional[str]:
+        if os.path.isdir(name):
+            return name
+        try:
+            from huggingface_hub import snapshot_download
+            return snapshot_download(name, local_files_only=True, cache_dir=cache_dir or os.environ.get("HF_HUB_CACHE"),
+                                     allow_patterns=["config.json", "model.safetensors", "pytorch_model.bin"])
+        except Exception:  # not cached (LocalEntryNotFoundError), malformed repo id, hub library missing
+            return None
 
     @classmethod
     def default_config(cls, name: str):

@@ -121,3 +121,105 @@ def test_reference_optimizer_groups_and_schedule():
         opt.step(); sched.step(); ref_opt.step(); ref.step()
     one = reference_param_groups(tiny_model(use_prefix=False), 1e-5, use_prefix=False)
     assert len(one) == 1 and len(one[0]["params"]) == len(list(tiny_model(use_prefix=False).parameters()))
+
+
+# ---- the reference trainer's own code, recorded (tests/golden/gen_trainer_fixture.py) -----------------------------------
+def _contract():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trainer_contract.json")))
+
+
+def _contract_model(use_prefix=True):
+    from mtvaf_amd.models.bert_model import TVNetSAModel2
+    c = _contract()["config"]
+    cfg = BertConfig(vocab_size=c["vocab"], hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=12,
+                     intermediate_size=c["inter"], max_position_embeddings=c["max_pos"], pad_token_id=0)
+    args = types.SimpleNamespace(bert_name="bert-base-uncased", bert_config=cfg, use_prefix=use_prefix, vao=False,
+                                 noauxloss=True, use_probe=False, n_gpu=1, alpha=0.0, prefix_len=4, prefix_dim=768,
+                                 device="cpu", resnet_root="random", use_152=False)
+    return TVNetSAModel2(LABELS, None, args)
+
+
+def test_state_dict_layout_matches_what_the_reference_trainer_saw():
+    """The reference's checkpoint loaders are positional and shape-driven (modules/train.py:928-975): same keys in the same
+    ORDER with the same shapes as when the fixture was recorded => they behave exactly as recorded.  Against the reference
+    class's own state_dict: every drop-in key exists there with the same shape and in the same relative order (the
+    reference hard-codes 12 projectors; the drop-in builds one per encoder layer)."""
+    c = _contract()
+    m = _contract_model()
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == c["dropin_state_dict"]
+    assert [n for n, _ in m.named_parameters()] == c["dropin_named_parameters"]
+    ref = {k: s for k, s in c["reference_state_dict"]}
+    ours = [k for k, _ in c["dropin_state_dict"]]
+    assert all(k in ref and ref[k] == s for k, s in c["dropin_state_dict"])
+    assert [k for k, _ in c["reference_state_dict"] if k in set(ours)] == ours
+    extra = [k for k, _ in c["reference_state_dict"] if k not in set(ours)]
+    assert all(k.startswith("projectors.") for k in extra), extra
+
+
+def test_reference_trainer_groups_frozen_set_and_schedule_recorded():
+    """`SATrainer2.multiModal_before_train` / `bert_before_train` run by the reference's own code on the drop-in
+    (fixture) == mtvaf_amd.optim.reference_param_groups / build_optimizer on today's drop-in."""
+    from mtvaf_amd.optim import build_optimizer, reference_param_groups
+    c = _contract()
+    m = _contract_model()
+    names = {id(p): n for n, p in m.named_parameters()}
+    groups = reference_param_groups(m, 3e-5)
+    assert [[names[id(p)] for p in g["params"]] for g in groups] == [g["params"] for g in c["multimodal_groups"]]
+    assert [g["lr"] for g in groups] == [g["lr"] for g in c["multimodal_groups"]]
+    assert [g["weight_decay"] for g in groups] == [g["weight_decay"] for g in c["multimodal_groups"]]
+    grouped = {n for g in c["multimodal_groups"] for n in g["params"]}
+    assert [n for n, _ in m.named_parameters() if n not in grouped] == c["multimodal_ungrouped"]
+    assert any(n.startswith("projectors.") for n in c["multimodal_ungrouped"])  # the reference quirk is real
+    args = types.SimpleNamespace(lr=3e-5, warmup_ratio=0.01, use_prefix=True)
+    opt, sched = build_optimizer(m, args, train_num_steps=c["train_num_steps"])
+    assert [n for n, p in m.named_parameters() if not p.requires_grad] == c["multimodal_frozen"]
+    for want in c["multimodal_lr_first_steps"]:
+        got = [g["lr"] for g in opt.param_groups]
+        assert all(abs(a - b) <= 1e-12 + 1e-9 * abs(b) for a, b in zip(got, want)), (got, want)
+        opt.step(); sched.step()
+    m2 = _contract_model(use_prefix=False)
+    one = reference_param_groups(m2, 3e-5, use_prefix=False)
+    n2 = {id(p): n for n, p in m2.named_parameters()}
+    assert [[n2[id(p)] for p in one[0]["params"]]] == [g["params"] for g in c["text_only_groups"]]
+
+
+def test_reference_checkpoint_loaders_fill_the_same_named_slots():
+    """A checkpoint written by the REFERENCE class and read by the reference's `load_pretrained2` (positional) / `load_bert`
+    (by key) lands in the drop-in's same-named tensors: every encoder tensor for the first, every shared key for the second."""
+    c = _contract()
+    floats = [k for k, _ in c["dropin_state_dict"] if "position_ids" not in k and "num_batches_tracked" not in k]
+    lp2 = c["load_pretrained2_applied"]
+    assert all(k == v for k, v in lp2.items())
+    assert sorted(lp2) == sorted(k for k in floats if k.startswith("bert."))
+    lb = c["load_bert_applied"]
+    assert all(k == v for k, v in lb.items())
+    assert sorted(lb) == sorted(floats)
+
+
+def test_from_pretrained_resolves_names_through_the_local_hf_cache(tmp_path, monkeypatch):
+    """`BertModel.from_pretrained("bert-base-uncased")` as the reference calls it (models/bert_model.py:425-429): a hub name
+    is looked up in the local Hugging Face cache layout (no network); an uncached name raises (or random-inits on request)."""
+    from safetensors.torch import save_file
+    from mtvaf_amd.models.modeling_bert import BertModel
+    cfg = BertConfig(vocab_size=64, hidden_size=128, num_hidden_layers=2, num_attention_heads=2, intermediate_size=256,
+                     max_position_embeddings=64)
+    src = BertModel(cfg)
+    snap = tmp_path / "models--bert-base-uncased" / "snapshots" / "0123abc"
+    snap.mkdir(parents=True)
+    (tmp_path / "models--bert-base-uncased" / "refs").mkdir()
+    (tmp_path / "models--bert-base-uncased" / "refs" / "main").write_text("0123abc")
+    cfg.save_pretrained(str(snap))
+    save_file({"bert." + k: v.contiguous() for k, v in src.state_dict().items() if "position_ids" not in k},
+              str(snap / "model.safetensors"))
+    monkeypatch.setenv("HF_HUB_CACHE", str(tmp_path))
+    monkeypatch.delenv("MTVAF_RANDOM_INIT", raising=False)
+    m = BertModel.from_pretrained("bert-base-uncased")
+    assert m.config.hidden_size == 128 and m.config.num_hidden_layers == 2
+    for (n1, p1), (n2, p2) in zip(src.named_parameters(), m.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    with pytest.raises(FileNotFoundError):
+        BertModel.from_pretrained("bert-large-uncased")
+    monkeypatch.setenv("MTVAF_RANDOM_INIT", "1")
+    assert BertModel.from_pretrained("bert-large-uncased", config=cfg).config.hidden_size == 128
