@@ -94,7 +94,8 @@ int mtvaf_roberta_position_ids(const int64_t* ids, int32_t* pos_ids, int B, int 
 int mtvaf_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids, const float* word,
                        const float* pos, const float* type, const float* gamma, const float* beta, float* out,
                        float* mean, float* rstd, int B, int S, int H, float eps, float p_drop, uint64_t seed,
-                       uint64_t offset, mtvaf_stream_t stream);
+                       uint64_t offset, void* out_bf16 /* nullable: bf16 copy of out (mixed-precision GEMM operand) */,
+                       mtvaf_stream_t stream);
 int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                        const float* word, const float* pos, const float* type, const float* gamma, const float* mean,
                        const float* rstd, float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta,
@@ -109,12 +110,12 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
 size_t mtvaf_ln_bwd_workspace_bytes(int M, int H);
 int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                              float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
-                             uint64_t offset, mtvaf_stream_t stream);
+                             uint64_t offset, void* out_bf16 /* nullable */, mtvaf_stream_t stream);
 int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma,
                              const float* mean, const float* rstd, float* dx, float* dres, int dres_accumulate,
                              float* dgamma, float* dbeta, float* dbias_x, int accumulate, int M, int H, float p_drop,
                              uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes,
-                             mtvaf_stream_t stream);
+                             void* dx_bf16 /* nullable: dx rounded to bf16; dx may then be NULL */, mtvaf_stream_t stream);
 
 /* ---- small reductions / elementwise ---------------------------------------------------------------------
  * bias gradients (column sums of dY) and nn.Dropout on the sequence output (bert_model.py:506). */
@@ -202,14 +203,22 @@ int mtvaf_ce_bwd(const float* grad_out, const float* logits, const int64_t* labe
 int mtvaf_mask_mul(const float* x, const float* row_keep, const float* col_keep, float* out, int B, int S, int H,
                    mtvaf_stream_t stream);
 
-/* bf16-OPERAND GEMM (mixed-precision configurations): C[M,N] fp32 = A[M,K] . B[N,K]^T with A, B stored as bf16
- * (K contiguous), fp32 accumulation, the epilogues / deterministic split-K of mtvaf_gemm_f32.  Aligned shapes only
- * (M % 128, N % 96 or 128, K % 64, 16-byte aligned operands): MTVAF_ERR_SHAPE / _ALIGN otherwise and the caller
- * uses mtvaf_gemm_bf16.  mtvaf_cast_bf16 prepares operands: a row-major and / or a transposed bf16 copy of an fp32
- * matrix (new functionality: the reference has no mixed precision). */
-int mtvaf_gemm_bf16kc(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
-                      const float* bias, int epi, float* aux, int ldaux, int accumulate, int allow_split,
-                      void* workspace, size_t workspace_bytes, int tile, int splits, mtvaf_stream_t stream);
+/* bf16-OPERAND GEMM of the mixed-precision mode (new functionality: the reference has no mixed precision, SURVEY.md
+ * fact 8): C[M,N] = opA[M,K] . opB[K,N] with A, B stored as bf16 and fp32 accumulation.  layout 0 (KC): reduction index
+ * contiguous (A[m][k], B[n][k]); layout 1 (KM): reduction index is the row (A[k][m], B[k][n]) -- so the forward product
+ * (0,0), dX = dY.W (0,1) and dW = dY^T.X (1,1) all read the same row-major bf16 tensors (transposing LDS reads; no
+ * transposed copies).  Results: C32 fp32 and / or C16 bf16 (either may be NULL); accumulate adds into C32.  epi 0 none,
+ * 1 bias + erf-GELU (pre-activation saved to aux16 as bf16), 3 multiply by GELU'(aux16).  colpart [M/128][N] (optional):
+ * per-tile column sums of the result, finished by mtvaf_colsum_small (the bias gradient of the layer that produced the
+ * operand).  Deterministic split-K as mtvaf_gemm_f32 (fp32 result only).  Aligned shapes only (M % 128, N % 128 -- N % 96
+ * also for layout_b 0 --, K % 64, ld % 8, 16-byte aligned pointers): MTVAF_ERR_SHAPE / _ALIGN otherwise.
+ * tile: 0 auto, 1 128x96, 2 128x128; stages: 0 auto, 2 (two blocks per CU), 3 (one block, two k-tiles in flight).
+ * mtvaf_cast_bf16 makes the bf16 copies of the fp32 master weights. */
+int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
+                     void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
+                     int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
+                     int splits, int stages, mtvaf_stream_t stream);
+int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, mtvaf_stream_t stream);
 int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int ldt, int R, int C,
                     mtvaf_stream_t stream);
 
@@ -220,10 +229,10 @@ int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int
  * launch, enqueued behind that layer's gradient all-reduce so the update overlaps the rest of the backward pass) and
  * optionally writes the updated parameters rounded to bf16 (the GEMM operand shadow of the bf16 compute mode).
  * mtvaf_adamw_multi updates `count` tensors of one parameter group per launch (host arrays of device pointers). */
-int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, double beta1, double beta2, float eps,
                 float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, mtvaf_stream_t stream);
 int mtvaf_adamw_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
-                      const long* n, float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
+                      const long* n, float lr, double beta1, double beta2, float eps, float weight_decay, float bc1,
                       float bc2_sqrt, float grad_scale, mtvaf_stream_t stream);
 
 /* ---- bf16 gradient wire format of the data-parallel exchange (mtvaf_amd/parallel.py; new functionality, the

@@ -17,39 +17,56 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmtvaf_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16kc.hip", "attention.hip", "rowops.hip", "crf.hip", "prompt.hip", "span.hip", "optim.hip", "runtime.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16x.hip", "attention.hip", "rowops.hip", "crf.hip", "prompt.hip", "span.hip", "optim.hip", "runtime.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 # The attention kernels read their MFMA results with VALU code every 16 products (softmax, dS): keeping the
 # accumulators in architectural VGPRs saves ~200 v_accvgpr moves per key tile (gfx950 has one unified file).
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
-def _digest() -> str:
+def _headers_digest() -> bytes:
     h = hashlib.sha256()
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".h")):
+        if f.endswith(".h"):
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
-    h.update(" ".join(FLAGS).encode())
-    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
+    return h.digest()
+
+
+def _src_digest(src: str, hdr: bytes) -> str:
+    h = hashlib.sha256()
+    h.update(hdr)
+    h.update(open(os.path.join(CSRC, src), "rb").read())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src, [])).encode())
     return h.hexdigest()
 
 
+def _digest() -> str:
+    hdr = _headers_digest()
+    return hashlib.sha256("".join(_src_digest(s, hdr) for s in SOURCES).encode()).hexdigest()
+
+
 def build_library(force: bool = False, verbose: bool = True) -> str:
+    """Compiles the sources whose text / headers / flags changed (one stamp per object) and links the library."""
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.stamp")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
+    hdr = _headers_digest()
 
     def compile_one(src):
         obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        ostamp, odig = obj + ".stamp", _src_digest(src, hdr)
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            return obj
         cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[mtvaf build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        with open(ostamp, "w") as f:
+            f.write(odig)
         return obj
 
     with ThreadPoolExecutor(max_workers=4) as ex:

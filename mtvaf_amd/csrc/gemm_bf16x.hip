@@ -1,0 +1,464 @@
+// bf16-operand GEMM of the mixed-precision mode (BASELINE configs 3-4): every dense product of the path -- forward
+// x.W^T, dX = dY.W, dW = dY^T.X -- on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, reading the SAME row-major bf16
+// tensors in all three roles (no transposed copies, no cast passes):
+//
+//   operand "KC": reduction index contiguous in memory (x[m][k], W[n][k] forward, dY[m][n] as A of dX).  LDS image: one
+//                 128-byte row of 64 k per tile row, fragments by ds_read_b128 (16-byte chunk 2*ks + h of row r holds
+//                 the 8 consecutive k of lane (r, h)); bank conflicts removed by chunk ^ ((row >> 1) & 7).
+//   operand "KM": reduction index is the ROW (W[n][k] as B of dX; dY[m][n] and x[m][k] as A / B of dW, reduction over
+//                 the tokens m).  LDS image: 64 reduction rows of 128 output columns (256-byte rows); fragments by
+//                 ds_read_b64_tr_b16, the gfx950 transposing LDS read: a 16-lane group fetches a 4 (reduction) x 16
+//                 (column) block and every lane receives ITS column's 4 reduction values, two reads per MFMA operand.
+//                 Conflict-free with the 16-byte chunk XOR  ((row & 3) << 2) | ((row >> 2) & 3).
+//
+// Tiles go HBM -> LDS with global_load_lds_dwordx4 (1 KiB per wave instruction; the LDS side is lane-linear, so both
+// swizzles are applied to the per-lane SOURCE address and again on the read).  Ring of NSTAGE k-tiles:
+//   NSTAGE 3: one block per CU, two k-tiles in flight across the barrier behind a COUNTED s_waitcnt vmcnt;
+//   NSTAGE 2: two blocks per CU that hide each other's barrier / prologue / epilogue stalls.
+// Epilogue (tile transposed through LDS, 8 columns per lane, 16-byte stores): bias, erf-GELU (pre-activation saved as
+// bf16), * GELU'(pre), accumulate into fp32 C, fp32 and / or bf16 result, and per-tile column sums of the result (the
+// bias gradient of the producing layer, finished by mtvaf_colsum_small) -- or fp32 split-K slabs + ordered reduction.
+#include "gemm_common.h"
+
+#include <algorithm>
+
+namespace mtvaf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
+                         int epi, const float* aux, int ldaux, hipStream_t stream);  // gemm.hip
+int prof_begin(const int key[8], hipStream_t stream);                                // gemm.hip (launch profiler)
+void prof_end(int rec, hipStream_t stream);
+
+struct GemmArgsX {
+  const __bf16* A;
+  const __bf16* B;
+  float* C32;        // fp32 result (or split-K slabs), may be NULL when C16 is given
+  __bf16* C16;       // bf16 result, may be NULL
+  const float* bias;
+  __bf16* aux16;     // EPI_GELU: pre-activation out; EPI_DGELU: pre-activation in
+  float* colpart;    // [M / BM][N] column sums of the result, or NULL
+  int M, N, K;
+  int lda, ldb, ldc32, ldc16, ldaux;  // elements
+  int k_chunk;
+  long slab_stride;
+  int epi, accumulate, tiles_n;
+};
+
+__device__ __forceinline__ void glds16x(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+#define MTVAF_X_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) MTVAF_X_WAIT(0);
+  else if constexpr (N == 7) MTVAF_X_WAIT(7);
+  else if constexpr (N == 8) MTVAF_X_WAIT(8);
+  else if constexpr (N == 4) MTVAF_X_WAIT(4);
+  else if constexpr (N == 6) MTVAF_X_WAIT(6);
+  else static_assert(N == 0, "add the count");
+}
+
+__device__ __forceinline__ int km_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// two transposing reads -> the 8 consecutive reduction values of this lane's output row / column
+__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE>
+__global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_bf16x_kernel(GemmArgsX p) {
+  constexpr int BK = 64;  // bf16 elements per k-tile
+  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int A_B = BM * 128, B_B = BN * 128, STAGE_B = A_B + B_B;  // bytes (KC: BM rows x 128 B; KM: 64 rows x 2*BM B)
+  constexpr int IA = A_B / 1024 / NW, IB = B_B / 1024 / NW;          // 1-KiB DMA instructions per wave
+  static_assert(A_B % (1024 * NW) == 0 && B_B % (1024 * NW) == 0, "tile must split into whole DMA pieces per wave");
+  static_assert((!A_KM || BM == 128) && (!B_KM || BN == 128), "the transposed-read image is built for 256-byte rows");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];  // the ONLY LDS object
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, h = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / p.tiles_n) * BM;
+  const int n0 = (bid % p.tiles_n) * BN;
+  const int kbeg = blockIdx.z * p.k_chunk;
+  const int kend = min(p.K, kbeg + p.k_chunk);
+  const int nk = (kend - kbeg) / BK;
+
+  // ---- per-lane DMA source addresses: LDS position (row, chunk position cp) receives source chunk cp ^ swizzle(row)
+  const unsigned char* pa[IA];
+  const unsigned char* pb[IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int f = (wave * IA + i) * 64 + lane;
+    if (!A_KM) {
+      const int r = f >> 3, cp = f & 7;
+      pa[i] = reinterpret_cast<const unsigned char*>(p.A + (long)(m0 + r) * p.lda + kbeg) + ((cp ^ ((r >> 1) & 7)) << 4);
+    } else {
+      const int r = f >> 4, cp = f & 15;
+      pa[i] = reinterpret_cast<const unsigned char*>(p.A + (long)(kbeg + r) * p.lda + m0) + ((cp ^ km_swz(r)) << 4);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int f = (wave * IB + i) * 64 + lane;
+    if (!B_KM) {
+      const int r = f >> 3, cp = f & 7;
+      pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(n0 + r) * p.ldb + kbeg) + ((cp ^ ((r >> 1) & 7)) << 4);
+    } else {
+      const int r = f >> 4, cp = f & 15;
+      pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(kbeg + r) * p.ldb + n0) + ((cp ^ km_swz(r)) << 4);
+    }
+  }
+  const long stepA = A_KM ? (long)BK * p.lda * 2 : BK * 2;
+  const long stepB = B_KM ? (long)BK * p.ldb * 2 : BK * 2;
+  auto issue = [&](int stage) {
+    unsigned char* sa = smem_b + stage * STAGE_B + wave * IA * 1024;
+    unsigned char* sb = smem_b + stage * STAGE_B + A_B + wave * IB * 1024;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      glds16x(pa[i], sa + i * 1024);
+      pa[i] += stepA;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      glds16x(pb[i], sb + i * 1024);
+      pb[i] += stepB;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- fragment read offsets (bytes inside an operand tile), k-step independent part
+  int offA[TM][2], offB[TN][2];
+  {
+    const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (!A_KM) {
+        const int row = (wm * TM + i) * 32 + li;
+        offA[i][0] = row * 128;
+        offA[i][1] = (row >> 1) & 7;
+      } else {
+        const int ms = wm * TM + i;  // 32-row sub-tile of the 128 output rows
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          offA[i][jj] = 256 * (8 * (g >> 1) + 4 * jj + q) +
+                        16 * ((((ms ^ q) & 3) << 2) | ((2 * (g & 1) + (pp >> 1)) ^ ((2 * (g >> 1) + jj) & 3))) + 8 * (pp & 1);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (!B_KM) {
+        const int col = (wn * TN + j) * 32 + li;
+        offB[j][0] = col * 128;
+        offB[j][1] = (col >> 1) & 7;
+      } else {
+        const int ns = wn * TN + j;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          offB[j][jj] = 256 * (8 * (g >> 1) + 4 * jj + q) +
+                        16 * ((((ns ^ q) & 3) << 2) | ((2 * (g & 1) + (pp >> 1)) ^ ((2 * (g >> 1) + jj) & 3))) + 8 * (pp & 1);
+      }
+    }
+  }
+
+  issue(0);
+  if (NSTAGE == 3 && nk > 1) issue(1);
+  int st = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (NSTAGE == 3 && kt + 1 < nk) wait_vm<IA + IB>();  // this wave's pieces of tile kt have landed; tile kt+1 stays in flight
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // ... and everybody else's; every wave is done reading tile kt-1
+    asm volatile("" ::: "memory");
+    if (kt + NSTAGE - 1 < nk) {
+      int si = st + NSTAGE - 1;
+      if (si >= NSTAGE) si -= NSTAGE;
+      issue(si);  // into the stage tile kt-1 occupied
+    }
+    const unsigned char* a = smem_b + st * STAGE_B;
+    const unsigned char* b = a + A_B;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (!A_KM) fa[i] = *reinterpret_cast<const bf16x8*>(a + offA[i][0] + (((2 * ks + h) ^ offA[i][1]) << 4));
+        else fa[i] = tr_read8(a + offA[i][0] + 4096 * ks, a + offA[i][1] + 4096 * ks);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!B_KM) fb[j] = *reinterpret_cast<const bf16x8*>(b + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
+        else fb[j] = tr_read8(b + offB[j][0] + 4096 * ks, b + offB[j][1] + 4096 * ks);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads of tile kt done before its stage can be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    st = st + 1 == NSTAGE ? 0 : st + 1;
+  }
+
+  // ---- epilogue: accumulator tile -> LDS (transposed to row-major) -> 8 columns per lane ----
+  constexpr int LDE = BN + 4;
+  float* smem = reinterpret_cast<float*>(smem_b);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        smem[row * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
+      }
+  __syncthreads();
+  const bool split = gridDim.z > 1;
+  float* C = p.C32 ? p.C32 + (long)blockIdx.z * p.slab_stride : nullptr;
+  constexpr int C8 = BN / 8;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int idx = tid; idx < BM * C8; idx += NT) {
+    const int r = idx / C8, c = (idx % C8) * 8;
+    float v[8];
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(smem + r * LDE + c + 4);
+    const long row = m0 + r;
+    const int col = n0 + c;
+    if (!split) {
+      if (p.bias) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { v[t] += b0[t]; v[4 + t] += b1[t]; }
+      }
+      if (p.epi == EPI_GELU) {
+        bf16x8 pre;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pre[t] = (__bf16)v[t];
+        *reinterpret_cast<bf16x8*>(p.aux16 + row * p.ldaux + col) = pre;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = gelu_erf((float)pre[t]);  // of the SAVED (rounded) pre-activation: fwd/bwd consistent
+      } else if (p.epi == EPI_DGELU) {
+        const bf16x8 pre = *reinterpret_cast<const bf16x8*>(p.aux16 + row * p.ldaux + col);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] *= gelu_erf_grad((float)pre[t]);
+      }
+      if (p.accumulate) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(C + row * p.ldc32 + col), c1 = *reinterpret_cast<const f32x4*>(C + row * p.ldc32 + col + 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { v[t] += c0[t]; v[4 + t] += c1[t]; }
+      }
+    }
+    if (C) {
+      *reinterpret_cast<f32x4*>(C + row * p.ldc32 + col) = *reinterpret_cast<const f32x4*>(v);
+      *reinterpret_cast<f32x4*>(C + row * p.ldc32 + col + 4) = *reinterpret_cast<const f32x4*>(v + 4);
+    }
+    if (p.C16 && !split) {
+      bf16x8 o;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) o[t] = (__bf16)v[t];
+      *reinterpret_cast<bf16x8*>(p.C16 + row * p.ldc16 + col) = o;
+    }
+    if (NT % C8 == 0) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) cs[t] += v[t];
+    }
+  }
+  if constexpr (NT % C8 == 0) {
+    if (p.colpart && !split) {  // (uniform) per-tile column sums: lanes sharing a column group are NT / C8 apart in rows
+      constexpr int G = NT / C8;
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) smem[(tid / C8) * BN + (tid % C8) * 8 + t] = cs[t];
+      __syncthreads();
+      for (int c = tid; c < BN; c += NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq) s += smem[gq * BN + c];
+        p.colpart[(long)(m0 / BM) * p.N + n0 + c] = s;
+      }
+    }
+  }
+}
+
+// out[c] (+)= sum_r part[r][c], r < rows (<= a few hundred): the second stage of the epilogue column sums
+__global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out,
+                                                          int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += part[(long)r * cols + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// out[r][c] = bf16(x[r][c]);  outT[c][r] = bf16(x[r][c]) (optional).  32x32 tiles through LDS for the transposed copy.
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ x, int ldx, __bf16* __restrict__ out, int ldo,
+                                                       __bf16* __restrict__ outT, int ldt, int R, int C) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) {
+      v = x[(long)r * ldx + c];
+      if (out) out[(long)r * ldo + c] = (__bf16)v;
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  if (!outT) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (r < R && c < C) outT[(long)c * ldt + r] = (__bf16)tile[tx][ty + 8 * i];
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE>
+static int launch_x(const GemmArgsX& a, dim3 grid, hipStream_t st) {
+  size_t smem = (size_t)NSTAGE * (BM + BN) * 128;
+  smem = std::max(smem, (size_t)BM * (BN + 4) * sizeof(float));  // epilogue image
+  auto kern = gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE>;
+  static bool attr_set = false;
+  if (smem > 64 * 1024 && !attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, a);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+template <bool A_KM, bool B_KM>
+static int launch_layout(const GemmArgsX& a, int bn, int stages, dim3 grid, hipStream_t st) {
+  if (bn == 128) {
+    return stages == 3 ? launch_x<128, 128, 2, 2, A_KM, B_KM, 3>(a, grid, st) : launch_x<128, 128, 2, 2, A_KM, B_KM, 2>(a, grid, st);
+  }
+  if constexpr (!B_KM) {
+    return stages == 3 ? launch_x<128, 96, 4, 1, A_KM, B_KM, 3>(a, grid, st) : launch_x<128, 96, 4, 1, A_KM, B_KM, 2>(a, grid, st);
+  }
+  return MTVAF_ERR_SHAPE;
+}
+
+}  // namespace mtvaf
+
+using namespace mtvaf;
+
+extern "C" {
+
+// C[M,N] = opA[M,K] . opB[K,N] with bf16 operands (uint16 storage) and fp32 accumulation.
+//   layout 0 (KC): reduction index contiguous -- A[m][k] (lda), B[n][k] (ldb);  layout 1 (KM): reduction index is the
+//   row -- A[k][m], B[k][n].  Combinations of the path: (0,0) forward, (0,1) dX, (1,1) dW.
+//   Results: C32 (fp32, ldc32) and / or C16 (bf16, ldc16); accumulate adds into C32.  epi: 0 none, 1 bias + erf-GELU
+//   (pre-activation stored to aux16 as bf16; GELU evaluated on the stored value), 3 multiply by GELU'(aux16).
+//   colpart [M/128][N] (optional, 128x128 tiles): per-tile column sums of the result for mtvaf_colsum_small.
+//   allow_split: deterministic split-K (fp32 slabs in workspace + ordered reduction; fp32 result only, epi 0).
+// Requirements (MTVAF_ERR_SHAPE / _ALIGN otherwise; no fallback): M % 128 == 0, K % 64 == 0, N % 128 == 0 (N % 96 == 0
+// also accepted for layout_b 0), leading dimensions % 8 == 0, 16-byte aligned pointers.  tile: 0 auto, 1 128x96,
+// 2 128x128.  stages: 0 auto, 2, 3.
+int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
+                     void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
+                     int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
+                     int splits, int stages, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_SHAPE;
+  if (!A || !B || (!C32 && !C16)) return MTVAF_ERR_ARG;
+  if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1 || (layout_a == 1 && layout_b == 0)) return MTVAF_ERR_ARG;
+  if (epi != EPI_NONE && epi != EPI_GELU && epi != EPI_DGELU) return MTVAF_ERR_ARG;
+  if ((epi == EPI_GELU || epi == EPI_DGELU) && !aux16) return MTVAF_ERR_ARG;
+  if (accumulate && !C32) return MTVAF_ERR_ARG;
+  if (M % 128 || K % 64 || (N % 96 && N % 128)) return MTVAF_ERR_SHAPE;
+  if (layout_b == 1 && N % 128) return MTVAF_ERR_SHAPE;
+  if (lda % 8 || ldb % 8 || (C32 && ldc32 % 4) || (C16 && ldc16 % 8) || (aux16 && ldaux % 8)) return MTVAF_ERR_ALIGN;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C32 | (uintptr_t)C16 | (uintptr_t)bias | (uintptr_t)aux16 | (uintptr_t)colpart) & 15)
+    return MTVAF_ERR_ALIGN;
+  const bool can128 = N % 128 == 0, can96 = N % 96 == 0 && layout_b == 0 && !colpart;
+  int bn = tile == 1 ? 96 : (tile == 2 ? 128 : 0);
+  if ((bn == 96 && !can96) || (bn == 128 && !can128)) return MTVAF_ERR_SHAPE;
+  if (bn == 0) {
+    const long t128 = can128 ? (long)(M / 128) * (N / 128) : 0;
+    if (!can96) bn = 128;
+    else if (!can128) bn = 96;
+    else bn = (epi == EPI_GELU || epi == EPI_DGELU || t128 >= 512) ? 128 : 96;
+  }
+  const long tiles = (long)(M / 128) * (N / bn);
+  const bool split_ok = allow_split && epi == EPI_NONE && C32 && !C16 && !colpart;
+  if (splits <= 0) {
+    splits = 1;
+    if (split_ok && tiles < 384) splits = (int)std::min<long>(std::max<long>(512 / tiles, 1), 8);
+  }
+  if (!split_ok) splits = 1;
+  while (splits > 1 && ((size_t)splits * M * N * sizeof(float) > workspace_bytes || (K / 64) / splits < 4)) --splits;
+  GemmArgsX a;
+  a.A = static_cast<const __bf16*>(A);
+  a.B = static_cast<const __bf16*>(B);
+  a.C16 = static_cast<__bf16*>(C16);
+  a.bias = bias;
+  a.aux16 = static_cast<__bf16*>(aux16);
+  a.colpart = colpart;
+  a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc16 = ldc16; a.ldaux = ldaux;
+  a.epi = epi; a.accumulate = accumulate;
+  int kc = (int)(((K / 64 + splits - 1) / splits) * 64);
+  splits = (K + kc - 1) / kc;
+  a.k_chunk = kc;
+  if (splits > 1) {
+    a.C32 = (float*)workspace; a.ldc32 = N; a.slab_stride = (long)M * N;
+  } else {
+    a.C32 = C32; a.ldc32 = ldc32; a.slab_stride = 0;
+  }
+  a.tiles_n = N / bn;
+  if (stages != 2 && stages != 3) stages = 2;  // measured (tools/bf16x_bench.py): two co-resident blocks beat the deeper ring on every shape of the path
+  dim3 grid((unsigned)tiles, 1, (unsigned)splits);
+  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages == 3) + 4 * layout_a + 8 * layout_b, layout_a, layout_b, 2, M, N, K, splits};
+  const int rec = prof_begin(key, stream);
+  int rc;
+  if (layout_a == 0 && layout_b == 0) rc = launch_layout<false, false>(a, bn, stages, grid, stream);
+  else if (layout_a == 0) rc = launch_layout<false, true>(a, bn, stages, grid, stream);
+  else rc = launch_layout<true, true>(a, bn, stages, grid, stream);
+  prof_end(rec, stream);
+  if (rc != MTVAF_OK) return rc;
+  if (splits > 1) return launch_splitk_reduce((const float*)workspace, splits, C32, M, N, ldc32, bias, accumulate, EPI_NONE, nullptr, 0, stream);
+  return MTVAF_OK;
+}
+
+// out[c] (+)= sum over rows of part[rows][cols] (fixed order): finishes the epilogue column sums of mtvaf_gemm_bf16x
+int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, hipStream_t stream) {
+  if (!part || !out || rows <= 0 || cols <= 0) return MTVAF_ERR_ARG;
+  hipLaunchKernelGGL(colsum_small_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, part, rows, cols, out, accumulate);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+// out [R,C] bf16 (ld ldo) and / or outT [C,R] bf16 (ld ldt) from x [R,C] fp32 (ld ldx); either output may be NULL.
+int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int ldt, int R, int C, hipStream_t stream) {
+  if (R <= 0 || C <= 0 || !x || (!out && !outT)) return MTVAF_ERR_ARG;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, x, ldx, static_cast<__bf16*>(out),
+                     ldo, static_cast<__bf16*>(outT), ldt, R, C);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+}  // extern "C"

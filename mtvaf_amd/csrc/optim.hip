@@ -4,7 +4,7 @@
 //
 //   AdamW, per element (decoupled weight decay, bias-corrected, as torch.optim.AdamW):
 //     p  -= lr * wd * p
-//     m   = m + (1 - b1) * (g - m)
+//     m   = m + (1 - b1) * (g - m)            (1 - b rounded once from double, like torch's python scalars)
 //     v   = b2 * v + (1 - b2) * g * g
 //     p  -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 //   7 fp32 streams per parameter (read p, g, m, v; write p, m, v) = 28 B; an optional bf16 copy of the new
@@ -15,13 +15,18 @@ namespace mtvaf {
 
 struct AdamHyper {
   float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale;
+  float omb1, omb2;  // 1 - beta, rounded ONCE from double (as torch does: float(1 - 0.999) != 1.f - float(0.999) by 1.3e-5)
 };
+static inline AdamHyper make_hyper(float lr, double beta1, double beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                   float grad_scale) {
+  return AdamHyper{lr, (float)beta1, (float)beta2, eps, wd, bc1, bc2_sqrt, grad_scale, (float)(1.0 - beta1), (float)(1.0 - beta2)};
+}
 
 __device__ __forceinline__ void adamw1(float& p, float g, float& m, float& v, const AdamHyper& h) {
   g *= h.grad_scale;
   p -= h.lr * h.wd * p;
-  m += (1.f - h.beta1) * (g - m);
-  v = h.beta2 * v + (1.f - h.beta2) * g * g;
+  m += h.omb1 * (g - m);
+  v = h.beta2 * v + h.omb2 * g * g;
   const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
   p -= (h.lr / h.bc1) * (m / denom);
 }
@@ -154,11 +159,11 @@ extern "C" {
 
 // One flat tensor (an encoder layer's parameter buffer).  bias corrections are passed in: bc1 = 1 - beta1^t,
 // bc2_sqrt = sqrt(1 - beta2^t).  p_bf16 (optional) receives the updated parameter rounded to bf16.
-int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, double beta1, double beta2, float eps,
                 float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, hipStream_t stream) {
   if (!p || !g || !m || !v || n <= 0) return MTVAF_ERR_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 3) return MTVAF_ERR_ALIGN;
-  AdamHyper h{lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale};
+  const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
   hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, stream, p, g, m, v,
                      static_cast<__bf16*>(p_bf16), n, h);
   MTVAF_LAUNCH_CHECK();
@@ -167,10 +172,10 @@ int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, 
 
 // `count` tensors sharing one set of hyper-parameters (a torch parameter group); host arrays of device pointers.
 int mtvaf_adamw_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v, const long* n,
-                      float lr, float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
+                      float lr, double beta1, double beta2, float eps, float weight_decay, float bc1, float bc2_sqrt,
                       float grad_scale, hipStream_t stream) {
   if (count < 0 || (count && (!p || !g || !m || !v || !n))) return MTVAF_ERR_ARG;
-  AdamHyper h{lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale};
+  const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
   for (int base = 0; base < count; base += ADAM_MAXT) {
     AdamMulti t;
     t.count = count - base < ADAM_MAXT ? count - base : ADAM_MAXT;

@@ -10,6 +10,7 @@
 namespace mtvaf {
 
 constexpr int MAXC = 4;  // float4 chunks per lane -> H <= 1024
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 struct RowCtx {
   int lane, nchunk, H;
@@ -28,7 +29,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                                     float* __restrict__ out, float* __restrict__ mean_o,
                                                     float* __restrict__ rstd_o, int M, int S, int H, float eps,
-                                                    float p_drop, uint64_t seed, uint64_t offset) {
+                                                    float p_drop, uint64_t seed, uint64_t offset,
+                                                    __bf16* __restrict__ out16) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nch = H >> 2;
@@ -89,6 +91,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
           y.z = (k & 4) ? y.z * scale : 0.f; y.w = (k & 8) ? y.w * scale : 0.f;
         }
         *reinterpret_cast<f32x4*>(out + (long)row * H + c * 4) = y;
+        if (out16)  // bf16 copy: the next projection's operand in the mixed-precision mode (no separate cast pass)
+          *reinterpret_cast<bf16x4*>(out16 + (long)row * H + c * 4) = bf16x4{(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
       }
     }
   }
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                     float* __restrict__ dx, float* __restrict__ dres, int dres_acc,
                                                     float* __restrict__ partials, int M, int S, int H, float p_drop,
-                                                    uint64_t seed, uint64_t offset) {
+                                                    uint64_t seed, uint64_t offset, __bf16* __restrict__ dx16) {
   constexpr int NP = MODE == 1 ? 4 : 3;
   __shared__ f32x4 red[4][MAXC * 64];  // [wave][H/4 <= 256]
   const int lane = threadIdx.x & 63;
@@ -182,7 +186,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             d.x = (keep[i] & 1) ? d.x * scale : 0.f; d.y = (keep[i] & 2) ? d.y * scale : 0.f;
             d.z = (keep[i] & 4) ? d.z * scale : 0.f; d.w = (keep[i] & 8) ? d.w * scale : 0.f;
           }
-          *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = d;
+          if (dx) *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = d;
+          if (dx16)  // the gradient is only a GEMM operand downstream (dX and dW products of the dense layer)
+            *reinterpret_cast<bf16x4*>(dx16 + (long)row * H + c * 4) = bf16x4{(__bf16)d.x, (__bf16)d.y, (__bf16)d.z, (__bf16)d.w};
           at0[i] += d;
         } else {
           *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = dz;
@@ -368,38 +374,43 @@ int mtvaf_roberta_position_ids(const int64_t* ids, int32_t* pos_ids, int B, int 
 int mtvaf_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids, const float* word,
                        const float* pos, const float* type, const float* gamma, const float* beta, float* out,
                        float* mean, float* rstd, int B, int S, int H, float eps, float p_drop, uint64_t seed,
-                       uint64_t offset, hipStream_t st) {
+                       uint64_t offset, void* out_bf16, hipStream_t st) {
   if (H % 4 || H > MAXC * 256 || B <= 0 || S <= 0) return MTVAF_ERR_SHAPE;
   const int M = B * S;
   hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3(row_grid(M)), dim3(256), 0, st, nullptr, nullptr, ids, type_ids, pos_ids,
-                     word, pos, type, gamma, beta, out, mean, rstd, M, S, H, eps, p_drop, seed, offset);
+                     word, pos, type, gamma, beta, out, mean, rstd, M, S, H, eps, p_drop, seed, offset,
+                     static_cast<__bf16*>(out_bf16));
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
 
 int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                              float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
-                             uint64_t offset, hipStream_t st) {
+                             uint64_t offset, void* out_bf16, hipStream_t st) {
   if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
   hipLaunchKernelGGL((ln_fwd_kernel<0>), dim3(row_grid(M)), dim3(256), 0, st, x, res, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, nullptr, gamma, beta, out, mean, rstd, M, 1, H, eps, p_drop, seed, offset);
+                     nullptr, nullptr, nullptr, gamma, beta, out, mean, rstd, M, 1, H, eps, p_drop, seed, offset,
+                     static_cast<__bf16*>(out_bf16));
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
 
 // dgamma/dbeta: overwritten (accumulate = 0) or added to.  dres_accumulate: dres += instead of =.
 // dbias_x (nullable): column sums of dx, i.e. the bias gradient of the dense layer whose output is x.
+// dx_bf16 (nullable): dx rounded to bf16 (mixed-precision mode: dx is only a GEMM operand downstream); dx may then be NULL.
 int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma,
                              const float* mean, const float* rstd, float* dx, float* dres, int dres_accumulate,
                              float* dgamma, float* dbeta, float* dbias_x, int accumulate, int M, int H, float p_drop,
-                             uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, hipStream_t st) {
+                             uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes, void* dx_bf16,
+                             hipStream_t st) {
   if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
+  if (!dx && !dx_bf16) return MTVAF_ERR_ARG;
   const int g = row_grid_bwd(M);
   if (workspace_bytes < (size_t)g * 3 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
-                     offset);
+                     offset, static_cast<__bf16*>(dx_bf16));
   MTVAF_LAUNCH_CHECK();
   OutPtrs outs{{dgamma, dbeta, dbias_x, nullptr}};
   hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((3 * H + 31) / 32), dim3(256), 0, st, part, g, H, 3, outs,
@@ -424,7 +435,8 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
   if (workspace_bytes < (size_t)g * 4 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(g), dim3(256), 0, st, dout, nullptr, nullptr, ids, type_ids, pos_ids,
-                     word, pos, type, gamma, mean, rstd, dz_ws, nullptr, 0, part, M, S, H, p_drop, seed, offset);
+                     word, pos, type, gamma, mean, rstd, dz_ws, nullptr, 0, part, M, S, H, p_drop, seed, offset,
+                     (__bf16*)nullptr);
   MTVAF_LAUNCH_CHECK();
   OutPtrs outs{{dgamma, dbeta, dtype, type_vocab > 1 ? dtype + H : nullptr}};
   hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((4 * H + 31) / 32), dim3(256), 0, st, part, g, H, 4, outs,

@@ -94,35 +94,59 @@ class EmbeddingsFunction(torch.autograd.Function):
 # -------------------------------------------------------------------------------------------------
 class LayerWeights:
     """Device pointers of one encoder layer in kernel-ready (QKV-packed) form."""
-    __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2", "wparams", "_h")
+    __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2", "wparams", "_h", "flat")
 
 
 def _bf16(*shape, like: torch.Tensor):
     return torch.empty(shape, device=like.device, dtype=torch.bfloat16)
 
 
-def _cast(x, transposed=False, both=False):
-    """fp32 [R,C] -> bf16 row-major copy, transposed copy, or (row-major, transposed)."""
-    R, C = x.shape
-    out = _bf16(R, C, like=x) if (both or not transposed) else None
-    out_t = _bf16(C, R, like=x) if (both or transposed) else None
-    hip.cast_bf16(x, out=out, out_t=out_t)
-    return (out, out_t) if both else (out_t if transposed else out)
+def _cast(x):
+    """fp32 [R,C] -> bf16 row-major copy (the operand of a following projection in the mixed-precision mode)."""
+    out = _bf16(*x.shape, like=x)
+    hip.cast_bf16(x, out=out)
+    return out
 
 
 def _weights_bf16(w: LayerWeights):
-    """bf16 shadows (row-major for the forward products, transposed for dX) of a layer's four weight matrices.
-    Rebuilt when the masters may have changed: after ANY torch optimizer step (global post-step hook -- the fused
-    optimizers update parameters without moving their version counters) or when a weight Parameter's version
-    counter has moved (load_state_dict, in-place updates through the Parameter).  Writes through ``.data`` are
-    invisible to both: MTVAF_BF16_WCACHE=0 rebuilds in every forward pass (85 M parameters, ~0.3 ms per step)."""
-    ver = (_OPT_EPOCH[0],) + tuple(p._version for p in w.wparams) if (BF16_WCACHE and getattr(w, "wparams", None)) else None
-    c = getattr(w, "_h", None)
+    """bf16 shadows of a layer's four weight matrices: views of ONE flat bf16 image of the layer's parameter buffer (same
+    offsets as the fp32 masters).  Every product reads them row-major -- forward as the KC operand, dX as the KM operand
+    (transposing LDS reads) -- so no transposed copies exist.  Freshness: ``mtvaf_amd.optim.AdamW`` writes the shadow in
+    its update kernel and stamps it; otherwise the image is rebuilt (one cast kernel per layer) when the masters may have
+    changed: after ANY torch optimizer step (global post-step hook -- the fused optimizers update parameters without
+    moving their version counters) or when a weight Parameter's version counter has moved (load_state_dict, in-place
+    updates through the Parameter).  Writes through ``.data`` are invisible to both: MTVAF_BF16_WCACHE=0 rebuilds in
+    every forward pass (85 M parameters, ~0.1 ms per step)."""
+    ver = shadow_version(w) if BF16_WCACHE else None
+    c = w._h
     if ver is None or c is None or c[0] != ver:
-        c = (ver, tuple(_cast(t, both=True) for t in (w.wqkv, w.wo, w.w1, w.w2)))
-        if ver is not None:
-            w._h = c
-    return c[1]
+        flat = w.flat
+        H = w.wo.shape[0]
+        img = c[1] if c is not None else torch.empty(flat.numel(), dtype=torch.bfloat16, device=flat.device)
+        hip.cast_bf16(flat.view(-1, H), out=img.view(-1, H))
+        c = w._h = [ver, img, None]
+    if c[2] is None:
+        img, base = c[1], w.flat.data_ptr()
+        view = lambda t: img[(t.data_ptr() - base) // 4:(t.data_ptr() - base) // 4 + t.numel()].view(t.shape)
+        c[2] = (view(w.wqkv), view(w.wo), view(w.w1), view(w.w2))
+    return c[2]
+
+
+def shadow_version(w: LayerWeights, epoch_ahead: int = 0):
+    return (_OPT_EPOCH[0] + epoch_ahead,) + tuple(p._version for p in w.wparams)
+
+
+def shadow_for_update(w: LayerWeights):
+    """The flat bf16 image an optimizer kernel may write while it updates ``w.flat`` (None until the first forward pass
+    in bf16 mode has built it); the caller stamps it with ``shadow_written`` afterwards."""
+    return w._h[1] if (hip.COMPUTE == "bf16" and w._h is not None) else None
+
+
+def shadow_written(w: LayerWeights):
+    """Called from inside ``optimizer.step()`` (or the backward pass preceding it): the image matches the masters as they
+    will be once this step's post-step hook has run."""
+    if w._h is not None:
+        w._h[0] = shadow_version(w, 1)
 
 
 _OPT_EPOCH = [0]
@@ -137,9 +161,9 @@ BF16_OPERANDS = os.environ.get("MTVAF_BF16_OPERANDS", "1") != "0"  # 0: fp32-ope
 
 
 def _bf16_ok(M, H, I):
-    """bf16-operand kernels need whole 128-row / 96- or 128-column tiles and 64-deep k-tiles."""
-    return (hip.COMPUTE == "bf16" and BF16_OPERANDS and M % 128 == 0 and H % 384 == 0 and I % 384 == 0 and
-            (3 * H) % 128 == 0)
+    """bf16-operand kernels need whole 128-row / 128-column tiles and 64-deep k-tiles (M is also the reduction length of
+    the weight-gradient products)."""
+    return hip.COMPUTE == "bf16" and BF16_OPERANDS and M % 128 == 0 and H % 128 == 0 and I % 128 == 0
 
 
 N_LAYER_PARAMS = 16  # q.w q.b k.w k.b v.w v.b ao.w ao.b ln1.w ln1.b i.w i.b o.w o.b ln2.w ln2.b
@@ -181,14 +205,17 @@ class EncoderFunction(torch.autograd.Function):
         outs = []
         use_h = _bf16_ok(M, H, weights[0].w1.shape[0]) if L else False
         wh = [_weights_bf16(w) for w in weights] if use_h else None
+        KC = hip.KC
+        # mixed precision: bf16 operands written by the producing kernels (LayerNorm, GELU epilogue), fp32 accumulation,
+        # residual stream / LayerNorm / softmax statistics in fp32
+        x_h = _cast(x) if use_h else None
         for li, w in enumerate(weights):
             I = w.w1.shape[0]
             off = RNG.next(3)
             qkv = _empty(M, 3 * H, like=x)
-            if use_h:  # mixed precision: bf16 operands prepared once per use, fp32 accumulation / results / statistics
-                (wqkv_h, _), (wo_h, _), (w1_h, _), (w2_h, _) = wh[li]
-                x_h, xT_h = _cast(x, both=True)  # the transposed copies are the B operands of the dW products
-                hip.gemm_bf16kc(x_h, wqkv_h, qkv, bias=w.bqkv)
+            if use_h:
+                wqkv_h, wo_h, w1_h, w2_h = wh[li]
+                hip.gemm_bf16x(x_h, KC, wqkv_h, KC, M, 3 * H, H, out32=qkv, bias=w.bqkv)
             else:
                 hip.linear_fwd(x, w.wqkv, w.bqkv, qkv)
             cx, lse = _empty(M, H, like=x), _empty(B, NH, S, like=x)
@@ -201,25 +228,28 @@ class EncoderFunction(torch.autograd.Function):
             hip.prefix_attn_fwd(qkv, pk, pv, addmask, cx, lse, B, S, Pn, NH, p_attn, seed, off)
             a = _empty(M, H, like=x)
             if use_h:
-                cx_h, cxT_h = _cast(cx, both=True)
-                hip.gemm_bf16kc(cx_h, wo_h, a, bias=w.bo)
+                cx_h = _cast(cx)
+                hip.gemm_bf16x(cx_h, KC, wo_h, KC, M, H, H, out32=a, bias=w.bo)
             else:
                 hip.linear_fwd(cx, w.wo, w.bo, a)
             h1, mean1, rstd1 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
-            hip.dropout_res_ln_fwd(a, x, w.g1, w.b1, h1, mean1, rstd1, eps, p_hidden, seed, off + 1)
-            pre, act = _empty(M, I, like=x), _empty(M, I, like=x)
             f = _empty(M, H, like=x)
+            h2, mean2, rstd2 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
             if use_h:
-                h1_h, h1T_h = _cast(h1, both=True)
-                hip.gemm_bf16kc(h1_h, w1_h, act, bias=w.bi1, epi=hip.EPI_GELU, aux=pre)
-                act_h, actT_h = _cast(act, both=True)
-                hip.gemm_bf16kc(act_h, w2_h, f, bias=w.bi2)
-                saved_t.extend((xT_h, cxT_h, h1T_h, actT_h))
+                h1_h, h2_h = _bf16(M, H, like=x), _bf16(M, H, like=x)
+                hip.dropout_res_ln_fwd(a, x, w.g1, w.b1, h1, mean1, rstd1, eps, p_hidden, seed, off + 1, out16=h1_h)
+                pre, act = _bf16(M, I, like=x), _bf16(M, I, like=x)  # bf16 only: pre feeds GELU', act the two products
+                hip.gemm_bf16x(h1_h, KC, w1_h, KC, M, I, H, out16=act, bias=w.bi1, epi=hip.EPI_GELU, aux16=pre)
+                hip.gemm_bf16x(act, KC, w2_h, KC, M, H, I, out32=f, bias=w.bi2)
+                hip.dropout_res_ln_fwd(f, h1, w.g2, w.b2, h2, mean2, rstd2, eps, p_hidden, seed, off + 2, out16=h2_h)
+                saved_t.extend((x_h, cx_h, h1_h))
+                x_h = h2_h
             else:
+                hip.dropout_res_ln_fwd(a, x, w.g1, w.b1, h1, mean1, rstd1, eps, p_hidden, seed, off + 1)
+                pre, act = _empty(M, I, like=x), _empty(M, I, like=x)
                 hip.linear_fwd(h1, w.w1, w.bi1, act, epi=hip.EPI_GELU, aux=pre)
                 hip.linear_fwd(act, w.w2, w.bi2, f)
-            h2, mean2, rstd2 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
-            hip.dropout_res_ln_fwd(f, h1, w.g2, w.b2, h2, mean2, rstd2, eps, p_hidden, seed, off + 2)
+                hip.dropout_res_ln_fwd(f, h1, w.g2, w.b2, h2, mean2, rstd2, eps, p_hidden, seed, off + 2)
             saved.extend((x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2))
             offs.append(off)
             outs.append(h2.view(B, S, H))
@@ -251,7 +281,8 @@ class EncoderFunction(torch.autograd.Function):
 
         wh = ctx.wh
         use_h = wh is not None
-        flat_t = flat[13 * L:]  # bf16 transposed activation copies (4 per layer) in mixed-precision mode
+        flat_t = flat[13 * L:]  # bf16 operand copies (x, ctx, h1 per layer) in mixed-precision mode
+        KC, KM = hip.KC, hip.KM
         main = torch.cuda.current_stream()
         # (small batches are host-bound: the extra events / stream switches cost more than the overlap returns)
         side = _side_stream(dev_like.device) if (DW_SIDE_STREAM and need_param_grads and M >= 1024) else None
@@ -295,25 +326,29 @@ class EncoderFunction(torch.autograd.Function):
                 G = [torch.empty_like(p) for p in params[base:base + N_LAYER_PARAMS]]
                 dwqkv, dbqkv = _empty(3 * H, H, like=dev_like), _empty(3 * H, like=dev_like)
             # ---- FFN block ----
-            df, dh1 = _empty(M, H, like=dev_like), _empty(M, H, like=dev_like)
-            hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, df, dh1, False, G[14], G[15], False, p_hidden, seed,
-                                   off + 2, dbias_x=G[13])
-            dpre = _empty(M, I, like=dev_like)
+            dh1 = _empty(M, H, like=dev_like)
             if use_h:
-                # dX = dY . W with the transposed bf16 weight shadow; dW = dY^T . X with both operands cast transposed
-                (_, wqkvT_h), (_, woT_h), (_, w1T_h), (_, w2T_h) = wh[li]
-                df_h, dfT_h = _cast(df, both=True)
-                xT_h, cxT_h, h1T_h, actT_h = flat_t[4 * li:4 * li + 4]
-                on_side((dfT_h,), lambda: hip.gemm_bf16kc(dfT_h, actT_h, G[12], allow_split=True))
-                hip.gemm_bf16kc(df_h, w2T_h, dpre, epi=hip.EPI_DGELU, aux=pre)
-                dpre_h, dpreT_h = _cast(dpre, both=True)
+                # every product reads the same row-major bf16 tensors: dX = dY . W takes W as the KM operand, dW = dY^T . X
+                # takes BOTH as KM operands (reduction over the token rows) -- no casts, no transposed copies
+                wqkv_h, wo_h, w1_h, w2_h = wh[li]
+                x_h, cx_h, h1_h = flat_t[3 * li:3 * li + 3]
+                df_h = _bf16(M, H, like=dev_like)
+                hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, None, dh1, False, G[14], G[15], False, p_hidden, seed,
+                                       off + 2, dbias_x=G[13], dx16=df_h)
+                on_side((df_h,), lambda: hip.gemm_bf16x(df_h, KM, act, KM, H, I, M, out32=G[12], allow_split=True))
+                dpre_h, part = _bf16(M, I, like=dev_like), _empty(M // 128, I, like=dev_like)
+                hip.gemm_bf16x(df_h, KC, w2_h, KM, M, I, H, out16=dpre_h, epi=hip.EPI_DGELU, aux16=pre, colpart=part)
 
                 def ffn1_grads():
-                    hip.colsum(dpre, G[11])
-                    hip.gemm_bf16kc(dpreT_h, h1T_h, G[10], allow_split=True)
-                on_side((dpre, dpreT_h), ffn1_grads)
-                hip.gemm_bf16kc(dpre_h, w1T_h, dh1, accumulate=True)
+                    hip.colsum_small(part, G[11])
+                    hip.gemm_bf16x(dpre_h, KM, h1_h, KM, I, H, M, out32=G[10], allow_split=True)
+                on_side((dpre_h, part), ffn1_grads)
+                hip.gemm_bf16x(dpre_h, KC, w1_h, KM, M, H, I, out32=dh1, accumulate=True)
             else:
+                df = _empty(M, H, like=dev_like)
+                hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, df, dh1, False, G[14], G[15], False, p_hidden, seed,
+                                       off + 2, dbias_x=G[13])
+                dpre = _empty(M, I, like=dev_like)
                 on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12]))
                 hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
 
@@ -323,16 +358,18 @@ class EncoderFunction(torch.autograd.Function):
                 on_side((dpre,), ffn1_grads)
                 hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
             # ---- attention block ----
-            da = df if side is None else _empty(M, H, like=dev_like)  # df is still being read on the side stream
             dh0 = dh  # reuse
-            hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
-                                   off + 1, dbias_x=G[7])
-            dctx = dh1
+            dctx = dh1  # reuse (LayerNorm backward has consumed it by the time the dX product writes)
             if use_h:
-                da_h, daT_h = _cast(da, both=True)
-                on_side((daT_h,), lambda: hip.gemm_bf16kc(daT_h, cxT_h, G[6], allow_split=True))
-                hip.gemm_bf16kc(da_h, woT_h, dctx)
+                da_h = _bf16(M, H, like=dev_like)
+                hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, None, dh0, False, G[8], G[9], False, p_hidden, seed,
+                                       off + 1, dbias_x=G[7], dx16=da_h)
+                on_side((da_h,), lambda: hip.gemm_bf16x(da_h, KM, cx_h, KM, H, H, M, out32=G[6], allow_split=True))
+                hip.gemm_bf16x(da_h, KC, wo_h, KM, M, H, H, out32=dctx)
             else:
+                da = df if side is None else _empty(M, H, like=dev_like)  # df is still being read on the side stream
+                hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
+                                       off + 1, dbias_x=G[7])
                 on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6]))
                 hip.linear_bwd_input(da, w.wo, dctx)
             dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
@@ -341,13 +378,13 @@ class EncoderFunction(torch.autograd.Function):
                                 p_attn, seed, off)
 
             if use_h:
-                dqkv_h, dqkvT_h = _cast(dqkv, both=True)
+                dqkv_h = _cast(dqkv)
 
                 def qkv_grads():
                     hip.colsum(dqkv, dbqkv)
-                    hip.gemm_bf16kc(dqkvT_h, xT_h, dwqkv, allow_split=True)
-                on_side((dqkv, dqkvT_h), qkv_grads)
-                hip.gemm_bf16kc(dqkv_h, wqkvT_h, dh0, accumulate=True)
+                    hip.gemm_bf16x(dqkv_h, KM, x_h, KM, 3 * H, H, M, out32=dwqkv, allow_split=True)
+                on_side((dqkv, dqkv_h), qkv_grads)
+                hip.gemm_bf16x(dqkv_h, KC, wqkv_h, KM, M, H, 3 * H, out32=dh0, accumulate=True)
             else:
                 def qkv_grads():
                     hip.colsum(dqkv, dbqkv)

@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_long, c_size_t, c_uint64, c_void_p
+from ctypes import c_double, c_float, c_int, c_int64, c_long, c_size_t, c_uint64, c_void_p
 from typing import Optional
 
 import torch
@@ -32,11 +32,11 @@ _SIGS = {
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_ln_bwd_workspace_bytes": (SZ, [I, I]),
     "mtvaf_roberta_position_ids": (c_int, [P, P, I, I, I, P]),
-    "mtvaf_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, U64, P]),
+    "mtvaf_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, U64, P, P]),
     "mtvaf_embed_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, U64,
                                    U64, P, P, SZ, P]),
-    "mtvaf_dropout_res_ln_fwd": (c_int, [P, P, P, P, P, P, P, I, I, F, F, U64, U64, P]),
-    "mtvaf_dropout_res_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, I, P, P, P, I, I, I, F, U64, U64, P, SZ, P]),
+    "mtvaf_dropout_res_ln_fwd": (c_int, [P, P, P, P, P, P, P, I, I, F, F, U64, U64, P, P]),
+    "mtvaf_dropout_res_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, I, P, P, P, I, I, I, F, U64, U64, P, SZ, P, P]),
     "mtvaf_colsum_workspace_bytes": (SZ, [I, I]),
     "mtvaf_colsum": (c_int, [P, I, I, I, P, I, P, SZ, P]),
     "mtvaf_dropout": (c_int, [P, P, L, F, U64, U64, P]),
@@ -63,10 +63,11 @@ _SIGS = {
     "mtvaf_ce_fwd": (c_int, [P, P, P, P, I, I, P]),
     "mtvaf_ce_bwd": (c_int, [P, P, P, P, P, I, I, P]),
     "mtvaf_mask_mul": (c_int, [P, P, P, P, I, I, I, P]),
-    "mtvaf_gemm_bf16kc": (c_int, [P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
+    "mtvaf_gemm_bf16x": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P]),
+    "mtvaf_colsum_small": (c_int, [P, I, I, P, I, P]),
     "mtvaf_cast_bf16": (c_int, [P, I, P, I, P, I, I, I, P]),
-    "mtvaf_adamw": (c_int, [P, P, P, P, L, F, F, F, F, F, F, F, F, P, P]),
-    "mtvaf_adamw_multi": (c_int, [I, P, P, P, P, P, F, F, F, F, F, F, F, F, P]),
+    "mtvaf_adamw": (c_int, [P, P, P, P, L, F, c_double, c_double, F, F, F, F, F, P, P]),
+    "mtvaf_adamw_multi": (c_int, [I, P, P, P, P, P, F, c_double, c_double, F, F, F, F, F, P]),
     "mtvaf_grad_pack_bf16": (c_int, [P, P, L, L, P]),
     "mtvaf_grad_reduce_bf16": (c_int, [P, P, I, L, F, P]),
     "mtvaf_grad_unpack_bf16": (c_int, [P, P, L, P]),
@@ -167,8 +168,10 @@ def kernel_symbol(cfg, la, lb, fast):
             8: (128, 192, 2, 2, 32), 9: (128, 96, 4, 1), 10: (128, 128, 2, 2), 11: (128, 192, 2, 2),
             12: (128, 96, 4, 1), 13: (128, 128, 2, 2)}.get(cfg)
     b = lambda x: "true" if x else "false"
-    if cfg >= 200:
-        return "gemm_bf16kc_kernel<128, 96, 4, 1>" if cfg == 200 else "gemm_bf16kc_kernel<128, 128, 2, 2>"
+    if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE>
+        c = cfg - 300
+        t = "128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"
+        return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}>"
     if cfg >= 100:
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
         return f"gemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(fast == 2)}>"
@@ -266,11 +269,11 @@ def dropout(x, out, p, seed, offset):
     return out
 
 
-def embed_ln_fwd(ids, tts, pos_ids, word, pos, typ, gamma, beta, out, mean, rstd, eps, p, seed, offset):
+def embed_ln_fwd(ids, tts, pos_ids, word, pos, typ, gamma, beta, out, mean, rstd, eps, p, seed, offset, out16=None):
     B, S = ids.shape
     H = word.shape[1]
     _ck(lib().mtvaf_embed_ln_fwd(_p(ids), _p(tts), _p(pos_ids), _p(word), _p(pos), _p(typ), _p(gamma), _p(beta), _p(out),
-                                 _p(mean), _p(rstd), B, S, H, float(eps), float(p), seed, offset, _st()),
+                                 _p(mean), _p(rstd), B, S, H, float(eps), float(p), seed, offset, _p(out16), _st()),
         "mtvaf_embed_ln_fwd")
 
 
@@ -292,21 +295,21 @@ def roberta_position_ids(ids, out, pad_idx):
     return out
 
 
-def dropout_res_ln_fwd(x, res, gamma, beta, out, mean, rstd, eps, p, seed, offset):
+def dropout_res_ln_fwd(x, res, gamma, beta, out, mean, rstd, eps, p, seed, offset, out16=None):
     M, H = x.shape
     _ck(lib().mtvaf_dropout_res_ln_fwd(_p(x), _p(res), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), M, H, float(eps),
-                                       float(p), seed, offset, _st()), "mtvaf_dropout_res_ln_fwd")
+                                       float(p), seed, offset, _p(out16), _st()), "mtvaf_dropout_res_ln_fwd")
 
 
 def dropout_res_ln_bwd(dout, x, res, gamma, mean, rstd, dx, dres, dres_accumulate, dgamma, dbeta, accumulate, p, seed,
-                       offset, dbias_x=None):
+                       offset, dbias_x=None, dx16=None):
     M, H = x.shape
     wsb = lib().mtvaf_ln_bwd_workspace_bytes(M, H)
     ws = workspace(wsb, x.device)
     _ck(lib().mtvaf_dropout_res_ln_bwd(_p(dout), _p(x), _p(res), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dres),
                                        int(dres_accumulate), _p(dgamma), _p(dbeta), _p(dbias_x), int(accumulate), M, H,
                                        float(p), seed,
-                                       offset, _p(ws), wsb, _st()), "mtvaf_dropout_res_ln_bwd")
+                                       offset, _p(ws), wsb, _p(dx16), _st()), "mtvaf_dropout_res_ln_bwd")
 
 
 def prefix_attn_fwd(qkv, pk, pv, addmask, ctx, lse, B, S, Pn, NH, p, seed, offset):
@@ -399,7 +402,7 @@ def mask_mul(x, row_keep, col_keep, out):
     return out
 
 
-# ---- bf16-operand GEMM (csrc/gemm_bf16kc.hip) ---------------------------------------------------------------------
+# ---- bf16-operand GEMM (csrc/gemm_bf16x.hip) ----------------------------------------------------------------------
 def cast_bf16(x, out=None, out_t=None):
     """x [R,C] fp32 -> out [R,C] bf16 and / or out_t [C,R] bf16 (either may be None)."""
     R, C = x.shape
@@ -407,17 +410,25 @@ def cast_bf16(x, out=None, out_t=None):
                               out_t.stride(0) if out_t is not None else 0, R, C, _st()), "mtvaf_cast_bf16")
 
 
-def gemm_bf16kc(a, b, out, bias=None, epi=EPI_NONE, aux=None, accumulate=False, allow_split=False, tile=0, splits=-1):
-    """out[M,N] fp32 = a[M,K] . b[N,K]^T, a / b bf16 with K contiguous (aligned shapes only; raises otherwise)."""
-    M, K = a.shape
-    N = b.shape[0]
+def gemm_bf16x(a, layout_a, b, layout_b, M, N, K, out32=None, out16=None, bias=None, epi=EPI_NONE, aux16=None,
+               accumulate=False, colpart=None, allow_split=False, tile=0, splits=-1, stages=0):
+    """out[M,N] = opA[M,K] . opB[K,N], bf16 operands, fp32 accumulation.  KC: a is [M,K] / b is [N,K]; KM: a is [K,M] /
+    b is [K,N] (the same row-major tensors read in their other role).  out32 fp32 and / or out16 bf16; aux16: bf16
+    pre-activation (written by EPI_GELU, read by EPI_DGELU); colpart [M/128, N] fp32 per-tile column sums of the result."""
     ws, wsb = None, 0
     if allow_split:
         wsb = 8 * M * N * 4
-        ws = workspace(wsb, out.device)
-    _ck(lib().mtvaf_gemm_bf16kc(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(bias), epi,
-                                _p(aux), aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws),
-                                wsb, tile, splits, _st()), "mtvaf_gemm_bf16kc")
+        ws = workspace(wsb, a.device)
+    _ck(lib().mtvaf_gemm_bf16x(layout_a, layout_b, _p(a), a.stride(0), _p(b), b.stride(0), _p(out32),
+                               out32.stride(0) if out32 is not None else 0, _p(out16),
+                               out16.stride(0) if out16 is not None else 0, M, N, K, _p(bias), epi, _p(aux16),
+                               aux16.stride(0) if aux16 is not None else 0, int(accumulate), _p(colpart), int(allow_split),
+                               _p(ws), wsb, tile, splits, stages, _st()), "mtvaf_gemm_bf16x")
+
+
+def colsum_small(part, out, accumulate=False):
+    rows, cols = part.shape
+    _ck(lib().mtvaf_colsum_small(_p(part), rows, cols, _p(out), int(accumulate), _st()), "mtvaf_colsum_small")
     return out
 
 

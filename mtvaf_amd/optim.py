@@ -48,7 +48,6 @@ class AdamW(torch.optim.Optimizer):
         self._layer_group: Dict[int, Optional[dict]] = {}
         self._early = set()
         self.suspended = False    # True: the backward hook does nothing (backward passes that are not followed by step())
-        self._bf16_shadow = None  # callable(layer_index) -> flat bf16 shadow tensor or None (bf16 compute mode)
         if model is not None:
             self.attach(model, grad_sync)
 
@@ -97,9 +96,12 @@ class AdamW(torch.optim.Optimizer):
         for p in self._encoder.layer[li].ordered_params():
             self.state[p]["step"] = st["step"]
         b1, b2 = group["betas"]
-        shadow = self._bf16_shadow(li) if self._bf16_shadow is not None else None
+        from . import engine
+        shadow = engine.shadow_for_update(store.weights)  # bf16 compute mode: the GEMM operand image, written in the same pass
         hip.adamw(store.flat, store.grad, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                   st["step"], p_bf16=shadow)
+        if shadow is not None:
+            engine.shadow_written(store.weights)
 
     def _early_layer_update(self, li: int):
         """Called from inside the backward pass (current stream: the one the layer's gradients are final on)."""

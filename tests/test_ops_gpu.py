@@ -544,36 +544,66 @@ def test_gemm_splitk_with_tanh_epilogues(hip):
     close(lg, F.linear(xs.double(), ws.double(), bs.double()), rtol=3e-4, name="auto split skinny")
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 96, 64), (256, 384, 192), (512, 768, 768), (384, 128, 4096)])
+@pytest.mark.parametrize("M,N,K", [(128, 96, 64), (256, 384, 192), (512, 768, 768), (384, 128, 4096), (128, 128, 64)])
 def test_gemm_bf16_operands(hip, M, N, K):
-    """bf16-OPERAND kernel (gemm_bf16kc.hip): exact model = fp32/fp64 products of the bf16-rounded operands; every
-    epilogue, accumulate, forced tiles and split-K; the cast kernel (row-major + transposed copies) is exact."""
+    """bf16-OPERAND kernel (gemm_bf16x.hip): exact model = fp64 products of the bf16-rounded operands.  All three operand
+    layout pairs of the path (forward KCxKC, dX KCxKM, dW KMxKM: the SAME row-major tensors read in both roles through
+    the transposing LDS read), both ring depths, forced tiles, every epilogue, fp32 / bf16 results, per-tile column
+    sums, accumulate, split-K; the cast kernel (row-major + transposed copies) is exact."""
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
     xh, xt = torch.empty(M, K, dtype=torch.bfloat16, device=DEV), torch.empty(K, M, dtype=torch.bfloat16, device=DEV)
     hip.cast_bf16(x.to(DEV), out=xh, out_t=xt)
     assert torch.equal(xh.cpu(), x.to(torch.bfloat16)) and torch.equal(xt.cpu(), x.t().contiguous().to(torch.bfloat16))
     wh = w.to(torch.bfloat16).to(DEV)
+    wt = wh.t().contiguous()  # [K, N]: the KM image of the same matrix
     ref = xh.double().cpu() @ wh.double().cpu().t()
     out = torch.empty(M, N, device=DEV)
-    for tile in ([0] + ([1] if N % 96 == 0 else []) + ([2] if N % 128 == 0 else [])):
-        hip.gemm_bf16kc(xh, wh, out, bias=b.to(DEV), tile=tile)
-        close(out, ref + b.double(), rtol=2e-5, name=f"bias tile {tile}")
-    aux = torch.empty(M, N, device=DEV)
-    hip.gemm_bf16kc(xh, wh, out, bias=b.to(DEV), epi=hip.EPI_GELU, aux=aux)
-    close(aux, ref + b.double(), rtol=2e-5, name="pre")
-    close(out, F.gelu((ref + b.double())), rtol=2e-5, atol=2e-6 * float(ref.abs().max()), name="gelu")
-    pre = rnd(M, N, seed=5)
-    hip.gemm_bf16kc(xh, wh, out, epi=hip.EPI_DGELU, aux=pre.to(DEV))
+    bd = b.to(DEV)
+    layouts = [("KCxKC", xh, hip.KC, wh, hip.KC)]
+    if N % 128 == 0:
+        layouts += [("KCxKM", xh, hip.KC, wt, hip.KM), ("KMxKM", xt, hip.KM, wt, hip.KM)]
+    for name, a_, la, b_, lb in layouts:
+        for stages in (2, 3):
+            for tile in ([0] + ([1] if (N % 96 == 0 and lb == hip.KC) else []) + ([2] if N % 128 == 0 else [])):
+                out.fill_(float("nan"))
+                hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, bias=bd, tile=tile, stages=stages)
+                close(out, ref + b.double(), rtol=2e-5, name=f"{name} bias tile {tile} stages {stages}")
+    a_, la, b_, lb = layouts[-1][1:]
+    # bf16 + fp32 results together; bf16 result = RNE of the fp32 one
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, out16=o16, bias=bd)
+    assert torch.equal(o16, out.to(torch.bfloat16))
+    hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out16=o16.zero_(), bias=bd)
+    assert torch.equal(o16, out.to(torch.bfloat16))
+    # GELU: pre-activation saved as bf16, activation evaluated on the saved value
+    pre16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_bf16x(xh, hip.KC, wh, hip.KC, M, N, K, out32=out, out16=o16, bias=bd, epi=hip.EPI_GELU, aux16=pre16)
+    pre_ref = (ref + b.double()).float().to(torch.bfloat16)
+    mism = (pre16.cpu() != pre_ref)
+    assert mism.float().mean() < 2e-3  # fp32-sum rounding at a bf16 tie flips a few
+    close(out, F.gelu(pre16.double().cpu()), rtol=2e-5, atol=2e-6 * float(ref.abs().max()), name="gelu")
+    assert torch.equal(o16, out.to(torch.bfloat16))
+    # dGELU with the bf16 pre-activation + per-tile column sums
+    pre = rnd(M, N, seed=5).to(torch.bfloat16)
     pd = pre.double().requires_grad_(True)
     F.gelu(pd).sum().backward()
-    close(out, ref * pd.grad, rtol=3e-5, atol=3e-6 * float(ref.abs().max()), name="dgelu")
+    if N % 128 == 0:
+        part = torch.full((M // 128, N), float("nan"), device=DEV)
+        hip.gemm_bf16x(xh, hip.KC, wt, hip.KM, M, N, K, out32=out, out16=o16, epi=hip.EPI_DGELU, aux16=pre.to(DEV), colpart=part)
+        close(out, ref * pd.grad, rtol=3e-5, atol=3e-6 * float(ref.abs().max()), name="dgelu")
+        cs = torch.empty(N, device=DEV)
+        hip.colsum_small(part, cs)
+        close(cs, out.double().sum(0), rtol=1e-5, atol=1e-5 * float(out.abs().sum(0).max()), name="colsum")
+        hip.colsum_small(part, cs, accumulate=True)
+        close(cs, 2 * out.double().sum(0), rtol=1e-5, atol=2e-5 * float(out.abs().sum(0).max()), name="colsum acc")
     acc0 = rnd(M, N, seed=6)
     out.copy_(acc0)
-    hip.gemm_bf16kc(xh, wh, out, accumulate=True)
+    hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, accumulate=True)
     close(out, ref + acc0.double(), rtol=2e-5, name="accumulate")
     if K >= 512:
-        for s in (2, 3):
-            hip.gemm_bf16kc(xh, wh, out, allow_split=True, splits=s)
-            close(out, ref, rtol=2e-5, name=f"split {s}")
+        for name, a2, la2, b2, lb2 in layouts:
+            for sp in (2, 3):
+                hip.gemm_bf16x(a2, la2, b2, lb2, M, N, K, out32=out, allow_split=True, splits=sp)
+                close(out, ref, rtol=2e-5, name=f"{name} split {sp}")
     with pytest.raises(RuntimeError):
-        hip.gemm_bf16kc(xh[:100], wh, out[:100])  # ragged M: the caller must use the fp32-operand kernels
+        hip.gemm_bf16x(xh[:100], hip.KC, wh, hip.KC, 100, N, K, out32=out[:100])  # ragged M: no fallback inside the library
