@@ -219,6 +219,19 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
                      int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
                      int splits, int stages, mtvaf_stream_t stream);
 int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, mtvaf_stream_t stream);
+
+/* Prefix attention of the mixed-precision mode: the algorithm of mtvaf_prefix_attn_fwd / _bwd (same key order, mask,
+ * dropout hash) on bf16 operands with fp32 softmax statistics and accumulation.  qkv16 [B*S,3H], pk16 / pv16 [B,P*H],
+ * ctx16 [B*S,H], dctx16, dqkv16: bf16; lse [B,NH,S], dpk / dpv [B,P*H]: fp32.  The backward also emits per-block column
+ * sums partq [B*ceil(S/64)][H] (dQ) and partkv [B*ceil((P+S)/64)][2H] (dK | dV over the text keys): summed over their rows
+ * (mtvaf_colsum_small / mtvaf_colsum) they are the query / key / value bias gradients. */
+int mtvaf_prefix_attn_bf16_fwd(const void* qkv16, const void* pk16, const void* pv16, const float* addmask, void* ctx16,
+                               float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                               uint64_t offset, mtvaf_stream_t stream);
+int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16,
+                               const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
+                               float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
+                               float p_drop, uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
 int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int ldt, int R, int C,
                     mtvaf_stream_t stream);
 

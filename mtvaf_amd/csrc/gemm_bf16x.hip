@@ -61,6 +61,7 @@ __device__ __forceinline__ void wait_vm() {
   else if constexpr (N == 8) MTVAF_X_WAIT(8);
   else if constexpr (N == 4) MTVAF_X_WAIT(4);
   else if constexpr (N == 6) MTVAF_X_WAIT(6);
+  else if constexpr (N == 5) MTVAF_X_WAIT(5);
   else static_assert(N == 0, "add the count");
 }
 
@@ -75,7 +76,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE>
-__global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_bf16x_kernel(GemmArgsX p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE == 3 ? 1 : 2)) void gemm_bf16x_kernel(GemmArgsX p) {
   constexpr int BK = 64;  // bf16 elements per k-tile
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -354,7 +355,13 @@ static int launch_x(const GemmArgsX& a, dim3 grid, hipStream_t st) {
 }
 
 template <bool A_KM, bool B_KM>
-static int launch_layout(const GemmArgsX& a, int bn, int stages, dim3 grid, hipStream_t st) {
+static int launch_layout(const GemmArgsX& a, int bm, int bn, int stages, dim3 grid, hipStream_t st) {
+  if (bm == 256) {  // 8 waves (two per SIMD), one block per CU: half the L2 -> LDS bytes per flop of the 128-row tiles
+    if constexpr (!A_KM) {
+      return stages == 3 ? launch_x<256, 128, 4, 2, A_KM, B_KM, 3>(a, grid, st) : launch_x<256, 128, 4, 2, A_KM, B_KM, 2>(a, grid, st);
+    }
+    return MTVAF_ERR_SHAPE;
+  }
   if (bn == 128) {
     return stages == 3 ? launch_x<128, 128, 2, 2, A_KM, B_KM, 3>(a, grid, st) : launch_x<128, 128, 2, 2, A_KM, B_KM, 2>(a, grid, st);
   }
@@ -379,7 +386,7 @@ extern "C" {
 //   allow_split: deterministic split-K (fp32 slabs in workspace + ordered reduction; fp32 result only, epi 0).
 // Requirements (MTVAF_ERR_SHAPE / _ALIGN otherwise; no fallback): M % 128 == 0, K % 64 == 0, N % 128 == 0 (N % 96 == 0
 // also accepted for layout_b 0), leading dimensions % 8 == 0, 16-byte aligned pointers.  tile: 0 auto, 1 128x96,
-// 2 128x128.  stages: 0 auto, 2, 3.
+// 2 128x128, 3 256x128 (8 waves; layout_a 0, M % 256 == 0, no colpart).  stages: 0 auto, 2, 3.
 int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
                      void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
                      int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
@@ -396,15 +403,19 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C32 | (uintptr_t)C16 | (uintptr_t)bias | (uintptr_t)aux16 | (uintptr_t)colpart) & 15)
     return MTVAF_ERR_ALIGN;
   const bool can128 = N % 128 == 0, can96 = N % 96 == 0 && layout_b == 0 && !colpart;
-  int bn = tile == 1 ? 96 : (tile == 2 ? 128 : 0);
-  if ((bn == 96 && !can96) || (bn == 128 && !can128)) return MTVAF_ERR_SHAPE;
+  const bool can256 = can128 && M % 256 == 0 && layout_a == 0 && !colpart;
+  int bn = tile == 1 ? 96 : ((tile == 2 || tile == 3) ? 128 : 0);
+  int bm = tile == 3 ? 256 : 128;
+  if ((bn == 96 && !can96) || (bn == 128 && !can128) || (bm == 256 && !can256)) return MTVAF_ERR_SHAPE;
   if (bn == 0) {
     const long t128 = can128 ? (long)(M / 128) * (N / 128) : 0;
     if (!can96) bn = 128;
     else if (!can128) bn = 96;
     else bn = (epi == EPI_GELU || epi == EPI_DGELU || t128 >= 512) ? 128 : 96;
+    // big problems: the 256-row tile once it still gives every CU several tiles
+    if (can256 && (long)(M / 256) * (N / 128) >= 1024) { bm = 256; bn = 128; }
   }
-  const long tiles = (long)(M / 128) * (N / bn);
+  const long tiles = (long)(M / bm) * (N / bn);
   const bool split_ok = allow_split && epi == EPI_NONE && C32 && !C16 && !colpart;
   if (splits <= 0) {
     splits = 1;
@@ -432,12 +443,12 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
   a.tiles_n = N / bn;
   if (stages != 2 && stages != 3) stages = 2;  // measured (tools/bf16x_bench.py): two co-resident blocks beat the deeper ring on every shape of the path
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
-  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages == 3) + 4 * layout_a + 8 * layout_b, layout_a, layout_b, 2, M, N, K, splits};
+  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages == 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256), layout_a, layout_b, 2, M, N, K, splits};
   const int rec = prof_begin(key, stream);
   int rc;
-  if (layout_a == 0 && layout_b == 0) rc = launch_layout<false, false>(a, bn, stages, grid, stream);
-  else if (layout_a == 0) rc = launch_layout<false, true>(a, bn, stages, grid, stream);
-  else rc = launch_layout<true, true>(a, bn, stages, grid, stream);
+  if (layout_a == 0 && layout_b == 0) rc = launch_layout<false, false>(a, bm, bn, stages, grid, stream);
+  else if (layout_a == 0) rc = launch_layout<false, true>(a, bm, bn, stages, grid, stream);
+  else rc = launch_layout<true, true>(a, bm, bn, stages, grid, stream);
   prof_end(rec, stream);
   if (rc != MTVAF_OK) return rc;
   if (splits > 1) return launch_splitk_reduce((const float*)workspace, splits, C32, M, N, ldc32, bias, accumulate, EPI_NONE, nullptr, 0, stream);

@@ -209,27 +209,39 @@ class EncoderFunction(torch.autograd.Function):
         # mixed precision: bf16 operands written by the producing kernels (LayerNorm, GELU epilogue), fp32 accumulation,
         # residual stream / LayerNorm / softmax statistics in fp32
         x_h = _cast(x) if use_h else None
+        pkv16 = None
         for li, w in enumerate(weights):
             I = w.w1.shape[0]
             off = RNG.next(3)
-            qkv = _empty(M, 3 * H, like=x)
+            lse = _empty(B, NH, S, like=x)
             if use_h:
+                # Q|K|V, the context and (in backward) their gradients exist only as bf16: written by the producing
+                # kernel's epilogue, read by the attention kernels / the next projection
                 wqkv_h, wo_h, w1_h, w2_h = wh[li]
-                hip.gemm_bf16x(x_h, KC, wqkv_h, KC, M, 3 * H, H, out32=qkv, bias=w.bqkv)
+                qkv, cx = _bf16(M, 3 * H, like=x), _bf16(M, H, like=x)
+                hip.gemm_bf16x(x_h, KC, wqkv_h, KC, M, 3 * H, H, out16=qkv, bias=w.bqkv)
+                if li == 0 and Pn:
+                    if pkv_ready is not None:  # prefix produced on the second stream (prompt generator)
+                        cur = torch.cuda.current_stream()
+                        cur.wait_event(pkv_ready)
+                        pkv.record_stream(cur)
+                    pkv16 = _bf16(*pkv.shape, like=x)  # one cast of all layers' prefix slabs per step
+                    hip.cast_bf16(pkv.view(-1, pkv.shape[3]), out=pkv16.view(-1, pkv.shape[3]))
+                hip.prefix_attn_bf16_fwd(qkv, pkv16[li, 0] if Pn else None, pkv16[li, 1] if Pn else None, addmask, cx, lse,
+                                         B, S, Pn, NH, p_attn, seed, off)
             else:
+                qkv, cx = _empty(M, 3 * H, like=x), _empty(M, H, like=x)
                 hip.linear_fwd(x, w.wqkv, w.bqkv, qkv)
-            cx, lse = _empty(M, H, like=x), _empty(B, NH, S, like=x)
-            pk = pkv[li, 0] if Pn else None
-            pv = pkv[li, 1] if Pn else None
-            if li == 0 and Pn and pkv_ready is not None:  # prefix produced on the second stream (prompt generator)
-                cur = torch.cuda.current_stream()
-                cur.wait_event(pkv_ready)
-                pkv.record_stream(cur)
-            hip.prefix_attn_fwd(qkv, pk, pv, addmask, cx, lse, B, S, Pn, NH, p_attn, seed, off)
+                pk = pkv[li, 0] if Pn else None
+                pv = pkv[li, 1] if Pn else None
+                if li == 0 and Pn and pkv_ready is not None:  # prefix produced on the second stream (prompt generator)
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(pkv_ready)
+                    pkv.record_stream(cur)
+                hip.prefix_attn_fwd(qkv, pk, pv, addmask, cx, lse, B, S, Pn, NH, p_attn, seed, off)
             a = _empty(M, H, like=x)
             if use_h:
-                cx_h = _cast(cx)
-                hip.gemm_bf16x(cx_h, KC, wo_h, KC, M, H, H, out32=a, bias=w.bo)
+                hip.gemm_bf16x(cx, KC, wo_h, KC, M, H, H, out32=a, bias=w.bo)
             else:
                 hip.linear_fwd(cx, w.wo, w.bo, a)
             h1, mean1, rstd1 = _empty(M, H, like=x), _empty(M, like=x), _empty(M, like=x)
@@ -242,7 +254,7 @@ class EncoderFunction(torch.autograd.Function):
                 hip.gemm_bf16x(h1_h, KC, w1_h, KC, M, I, H, out16=act, bias=w.bi1, epi=hip.EPI_GELU, aux16=pre)
                 hip.gemm_bf16x(act, KC, w2_h, KC, M, H, I, out32=f, bias=w.bi2)
                 hip.dropout_res_ln_fwd(f, h1, w.g2, w.b2, h2, mean2, rstd2, eps, p_hidden, seed, off + 2, out16=h2_h)
-                saved_t.extend((x_h, cx_h, h1_h))
+                saved_t.extend((x_h, h1_h))
                 x_h = h2_h
             else:
                 hip.dropout_res_ln_fwd(a, x, w.g1, w.b1, h1, mean1, rstd1, eps, p_hidden, seed, off + 1)
@@ -259,6 +271,7 @@ class EncoderFunction(torch.autograd.Function):
         ctx.save_for_backward(*saved, *saved_t)
         ctx.stash = (offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
         ctx.wh = wh
+        ctx.pkv16 = pkv16
         if grad_sink is not None:
             grad_sink.node_created()
         ctx.set_materialize_grads(False)  # unused hidden states arrive as None, not as [B,S,H] zero fills + adds
@@ -281,7 +294,8 @@ class EncoderFunction(torch.autograd.Function):
 
         wh = ctx.wh
         use_h = wh is not None
-        flat_t = flat[13 * L:]  # bf16 operand copies (x, ctx, h1 per layer) in mixed-precision mode
+        flat_t = flat[13 * L:]  # bf16 operand copies (x, h1 per layer) in mixed-precision mode
+        pkv16 = ctx.pkv16
         KC, KM = hip.KC, hip.KM
         main = torch.cuda.current_stream()
         # (small batches are host-bound: the extra events / stream switches cost more than the overlap returns)
@@ -331,7 +345,7 @@ class EncoderFunction(torch.autograd.Function):
                 # every product reads the same row-major bf16 tensors: dX = dY . W takes W as the KM operand, dW = dY^T . X
                 # takes BOTH as KM operands (reduction over the token rows) -- no casts, no transposed copies
                 wqkv_h, wo_h, w1_h, w2_h = wh[li]
-                x_h, cx_h, h1_h = flat_t[3 * li:3 * li + 3]
+                x_h, h1_h = flat_t[2 * li:2 * li + 2]
                 df_h = _bf16(M, H, like=dev_like)
                 hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, None, dh1, False, G[14], G[15], False, p_hidden, seed,
                                        off + 2, dbias_x=G[13], dx16=df_h)
@@ -359,33 +373,37 @@ class EncoderFunction(torch.autograd.Function):
                 hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
             # ---- attention block ----
             dh0 = dh  # reuse
-            dctx = dh1  # reuse (LayerNorm backward has consumed it by the time the dX product writes)
             if use_h:
-                da_h = _bf16(M, H, like=dev_like)
+                da_h, dctx = _bf16(M, H, like=dev_like), _bf16(M, H, like=dev_like)
                 hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, None, dh0, False, G[8], G[9], False, p_hidden, seed,
                                        off + 1, dbias_x=G[7], dx16=da_h)
-                on_side((da_h,), lambda: hip.gemm_bf16x(da_h, KM, cx_h, KM, H, H, M, out32=G[6], allow_split=True))
-                hip.gemm_bf16x(da_h, KC, wo_h, KM, M, H, H, out32=dctx)
+                on_side((da_h,), lambda: hip.gemm_bf16x(da_h, KM, cx, KM, H, H, M, out32=G[6], allow_split=True))
+                hip.gemm_bf16x(da_h, KC, wo_h, KM, M, H, H, out16=dctx)
+                dqkv = _bf16(M, 3 * H, like=dev_like)
+                nqt, nkt = (S + 63) // 64, (Pn + S + 63) // 64
+                partq, partkv = _empty(B * nqt, H, like=dev_like), _empty(B * nkt, 2 * H, like=dev_like)
+                hip.prefix_attn_bf16_bwd(dctx, qkv, pkv16[li, 0] if Pn else None, pkv16[li, 1] if Pn else None, addmask, cx,
+                                         lse, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, partq, partkv,
+                                         B, S, Pn, NH, p_attn, seed, off)
+
+                def qkv_grads():
+                    (hip.colsum_small if partq.shape[0] <= 256 else hip.colsum)(partq, dbqkv[:H])
+                    (hip.colsum_small if partkv.shape[0] <= 256 else hip.colsum)(partkv, dbqkv[H:])
+                    hip.gemm_bf16x(dqkv, KM, x_h, KM, 3 * H, H, M, out32=dwqkv, allow_split=True)
+                on_side((dqkv, partq, partkv), qkv_grads)
+                hip.gemm_bf16x(dqkv, KC, wqkv_h, KM, M, H, 3 * H, out32=dh0, accumulate=True)
             else:
+                dctx = dh1  # reuse (LayerNorm backward has consumed it by the time the dX product writes)
                 da = df if side is None else _empty(M, H, like=dev_like)  # df is still being read on the side stream
                 hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
                                        off + 1, dbias_x=G[7])
                 on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6]))
                 hip.linear_bwd_input(da, w.wo, dctx)
-            dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
-            hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
-                                delta, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, B, S, Pn, NH,
-                                p_attn, seed, off)
+                dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
+                hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
+                                    delta, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, B, S, Pn, NH,
+                                    p_attn, seed, off)
 
-            if use_h:
-                dqkv_h = _cast(dqkv)
-
-                def qkv_grads():
-                    hip.colsum(dqkv, dbqkv)
-                    hip.gemm_bf16x(dqkv_h, KM, x_h, KM, 3 * H, H, M, out32=dwqkv, allow_split=True)
-                on_side((dqkv, dqkv_h), qkv_grads)
-                hip.gemm_bf16x(dqkv_h, KC, wqkv_h, KM, M, H, 3 * H, out32=dh0, accumulate=True)
-            else:
                 def qkv_grads():
                     hip.colsum(dqkv, dbqkv)
                     hip.linear_bwd_weight(dqkv, x, dwqkv)

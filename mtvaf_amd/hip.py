@@ -30,6 +30,8 @@ _SIGS = {
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_bf16_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_bf16_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_ln_bwd_workspace_bytes": (SZ, [I, I]),
     "mtvaf_roberta_position_ids": (c_int, [P, P, I, I, I, P]),
     "mtvaf_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, U64, P, P]),
@@ -170,7 +172,7 @@ def kernel_symbol(cfg, la, lb, fast):
     b = lambda x: "true" if x else "false"
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE>
         c = cfg - 300
-        t = "128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"
+        t = "256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1")
         return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}>"
     if cfg >= 100:
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
@@ -321,6 +323,19 @@ def prefix_attn_bwd(dctx, qkv, pk, pv, addmask, ctx, lse, delta, dqkv, dpk, dpv,
     _ck(lib().mtvaf_prefix_attn_bwd(_p(dctx), _p(qkv), _p(pk), _p(pv), _p(addmask), _p(ctx), _p(lse), _p(delta), _p(dqkv),
                                     _p(dpk), _p(dpv), B, S, Pn, NH, 64, float(p), seed, offset, _st()),
         "mtvaf_prefix_attn_bwd")
+
+
+def prefix_attn_bf16_fwd(qkv16, pk16, pv16, addmask, ctx16, lse, B, S, Pn, NH, p, seed, offset):
+    _ck(lib().mtvaf_prefix_attn_bf16_fwd(_p(qkv16), _p(pk16), _p(pv16), _p(addmask), _p(ctx16), _p(lse), B, S, Pn, NH, 64,
+                                         float(p), seed, offset, _st()), "mtvaf_prefix_attn_bf16_fwd")
+
+
+def prefix_attn_bf16_bwd(dctx16, qkv16, pk16, pv16, addmask, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, Pn, NH, p,
+                         seed, offset):
+    """partq [B*ceil(S/64), H], partkv [B*ceil((Pn+S)/64), 2H]: per-block column sums of dQ and dK|dV (QKV bias gradient)."""
+    _ck(lib().mtvaf_prefix_attn_bf16_bwd(_p(dctx16), _p(qkv16), _p(pk16), _p(pv16), _p(addmask), _p(ctx16), _p(lse),
+                                         _p(dqkv16), _p(dpk), _p(dpv), _p(partq), _p(partkv), B, S, Pn, NH, 64, float(p),
+                                         seed, offset, _st()), "mtvaf_prefix_attn_bf16_bwd")
 
 
 def crf_workspace(B, S, C, device):

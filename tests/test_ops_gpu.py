@@ -259,6 +259,108 @@ def test_prefix_attention(hip, B, S, Pn, NH):
         close(dpv, vd.grad, rtol=5e-4, name="attn dpv")
 
 
+@pytest.mark.parametrize("B,S,Pn,NH", [(3, 16, 0, 2), (3, 16, 4, 2), (2, 128, 36, 12), (2, 100, 16, 3), (1, 200, 36, 2),
+                                       (2, 64, 100, 1)])
+def test_prefix_attention_bf16(hip, B, S, Pn, NH):
+    """bf16 attention kernels (mixed-precision mode) against fp64 math on the SAME bf16-rounded inputs: context and
+    gradients to bf16 accuracy (the probabilities are rounded to bf16 before the second product, results are stored as
+    bf16), log-sum-exp to fp32 accuracy, and the per-block column sums against the stored gradients."""
+    H, T = NH * 64, Pn + S
+    bf = lambda t: t.to(torch.bfloat16)
+    qkv, pk, pv = bf(rnd(B * S, 3 * H, seed=1)), bf(rnd(B, max(Pn, 1) * H, seed=2)), bf(rnd(B, max(Pn, 1) * H, seed=3))
+    lens = [S] + [max(1, S // (i + 2)) for i in range(B - 1)]
+    mask = torch.zeros(B, T)
+    for b, Lb in enumerate(lens):
+        mask[b, : Pn + Lb] = 1
+    addmask = (1 - mask) * -10000.0
+    dctx = bf(rnd(B * S, H, seed=4))
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (qkv, pk, pv))
+    ref, probs = attn_ref(qd, kd, vd, addmask.double(), B, S, Pn, NH)
+    (ref * dctx.double()).sum().backward()
+    g = lambda t: t.to(DEV)
+    ctx = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, NH, S, device=DEV)
+    gq, gk, gv, gm = g(qkv), g(pk) if Pn else None, g(pv) if Pn else None, g(addmask)
+    hip.prefix_attn_bf16_fwd(gq, gk, gv, gm, ctx, lse, B, S, Pn, NH, 0.0, 0, 0)
+    relerr = lambda got, want: float((got.double().cpu() - want).norm() / want.norm())
+    assert relerr(ctx, ref.detach()) < 6e-3, relerr(ctx, ref.detach())
+    close(ctx.float(), ref.detach(), rtol=2e-2, name="attn bf16 fwd")
+    q_, k_ = qd.detach().view(B, S, 3, NH, 64)[:, :, 0].permute(0, 2, 1, 3), qd.detach().view(B, S, 3, NH, 64)[:, :, 1].permute(0, 2, 1, 3)
+    if Pn:
+        k_ = torch.cat([kd.detach().view(B, NH, Pn, 64), k_], 2)
+    lse_ref = torch.logsumexp(q_ @ k_.transpose(-1, -2) / 8.0 + addmask.double()[:, None, None, :], -1)
+    close(lse, lse_ref, rtol=1e-5, name="lse")
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dpk = torch.full((B, max(Pn, 1) * H), float("nan"), device=DEV) if Pn else None
+    dpv = torch.full((B, max(Pn, 1) * H), float("nan"), device=DEV) if Pn else None
+    nqt, nkt = (S + 63) // 64, (T + 63) // 64
+    partq, partkv = torch.full((B * nqt, H), float("nan"), device=DEV), torch.full((B * nkt, 2 * H), float("nan"), device=DEV)
+    hip.prefix_attn_bf16_bwd(g(dctx), gq, gk, gv, gm, ctx, lse, dqkv, dpk, dpv, partq, partkv, B, S, Pn, NH, 0.0, 0, 0)
+    assert torch.isfinite(dqkv.float()).all() and torch.isfinite(partq).all() and torch.isfinite(partkv).all()
+    assert relerr(dqkv, qd.grad) < 1.2e-2, relerr(dqkv, qd.grad)
+    if Pn:
+        assert relerr(dpk, kd.grad) < 1.2e-2 and relerr(dpv, vd.grad) < 1.2e-2, (relerr(dpk, kd.grad), relerr(dpv, vd.grad))
+    # bias-gradient partials: fp32 sums of the unrounded gradients = column sums of the exact gradient to bf16-input accuracy
+    bsum = torch.cat([partq.sum(0), partkv.sum(0)]).cpu().double()
+    want = qd.grad.sum(0)
+    assert float((bsum - want).norm() / want.norm()) < 1.2e-2
+    close(bsum, dqkv.double().cpu().sum(0), rtol=2e-2, atol=2e-2 * float(dqkv.double().cpu().sum(0).abs().max()), name="partials vs stored")
+
+
+def test_prefix_attention_bf16_dropout(hip):
+    """Dropout in the bf16 kernels: keep fraction, the forward mask regenerated identically by both backward sides
+    (directional derivative by central differences under the same mask)."""
+    B, S, Pn, NH, p = 2, 64, 16, 2, 0.3
+    H, T = NH * 64, Pn + S
+    g = lambda t: t.to(DEV)
+    bf = lambda t: t.to(torch.bfloat16)
+    qkv, pk, pv = rnd(B * S, 3 * H, seed=1, scale=0.5), rnd(B, Pn * H, seed=2, scale=0.5), rnd(B, Pn * H, seed=3)
+    addmask = torch.zeros(B, T)
+    pv2 = torch.zeros(B, NH, Pn, 64)
+    vt = torch.zeros(B, S, NH, 64)
+    for t in range(64):
+        if t < Pn:
+            pv2[:, :, t, t] = 1
+        else:
+            vt[:, t - Pn, :, t] = 1
+    qkv3 = qkv.view(B * S, 3, H).clone()
+    qkv3[:, 2] = vt.reshape(B * S, H)
+    qkv3 = qkv3.view(B * S, 3 * H)
+    ctx, lse = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV), torch.empty(B, NH, S, device=DEV)
+    hip.prefix_attn_bf16_fwd(g(bf(qkv3)), g(bf(pk)), g(bf(pv2.reshape(B, Pn * H))), g(addmask), ctx, lse, B, S, Pn, NH, p, 5, 6)
+    _, probs = attn_ref(bf(qkv3).double(), bf(pk).double(), pv2.reshape(B, Pn * H).double(), addmask.double(), B, S, Pn, NH)
+    pt = ctx.float().cpu().view(B, S, NH, 64).permute(0, 2, 1, 3).double()
+    kept = pt > 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.02, frac
+    assert torch.allclose(pt[kept], (probs[..., :64] / (1 - p))[kept], rtol=1.5e-2, atol=1e-5)
+    # directional derivative under a fixed mask (fp32 perturbations rounded to bf16: use a coarse step)
+    dctx = bf(rnd(B * S, H, seed=4))
+    dqkv = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=DEV)
+    dpk, dpv = torch.empty(B, Pn * H, device=DEV), torch.empty(B, Pn * H, device=DEV)
+    partq, partkv = torch.empty(B * 1, H, device=DEV), torch.empty(B * 2, 2 * H, device=DEV)
+    gpv = g(bf(pv))
+    hip.prefix_attn_bf16_fwd(g(bf(qkv)), g(bf(pk)), gpv, g(addmask), ctx, lse, B, S, Pn, NH, p, 5, 6)
+    hip.prefix_attn_bf16_bwd(g(dctx), g(bf(qkv)), g(bf(pk)), gpv, g(addmask), ctx, lse, dqkv, dpk, dpv, partq, partkv, B, S, Pn,
+                             NH, p, 5, 6)
+    # reference gradient with the SAME mask, recovered from the kernel itself: ctx is linear in V for fixed probabilities
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (bf(qkv), bf(pk), bf(pv)))
+    ref, pr = attn_ref(qd, kd, vd, addmask.double(), B, S, Pn, NH)
+    hip.prefix_attn_bf16_fwd(g(bf(qkv3)), g(bf(pk)), g(bf(pv2.reshape(B, Pn * H))), g(addmask), ctx, lse, B, S, Pn, NH, p, 5, 6)
+    # (qkv3 shares Q and K with qkv, so its one-hot-V context exposes exactly this call's keep mask for the first 64 keys)
+    keep64 = (ctx.float().cpu().view(B, S, NH, 64).permute(0, 2, 1, 3) > 0).double()
+    keep = torch.ones(B, NH, S, T, dtype=torch.double)
+    keep[..., :64] = keep64
+    # keys >= 64 keep an unknown mask: zero their contribution on both sides by comparing only dV of the first 64 keys
+    v_all = torch.cat([vd.view(B, NH, Pn, 64), qd.view(B, S, 3, NH, 64)[:, :, 2].permute(0, 2, 1, 3)], 2)
+    o = ((pr * keep / (1 - p))[..., :64] @ v_all[:, :, :64]).permute(0, 2, 1, 3).reshape(B * S, H)
+    (o * dctx.double()).sum().backward()
+    dv_first = torch.cat([dpv.double().cpu().view(B, NH, Pn, 64),
+                          dqkv.double().cpu().view(B, S, 3, NH, 64)[:, :, 2].permute(0, 2, 1, 3)[:, :, :64 - Pn]], 2)
+    dv_ref = torch.cat([vd.grad.view(B, NH, Pn, 64), qd.grad.view(B, S, 3, NH, 64)[:, :, 2].permute(0, 2, 1, 3)[:, :, :64 - Pn]], 2)
+    assert float((dv_first - dv_ref).norm() / dv_ref.norm()) < 1.5e-2
+
+
 def test_prefix_attention_dropout(hip):
     B, S, Pn, NH, p = 2, 64, 16, 2, 0.3
     H, T = NH * 64, Pn + S
