@@ -210,8 +210,7 @@ int mtvaf_mask_mul(const float* x, const float* row_keep, const float* col_keep,
  * transposed copies).  Results: C32 fp32 and / or C16 bf16 (either may be NULL); accumulate adds into C32.  epi 0 none,
  * 1 bias + erf-GELU (pre-activation saved to aux16 as bf16), 3 multiply by GELU'(aux16).  colpart [M/128][N] (optional):
  * per-tile column sums of the result, finished by mtvaf_colsum_small (the bias gradient of the layer that produced the
- * operand).  Deterministic split-K as mtvaf_gemm_f32 (fp32 result only).  Aligned shapes only (M % 128, N % 128 -- N % 96
- * also for layout_b 0 --, K % 64, ld % 8, 16-byte aligned pointers): MTVAF_ERR_SHAPE / _ALIGN otherwise.
+ * operand).  Deterministic split-K as mtvaf_gemm_f32 (fp32 result only).  Aligned shapes only (M % 128, N % 128 or N % 96, K % 64, ld % 8, 16-byte aligned pointers): MTVAF_ERR_SHAPE / _ALIGN otherwise.
  * tile: 0 auto, 1 128x96, 2 128x128; stages: 0 auto, 2 (two blocks per CU), 3 (one block, two k-tiles in flight).
  * mtvaf_cast_bf16 makes the bf16 copies of the fp32 master weights. */
 int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE == 3 ? 1 
   constexpr int A_B = BM * 128, B_B = BN * 128, STAGE_B = A_B + B_B;  // bytes (KC: BM rows x 128 B; KM: 64 rows x 2*BM B)
   constexpr int IA = A_B / 1024 / NW, IB = B_B / 1024 / NW;          // 1-KiB DMA instructions per wave
   static_assert(A_B % (1024 * NW) == 0 && B_B % (1024 * NW) == 0, "tile must split into whole DMA pieces per wave");
-  static_assert((!A_KM || BM == 128) && (!B_KM || BN == 128), "the transposed-read image is built for 256-byte rows");
+  static_assert((!A_KM || BM == 128) && (!B_KM || BN == 128 || BN == 96), "k-major images: 256-byte rows (XOR swizzle) or 192-byte rows");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];  // the ONLY LDS object
 
@@ -119,9 +119,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE == 3 ? 1 
     if (!B_KM) {
       const int r = f >> 3, cp = f & 7;
       pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(n0 + r) * p.ldb + kbeg) + ((cp ^ ((r >> 1) & 7)) << 4);
-    } else {
+    } else if (BN == 128) {
       const int r = f >> 4, cp = f & 15;
       pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(kbeg + r) * p.ldb + n0) + ((cp ^ km_swz(r)) << 4);
+    } else {  // 192-byte rows: consecutive rows start 48 banks apart, the transposing reads are conflict-free unswizzled
+      const int o = f << 4, r = o / (BN * 2), cb = o % (BN * 2);
+      pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(kbeg + r) * p.ldb + n0) + cb;
     }
   }
   const long stepA = A_KM ? (long)BK * p.lda * 2 : BK * 2;
@@ -173,12 +176,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE == 3 ? 1 
         const int col = (wn * TN + j) * 32 + li;
         offB[j][0] = col * 128;
         offB[j][1] = (col >> 1) & 7;
-      } else {
+      } else if (BN == 128) {
         const int ns = wn * TN + j;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
           offB[j][jj] = 256 * (8 * (g >> 1) + 4 * jj + q) +
                         16 * ((((ns ^ q) & 3) << 2) | ((2 * (g & 1) + (pp >> 1)) ^ ((2 * (g >> 1) + jj) & 3))) + 8 * (pp & 1);
+      } else {
+        const int ns = wn * TN + j;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) offB[j][jj] = (BN * 2) * (8 * (g >> 1) + 4 * jj + q) + ns * 64 + 32 * (g & 1) + 8 * pp;
       }
     }
   }
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE == 3 ? 1 
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (!B_KM) fb[j] = *reinterpret_cast<const bf16x8*>(b + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
-        else fb[j] = tr_read8(b + offB[j][0] + 4096 * ks, b + offB[j][1] + 4096 * ks);
+        else fb[j] = tr_read8(b + offB[j][0] + (BN * 32) * ks, b + offB[j][1] + (BN * 32) * ks);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -303,14 +310,24 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE == 3 ? 1 
   }
 }
 
-// out[c] (+)= sum_r part[r][c], r < rows (<= a few hundred): the second stage of the epilogue column sums
+// out[c] (+)= sum_r part[r][c], r < rows (<= a few hundred): the second stage of the epilogue column sums.
+// Block = 32 columns x 8 row groups, combined in fixed order through LDS (deterministic).
 __global__ __launch_bounds__(256) void colsum_small_kernel(const float* __restrict__ part, int rows, int cols, float* __restrict__ out,
                                                           int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[8][32];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += part[(long)r * cols + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < cols)
+    for (int r = rg; r < rows; r += 8) s += part[(long)r * cols + c];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg == 0 && c < cols) {
+    float t = red[0][cl];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) t += red[i][cl];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // out[r][c] = bf16(x[r][c]);  outT[c][r] = bf16(x[r][c]) (optional).  32x32 tiles through LDS for the transposed copy.
@@ -365,10 +382,7 @@ static int launch_layout(const GemmArgsX& a, int bm, int bn, int stages, dim3 gr
   if (bn == 128) {
     return stages == 3 ? launch_x<128, 128, 2, 2, A_KM, B_KM, 3>(a, grid, st) : launch_x<128, 128, 2, 2, A_KM, B_KM, 2>(a, grid, st);
   }
-  if constexpr (!B_KM) {
-    return stages == 3 ? launch_x<128, 96, 4, 1, A_KM, B_KM, 3>(a, grid, st) : launch_x<128, 96, 4, 1, A_KM, B_KM, 2>(a, grid, st);
-  }
-  return MTVAF_ERR_SHAPE;
+  return stages == 3 ? launch_x<128, 96, 4, 1, A_KM, B_KM, 3>(a, grid, st) : launch_x<128, 96, 4, 1, A_KM, B_KM, 2>(a, grid, st);
 }
 
 }  // namespace mtvaf
@@ -384,8 +398,7 @@ extern "C" {
 //   (pre-activation stored to aux16 as bf16; GELU evaluated on the stored value), 3 multiply by GELU'(aux16).
 //   colpart [M/128][N] (optional, 128x128 tiles): per-tile column sums of the result for mtvaf_colsum_small.
 //   allow_split: deterministic split-K (fp32 slabs in workspace + ordered reduction; fp32 result only, epi 0).
-// Requirements (MTVAF_ERR_SHAPE / _ALIGN otherwise; no fallback): M % 128 == 0, K % 64 == 0, N % 128 == 0 (N % 96 == 0
-// also accepted for layout_b 0), leading dimensions % 8 == 0, 16-byte aligned pointers.  tile: 0 auto, 1 128x96,
+// Requirements (MTVAF_ERR_SHAPE / _ALIGN otherwise; no fallback): M % 128 == 0, K % 64 == 0, N % 128 == 0 or N % 96 == 0, leading dimensions % 8 == 0, 16-byte aligned pointers.  tile: 0 auto, 1 128x96,
 // 2 128x128, 3 256x128 (8 waves; layout_a 0, M % 256 == 0, no colpart).  stages: 0 auto, 2, 3.
 int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
                      void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
@@ -398,11 +411,10 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
   if ((epi == EPI_GELU || epi == EPI_DGELU) && !aux16) return MTVAF_ERR_ARG;
   if (accumulate && !C32) return MTVAF_ERR_ARG;
   if (M % 128 || K % 64 || (N % 96 && N % 128)) return MTVAF_ERR_SHAPE;
-  if (layout_b == 1 && N % 128) return MTVAF_ERR_SHAPE;
   if (lda % 8 || ldb % 8 || (C32 && ldc32 % 4) || (C16 && ldc16 % 8) || (aux16 && ldaux % 8)) return MTVAF_ERR_ALIGN;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C32 | (uintptr_t)C16 | (uintptr_t)bias | (uintptr_t)aux16 | (uintptr_t)colpart) & 15)
     return MTVAF_ERR_ALIGN;
-  const bool can128 = N % 128 == 0, can96 = N % 96 == 0 && layout_b == 0 && !colpart;
+  const bool can128 = N % 128 == 0, can96 = N % 96 == 0 && !colpart;
   const bool can256 = can128 && M % 256 == 0 && layout_a == 0 && !colpart;
   int bn = tile == 1 ? 96 : ((tile == 2 || tile == 3) ? 128 : 0);
   int bm = tile == 3 ? 256 : 128;
@@ -411,9 +423,11 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
     const long t128 = can128 ? (long)(M / 128) * (N / 128) : 0;
     if (!can96) bn = 128;
     else if (!can128) bn = 96;
-    else bn = (epi == EPI_GELU || epi == EPI_DGELU || t128 >= 512) ? 128 : 96;
+    else bn = (epi == EPI_GELU || epi == EPI_DGELU || t128 >= 512) ? 128 : 96;  // 96: more tiles for the 768-wide outputs
     // big problems: the 256-row tile once it still gives every CU several tiles
-    if (can256 && (long)(M / 256) * (N / 128) >= 1024) { bm = 256; bn = 128; }
+    // (measured, tools/bf16x_bench.py at M = 65536: +6..10 % on the KC x KC products with the 3-deep ring; no gain with a
+    // k-major B operand)
+    if (can256 && layout_b == 0 && (long)(M / 256) * (N / 128) >= 1024) { bm = 256; bn = 128; }
   }
   const long tiles = (long)(M / bm) * (N / bn);
   const bool split_ok = allow_split && epi == EPI_NONE && C32 && !C16 && !colpart;
@@ -441,7 +455,9 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
     a.C32 = C32; a.ldc32 = ldc32; a.slab_stride = 0;
   }
   a.tiles_n = N / bn;
-  if (stages != 2 && stages != 3) stages = 2;  // measured (tools/bf16x_bench.py): two co-resident blocks beat the deeper ring on every shape of the path
+  // measured (tools/bf16x_bench.py): with 4-wave blocks two co-resident blocks beat the deeper ring on every shape of the
+  // path; the 8-wave 256x128 block (one per CU) wants the 3-deep ring
+  if (stages != 2 && stages != 3) stages = bm == 256 ? 3 : 2;
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
   const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages == 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256), layout_a, layout_b, 2, M, N, K, splits};
   const int rec = prof_begin(key, stream);
@@ -458,7 +474,7 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
 // out[c] (+)= sum over rows of part[rows][cols] (fixed order): finishes the epilogue column sums of mtvaf_gemm_bf16x
 int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, hipStream_t stream) {
   if (!part || !out || rows <= 0 || cols <= 0) return MTVAF_ERR_ARG;
-  hipLaunchKernelGGL(colsum_small_kernel, dim3((cols + 255) / 256), dim3(256), 0, stream, part, rows, cols, out, accumulate);
+  hipLaunchKernelGGL(colsum_small_kernel, dim3((cols + 31) / 32), dim3(256), 0, stream, part, rows, cols, out, accumulate);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

@@ -662,11 +662,11 @@ def test_gemm_bf16_operands(hip, M, N, K):
     out = torch.empty(M, N, device=DEV)
     bd = b.to(DEV)
     layouts = [("KCxKC", xh, hip.KC, wh, hip.KC)]
-    if N % 128 == 0:
-        layouts += [("KCxKM", xh, hip.KC, wt, hip.KM), ("KMxKM", xt, hip.KM, wt, hip.KM)]
+    layouts += [("KCxKM", xh, hip.KC, wt, hip.KM), ("KMxKM", xt, hip.KM, wt, hip.KM)]
     for name, a_, la, b_, lb in layouts:
         for stages in (2, 3):
-            for tile in ([0] + ([1] if (N % 96 == 0 and lb == hip.KC) else []) + ([2] if N % 128 == 0 else [])):
+            for tile in ([0] + ([1] if N % 96 == 0 else []) + ([2] if N % 128 == 0 else []) +
+                         ([3] if (N % 128 == 0 and M % 256 == 0 and la == hip.KC) else [])):
                 out.fill_(float("nan"))
                 hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, bias=bd, tile=tile, stages=stages)
                 close(out, ref + b.double(), rtol=2e-5, name=f"{name} bias tile {tile} stages {stages}")

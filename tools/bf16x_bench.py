@@ -42,7 +42,7 @@ def main():
             bias = torch.randn(n, device=dev)
             best = None
             for tile in (1, 2, 3):
-                if (tile == 1 and (n % 96 or lb == 1)) or (tile == 3 and (la == 1 or m % 256 or kw.get("dgelu"))):
+                if (tile == 1 and n % 96) or (tile == 3 and (la == 1 or m % 256 or kw.get("dgelu"))):
                     continue
                 for stages in (2, 3):
                     def run():
