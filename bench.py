@@ -158,6 +158,9 @@ def main():
                     help="all: mtvaf_amd.optim.AdamW (HIP kernels, per-layer updates enqueued inside the backward pass) over "
                          "every parameter; reference: the same optimizer on the three name-matched groups + linear warm-up "
                          "schedule of modules/train.py:894-926; torch: torch.optim.AdamW(fused=True) after the backward")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay forward + backward as ONE HIP graph (mtvaf_amd.graph.GraphedTrainStep: device-side dropout "
+                         "epoch, eager optimizer step) -- for the launch-bound shapes (bs 4 / S 64, bf16 at bs 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -207,7 +210,7 @@ def main():
     else:
         from mtvaf_amd.optim import AdamW
         opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model,
-                    overlap=True, grad_sync=sync)
+                    overlap=not a.graph, grad_sync=sync)  # (a captured backward cannot carry the per-step learning rate)
     batch = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, a.full_length)
     ids, mask, tt, labels, feats, aux = batch
 
@@ -225,6 +228,24 @@ def main():
                 p.grad = None
         assert len(out.logits) == B  # the trainer reads the decoded tags after the update (modules/train.py:627-647)
         return out
+
+    eager_step = step
+    if a.graph:
+        if world > 1:
+            raise SystemExit("--graph is a single-GPU option (the gradient all-reduce hooks are not captured)")
+        from mtvaf_amd.graph import GraphedTrainStep
+        gstep = GraphedTrainStep(model, dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels,
+                                             imagelabel=None, images=feats, aux_imgs=aux))
+
+        def step():  # noqa: F811
+            out = gstep(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+            if opt is not None:
+                opt.step()
+                if sched is not None:
+                    sched.step()
+                opt.zero_grad(set_to_none=True)
+            assert len(out.logits) == B
+            return out
 
     def barrier():
         torch.cuda.synchronize()
@@ -258,7 +279,7 @@ def main():
     ftrain = 3 * f_fwd(S, P)
 
     fwd_bwd_only = None
-    if opt is not None:
+    if opt is not None and not a.graph:
         # secondary figure: the same K steps without the optimizer update (the metric's literal "fwd+bwd")
         def step_nb():
             out = model(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None,
@@ -288,7 +309,7 @@ def main():
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype if a.dtype == "fp32" else "bf16 MFMA / fp32 accumulate+storage",
            "data": "synthetic",
-           "config": {"workload": f"TVNetSAModel2 {'RoBERTa' if a.model == 'roberta' else 'BERT'}-base random-init, fwd+bwd{'' if a.no_optimizer else {'torch': '+AdamW(torch fused)'}.get(a.optimizer, '+AdamW(HIP, overlapped with backward)')}, "
+           "config": {"workload": f"TVNetSAModel2 {'RoBERTa' if a.model == 'roberta' else 'BERT'}-base random-init, fwd+bwd{' as one HIP graph' if a.graph else ''}{'' if a.no_optimizer else {'torch': '+AdamW(torch fused)'}.get(a.optimizer, '+AdamW(HIP' + (', eager after the replay)' if a.graph else ', overlapped with backward)'))}, "
                                   f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
                                   f"images through the prompt generator), train mode (dropout live), "
                                   f"{'full-length' if a.full_length else 'ragged 16..S'} sequences",
@@ -311,11 +332,15 @@ def main():
         from mtvaf_amd import engine as _engine
         side_was = _engine.DW_SIDE_STREAM
         _engine.DW_SIDE_STREAM = False
-        step()
+        if a.graph:
+            gstep.close()  # the profiled steps run eagerly (the launch profiler brackets individual launches)
+            if hasattr(opt, "suspended"):
+                pass
+        eager_step()
         torch.cuda.synchronize()
         hip.prof_start(8192)
         for _ in range(NPROF):
-            step()
+            eager_step()
         torch.cuda.synchronize()
         recs = hip.prof_stop(8192)
         _engine.DW_SIDE_STREAM = side_was

@@ -46,6 +46,13 @@ typedef void* mtvaf_stream_t; /* hipStream_t */
 #define MTVAF_EPI_DGELU 3 /* C = acc * gelu_erf'(aux)                                                   */
 #define MTVAF_EPI_DTANH 4 /* C = acc * (1 - aux^2)                                                      */
 
+/* Device-side dropout epoch for captured launches (HIP graph replay freezes kernel arguments, so host-fed (seed, offset)
+ * pairs would repeat the same masks): while a device uint64 word is registered, every dropout-drawing kernel of the
+ * library folds its value into its counter stream; mtvaf_rng_epoch_advance (*word += 1, captured as the first node of a
+ * training-step graph) makes every replay draw fresh masks, identically in its forward and backward kernels.  NULL
+ * restores host-fed masks.  Process-global state (like the launch profiler). */
+int mtvaf_rng_set_epoch_ptr(const uint64_t* dev_word);
+int mtvaf_rng_epoch_advance(uint64_t* dev_word, mtvaf_stream_t stream);
 int mtvaf_version(void);
 int mtvaf_device_cus(void);
 

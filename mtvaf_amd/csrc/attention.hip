@@ -44,6 +44,7 @@ struct AttnArgs {
   int B, S, P, NH, H;
   float scale, p_drop;
   uint32_t drop_key, drop_thr;
+  const uint64_t* epoch;  // device-side dropout epoch (captured launches), or NULL
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int T = a.P + a.S;
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const uint32_t rowh = attn_dropout_rowhash(a.drop_key, (uint32_t)((b * a.NH + h) * a.S + q));
+  const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;  // scores are kept in the log2 domain: one v_exp_f32 per probability
 
   const int c4 = (threadIdx.x & 15) * 4;
@@ -203,7 +204,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
   const int T = a.P + a.S;
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const uint32_t rowh = attn_dropout_rowhash(a.drop_key, (uint32_t)((b * a.NH + h) * a.S + q));
+  const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
 
   const int c4 = (threadIdx.x & 15) * 4;
@@ -378,7 +379,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
     if (threadIdx.x < KT) {
       const int qq = q0 + threadIdx.x;
       lse_s[threadIdx.x] = qq < a.S ? lreg : 1.0e30f;
-      rh_s[threadIdx.x] = attn_dropout_rowhash(a.drop_key, row_base + (uint32_t)qq);
+      rh_s[threadIdx.x] = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), row_base + (uint32_t)qq);
     }
     __syncthreads();
     // a wave whose 16 keys all lie beyond T (last key tile) only takes part in the staging and the barriers
@@ -489,6 +490,7 @@ int mtvaf_prefix_attn_fwd(const float* qkv, const float* pk, const float* pv, co
     auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
     a.drop_key = mix((uint32_t)seed ^ mix((uint32_t)(seed >> 32) ^ mix((uint32_t)offset ^ 0x9E3779B9u)));
   }
+  a.epoch = rng_epoch_ptr();
   int rc = check(a);
   if (rc) return rc;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, NH, B), dim3(256), 0, st, a);
@@ -512,6 +514,7 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
     auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
     a.drop_key = mix((uint32_t)seed ^ mix((uint32_t)(seed >> 32) ^ mix((uint32_t)offset ^ 0x9E3779B9u)));
   }
+  a.epoch = rng_epoch_ptr();
   int rc = check(a);
   if (rc) return rc;
   if (P > 0 && (!dpk || !dpv)) return MTVAF_ERR_ARG;

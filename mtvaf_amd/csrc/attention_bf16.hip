@@ -53,6 +53,7 @@ struct Args {
   int B, S, P, NH, H;
   float scale, p_drop;
   uint32_t drop_key, drop_thr;
+  const uint64_t* epoch;  // device-side dropout epoch (captured launches), or NULL
 };
 
 // byte offset of 16-byte chunk c (0..7) of row r in a [64][64] bf16 tile image
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
   const int T = a.P + a.S;
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const uint32_t rowh = attn_dropout_rowhash(a.drop_key, (uint32_t)((b * a.NH + h) * a.S + q));
+  const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
 
   KvSrc ksrc, vsrc;
@@ -224,7 +225,7 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
   const int T = a.P + a.S;
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const uint32_t rowh = attn_dropout_rowhash(a.drop_key, (uint32_t)((b * a.NH + h) * a.S + q));
+  const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
 
   KvSrc ksrc, vsrc;
@@ -396,7 +397,7 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
     if (threadIdx.x < KT) {
       const int qq = q0 + threadIdx.x;
       lse_s[threadIdx.x] = qq < a.S ? lreg : 1.0e30f;
-      rh_s[threadIdx.x] = attn_dropout_rowhash(a.drop_key, row_base + (uint32_t)qq);
+      rh_s[threadIdx.x] = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), row_base + (uint32_t)qq);
     }
     __syncthreads();
     // a wave whose 16 keys all lie beyond T (last key tile) only takes part in the staging and the barriers
@@ -528,6 +529,7 @@ int mtvaf_prefix_attn_bf16_fwd(const void* qkv16, const void* pk16, const void* 
   a.scale = 0.125f; a.p_drop = p_drop;
   a.drop_thr = p_drop > 0.f ? (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f) : 0u;
   a.drop_key = ab::host_drop_key(seed, offset);
+  a.epoch = rng_epoch_ptr();
   int rc = ab::check(a);
   if (rc) return rc;
   if (!ctx16 || !lse || !addmask) return MTVAF_ERR_ARG;
@@ -553,6 +555,7 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
   a.scale = 0.125f; a.p_drop = p_drop;
   a.drop_thr = p_drop > 0.f ? (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f) : 0u;
   a.drop_key = ab::host_drop_key(seed, offset);
+  a.epoch = rng_epoch_ptr();
   int rc = ab::check(a);
   if (rc) return rc;
   if (!dctx16 || !ctx16 || !lse || !dqkv16 || !partq || !partkv || !addmask) return MTVAF_ERR_ARG;

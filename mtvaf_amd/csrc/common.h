@@ -22,6 +22,15 @@ namespace mtvaf {
 
 constexpr int WAVE = 64;
 
+// Device-side dropout epoch (runtime.hip: mtvaf_rng_set_epoch_ptr).  NULL (default): masks are a pure function of the
+// (seed, offset) passed by the host.  Non-NULL: every dropout kernel adds the 64-bit word it points to into its counter
+// stream, so a CAPTURED launch (HIP graph replay: kernel arguments are frozen) draws fresh masks on every replay once a
+// captured mtvaf_rng_epoch_advance has bumped the word.  Forward and backward kernels of one step read the same value.
+const uint64_t* rng_epoch_ptr();
+__device__ __forceinline__ uint64_t epoch_offset(uint64_t offset, const uint64_t* __restrict__ ep) {
+  return ep ? offset + (*ep << 20) : offset;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -87,6 +96,9 @@ __device__ __forceinline__ uint32_t attn_dropout_rowhash(uint32_t key, uint32_t 
 __device__ __forceinline__ bool attn_dropout_keep2(uint32_t rowhash, uint32_t col_term, uint32_t thr) {
   // col_term = col * ATTN_DROP_C2
   return (rowhash ^ col_term) * 0x2c1b3c6du >= thr;
+}
+__device__ __forceinline__ uint32_t attn_epoch_key(uint32_t key, const uint64_t* __restrict__ ep) {
+  return ep ? mix32(key ^ ((uint32_t)(*ep) * 0x9E3779B9u + 0x7F4A7C15u)) : key;
 }
 __device__ __forceinline__ uint32_t dropout_threshold(float p_drop) {
   return (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f);

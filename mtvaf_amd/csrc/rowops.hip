@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                     float* __restrict__ out, float* __restrict__ mean_o,
                                                     float* __restrict__ rstd_o, int M, int S, int H, float eps,
                                                     float p_drop, uint64_t seed, uint64_t offset,
-                                                    __bf16* __restrict__ out16) {
+                                                    __bf16* __restrict__ out16, const uint64_t* __restrict__ epoch) {
+  offset = epoch_offset(offset, epoch);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nch = H >> 2;
@@ -112,7 +113,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                     float* __restrict__ dx, float* __restrict__ dres, int dres_acc,
                                                     float* __restrict__ partials, int M, int S, int H, float p_drop,
-                                                    uint64_t seed, uint64_t offset, __bf16* __restrict__ dx16) {
+                                                    uint64_t seed, uint64_t offset, __bf16* __restrict__ dx16,
+                                                    const uint64_t* __restrict__ epoch) {
+  offset = epoch_offset(offset, epoch);
   constexpr int NP = MODE == 1 ? 4 : 3;
   __shared__ f32x4 red[4][MAXC * 64];  // [wave][H/4 <= 256]
   const int lane = threadIdx.x & 63;
@@ -322,7 +325,8 @@ __global__ void pos_reduce_kernel(const float* __restrict__ dz, float* __restric
 }
 
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, float p_drop,
-                               uint64_t seed, uint64_t offset) {
+                               uint64_t seed, uint64_t offset, const uint64_t* __restrict__ epoch) {
+  offset = epoch_offset(offset, epoch);
   const float scale = 1.f / (1.f - p_drop);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
@@ -352,6 +356,19 @@ __global__ void roberta_pos_kernel(const int64_t* __restrict__ ids, int32_t* __r
   }
 }
 
+// zero fill as a KERNEL (not hipMemsetAsync): a captured 94-MB memset node replayed wrongly on ROCm 7.2 (every fourth
+// column of the word-table gradient kept stale data under HIP graph replay), a kernel node replays exactly
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+    reinterpret_cast<f32x4*>(p)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
+}
+static inline void zero_f32(float* p, long n, hipStream_t st) {
+  const long b = ((n >> 2) + 255) / 256;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b))), dim3(256), 0, st, p, n);
+}
+
 static inline int row_grid(int M) { return std::max(1, std::min((M + 3) / 4, 1024)); }
 // LN backward keeps per-block column partials: fewer, fatter blocks (2 per CU) keep the partial slab small
 static inline int row_grid_bwd(int M) { return std::max(1, std::min((M + 3) / 4, 512)); }
@@ -379,7 +396,7 @@ int mtvaf_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_
   const int M = B * S;
   hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3(row_grid(M)), dim3(256), 0, st, nullptr, nullptr, ids, type_ids, pos_ids,
                      word, pos, type, gamma, beta, out, mean, rstd, M, S, H, eps, p_drop, seed, offset,
-                     static_cast<__bf16*>(out_bf16));
+                     static_cast<__bf16*>(out_bf16), rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -390,7 +407,7 @@ int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamm
   if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
   hipLaunchKernelGGL((ln_fwd_kernel<0>), dim3(row_grid(M)), dim3(256), 0, st, x, res, nullptr, nullptr, nullptr,
                      nullptr, nullptr, nullptr, gamma, beta, out, mean, rstd, M, 1, H, eps, p_drop, seed, offset,
-                     static_cast<__bf16*>(out_bf16));
+                     static_cast<__bf16*>(out_bf16), rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -410,7 +427,7 @@ int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
-                     offset, static_cast<__bf16*>(dx_bf16));
+                     offset, static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   OutPtrs outs{{dgamma, dbeta, dbias_x, nullptr}};
   hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((3 * H + 31) / 32), dim3(256), 0, st, part, g, H, 3, outs,
@@ -436,26 +453,19 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(g), dim3(256), 0, st, dout, nullptr, nullptr, ids, type_ids, pos_ids,
                      word, pos, type, gamma, mean, rstd, dz_ws, nullptr, 0, part, M, S, H, p_drop, seed, offset,
-                     (__bf16*)nullptr);
+                     (__bf16*)nullptr, rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   OutPtrs outs{{dgamma, dbeta, dtype, type_vocab > 1 ? dtype + H : nullptr}};
   hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((4 * H + 31) / 32), dim3(256), 0, st, part, g, H, 4, outs,
                      accumulate);
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(dword, 0, (size_t)vocab * H * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    if (pos_ids) {
-      e = hipMemsetAsync(dpos, 0, (size_t)max_pos * H * sizeof(float), st);
-      if (e != hipSuccess) return (int)e;
-    }
+    zero_f32(dword, (long)vocab * H, st);
+    if (pos_ids) zero_f32(dpos, (long)max_pos * H, st);
   }
   hipLaunchKernelGGL(embed_scatter_kernel, dim3(g), dim3(256), 0, st, dz_ws, ids, pos_ids, dword, dpos, M, H, word_pad,
                      pos_pad);
   if (!pos_ids) {
-    if (!accumulate && max_pos > S) {
-      hipError_t e = hipMemsetAsync(dpos + (long)S * H, 0, (size_t)(max_pos - S) * H * sizeof(float), st);
-      if (e != hipSuccess) return (int)e;
-    }
+    if (!accumulate && max_pos > S) zero_f32(dpos + (long)S * H, (long)(max_pos - S) * H, st);
     hipLaunchKernelGGL(pos_reduce_kernel, dim3(S), dim3(256), 0, st, dz_ws, dpos, B, S, H, accumulate);
   }
   MTVAF_LAUNCH_CHECK();
@@ -493,7 +503,7 @@ int mtvaf_dropout(const float* x, float* y, long n, float p_drop, uint64_t seed,
   }
   const long n4 = n / 4;
   const int blocks = (int)std::min<long>((n4 + 255) / 256, 2048);
-  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, st, x, y, n4, p_drop, seed, offset);
+  hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, st, x, y, n4, p_drop, seed, offset, rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

@@ -117,7 +117,7 @@ def _weights_bf16(w: LayerWeights):
     moving their version counters) or when a weight Parameter's version counter has moved (load_state_dict, in-place
     updates through the Parameter).  Writes through ``.data`` are invisible to both: MTVAF_BF16_WCACHE=0 rebuilds in
     every forward pass (85 M parameters, ~0.1 ms per step)."""
-    ver = shadow_version(w) if BF16_WCACHE else None
+    ver = shadow_version(w) if (BF16_WCACHE and not FORCE_SHADOW_REFRESH) else None
     c = w._h
     if ver is None or c is None or c[0] != ver:
         flat = w.flat
@@ -157,6 +157,7 @@ try:  # every optimizer step invalidates the bf16 weight shadows
 except Exception:  # pragma: no cover - very old torch: never cache
     _HAVE_OPT_HOOK = False
 BF16_WCACHE = os.environ.get("MTVAF_BF16_WCACHE", "1") != "0" and _HAVE_OPT_HOOK
+FORCE_SHADOW_REFRESH = False  # set while a whole-step graph is captured (mtvaf_amd.graph): the cast becomes a graph node
 BF16_OPERANDS = os.environ.get("MTVAF_BF16_OPERANDS", "1") != "0"  # 0: fp32-operand bf16 kernels only (gemm_bf16.hip)
 
 

@@ -21,6 +21,8 @@ P, I, L, F, U64, SZ = c_void_p, c_int, c_long, c_float, c_uint64, c_size_t
 
 _SIGS = {
     "mtvaf_version": (c_int, []),
+    "mtvaf_rng_set_epoch_ptr": (c_int, [P]),
+    "mtvaf_rng_epoch_advance": (c_int, [P, P]),
     "mtvaf_device_cus": (c_int, []),
     "mtvaf_gemm_f32_workspace_bytes": (SZ, [I, I, I, I]),
     "mtvaf_prof_start": (c_int, [I]),
