@@ -38,6 +38,15 @@ class DeferredTags(list):
             self._give_back()
         return self
 
+    def packed(self):
+        """The packed [B, S+1] int32 host array (tags padded with -1 | length) after waiting for the copy, or None once
+        the list has been materialised -- array consumers (``mtvaf_amd.metrics.label_sequences``) skip the Python lists."""
+        if self._packed is None:
+            return None
+        if self._event is not None:
+            self._event.synchronize()
+        return self._packed.numpy()
+
     def _give_back(self):
         if self._release is not None:
             self._release()

@@ -94,7 +94,10 @@ def test_overlap_update_inside_backward_equals_the_plain_schedule():
     for n, p in outs[0][1].items():
         if "key.bias" in n:
             continue
-        torch.testing.assert_close(p, outs[1][1][n], rtol=0, atol=5e-6, msg=n)
+        # Adam turns a relative gradient perturbation e into a step perturbation ~ lr * e: the crf / fc group runs at the
+        # reference's lr 5e-2 (modules/train.py:911), 50x the encoder's 1e-3 here
+        atol = 2.5e-4 if (n.startswith("crf") or n.startswith("fc")) else 5e-6
+        torch.testing.assert_close(p, outs[1][1][n], rtol=0, atol=atol, msg=n)
 
 
 def test_overlap_contract_violation_raises():
