@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay forward + backward as ONE HIP graph (mtvaf_amd.graph.GraphedTrainStep: device-side dropout "
                          "epoch, eager optimizer step) -- for the launch-bound shapes (bs 4 / S 64, bf16 at bs 32)")
+    ap.add_argument("--no-overlap-optimizer", action="store_true", help="HIP AdamW launched by step() only (after the backward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -210,7 +211,7 @@ def main():
     else:
         from mtvaf_amd.optim import AdamW
         opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model,
-                    overlap=not a.graph, grad_sync=sync)  # (a captured backward cannot carry the per-step learning rate)
+                    overlap=not (a.graph or a.no_overlap_optimizer), grad_sync=sync)  # (a captured backward cannot carry the per-step learning rate)
     batch = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, a.full_length)
     ids, mask, tt, labels, feats, aux = batch
 

@@ -39,19 +39,21 @@ __device__ __forceinline__ void adamw_span(float* __restrict__ p, const float* _
   const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0) && (!ph || ((uintptr_t)ph & 7) == 0);
   const long n4 = vec ? (n >> 2) : 0;
   for (long i = i0; i < n4; i += stride) {
-    f32x4 P = reinterpret_cast<f32x4*>(p)[i];
-    const f32x4 G = reinterpret_cast<const f32x4*>(g)[i];
-    f32x4 M = reinterpret_cast<f32x4*>(m)[i];
-    f32x4 V = reinterpret_cast<f32x4*>(v)[i];
+    // non-temporal streams: 28 bytes per parameter pass through once per step -- keeping them out of L2 / Infinity Cache
+    // leaves the GEMM panels of the backward pass this update runs next to (overlap mode) resident
+    f32x4 P = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + i);
+    const f32x4 G = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+    f32x4 M = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i);
+    f32x4 V = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float pj = P[j], mj = M[j], vj = V[j];
       adamw1(pj, G[j], mj, vj, h);
       P[j] = pj; M[j] = mj; V[j] = vj;
     }
-    reinterpret_cast<f32x4*>(p)[i] = P;
-    reinterpret_cast<f32x4*>(m)[i] = M;
-    reinterpret_cast<f32x4*>(v)[i] = V;
+    reinterpret_cast<f32x4*>(p)[i] = P;  // (read again by the next forward pass)
+    __builtin_nontemporal_store(M, reinterpret_cast<f32x4*>(m) + i);
+    __builtin_nontemporal_store(V, reinterpret_cast<f32x4*>(v) + i);
     if (ph) {
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 o = {(__bf16)P.x, (__bf16)P.y, (__bf16)P.z, (__bf16)P.w};
