@@ -119,12 +119,12 @@ def cpu_baseline(B, S, n_aux, seconds_budget=60.0, min_steps=3):
             "seconds_per_step": round(med, 3)}
 
 
-def pmc_traffic(symbol):
+def pmc_traffic(symbol, dtype="fp32"):
     """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/pmc_gemm.json, written by
     tools/pmc_to_json.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams, plus
     WRITE_SIZE).  -> (bytes or None, provenance string): the counters come from a separate profiled run of this same
     command, not from the run that prints the line."""
-    path = os.path.join(ROOT, "profiles", "pmc_gemm.json")
+    path = os.path.join(ROOT, "profiles", "pmc_gemm.json" if dtype == "fp32" else "pmc_gemm_bf16.json")
     if not os.path.exists(path):
         return None, None
     try:
@@ -132,7 +132,7 @@ def pmc_traffic(symbol):
         rec = d.get(symbol)
         if rec is None:
             return None, None
-        return rec["traffic_bytes_per_launch"], d.get("_source", "profiles/pmc_gemm.json (rocprofv3 --pmc passes, committed)")
+        return rec["traffic_bytes_per_launch"], d.get("_source", os.path.basename(path) + " (rocprofv3 --pmc passes, committed)")
     except Exception:
         return None, None
 
@@ -361,7 +361,7 @@ def main():
         sym, (ms, cnt, fl) = max(by_sym.items(), key=lambda kv: kv[1][0])
         avg_us = 1e3 * ms / cnt
         ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
-        traffic, traffic_src = pmc_traffic(sym)
+        traffic, traffic_src = pmc_traffic(sym, a.dtype)
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
             "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": sym,

@@ -10,3 +10,6 @@ run --batch 128 --seq 512 --steps 5 --warmup 4
 run --batch 128 --seq 512 --dtype bf16 --steps 5 --warmup 4
 run --dtype bf16
 run --optimizer reference
+run --batch 4 --seq 64 --aux 3 --graph
+run --dtype bf16 --graph
+run --batch 4 --seq 64 --aux 3 --dtype bf16

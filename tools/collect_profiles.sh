@@ -1,0 +1,35 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, in one GPU call:  tools/collect_profiles.sh r02   (writes gpurun_out/<tag>/)
+# Bench lines, rocprofv3 kernel stats (default = two streams, and serialised = one kernel at a time), PMC passes.
+export TMPDIR=/tmp
+T=${1:-r02}
+R=$PWD
+O=$R/gpurun_out/$T
+mkdir -p $O
+S="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-optimizer"   # 7 model steps per process
+stats() {  # <name> <env> <bench args...>
+  local name=$1 envv=$2; shift 2
+  env $envv TMPDIR=/tmp true
+  ( export $envv; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -- python3 bench.py $S "$@" > $O/prof_$name.log 2>&1 )
+  cp $(find $O/prof_$name -name "*kernel_stats.csv" | tail -1) $O/${T}_${name}_kernel_stats.csv
+  python tools/prof_summary.py $O/${T}_${name}_kernel_stats.csv 7 60 > $O/${T}_${name}_kernel_stats_per_step.txt
+  rm -rf $O/prof_$name
+}
+echo "== bench lines"; date
+python bench.py --steps 20 --warmup 5 > $O/${T}_bench_line.json 2> $O/bench_fp32.err
+python bench.py --steps 20 --warmup 5 --dtype bf16 --model roberta --no-cpu-baseline > $O/${T}_bench_line_bf16_c3.json 2> $O/bench_c3.err
+python bench.py --steps 20 --warmup 5 --dtype bf16 --batch 64 --no-cpu-baseline > $O/${T}_bench_line_bf16_c4.json 2> $O/bench_c4.err
+python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/${T}_bench_line_bf16_c2shape.json 2> $O/bench_c2b.err
+echo "== kernel stats"; date
+stats fp32 MTVAF_DW_STREAM=1
+stats fp32_serial MTVAF_DW_STREAM=0
+stats bf16_c3_serial MTVAF_DW_STREAM=0 --dtype bf16 --model roberta
+stats bf16_c4_serial MTVAF_DW_STREAM=0 --dtype bf16 --batch 64
+stats bf16_c4 MTVAF_DW_STREAM=1 --dtype bf16 --batch 64
+echo "== pmc"; date
+bash tools/pmc_passes.sh $T/pmc_fp32 > /dev/null
+bash tools/pmc_passes.sh $T/pmc_bf16_c4 --dtype bf16 --batch 64 > /dev/null
+python tools/pmc_to_json.py $O/pmc_fp32 $O $T pmc_gemm.json > /dev/null
+python tools/pmc_to_json.py $O/pmc_bf16_c4 $O $T pmc_gemm_bf16.json > /dev/null
+rm -rf $O/pmc_fp32 $O/pmc_bf16_c4
+date; ls -la $O
