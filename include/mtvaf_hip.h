@@ -241,6 +241,55 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
 int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int ldt, int R, int C,
                     mtvaf_stream_t stream);
 
+/* ---- native per-layer executor ----------------------------------------------------------
+ * One call enqueues ALL kernels of a BertLayer forward / backward (models/modeling_bert.py:439-522 and its autograd
+ * backward) -- the same kernels in the same order as the Python engine, composed inside the library -- so a training step
+ * costs one host call per layer and direction instead of ~65.  `bf16` selects the kernel family: 0 = fp32 (qkv / cx / pre /
+ * act are float*, weights w*, prefix slabs float*), 1 = mixed precision (those four are bf16, weights the bf16 images
+ * w*_h, x_h / h1_h / h2_h bf16 copies, prefix slabs bf16).  Dropout sites: attention `offset`, attention output
+ * `offset + 1`, FFN output `offset + 2`.  All buffers caller-owned; workspaces as the composed entry points need them. */
+typedef struct {
+  int B, S, P, NH, H, I;
+  int bf16;
+  float eps, p_hidden, p_attn;
+  uint64_t seed, offset;
+  const float *wqkv, *wo, *w1, *w2;
+  const void *wqkv_h, *wo_h, *w1_h, *w2_h;
+  const float *bqkv, *bo, *g1, *b1, *bi1, *bi2, *g2, *b2;
+  const float* x;
+  const void* x_h;
+  const void *pk, *pv;
+  const float* addmask;
+  void *qkv, *cx;
+  float *lse, *a, *h1;
+  void* h1_h;
+  float *mean1, *rstd1;
+  void *pre, *act;
+  float *f, *h2;
+  void* h2_h;
+  float *mean2, *rstd2;
+  void* ws; size_t ws_bytes;
+} mtvaf_layer_t;
+
+typedef struct {
+  float* dh;                              /* in: d loss / d h2 [M,H]; out: d loss / d x */
+  float* dh1;
+  void *df, *dpre, *da, *dctx, *dqkv;
+  float *part, *partq, *partkv;           /* bf16 mode: epilogue / attention column-sum partials */
+  float* delta;                           /* fp32 mode: [B,NH,S] */
+  float *dwqkv, *dbqkv, *dwo, *dbo, *dg1, *db1, *dw1, *dbi1, *dw2, *dbi2, *dg2, *db2;
+  float *dpk, *dpv;
+  void* ws_main; size_t ws_main_bytes;
+  void* ws_side; size_t ws_side_bytes;
+} mtvaf_layer_grads_t;
+
+int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* layer, mtvaf_stream_t stream);
+/* weight-gradient products on `side` behind events of `main` (side == main serialises); settle != 0: `side` also waits for
+ * the layer's last main-stream kernel (an optimizer update hanging off the caller's hook must not overtake it). */
+int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* layer, const mtvaf_layer_grads_t* grads, mtvaf_stream_t main,
+                            mtvaf_stream_t side, int settle);
+size_t mtvaf_layer_struct_bytes(int which /* 0: mtvaf_layer_t, 1: mtvaf_layer_grads_t */);
+
 /* ---- optimizer step ------------------------------------------------------------
  * AdamW exactly as torch.optim.AdamW, which the reference trainer builds (modules/train.py:887-926) and steps
  * (:621-625): decoupled weight decay, bias corrections passed in (bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t)).

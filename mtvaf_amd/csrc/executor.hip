@@ -1,0 +1,239 @@
+// Native per-layer executor: one C call enqueues ALL kernels of a BertLayer forward or
+// backward -- reference models/modeling_bert.py:439-522 (BertLayer = BertAttention + BertIntermediate + BertOutput) and
+// its autograd backward -- instead of ~20 (forward) / ~45 (backward) Python-level calls, buffer allocations and stream /
+// event objects per layer.  At bs 32 in the mixed-precision mode and at bs 4 the step is bound by the HOST (8.5 ms of
+// Python to enqueue 7 ms of GPU work); the executor cuts that to one ctypes call per layer and direction.  The kernels
+// and their order are exactly those of the Python engine (mtvaf_amd/engine.py keeps that path as MTVAF_NATIVE_EXEC=0
+// for A/B tests): this file only composes the library's own entry points.
+//
+// Backward: the weight-gradient products (and the bias column sums) depend only on tensors the dX chain has already
+// produced, so they are enqueued on `side` behind an event of `main`; `side == main` serialises.
+#include "common.h"
+
+#include <cstddef>
+
+extern "C" {
+// (the library's own C ABI; declared here instead of including the public header, which is C99 with void* streams)
+int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                   int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate, int allow_split,
+                   void* workspace, size_t workspace_bytes, int cfg, int splits, hipStream_t stream);
+int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
+                     void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
+                     int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
+                     int splits, int stages, hipStream_t stream);
+int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, hipStream_t stream);
+int mtvaf_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* workspace,
+                 size_t workspace_bytes, hipStream_t st);
+int mtvaf_prefix_attn_fwd(const float* qkv, const float* pk, const float* pv, const float* addmask, float* ctx, float* lse,
+                          int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                          hipStream_t st);
+int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
+                          const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B,
+                          int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
+int mtvaf_prefix_attn_bf16_fwd(const void* qkv16, const void* pk16, const void* pv16, const float* addmask, void* ctx16,
+                               float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                               uint64_t offset, hipStream_t st);
+int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16,
+                               const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
+                               float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
+                               float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
+int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
+                             float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
+                             uint64_t offset, void* out_bf16, hipStream_t st);
+int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma, const float* mean,
+                             const float* rstd, float* dx, float* dres, int dres_accumulate, float* dgamma, float* dbeta,
+                             float* dbias_x, int accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset,
+                             void* workspace, size_t workspace_bytes, void* dx_bf16, hipStream_t st);
+}
+
+namespace mtvaf {
+enum { X_KC = 0, X_KM = 1 };
+enum { X_EPI_NONE = 0, X_EPI_GELU = 1, X_EPI_DGELU = 3 };
+
+// events that order the second stream behind the main one: recycled ring (a wait captures the record that precedes it)
+static hipEvent_t g_ev[64];
+static int g_ev_n = 0, g_ev_i = 0;
+static int fork_to(hipStream_t from, hipStream_t to) {
+  if (from == to) return MTVAF_OK;
+  if (g_ev_n == 0) {
+    for (int i = 0; i < 64; ++i)
+      if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) return MTVAF_ERR_ARG;
+    g_ev_n = 64;
+  }
+  hipEvent_t e = g_ev[g_ev_i];
+  g_ev_i = (g_ev_i + 1) & 63;
+  hipError_t rc = hipEventRecord(e, from);
+  if (rc != hipSuccess) return (int)rc;
+  rc = hipStreamWaitEvent(to, e, 0);
+  return rc == hipSuccess ? MTVAF_OK : (int)rc;
+}
+}  // namespace mtvaf
+
+using namespace mtvaf;
+
+#define MTVAF_TRY(call)            \
+  do {                             \
+    const int rc_ = (call);        \
+    if (rc_ != MTVAF_OK) return rc_; \
+  } while (0)
+
+extern "C" {
+
+// One encoder layer.  `bf16` selects the kernel family: 0 = fp32 (qkv / cx / pre / act are float*, weights w*, prefix pk /
+// pv float*), 1 = mixed precision (those four are bf16, weights w*_h bf16 images, x_h / h1_h / h2_h bf16 copies, prefix
+// bf16).  Dropout sites of the layer: attention `offset`, attention-output `offset + 1`, FFN-output `offset + 2`.
+struct mtvaf_layer_t {
+  int B, S, P, NH, H, I;
+  int bf16;
+  float eps, p_hidden, p_attn;
+  uint64_t seed, offset;
+  const float *wqkv, *wo, *w1, *w2;            // fp32 masters [3H,H] [H,H] [I,H] [H,I] (fp32 mode)
+  const void *wqkv_h, *wo_h, *w1_h, *w2_h;     // bf16 images (bf16 mode)
+  const float *bqkv, *bo, *g1, *b1, *bi1, *bi2, *g2, *b2;
+  const float* x;                              // [M,H] layer input
+  const void* x_h;                             // bf16 copy (bf16 mode)
+  const void *pk, *pv;                         // prefix slabs [B, P*H] or NULL
+  const float* addmask;                        // [B, P+S]
+  void *qkv, *cx;                              // [M,3H], [M,H]
+  float *lse, *a, *h1;                         // [B,NH,S], [M,H], [M,H]
+  void* h1_h;
+  float *mean1, *rstd1;
+  void *pre, *act;                             // [M,I]
+  float *f, *h2;                               // [M,H]
+  void* h2_h;
+  float *mean2, *rstd2;
+  void* ws; size_t ws_bytes;                   // main-stream scratch of the forward pass (split-K slabs of small-M products)
+};
+
+struct mtvaf_layer_grads_t {
+  float* dh;                                   // in: d/d h2, out: d/d x  [M,H]
+  float* dh1;                                  // [M,H] scratch
+  void *df, *dpre, *da, *dctx, *dqkv;          // [M,H] [M,I] [M,H] [M,H] [M,3H]  (bf16 in bf16 mode)
+  float *part, *partq, *partkv;                // bf16 mode: [M/128, I], [B*ceil(S/64), H], [B*ceil((P+S)/64), 2H]
+  float* delta;                                // fp32 mode: [B,NH,S]
+  float *dwqkv, *dbqkv, *dwo, *dbo, *dg1, *db1, *dw1, *dbi1, *dw2, *dbi2, *dg2, *db2;
+  float *dpk, *dpv;                            // [B, P*H] or NULL
+  void* ws_main; size_t ws_main_bytes;         // scratch of the main stream (LayerNorm partials, split-K slabs)
+  void* ws_side; size_t ws_side_bytes;         // scratch of the second stream (split-K slabs, column-sum partials)
+};
+
+int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
+  if (!L) return MTVAF_ERR_ARG;
+  const int M = L->B * L->S, H = L->H, I = L->I;
+  if (L->bf16) {
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KC, L->x_h, H, L->wqkv_h, H, nullptr, 0, L->qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE,
+                               nullptr, 0, 0, nullptr, 0, nullptr, 0, 0, -1, 0, st));
+    MTVAF_TRY(mtvaf_prefix_attn_bf16_fwd(L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn,
+                                         L->seed, L->offset, st));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KC, L->cx, H, L->wo_h, H, L->a, H, nullptr, 0, M, H, H, L->bo, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 0, nullptr, 0, 0, -1, 0, st));
+    MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden, L->seed,
+                                       L->offset + 1, L->h1_h, st));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KC, L->h1_h, H, L->w1_h, H, nullptr, 0, L->act, I, M, I, H, L->bi1, X_EPI_GELU, L->pre, I, 0,
+                               nullptr, 0, nullptr, 0, 0, -1, 0, st));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KC, L->act, I, L->w2_h, I, L->f, H, nullptr, 0, M, H, I, L->bi2, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 0, nullptr, 0, 0, -1, 0, st));
+    MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->f, L->h1, L->g2, L->b2, L->h2, L->mean2, L->rstd2, M, H, L->eps, L->p_hidden, L->seed,
+                                       L->offset + 2, L->h2_h, st));
+    return MTVAF_OK;
+  }
+  float* qkv = static_cast<float*>(L->qkv);
+  float* cx = static_cast<float*>(L->cx);
+  float* pre = static_cast<float*>(L->pre);
+  float* act = static_cast<float*>(L->act);
+  // (plain-bias products may use the deterministic split-K: the planner only splits when the tile grid underfills the chip)
+  MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, L->x, H, L->wqkv, H, qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE, nullptr, 0, 0, 1, L->ws,
+                           L->ws_bytes, -1, -1, st));
+  MTVAF_TRY(mtvaf_prefix_attn_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx, L->lse,
+                                  L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
+  MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, cx, H, L->wo, H, L->a, H, M, H, H, L->bo, X_EPI_NONE, nullptr, 0, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
+  MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden, L->seed,
+                                     L->offset + 1, nullptr, st));
+  MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, L->h1, H, L->w1, H, act, I, M, I, H, L->bi1, X_EPI_GELU, pre, I, 0, 0, nullptr, 0, -1, -1, st));
+  MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, act, I, L->w2, I, L->f, H, M, H, I, L->bi2, X_EPI_NONE, nullptr, 0, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
+  MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->f, L->h1, L->g2, L->b2, L->h2, L->mean2, L->rstd2, M, H, L->eps, L->p_hidden, L->seed,
+                                     L->offset + 2, nullptr, st));
+  return MTVAF_OK;
+}
+
+// Backward of one layer.  g->dh holds d loss / d h2 on entry and d loss / d x on return.  `settle` != 0: the second stream
+// additionally waits for the layer's LAST main-stream kernel (an optimizer update hanging off the caller's hook must be
+// behind every product that still reads the weights).
+int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g, hipStream_t mainS, hipStream_t side, int settle) {
+  if (!L || !g) return MTVAF_ERR_ARG;
+  const int M = L->B * L->S, H = L->H, I = L->I, B = L->B, S = L->S, P = L->P, NH = L->NH;
+  if (L->bf16) {
+    MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0,
+                                       M, H, L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, g->df, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KM, X_KM, g->df, H, L->act, I, g->dw2, I, nullptr, 0, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->df, H, L->w2_h, I, nullptr, 0, g->dpre, I, M, I, H, nullptr, X_EPI_DGELU, L->pre, I, 0,
+                               g->part, 0, nullptr, 0, 0, -1, 0, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(mtvaf_colsum_small(g->part, M / 128, I, g->dbi1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KM, X_KM, g->dpre, I, L->h1_h, H, g->dw1, H, nullptr, 0, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->dpre, I, L->w1_h, H, g->dh1, H, nullptr, 0, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1,
+                               nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
+    MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, nullptr, g->dh, 0, g->dg1, g->db1, g->dbo, 0, M,
+                                       H, L->p_hidden, L->seed, L->offset + 1, g->ws_main, g->ws_main_bytes, g->da, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KM, X_KM, g->da, H, L->cx, H, g->dwo, H, nullptr, 0, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->da, H, L->wo_h, H, nullptr, 0, g->dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
+    MTVAF_TRY(mtvaf_prefix_attn_bf16_bwd(g->dctx, L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, g->dqkv, g->dpk, g->dpv, g->partq,
+                                         g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(mtvaf_colsum_small(g->partq, B * ((S + 63) / 64), H, g->dbqkv, 0, side));
+    MTVAF_TRY(mtvaf_colsum_small(g->partkv, B * ((P + S + 63) / 64), 2 * H, g->dbqkv + H, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KM, X_KM, g->dqkv, 3 * H, L->x_h, H, g->dwqkv, H, nullptr, 0, 3 * H, H, M, nullptr, X_EPI_NONE,
+                               nullptr, 0, 0, nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->dqkv, 3 * H, L->wqkv_h, H, g->dh, H, nullptr, 0, M, H, 3 * H, nullptr, X_EPI_NONE,
+                               nullptr, 0, 1, nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
+  } else {
+    float* df = static_cast<float*>(g->df);
+    float* dpre = static_cast<float*>(g->dpre);
+    float* da = static_cast<float*>(g->da);
+    float* dctx = static_cast<float*>(g->dctx);
+    float* dqkv = static_cast<float*>(g->dqkv);
+    const float* qkv = static_cast<const float*>(L->qkv);
+    const float* cx = static_cast<const float*>(L->cx);
+    float* pre = static_cast<float*>(L->pre);
+    const float* act = static_cast<const float*>(L->act);
+    MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0, M, H,
+                                       L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, nullptr, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, df, H, act, I, g->dw2, I, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+                             g->ws_side_bytes, -1, -1, side));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, df, H, L->w2, I, dpre, I, M, I, H, nullptr, X_EPI_DGELU, pre, I, 0, 0, nullptr, 0, -1, -1, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, dpre, I, L->h1, H, g->dw1, H, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+                             g->ws_side_bytes, -1, -1, side));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dpre, I, L->w1, H, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, 1, g->ws_main,
+                             g->ws_main_bytes, -1, -1, mainS));
+    MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, 0, g->dg1, g->db1, g->dbo, 0, M, H,
+                                       L->p_hidden, L->seed, L->offset + 1, g->ws_main, g->ws_main_bytes, nullptr, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, da, H, cx, H, g->dwo, H, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+                             g->ws_side_bytes, -1, -1, side));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, da, H, L->wo, H, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_main,
+                             g->ws_main_bytes, -1, -1, mainS));
+    MTVAF_TRY(mtvaf_prefix_attn_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx,
+                                    L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, dqkv, 3 * H, L->x, H, g->dwqkv, H, 3 * H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1,
+                             g->ws_side, g->ws_side_bytes, -1, -1, side));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dqkv, 3 * H, L->wqkv, H, g->dh, H, M, H, 3 * H, nullptr, X_EPI_NONE, nullptr, 0, 1, 1,
+                             g->ws_main, g->ws_main_bytes, -1, -1, mainS));
+  }
+  if (settle) MTVAF_TRY(fork_to(mainS, side));
+  return MTVAF_OK;
+}
+
+size_t mtvaf_layer_struct_bytes(int which) { return which == 0 ? sizeof(mtvaf_layer_t) : sizeof(mtvaf_layer_grads_t); }
+
+}  // extern "C"

@@ -13,6 +13,7 @@ nothing but the C-ABI kernels for arithmetic; torch is used for buffer allocatio
 """
 from __future__ import annotations
 
+import ctypes
 import os
 from typing import List, Optional
 
@@ -94,7 +95,8 @@ class EmbeddingsFunction(torch.autograd.Function):
 # -------------------------------------------------------------------------------------------------
 class LayerWeights:
     """Device pointers of one encoder layer in kernel-ready (QKV-packed) form."""
-    __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2", "wparams", "_h", "flat")
+    __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2", "wparams", "_h", "flat", "_st",
+                 "_gst")
 
 
 def _bf16(*shape, like: torch.Tensor):
@@ -185,6 +187,256 @@ def _side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+# -------------------------------------------------------------------------------------------------
+# native per-layer executor (csrc/executor.hip): one C call per layer and direction instead of ~65 Python-level calls.
+# MTVAF_NATIVE_EXEC=0 keeps the Python orchestration below (same kernels, same order) for A/B tests.
+# -------------------------------------------------------------------------------------------------
+NATIVE_EXEC = os.environ.get("MTVAF_NATIVE_EXEC", "1") != "0"
+DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
+_layouts = {}
+
+
+def _layout(fields):
+    off, out = 0, []
+    for name, nbytes in fields:
+        out.append((name, off if nbytes else -1))
+        off += (nbytes + 255) & ~255
+    return out, max(off, 256)
+
+
+def _fwd_layout(M, H, I, B, NH, S, use_h):
+    """Offsets of one layer's activation buffers inside its arena (one allocation per layer, saved for backward)."""
+    key = ("f", M, H, I, B, NH, S, use_h)
+    lay = _layouts.get(key)
+    if lay is None:
+        e = 2 if use_h else 4
+        lay = _layouts[key] = _layout([("qkv", M * 3 * H * e), ("cx", M * H * e), ("lse", B * NH * S * 4), ("a", M * H * 4),
+                                       ("h1", M * H * 4), ("h1_h", M * H * 2 if use_h else 0), ("mean1", M * 4), ("rstd1", M * 4),
+                                       ("pre", M * I * e), ("act", M * I * e), ("f", M * H * 4), ("h2", M * H * 4),
+                                       ("h2_h", M * H * 2 if use_h else 0), ("mean2", M * 4), ("rstd2", M * 4)])
+    return lay
+
+
+def _bwd_layout(M, H, I, B, NH, S, Pn, use_h):
+    key = ("b", M, H, I, B, NH, S, Pn, use_h)
+    lay = _layouts.get(key)
+    if lay is None:
+        e = 2 if use_h else 4
+        nqt, nkt = (S + 63) // 64, (Pn + S + 63) // 64
+        lay = _layouts[key] = _layout([("dh1", M * H * 4), ("df", M * H * e), ("dpre", M * I * e), ("da", M * H * e),
+                                       ("dctx", M * H * e), ("dqkv", M * 3 * H * e),
+                                       ("part", (M // 128) * I * 4 if use_h else 0), ("partq", B * nqt * H * 4 if use_h else 0),
+                                       ("partkv", B * nkt * 2 * H * 4 if use_h else 0), ("delta", 0 if use_h else B * NH * S * 4)])
+    return lay
+
+
+def _exec_workspace_bytes(M, H, I, use_h):
+    """Scratch one stream of the executor may need: split-K slabs of the largest product, LayerNorm / column-sum partials."""
+    big = max(M * 3 * H, M * I, I * H, 3 * H * H)
+    return max((8 if use_h else 16) * big * 4, 512 * 4 * H * 4, 64 * max(3 * H, I) * 4, 64 << 20)
+
+
+def _layer_struct(w: LayerWeights, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed):
+    c = w._st
+    key = (B, S, Pn, NH, H, I, use_h, w.flat.data_ptr())
+    if c is None or c[0] != key:  # shapes and parameter pointers: refilled only when they change
+        st = hip.LayerStruct()
+        st.B, st.S, st.P, st.NH, st.H, st.I, st.bf16 = B, S, Pn, NH, H, I, int(use_h)
+        st.wqkv, st.wo, st.w1, st.w2 = w.wqkv.data_ptr(), w.wo.data_ptr(), w.w1.data_ptr(), w.w2.data_ptr()
+        st.bqkv, st.bo, st.g1, st.b1 = w.bqkv.data_ptr(), w.bo.data_ptr(), w.g1.data_ptr(), w.b1.data_ptr()
+        st.bi1, st.bi2, st.g2, st.b2 = w.bi1.data_ptr(), w.bi2.data_ptr(), w.g2.data_ptr(), w.b2.data_ptr()
+        c = w._st = [key, st, None]
+    st = c[1]
+    st.eps, st.p_hidden, st.p_attn, st.seed = eps, p_hidden, p_attn, seed
+    if use_h:
+        wh = _weights_bf16(w)  # (freshness check; the image keeps its address)
+        if c[2] is not wh:
+            st.wqkv_h, st.wo_h, st.w1_h, st.w2_h = (t.data_ptr() for t in wh)
+            c[2] = wh
+    return st
+
+
+def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
+    B, S, H = h0.shape
+    NH, eps, p_hidden, p_attn, pkv_ready = cfg
+    M, L = B * S, len(weights)
+    Pn = 0 if pkv is None else pkv.shape[3] // H
+    I = weights[0].w1.shape[0]
+    use_h = _bf16_ok(M, H, I)
+    x = h0.contiguous().view(M, H)
+    seed = RNG.seed()
+    dev = x.device
+    x0_h = _cast(x) if use_h else None
+    pkv_k = pkv
+    if Pn:
+        if pkv_ready is not None:  # prefix produced on the second stream (prompt generator)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pkv_ready)
+            pkv.record_stream(cur)
+        if use_h:
+            pkv_k = _bf16(*pkv.shape, like=x)  # one cast of all layers' prefix slabs per step
+            hip.cast_bf16(pkv.view(-1, pkv.shape[3]), out=pkv_k.view(-1, pkv.shape[3]))
+    (lay, total) = _fwd_layout(M, H, I, B, NH, S, use_h)
+    o_h2 = dict(lay)["h2"]
+    o_h2h = dict(lay)["h2_h"]
+    ws = None if use_h else hip.workspace(_exec_workspace_bytes(M, H, I, use_h), dev)
+    fn, stream = hip.lib().mtvaf_encoder_layer_fwd, hip._st()
+    pk_ptr = pkv_k.data_ptr() if Pn else 0
+    pk_step = (pkv_k.stride(1) * pkv_k.element_size()) if Pn else 0   # [L,2,B,P*H]: K then V slab of a layer
+    pk_layer = (pkv_k.stride(0) * pkv_k.element_size()) if Pn else 0
+    am_ptr = addmask.data_ptr()
+    x_ptr, xh_ptr = x.data_ptr(), (x0_h.data_ptr() if use_h else 0)
+    arenas, offs, outs = [], [], []
+    for li, w in enumerate(weights):
+        off = RNG.next(3)
+        arena = torch.empty(total, dtype=torch.uint8, device=dev)
+        base = arena.data_ptr()
+        st = _layer_struct(w, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed)
+        st.offset = off
+        st.x, st.x_h, st.addmask = x_ptr, xh_ptr, am_ptr
+        st.pk = (pk_ptr + li * pk_layer) if Pn else None
+        st.pv = (pk_ptr + li * pk_layer + pk_step) if Pn else None
+        for name, o in lay:
+            setattr(st, name, base + o if o >= 0 else None)
+        st.ws, st.ws_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
+        hip._ck(fn(ctypes.byref(st), stream), "mtvaf_encoder_layer_fwd")
+        outs.append(arena[o_h2:o_h2 + M * H * 4].view(torch.float32).view(B, S, H))
+        arenas.append(arena)
+        offs.append(off)
+        x_ptr, xh_ptr = base + o_h2, (base + o_h2h if use_h else 0)
+    saved = [x] + ([x0_h] if use_h else []) + arenas
+    ctx.save_for_backward(*saved)
+    ctx.stash = (offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
+    ctx.native = (use_h, pkv_k if (use_h and Pn) else None)
+    if grad_sink is not None:
+        grad_sink.node_created()
+    ctx.set_materialize_grads(False)
+    return tuple(outs)
+
+
+def _native_backward(ctx, douts):
+    offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params = ctx.stash
+    use_h, pkv16 = ctx.native
+    saved = ctx.saved_tensors
+    x0 = saved[0]
+    x0_h = saved[1] if use_h else None
+    arenas = saved[2:] if use_h else saved[1:]
+    NH, eps, p_hidden, p_attn = cfg[:4]
+    L, M = len(weights), B * S
+    I = weights[0].w1.shape[0]
+    dev = x0.device
+    dpkv = torch.empty_like(pkv) if Pn else None
+    need_param_grads = any(p.requires_grad for p in params)
+    gviews = grad_sink.acquire(params) if grad_sink is not None else None
+    direct = gviews is not None and DIRECT_GRADS
+    pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
+    main = torch.cuda.current_stream()
+    side = _side_stream(dev) if (DW_SIDE_STREAM and need_param_grads and M >= 1024) else None
+    main_h = hip._st()
+    if side is not None:
+        with torch.cuda.stream(side):
+            side_h = hip._st()
+            ws_side = hip.workspace(_exec_workspace_bytes(M, H, I, use_h), dev)
+    else:
+        side_h, ws_side = main_h, None
+    ws_main = hip.workspace(_exec_workspace_bytes(M, H, I, use_h), dev)
+    if ws_side is None:
+        ws_side = ws_main
+    (flay, _), (blay, btotal) = _fwd_layout(M, H, I, B, NH, S, use_h), _bwd_layout(M, H, I, B, NH, S, Pn, use_h)
+    o_h2, o_h2h = dict(flay)["h2"], dict(flay)["h2_h"]
+    fn = hip.lib().mtvaf_encoder_layer_bwd
+    pk_src = pkv16 if use_h else pkv
+    pk_ptr = pk_src.data_ptr() if Pn else 0
+    pk_step = (pk_src.stride(1) * pk_src.element_size()) if Pn else 0
+    pk_layer = (pk_src.stride(0) * pk_src.element_size()) if Pn else 0
+    dpk_ptr = dpkv.data_ptr() if Pn else 0
+    dpk_step, dpk_layer = ((dpkv.stride(1) * 4, dpkv.stride(0) * 4) if Pn else (0, 0))
+    am_ptr = addmask.data_ptr()
+    settle = int(grad_sink is not None and side is not None and grad_sink.on_layer_done is not None and grad_sink.settle_params)
+    keep = []  # temporaries the second stream still reads: alive until the join below
+    dh = None
+    for li in range(L - 1, -1, -1):
+        w = weights[li]
+        g_out = douts[li]
+        if dh is None:
+            if g_out is None:
+                if Pn:
+                    dpkv[li].zero_()  # layers above the last used hidden state get no gradient
+                continue
+            dh = g_out.contiguous().view(M, H)
+            if dh.data_ptr() == g_out.data_ptr():
+                dh = dh.clone()  # we modify / free it
+        elif g_out is not None:
+            dh = dh + g_out.reshape(M, H)
+        base_i = li * N_LAYER_PARAMS
+        if gviews is not None:
+            G = gviews[base_i:base_i + N_LAYER_PARAMS]
+            dwqkv, dbqkv = grad_sink.packed_qkv(li)
+        else:
+            G = [torch.empty_like(p) for p in params[base_i:base_i + N_LAYER_PARAMS]]
+            dwqkv, dbqkv = _empty(3 * H, H, like=x0), _empty(3 * H, like=x0)
+        st = _layer_struct(w, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed)
+        st.offset = offs[li]
+        base = arenas[li].data_ptr()
+        for name, o in flay:
+            setattr(st, name, base + o if o >= 0 else None)
+        if li == 0:
+            st.x, st.x_h = x0.data_ptr(), (x0_h.data_ptr() if use_h else None)
+        else:
+            pb = arenas[li - 1].data_ptr()
+            st.x, st.x_h = pb + o_h2, (pb + o_h2h if use_h else None)
+        st.addmask = am_ptr
+        st.pk = (pk_ptr + li * pk_layer) if Pn else None
+        st.pv = (pk_ptr + li * pk_layer + pk_step) if Pn else None
+        gs = getattr(w, "_gst", None)
+        if gs is None:
+            gs = w._gst = hip.LayerGradsStruct()
+        barena = torch.empty(btotal, dtype=torch.uint8, device=dev)
+        keep.append(barena)
+        bb = barena.data_ptr()
+        for name, o in blay:
+            setattr(gs, name, bb + o if o >= 0 else None)
+        gs.dh = dh.data_ptr()
+        gs.dwqkv, gs.dbqkv = dwqkv.data_ptr(), dbqkv.data_ptr()
+        (gs.dwo, gs.dbo, gs.dg1, gs.db1, gs.dw1, gs.dbi1, gs.dw2, gs.dbi2, gs.dg2, gs.db2) = [t.data_ptr() for t in G[6:16]]
+        gs.dpk = (dpk_ptr + li * dpk_layer) if Pn else None
+        gs.dpv = (dpk_ptr + li * dpk_layer + dpk_step) if Pn else None
+        gs.ws_main, gs.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()
+        gs.ws_side, gs.ws_side_bytes = ws_side.data_ptr(), ws_side.numel()
+        hip._ck(fn(ctypes.byref(st), ctypes.byref(gs), main_h, side_h, settle), "mtvaf_encoder_layer_bwd")
+        if gviews is None:
+            G[0], G[2], G[4] = dwqkv[:H], dwqkv[H:2 * H], dwqkv[2 * H:]
+            G[1], G[3], G[5] = dbqkv[:H], dbqkv[H:2 * H], dbqkv[2 * H:]
+            keep.append((dwqkv, dbqkv))
+        if direct:
+            # zero-copy fast path: the flat-buffer views become .grad directly (what AccumulateGrad would do with a
+            # stolen gradient), and autograd is handed None for these 16 inputs -- 192 accumulation nodes less per step
+            for p, gt in zip(params[base_i:base_i + N_LAYER_PARAMS], G):
+                p.grad = gt
+        else:
+            pgrads[base_i:base_i + N_LAYER_PARAMS] = G
+        if grad_sink is not None:
+            if side is not None and grad_sink.on_layer_done is not None:
+                if grad_sink.raw_stream_hook:  # the hook only enqueues library kernels: hand it the stream, skip the context
+                    hip.STREAM_OVERRIDE = side_h
+                    try:
+                        grad_sink.layer_done(li)
+                    finally:
+                        hip.STREAM_OVERRIDE = None
+                else:
+                    with torch.cuda.stream(side):
+                        grad_sink.layer_done(li)
+            else:
+                grad_sink.layer_done(li)
+    if side is not None:
+        main.wait_stream(side)  # join: gradients (and every buffer the second stream read) are settled from here on
+    del keep
+    dh0_out = dh.view(B, S, H) if dh is not None else None
+    if not need_param_grads:
+        pgrads = [None] * len(params)
+    return (dh0_out, dpkv, None, None, None, None, *pgrads)
+
+
 class EncoderFunction(torch.autograd.Function):
     """All encoder layers in one autograd node.
 
@@ -195,6 +447,9 @@ class EncoderFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, *params):
+        ctx.native = None
+        if NATIVE_EXEC and len(weights):
+            return _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params)
         B, S, H = h0.shape
         NH, eps, p_hidden, p_attn, pkv_ready = cfg
         L = len(weights)
@@ -280,6 +535,8 @@ class EncoderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        if ctx.native is not None:
+            return _native_backward(ctx, douts)
         offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params = ctx.stash
         flat = ctx.saved_tensors
         NH, eps, p_hidden, p_attn = cfg[:4]

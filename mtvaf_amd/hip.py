@@ -21,6 +21,9 @@ P, I, L, F, U64, SZ = c_void_p, c_int, c_long, c_float, c_uint64, c_size_t
 
 _SIGS = {
     "mtvaf_version": (c_int, []),
+    "mtvaf_encoder_layer_fwd": (c_int, [P, P]),
+    "mtvaf_encoder_layer_bwd": (c_int, [P, P, P, P, I]),
+    "mtvaf_layer_struct_bytes": (SZ, [I]),
     "mtvaf_rng_set_epoch_ptr": (c_int, [P]),
     "mtvaf_rng_epoch_advance": (c_int, [P, P]),
     "mtvaf_device_cus": (c_int, []),
@@ -77,6 +80,24 @@ _SIGS = {
     "mtvaf_grad_unpack_bf16": (c_int, [P, P, L, P]),
 }
 
+class LayerStruct(ctypes.Structure):
+    """mtvaf_layer_t (include/mtvaf_hip.h): one encoder layer's shapes, parameters, input and activation buffers."""
+    _fields_ = ([(n, c_int) for n in ("B", "S", "P", "NH", "H", "I", "bf16")] +
+                [(n, c_float) for n in ("eps", "p_hidden", "p_attn")] + [("seed", c_uint64), ("offset", c_uint64)] +
+                [(n, c_void_p) for n in ("wqkv", "wo", "w1", "w2", "wqkv_h", "wo_h", "w1_h", "w2_h", "bqkv", "bo", "g1", "b1",
+                                         "bi1", "bi2", "g2", "b2", "x", "x_h", "pk", "pv", "addmask", "qkv", "cx", "lse", "a",
+                                         "h1", "h1_h", "mean1", "rstd1", "pre", "act", "f", "h2", "h2_h", "mean2", "rstd2",
+                                         "ws")] + [("ws_bytes", c_size_t)])
+
+
+class LayerGradsStruct(ctypes.Structure):
+    """mtvaf_layer_grads_t: gradient in / out, temporaries, parameter-gradient destinations, per-stream scratch."""
+    _fields_ = ([(n, c_void_p) for n in ("dh", "dh1", "df", "dpre", "da", "dctx", "dqkv", "part", "partq", "partkv", "delta",
+                                         "dwqkv", "dbqkv", "dwo", "dbo", "dg1", "db1", "dw1", "dbi1", "dw2", "dbi2", "dg2",
+                                         "db2", "dpk", "dpv", "ws_main")] + [("ws_main_bytes", c_size_t), ("ws_side", c_void_p),
+                                                                            ("ws_side_bytes", c_size_t)])
+
+
 _lib = None
 
 
@@ -92,6 +113,8 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
+        if (l.mtvaf_layer_struct_bytes(0), l.mtvaf_layer_struct_bytes(1)) != (ctypes.sizeof(LayerStruct), ctypes.sizeof(LayerGradsStruct)):
+            raise RuntimeError("mtvaf_amd: the ctypes mirrors of mtvaf_layer_t / mtvaf_layer_grads_t do not match the library")
         _lib = l
     return _lib
 
@@ -107,9 +130,14 @@ def _p(t: Optional[torch.Tensor]):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+STREAM_OVERRIDE = None  # raw hipStream_t: set by the native executor around hooks that only enqueue library kernels
+
+
 def _st():
     """hipStream_t of torch's current stream on the current device (one C call: torch.cuda.current_stream() builds a
     Stream object and costs ~8 us, which adds up over ~130 launches per step in the launch-bound configurations)."""
+    if STREAM_OVERRIDE is not None:
+        return STREAM_OVERRIDE
     if _raw_stream is not None:
         return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

@@ -170,6 +170,8 @@ class _LayerStore:
         (w.wo, w.bo, w.g1, w.b1, w.w1, w.bi1, w.w2, w.bi2, w.g2, w.b2) = [p.data for p in ps[6:]]
         w.wparams = (ps[0], ps[2], ps[4], ps[6], ps[10], ps[12])  # the weight matrices' Parameters (version counters)
         w._h = None
+        w._st = None
+        w._gst = None
         w.flat = self.flat
         self.weights = w
         self.shapes = [p.shape for p in ps]
@@ -180,7 +182,10 @@ class _LayerStore:
     def grad_views(self):
         if self.grad is None:
             self.grad = torch.empty_like(self.flat)
-        return [self.grad[self.offsets[i]:self.offsets[i] + s.numel()].view(s) for i, s in enumerate(self.shapes)]
+            self._gv = None
+        if getattr(self, "_gv", None) is None:  # the views are as persistent as the buffer: built once
+            self._gv = [self.grad[self.offsets[i]:self.offsets[i] + s.numel()].view(s) for i, s in enumerate(self.shapes)]
+        return self._gv
 
     def packed_qkv_grad(self):
         H = self.H
@@ -207,6 +212,7 @@ class GradSink:
         self.on_layer_done = None  # callable(layer_index, flat_grad_tensor) or None
         self.fast = False
         self.settle_params = False  # set by an optimizer that updates parameters from the hook (mtvaf_amd.optim.AdamW)
+        self.raw_stream_hook = False  # the hook only enqueues library kernels on hip._st() (no torch stream semantics needed)
         self.live_nodes = 0
         self._reset_armed = False
 
@@ -256,6 +262,7 @@ class BertEncoder(nn.Module):
             self._sink = GradSink(self._stores)
             if old is not None:
                 self._sink.on_layer_done, self._sink.settle_params = old.on_layer_done, old.settle_params
+                self._sink.raw_stream_hook = old.raw_stream_hook
         return self._stores, self._sink
 
     @property

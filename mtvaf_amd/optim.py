@@ -65,6 +65,7 @@ class AdamW(torch.optim.Optimizer):
                 grad_sync.after_layer_reduced = self._early_layer_update
             else:
                 sink.on_layer_done = lambda li, flat: self._early_layer_update(li) if flat is not None else None
+                sink.raw_stream_hook = True  # the update is one library launch on hip._st()
         return self
 
     def _map_layers(self):
@@ -80,21 +81,21 @@ class AdamW(torch.optim.Optimizer):
         key = ("layer", li)
         st = self.__dict__.setdefault("_flat_state", {}).get(key)
         if st is None or st["m"].numel() != store.flat.numel() or st["m"].device != store.flat.device:
-            st = {"m": torch.zeros_like(store.flat), "v": torch.zeros_like(store.flat), "step": 0}
+            st = {"m": torch.zeros_like(store.flat), "v": torch.zeros_like(store.flat), "step": 0,
+                  "step_t": torch.zeros((), dtype=torch.float32)}
             self._flat_state[key] = st
             for i, p in enumerate(self._encoder.layer[li].ordered_params()):
                 off, n = store.offsets[i], p.numel()
                 ps = self.state[p]
                 ps["exp_avg"] = st["m"][off:off + n].view(p.shape)
                 ps["exp_avg_sq"] = st["v"][off:off + n].view(p.shape)
-                ps["step"] = st["step"]
+                ps["step"] = st["step_t"]  # (torch.optim keeps `step` as a tensor too)
         return st
 
     def _update_layer_flat(self, li: int, group: dict, store):
         st = self._layer_state(li, store)
         st["step"] += 1
-        for p in self._encoder.layer[li].ordered_params():
-            self.state[p]["step"] = st["step"]
+        st["step_t"].fill_(st["step"])  # the 16 per-parameter state entries share this 0-dim tensor
         b1, b2 = group["betas"]
         from . import engine
         shadow = engine.shadow_for_update(store.weights)  # bf16 compute mode: the GEMM operand image, written in the same pass
@@ -151,6 +152,8 @@ class AdamW(torch.optim.Optimizer):
                 stt = self.state[p]
                 if "exp_avg" not in stt:
                     stt["exp_avg"], stt["exp_avg_sq"], stt["step"] = torch.zeros_like(p), torch.zeros_like(p), 0
+                if torch.is_tensor(stt["step"]):  # was updated through a layer-flat launch before: own counter from here on
+                    stt["step"] = int(stt["step"])
                 stt["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.is_contiguous():
