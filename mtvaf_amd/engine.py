@@ -192,6 +192,10 @@ def _side_stream(device) -> "torch.cuda.Stream":
 # MTVAF_NATIVE_EXEC=0 keeps the Python orchestration below (same kernels, same order) for A/B tests.
 # -------------------------------------------------------------------------------------------------
 NATIVE_EXEC = os.environ.get("MTVAF_NATIVE_EXEC", "1") != "0"
+# Zero-copy gradient path of the native backward: the flat-buffer views are assigned to `.grad` directly and autograd gets
+# None for the encoder parameters.  That is what `loss.backward()` (the reference trainer, modules/train.py:620) needs;
+# `torch.autograd.grad(loss, encoder_params)` wants the gradients RETURNED instead: set MTVAF_DIRECT_GRADS=0 (or
+# engine.DIRECT_GRADS = False) for such callers.
 DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
 _layouts = {}
 

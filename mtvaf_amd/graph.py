@@ -103,6 +103,8 @@ class GraphedTrainStep:
         self.epoch.fill_(int(value))
 
     def __call__(self, **batch) -> TokenClassifierOutput:
+        if self.epoch is None:
+            raise RuntimeError("GraphedTrainStep was closed")
         for k, v in batch.items():
             if torch.is_tensor(v):
                 dst = self.static.get(k)
@@ -121,4 +123,14 @@ class GraphedTrainStep:
         return TokenClassifierOutput(loss=self.loss, logits=logits)
 
     def close(self):
-        hip._ck(hip.lib().mtvaf_rng_set_epoch_ptr(None), "mtvaf_rng_set_epoch_ptr")
+        """Unregister the device-side dropout epoch (the word is owned by this object: the library must not keep its
+        address once the object dies)."""
+        if getattr(self, "epoch", None) is not None:
+            hip._ck(hip.lib().mtvaf_rng_set_epoch_ptr(None), "mtvaf_rng_set_epoch_ptr")
+            self.epoch = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
