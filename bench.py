@@ -119,12 +119,16 @@ def cpu_baseline(B, S, n_aux, seconds_budget=60.0, min_steps=3):
             "seconds_per_step": round(med, 3)}
 
 
-def pmc_traffic(symbol, dtype="fp32"):
+def pmc_traffic(symbol, dtype="fp32", batch=32, seq=128):
     """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/pmc_gemm.json, written by
     tools/pmc_to_json.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams, plus
     WRITE_SIZE).  -> (bytes or None, provenance string): the counters come from a separate profiled run of this same
     command, not from the run that prints the line."""
-    path = os.path.join(ROOT, "profiles", "pmc_gemm.json" if dtype == "fp32" else "pmc_gemm_bf16.json")
+    # one file per measured workload (bytes per launch depend on the token count): the fp32 headline, bf16 at bs 32 / bs 64
+    name = "pmc_gemm.json" if (dtype, batch, seq) == ("fp32", 32, 128) else f"pmc_gemm_{dtype}_b{batch}.json"
+    path = os.path.join(ROOT, "profiles", name)
+    if seq != 128:
+        return None, None
     if not os.path.exists(path):
         return None, None
     try:
@@ -361,7 +365,7 @@ def main():
         sym, (ms, cnt, fl) = max(by_sym.items(), key=lambda kv: kv[1][0])
         avg_us = 1e3 * ms / cnt
         ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
-        traffic, traffic_src = pmc_traffic(sym, a.dtype)
+        traffic, traffic_src = pmc_traffic(sym, a.dtype, B, S)
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
             "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": sym,

@@ -29,7 +29,9 @@ stats bf16_c4 MTVAF_DW_STREAM=1 --dtype bf16 --batch 64
 echo "== pmc"; date
 bash tools/pmc_passes.sh $T/pmc_fp32 > /dev/null
 bash tools/pmc_passes.sh $T/pmc_bf16_c4 --dtype bf16 --batch 64 > /dev/null
+bash tools/pmc_passes.sh $T/pmc_bf16_c3 --dtype bf16 --model roberta > /dev/null
 python tools/pmc_to_json.py $O/pmc_fp32 $O $T pmc_gemm.json > /dev/null
-python tools/pmc_to_json.py $O/pmc_bf16_c4 $O $T pmc_gemm_bf16.json > /dev/null
-rm -rf $O/pmc_fp32 $O/pmc_bf16_c4
+python tools/pmc_to_json.py $O/pmc_bf16_c4 $O $T pmc_gemm_bf16_b64.json > /dev/null
+python tools/pmc_to_json.py $O/pmc_bf16_c3 $O $T pmc_gemm_bf16_b32.json > /dev/null
+rm -rf $O/pmc_fp32 $O/pmc_bf16_c4 $O/pmc_bf16_c3
 date; ls -la $O
