@@ -47,6 +47,23 @@ struct AttnArgs {
   const uint64_t* epoch;  // device-side dropout epoch (captured launches), or NULL
 };
 
+
+// Keys behind the LAST unmasked text position of a sentence (trailing padding: additive mask -10000) contribute exactly 0
+// to every probability sum -- exp2 underflows to 0 -- and leave the running maximum untouched, so whole key tiles made of
+// them can be skipped with bit-identical results.  -> T_eff = P + 1 + max{s : addmask[b][P+s] > -5000}; the full T when
+// no text key is unmasked (nothing is skipped then).  Masked keys BEFORE that position ("holes") stay in the loop.
+__device__ __forceinline__ int effective_keys(const float* __restrict__ addmask_row, int P, int S, int* lds_slot) {
+  if (threadIdx.x == 0) *lds_slot = -1;
+  __syncthreads();
+  int last = -1;
+  for (int t = threadIdx.x; t < S; t += blockDim.x)
+    if (addmask_row[P + t] > -5000.f) last = t;
+  if (last >= 0) atomicMax(lds_slot, last);
+  __syncthreads();
+  const int l = *lds_slot;
+  return l >= 0 ? P + l + 1 : P + S;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: grid (ceil(S/64), NH, B), 256 threads; wave w owns queries q0+16w .. +15
 // ---------------------------------------------------------------------------------------------
@@ -91,7 +108,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 64 + wave * 16 + lq;
-  const int T = a.P + a.S;
+  const int Tf = a.P + a.S;  // row length of the additive mask
+  __shared__ int t_eff_slot;
+  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     kv_load(kreg, ksrc, a.P, T, ldt, t0);
     kv_load(vreg, vsrc, a.P, T, ldt, t0);
     float mreg = NEG_BIG;
-    if (threadIdx.x < KT) mreg = a.addmask[(long)b * T + min(t0 + (int)threadIdx.x, T - 1)];
+    if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
     __syncthreads();
     kv_store<LDK>(Ks, kreg);
     kv_store<LDT>(Vs, vreg);
@@ -196,12 +215,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // backward, query side: dQ (and delta = rowsum(dO.O)); same decomposition as the forward.
 // ---------------------------------------------------------------------------------------------
 // Ks [KT*LDT]: read as row fragments AND as columns; Vs [KT*LDK]: row fragments only; Ms [KT]
-__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, float* Ks, float* Vs, float* Ms) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, float* Ks, float* Vs, float* Ms, int* t_eff_slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = qtile * 64 + wave * 16 + lq;
-  const int T = a.P + a.S;
+  const int Tf = a.P + a.S;
+  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
@@ -248,7 +268,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
     kv_load(kreg, ksrc, a.P, T, ldt, t0);
     kv_load(vreg, vsrc, a.P, T, ldt, t0);
     float mreg = NEG_BIG;
-    if (threadIdx.x < KT) mreg = a.addmask[(long)b * T + min(t0 + (int)threadIdx.x, T - 1)];
+    if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
     __syncthreads();
     kv_store<LDT>(Ks, kreg);
     kv_store<LDK>(Vs, vreg);
@@ -305,18 +325,31 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
 // from the staged dO tile and the matching O rows so that this side does not depend on the query side (both run in
 // one launch); rh_s [KT] = dropout row hashes of the tile's queries.
 __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, float* Qs, float* dOs, float* lse_s,
-                                                  float* del_s, uint32_t* rh_s) {
+                                                  float* del_s, uint32_t* rh_s, int* t_eff_slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lk = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int T = a.P + a.S;
+  const int Tf = a.P + a.S;
+  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);  // keys >= T: trailing padding, dK = dV = 0
   const int key = ktile * 64 + wave * 16 + lk;
+  if (ktile * 64 >= T) {  // (block-uniform) a key tile of trailing padding only: exact zeros, no query loop
+    if (key < Tf) {
+      float* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<f32x4*>(dkrow + 16 * dt) = z;
+        *reinterpret_cast<f32x4*>(dkrow + a.H + 16 * dt) = z;
+      }
+    }
+    return;
+  }
   const bool kok = key < T;
   const bool wave_live = (int)(ktile * 64 + wave * 16) < T;
   const int keyc = min(key, T - 1);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   // keys beyond T: mask -1e30 makes their probabilities exactly 0
-  const float mval2 = kok ? a.addmask[(long)b * T + key] * LOG2E : NEG_BIG;
+  const float mval2 = kok ? a.addmask[(long)b * Tf + key] * LOG2E : NEG_BIG;
   const float sc2 = a.scale * LOG2E;
   const uint32_t cterm = (uint32_t)key * ATTN_DROP_C2;
 
@@ -428,6 +461,15 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
       }
     }
   }
+  if (!kok && key < Tf) {  // trailing padding inside a partially valid tile
+    float* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *reinterpret_cast<f32x4*>(dkrow + 16 * dt) = z;
+      *reinterpret_cast<f32x4*>(dkrow + a.H + 16 * dt) = z;
+    }
+  }
   if (kok) {
     float* dkrow;
     float* dvrow;
@@ -454,10 +496,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(AttnArgs a, int nq) { 
   __shared__ __attribute__((aligned(16))) float tile0[KT * LDK];
   __shared__ __attribute__((aligned(16))) float tile1[KT * LDK];
   __shared__ __attribute__((aligned(16))) float small[3 * KT];
+  __shared__ int t_eff_slot;
   if ((int)blockIdx.x < nq) {
-    attn_bwd_dq_body(a, blockIdx.x, tile0, tile1, small);
+    attn_bwd_dq_body(a, blockIdx.x, tile0, tile1, small, &t_eff_slot);
   } else {
-    attn_bwd_dkv_body(a, blockIdx.x - nq, tile0, tile1, small, small + KT, reinterpret_cast<uint32_t*>(small + 2 * KT));
+    attn_bwd_dkv_body(a, blockIdx.x - nq, tile0, tile1, small, small + KT, reinterpret_cast<uint32_t*>(small + 2 * KT), &t_eff_slot);
   }
 }
 

@@ -109,6 +109,23 @@ __device__ __forceinline__ float dot8(const bf16x8& a, const bf16x8& b) {
   return s;
 }
 
+
+// Keys behind the LAST unmasked text position of a sentence (trailing padding: additive mask -10000) contribute exactly 0
+// to every probability sum -- exp2 underflows to 0 -- and leave the running maximum untouched, so whole key tiles made of
+// them can be skipped with bit-identical results.  -> T_eff = P + 1 + max{s : addmask[b][P+s] > -5000}; the full T when
+// no text key is unmasked (nothing is skipped then).  Masked keys BEFORE that position ("holes") stay in the loop.
+__device__ __forceinline__ int effective_keys(const float* __restrict__ addmask_row, int P, int S, int* lds_slot) {
+  if (threadIdx.x == 0) *lds_slot = -1;
+  __syncthreads();
+  int last = -1;
+  for (int t = threadIdx.x; t < S; t += blockDim.x)
+    if (addmask_row[P + t] > -5000.f) last = t;
+  if (last >= 0) atomicMax(lds_slot, last);
+  __syncthreads();
+  const int l = *lds_slot;
+  return l >= 0 ? P + l + 1 : P + S;
+}
+
 // ---------------------------------------------------------------------------------------------
 // forward: grid (ceil(S/64), NH, B), 256 threads; wave w owns queries q0+16w .. +15
 // ---------------------------------------------------------------------------------------------
@@ -120,7 +137,9 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 64 + wave * 16 + lq;
-  const int T = a.P + a.S;
+  const int Tf = a.P + a.S;  // row length of the additive mask
+  __shared__ int t_eff_slot;
+  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
@@ -149,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
     tile_load_kv(kreg, ksrc, a.P, T, ldt, t0);
     tile_load_kv(vreg, vsrc, a.P, T, ldt, t0);
     float mreg = NEG_BIG;
-    if (threadIdx.x < KT) mreg = a.addmask[(long)b * T + min(t0 + (int)threadIdx.x, T - 1)];
+    if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
     __syncthreads();
     tile_store(Ks, kreg);
     tile_store(Vs, vreg);
@@ -217,12 +236,14 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
 // ---------------------------------------------------------------------------------------------
 // backward, query side: dQ for 64 queries per block (wave w: 16 of them), loop over key tiles
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned char* Ks, unsigned char* Vs, float* Ms, float* red) {
+__device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned char* Ks, unsigned char* Vs, float* Ms, float* red,
+                                            int* t_eff_slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = qtile * 64 + wave * 16 + lq;
-  const int T = a.P + a.S;
+  const int Tf = a.P + a.S;
+  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
   const bool qok = q < a.S;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
@@ -263,7 +284,7 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
     tile_load_kv(kreg, ksrc, a.P, T, ldt, t0);
     tile_load_kv(vreg, vsrc, a.P, T, ldt, t0);
     float mreg = NEG_BIG;
-    if (threadIdx.x < KT) mreg = a.addmask[(long)b * T + min(t0 + (int)threadIdx.x, T - 1)];
+    if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
     __syncthreads();
     tile_store(Ks, kreg);
     tile_store(Vs, vreg);
@@ -330,17 +351,34 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
 // backward, key side: dK, dV for 64 keys of the [prefix ; text] axis per block; loops over query tiles.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned char* Qs, unsigned char* dOs, float* lse_s,
-                                             float* del_s, uint32_t* rh_s, float* red) {
+                                             float* del_s, uint32_t* rh_s, float* red, int* t_eff_slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lk = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int T = a.P + a.S;
+  const int Tf = a.P + a.S;
+  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);  // keys >= T: trailing padding, dK = dV = 0
   const int key = ktile * 64 + wave * 16 + lk;
+  if (ktile * 64 >= T) {  // (block-uniform) a key tile of trailing padding only: exact zeros, no query loop
+    if (key < Tf) {
+      __bf16* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+      const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<bf16x4*>(dkrow + 16 * dt) = z;
+        *reinterpret_cast<bf16x4*>(dkrow + a.H + 16 * dt) = z;
+      }
+    }
+    if (threadIdx.x < 128) {
+      const int nkt = (Tf + 63) / 64;
+      a.partkv[((long)b * nkt + ktile) * 2 * a.H + (threadIdx.x >> 6) * a.H + h * D + (threadIdx.x & 63)] = 0.f;
+    }
+    return;
+  }
   const bool kok = key < T;
   const bool wave_live = (int)(ktile * 64 + wave * 16) < T;
   const int keyc = min(key, T - 1);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const float mval2 = kok ? a.addmask[(long)b * T + key] * LOG2E : NEG_BIG;  // keys beyond T: probability exactly 0
+  const float mval2 = kok ? a.addmask[(long)b * Tf + key] * LOG2E : NEG_BIG;  // keys beyond T: probability exactly 0
   const float sc2 = a.scale * LOG2E;
   const uint32_t cterm = (uint32_t)key * ATTN_DROP_C2;
 
@@ -444,6 +482,15 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
     }
   }
   const bool is_text = kok && key >= a.P;
+  if (!kok && key < Tf) {  // trailing padding inside a partially valid tile
+    __bf16* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+    const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      *reinterpret_cast<bf16x4*>(dkrow + 16 * dt) = z;
+      *reinterpret_cast<bf16x4*>(dkrow + a.H + 16 * dt) = z;
+    }
+  }
   if (kok) {
     if (key < a.P) {
       float* dkrow = a.dpk + ((long)b * a.P * a.NH + (long)h * a.P + key) * D + 4 * g;
@@ -478,7 +525,7 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
   __syncthreads();
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6, d = threadIdx.x & 63;
-    const int nkt = (T + 63) / 64;
+    const int nkt = (Tf + 63) / 64;
     const float* rr = red + which * 256 + d;
     a.partkv[((long)b * nkt + ktile) * 2 * a.H + which * a.H + h * D + d] = rr[0] + rr[64] + rr[128] + rr[192];
   }
@@ -490,10 +537,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_bwd_kernel(Args a, int nq) {
   __shared__ __attribute__((aligned(16))) unsigned char tile1[KT * 128];
   __shared__ __attribute__((aligned(16))) float small[3 * KT];
   __shared__ __attribute__((aligned(16))) float red[8 * 64];
+  __shared__ int t_eff_slot;
   if ((int)blockIdx.x < nq) {
-    bwd_dq_body(a, blockIdx.x, tile0, tile1, small, red);
+    bwd_dq_body(a, blockIdx.x, tile0, tile1, small, red, &t_eff_slot);
   } else {
-    bwd_dkv_body(a, blockIdx.x - nq, tile0, tile1, small, small + KT, reinterpret_cast<uint32_t*>(small + 2 * KT), red);
+    bwd_dkv_body(a, blockIdx.x - nq, tile0, tile1, small, small + KT, reinterpret_cast<uint32_t*>(small + 2 * KT), red, &t_eff_slot);
   }
 }
 
