@@ -111,3 +111,52 @@ def test_graph_replay_draws_fresh_reproducible_dropout_masks(dtype):
             g.close()
     finally:
         hip.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_graphed_training_trajectory_equals_eager(dtype):
+    """Three optimizer steps with the graph (replay + eager AdamW between replays) leave the parameters where three eager
+    steps leave them: the masters move between replays, so the bf16 weight images must be rebuilt inside the graph."""
+    from mtvaf_amd import hip
+    from mtvaf_amd.graph import GraphedTrainStep
+    from mtvaf_amd.optim import AdamW
+    from test_configs_gpu import _props_model
+    from test_model_gpu import _prompt_inputs
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=2, max_pos=512)
+    hip.set_compute_dtype(dtype)
+    try:
+        # eval mode: the model-level nn.Dropout modules would draw different host-seeded masks in the two models
+        m1 = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+        m2 = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()  # same seed: identical initial parameters
+        ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 81, 8, 128, lo_id=1000))
+        feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(82, 8, 8))
+        kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+        o1 = AdamW([p for p in m1.parameters() if p.requires_grad], lr=1e-3, model=m1, overlap=False)
+        o2 = AdamW([p for p in m2.parameters() if p.requires_grad], lr=1e-3, model=m2, overlap=False)
+        g = GraphedTrainStep(m2, kw)
+        try:
+            l1, l2 = [], []
+            for _ in range(3):
+                out = m1(**kw)
+                out.loss.backward()
+                o1.step()
+                o1.zero_grad(set_to_none=True)
+                l1.append(float(out.loss))
+                out2 = g(**kw)
+                o2.step()
+                o2.zero_grad(set_to_none=True)
+                l2.append(float(out2.loss))
+            torch.cuda.synchronize()
+            assert l1[0] == l2[0]
+            assert l1[1] != l1[0], "the parameters did not move"
+            for a, b in zip(l1, l2):  # (the word-table scatter-add is order-dependent in the last bits: later steps to 1e-5)
+                assert abs(a - b) <= 1e-5 * abs(a), (l1, l2)
+            n2 = dict(m2.named_parameters())
+            for n, p in m1.named_parameters():
+                if "key.bias" in n:
+                    continue  # pure-noise gradient whose sign Adam amplifies (softmax is invariant to the key bias)
+                torch.testing.assert_close(p, n2[n], rtol=0, atol=5e-5, msg=n)
+        finally:
+            g.close()
+    finally:
+        hip.set_compute_dtype("fp32")
