@@ -427,9 +427,19 @@ def _crf_inputs(B, S, C, seed, lengths=None):
     return em, tags, mask, start, end, trans
 
 
-@pytest.mark.parametrize("B,S,C", [(4, 5, 11), (32, 128, 11), (3, 70, 5), (2, 1, 11)])
-def test_crf(hip, B, S, C):
+@pytest.mark.parametrize("B,S,C,scale", [(4, 5, 11, 1), (32, 128, 11, 1), (3, 70, 5, 1), (2, 1, 11, 1), (3, 512, 11, 1),
+                                          (5, 131, 16, 1), (4, 9, 1, 1), (6, 128, 11, 6), (4, 66, 11, -1)])
+def test_crf(hip, B, S, C, scale):
+    """scale > 1: emissions and transitions spread over tens of nats (confident model, near-forbidden transitions) -- the
+    scaled linear-domain recursion must stay in range; scale < 0: masks with holes (pytorch-crf carries the score over
+    a masked step and scores the edge from the literal previous position)."""
     em, tags, mask, start, end, trans = _crf_inputs(B, S, C, 3 + S)
+    if scale > 1:
+        em, trans = em * scale, trans * 4 * scale
+    if scale < 0:
+        holes = torch.rand(B, S, generator=torch.Generator().manual_seed(5)) < 0.2
+        holes[:, 0] = False
+        mask = mask * (~holes).to(mask.dtype)
     g = lambda t: t.to(DEV)
     emd, sd_, ed, td = (t.double().requires_grad_(True) for t in (em, start, end, trans))
     ref = -O.crf_log_likelihood(emd, tags, mask, sd_, ed, td, "mean")
