@@ -53,16 +53,10 @@ __device__ __forceinline__ void glds16x(const void* src, void* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-#define MTVAF_X_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 template <int N>
-__device__ __forceinline__ void wait_vm() {
-  if constexpr (N == 0) MTVAF_X_WAIT(0);
-  else if constexpr (N == 7) MTVAF_X_WAIT(7);
-  else if constexpr (N == 8) MTVAF_X_WAIT(8);
-  else if constexpr (N == 4) MTVAF_X_WAIT(4);
-  else if constexpr (N == 6) MTVAF_X_WAIT(6);
-  else if constexpr (N == 5) MTVAF_X_WAIT(5);
-  else static_assert(N == 0, "add the count");
+__device__ __forceinline__ void wait_vm() {  // counted wait: the N most recent DMA instructions of this wave may stay in flight
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 __device__ __forceinline__ int km_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -76,7 +70,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE == 3 ? 1 : 2)) void gemm_bf16x_kernel(GemmArgsX p) {
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 : 2)) void gemm_bf16x_kernel(GemmArgsX p) {
   constexpr int BK = 64;  // bf16 elements per k-tile
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -190,11 +184,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE == 3 ? 1 
     }
   }
 
-  issue(0);
-  if (NSTAGE == 3 && nk > 1) issue(1);
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s);
   int st = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (NSTAGE == 3 && kt + 1 < nk) wait_vm<IA + IB>();  // this wave's pieces of tile kt have landed; tile kt+1 stays in flight
+    // this wave's pieces of tile kt have landed; the (up to NSTAGE - 2) tiles issued after it stay in flight
+    const int ahead = min(NSTAGE - 2, nk - 1 - kt);
+    if (NSTAGE >= 5 && ahead == 3) wait_vm<3 * (IA + IB)>();
+    else if (NSTAGE >= 4 && ahead == 2) wait_vm<2 * (IA + IB)>();
+    else if (NSTAGE >= 3 && ahead == 1) wait_vm<IA + IB>();
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();  // ... and everybody else's; every wave is done reading tile kt-1
     asm volatile("" ::: "memory");
@@ -371,18 +370,26 @@ static int launch_x(const GemmArgsX& a, dim3 grid, hipStream_t st) {
   return MTVAF_OK;
 }
 
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM>
+static int launch_stages(const GemmArgsX& a, int stages, dim3 grid, hipStream_t st) {
+  switch (stages) {
+    case 3: return launch_x<BM, BN, WM, WN, A_KM, B_KM, 3>(a, grid, st);
+    case 4: return launch_x<BM, BN, WM, WN, A_KM, B_KM, 4>(a, grid, st);
+    case 5:
+      if constexpr (5 * (BM + BN) * 128 <= 160 * 1024) return launch_x<BM, BN, WM, WN, A_KM, B_KM, 5>(a, grid, st);
+      return MTVAF_ERR_SHAPE;
+    default: return launch_x<BM, BN, WM, WN, A_KM, B_KM, 2>(a, grid, st);
+  }
+}
+
 template <bool A_KM, bool B_KM>
 static int launch_layout(const GemmArgsX& a, int bm, int bn, int stages, dim3 grid, hipStream_t st) {
   if (bm == 256) {  // 8 waves (two per SIMD), one block per CU: half the L2 -> LDS bytes per flop of the 128-row tiles
-    if constexpr (!A_KM) {
-      return stages == 3 ? launch_x<256, 128, 4, 2, A_KM, B_KM, 3>(a, grid, st) : launch_x<256, 128, 4, 2, A_KM, B_KM, 2>(a, grid, st);
-    }
+    if constexpr (!A_KM) return launch_stages<256, 128, 4, 2, A_KM, B_KM>(a, stages > 3 ? 3 : stages, grid, st);
     return MTVAF_ERR_SHAPE;
   }
-  if (bn == 128) {
-    return stages == 3 ? launch_x<128, 128, 2, 2, A_KM, B_KM, 3>(a, grid, st) : launch_x<128, 128, 2, 2, A_KM, B_KM, 2>(a, grid, st);
-  }
-  return stages == 3 ? launch_x<128, 96, 4, 1, A_KM, B_KM, 3>(a, grid, st) : launch_x<128, 96, 4, 1, A_KM, B_KM, 2>(a, grid, st);
+  if (bn == 128) return launch_stages<128, 128, 2, 2, A_KM, B_KM>(a, stages, grid, st);
+  return launch_stages<128, 96, 4, 1, A_KM, B_KM>(a, stages, grid, st);
 }
 
 }  // namespace mtvaf
@@ -457,9 +464,9 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
   a.tiles_n = N / bn;
   // measured (tools/bf16x_bench.py): with 4-wave blocks two co-resident blocks beat the deeper ring on every shape of the
   // path; the 8-wave 256x128 block (one per CU) wants the 3-deep ring
-  if (stages != 2 && stages != 3) stages = bm == 256 ? 3 : 2;
+  if (stages < 2 || stages > 5) stages = bm == 256 ? 3 : 2;
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
-  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages == 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256), layout_a, layout_b, 2, M, N, K, splits};
+  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages >= 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256), layout_a, layout_b, 2, M, N, K, splits};
   const int rec = prof_begin(key, stream);
   int rc;
   if (layout_a == 0 && layout_b == 0) rc = launch_layout<false, false>(a, bm, bn, stages, grid, stream);

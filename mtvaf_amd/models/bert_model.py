@@ -193,8 +193,10 @@ class TVNetSAModel2(nn.Module):
             decoded = None
         loss = None
         if labels is not None:
-            loss = -1 * self.crf(emissions, labels, mask=mask_u8, reduction="mean")
-            loss = loss + _arg(self.args, "alpha", 0.0) * img_tag_loss
+            loss = self.crf.nll_mean(emissions, labels, mask=mask_u8)  # = -1 * crf(..., reduction='mean'), bert_model.py:521
+            extra = _arg(self.args, "alpha", 0.0) * img_tag_loss
+            if torch.is_tensor(extra) or extra != 0:  # (adding the literal 0.0 of a VAO-less run is two kernels for nothing)
+                loss = loss + extra
         if decoded is not None:
             # the decode reads the CRF parameters: whatever follows on the main stream (optimizer.step() updates them in
             # place) is ordered behind it here, not only by the join inside the encoder backward (frozen encoders skip it)

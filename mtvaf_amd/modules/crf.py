@@ -136,6 +136,13 @@ class CRF(nn.Module):
             return -nll_mean * emissions.shape[0]
         raise NotImplementedError(f"reduction={reduction!r} is not on the MTVAF path (the reference uses 'mean')")
 
+    def nll_mean(self, emissions, tags, mask: Optional[torch.Tensor] = None):
+        """``-1 * self(emissions, tags, mask=mask, reduction='mean')`` (models/bert_model.py:521) as ONE autograd node: the
+        kernel's result is that quantity, so the two negations (and their two backward kernels) are not launched."""
+        emissions, tags, mask = self._prep(emissions, tags, mask)
+        return engine.CRFNLLFunction.apply(emissions, self.start_transitions, self.end_transitions, self.transitions,
+                                           tags, mask)
+
     @torch.no_grad()
     def decode_packed(self, emissions, mask: Optional[torch.Tensor] = None):
         """Viterbi on device -> (tags int32 [B,S] padded with -1, lengths int32 [B]); no host sync."""

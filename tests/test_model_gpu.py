@@ -416,3 +416,22 @@ def test_deferred_tags_behave_like_the_eager_list():
     assert out.logits[2][1] == eager[2][1] and [len(t) for t in out.logits] == mask.sum(1).tolist()
     import copy, json
     assert json.loads(json.dumps(out.logits)) == eager and copy.deepcopy(out.logits) == eager
+
+
+def test_crf_module_nll_mean_is_the_negated_mean_log_likelihood():
+    """``crf.nll_mean`` (one autograd node, used by the model's forward) against the public torchcrf-style call the
+    reference makes, ``-1 * crf(emissions, tags, mask=mask, reduction='mean')`` (models/bert_model.py:521): same value,
+    same gradients, bit for bit."""
+    from mtvaf_amd.modules.crf import CRF
+    torch.manual_seed(3)
+    crf = CRF(11, batch_first=True).to(DEV)
+    em = torch.randn(6, 40, 11, device=DEV, requires_grad=True)
+    tags = torch.randint(0, 11, (6, 40), device=DEV)
+    mask = (torch.arange(40, device=DEV)[None] < torch.tensor([40, 33, 1, 17, 40, 8], device=DEV)[:, None]).to(torch.uint8)
+    a = -1 * crf(em, tags, mask=mask, reduction="mean")
+    ga = torch.autograd.grad(a, [em, crf.transitions, crf.start_transitions, crf.end_transitions])
+    b = crf.nll_mean(em, tags, mask=mask)
+    gb = torch.autograd.grad(b, [em, crf.transitions, crf.start_transitions, crf.end_transitions])
+    assert torch.equal(a, b)
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)

@@ -44,7 +44,9 @@ def main():
             for tile in (1, 2, 3):
                 if (tile == 1 and n % 96) or (tile == 3 and (la == 1 or m % 256 or kw.get("dgelu"))):
                     continue
-                for stages in (2, 3):
+                for stages in (2, 3, 4, 5):
+                    if (tile == 3 and stages > 3) or (tile == 2 and stages > 4):
+                        continue
                     def run():
                         if kw.get("split"):
                             hip.gemm_bf16x(a, la, b, lb, m, n, k, out32=out32, allow_split=True, tile=tile, stages=stages)
