@@ -70,14 +70,16 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 : 2)) void gemm_bf16x_kernel(GemmArgsX p) {
+__global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 : 2))) void gemm_bf16x_kernel(GemmArgsX p) {
   constexpr int BK = 64;  // bf16 elements per k-tile
   constexpr int NW = WM * WN, NT = NW * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int A_B = BM * 128, B_B = BN * 128, STAGE_B = A_B + B_B;  // bytes (KC: BM rows x 128 B; KM: 64 rows x 2*BM B)
   constexpr int IA = A_B / 1024 / NW, IB = B_B / 1024 / NW;          // 1-KiB DMA instructions per wave
   static_assert(A_B % (1024 * NW) == 0 && B_B % (1024 * NW) == 0, "tile must split into whole DMA pieces per wave");
-  static_assert((!A_KM || BM == 128) && (!B_KM || BN == 128 || BN == 96), "k-major images: 256-byte rows (XOR swizzle) or 192-byte rows");
+  static_assert((!A_KM || BM == 128) && (!B_KM || BN == 128 || BN == 96 || BN == 192),
+                "k-major images: 256-byte rows (XOR swizzle) or 192-byte rows (BN = 192: two 96-column images side by side)");
+  constexpr int KM96_HALF_B = 64 * 192;  // bytes of one [64 k-rows][96 columns] image
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];  // the ONLY LDS object
 
@@ -117,8 +119,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 
       const int r = f >> 4, cp = f & 15;
       pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(kbeg + r) * p.ldb + n0) + ((cp ^ km_swz(r)) << 4);
     } else {  // 192-byte rows: consecutive rows start 48 banks apart, the transposing reads are conflict-free unswizzled
-      const int o = f << 4, r = o / (BN * 2), cb = o % (BN * 2);
-      pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(kbeg + r) * p.ldb + n0) + cb;
+      const int o = f << 4, half = o / KM96_HALF_B, oo = o % KM96_HALF_B, r = oo / 192, cb = oo % 192;
+      pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(kbeg + r) * p.ldb + n0 + half * 96) + cb;
     }
   }
   const long stepA = A_KM ? (long)BK * p.lda * 2 : BK * 2;
@@ -177,9 +179,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 
           offB[j][jj] = 256 * (8 * (g >> 1) + 4 * jj + q) +
                         16 * ((((ns ^ q) & 3) << 2) | ((2 * (g & 1) + (pp >> 1)) ^ ((2 * (g >> 1) + jj) & 3))) + 8 * (pp & 1);
       } else {
-        const int ns = wn * TN + j;
+        const int ns = wn * TN + j, half = ns / 3, nl = ns % 3;
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj) offB[j][jj] = (BN * 2) * (8 * (g >> 1) + 4 * jj + q) + ns * 64 + 32 * (g & 1) + 8 * pp;
+        for (int jj = 0; jj < 2; ++jj)
+          offB[j][jj] = half * KM96_HALF_B + 192 * (8 * (g >> 1) + 4 * jj + q) + nl * 64 + 32 * (g & 1) + 8 * pp;
       }
     }
   }
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         if (!B_KM) fb[j] = *reinterpret_cast<const bf16x8*>(b + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
-        else fb[j] = tr_read8(b + offB[j][0] + (BN * 32) * ks, b + offB[j][1] + (BN * 32) * ks);
+        else fb[j] = tr_read8(b + offB[j][0] + (BN == 128 ? 4096 : 3072) * ks, b + offB[j][1] + (BN == 128 ? 4096 : 3072) * ks);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -228,82 +231,93 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 
   }
 
   // ---- epilogue: accumulator tile -> LDS (transposed to row-major) -> 8 columns per lane ----
+  // in passes of 128 rows (one pass for the 128-row tiles): a [256][BN + 4] fp32 image does not fit the LDS at BN = 192,
+  // and a pass is exactly one row of the per-128-row column-sum partials
   constexpr int LDE = BN + 4;
+  constexpr int EPR = 128, NPASS = BM / EPR;  // rows per pass
+  constexpr int WPP = WM / NPASS;             // wave rows (wm) per pass
+  static_assert(BM % EPR == 0 && WM % NPASS == 0 && (WPP * TM * 32 == EPR), "whole wave rows per epilogue pass");
   float* smem = reinterpret_cast<float*>(smem_b);
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        smem[row * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
-      }
-  __syncthreads();
   const bool split = gridDim.z > 1;
   float* C = p.C32 ? p.C32 + (long)blockIdx.z * p.slab_stride : nullptr;
   constexpr int C8 = BN / 8;
-  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    __syncthreads();
+    if (wm / WPP == pass) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = ((wm % WPP) * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            smem[row * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // a thread keeps ONE 8-column group and walks rows G apart (G = NT / C8 row groups; NT - G * C8 threads idle when C8
+    // does not divide NT): its running sums are the column sums of its rows
+    constexpr int G = NT / C8;
+    const int c = (tid % C8) * 8;
 #pragma unroll 2
-  for (int idx = tid; idx < BM * C8; idx += NT) {
-    const int r = idx / C8, c = (idx % C8) * 8;
-    float v[8];
-    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
-    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(smem + r * LDE + c + 4);
-    const long row = m0 + r;
-    const int col = n0 + c;
-    if (!split) {
-      if (p.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
+    for (int r = tid / C8; r < EPR && tid < G * C8; r += G) {
+      float v[8];
+      *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
+      *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(smem + r * LDE + c + 4);
+      const long row = m0 + pass * EPR + r;
+      const int col = n0 + c;
+      if (!split) {
+        if (p.bias) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + col), b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { v[t] += b0[t]; v[4 + t] += b1[t]; }
+          for (int t = 0; t < 4; ++t) { v[t] += b0[t]; v[4 + t] += b1[t]; }
+        }
+        if (p.epi == EPI_GELU) {
+          bf16x8 pre;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) pre[t] = (__bf16)v[t];
+          *reinterpret_cast<bf16x8*>(p.aux16 + row * p.ldaux + col) = pre;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) v[t] = gelu_erf((float)pre[t]);  // of the SAVED (rounded) pre-activation: fwd/bwd consistent
+        } else if (p.epi == EPI_DGELU) {
+          const bf16x8 pre = *reinterpret_cast<const bf16x8*>(p.aux16 + row * p.ldaux + col);
+#pragma unroll
+          for (int t = 0; t < 8; ++t) v[t] *= gelu_erf_grad((float)pre[t]);
+        }
+        if (p.accumulate) {
+          const f32x4 c0 = *reinterpret_cast<const f32x4*>(C + row * p.ldc32 + col), c1 = *reinterpret_cast<const f32x4*>(C + row * p.ldc32 + col + 4);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { v[t] += c0[t]; v[4 + t] += c1[t]; }
+        }
       }
-      if (p.epi == EPI_GELU) {
-        bf16x8 pre;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) pre[t] = (__bf16)v[t];
-        *reinterpret_cast<bf16x8*>(p.aux16 + row * p.ldaux + col) = pre;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = gelu_erf((float)pre[t]);  // of the SAVED (rounded) pre-activation: fwd/bwd consistent
-      } else if (p.epi == EPI_DGELU) {
-        const bf16x8 pre = *reinterpret_cast<const bf16x8*>(p.aux16 + row * p.ldaux + col);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] *= gelu_erf_grad((float)pre[t]);
+      if (C) {
+        *reinterpret_cast<f32x4*>(C + row * p.ldc32 + col) = *reinterpret_cast<const f32x4*>(v);
+        *reinterpret_cast<f32x4*>(C + row * p.ldc32 + col + 4) = *reinterpret_cast<const f32x4*>(v + 4);
       }
-      if (p.accumulate) {
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(C + row * p.ldc32 + col), c1 = *reinterpret_cast<const f32x4*>(C + row * p.ldc32 + col + 4);
+      if (p.C16 && !split) {
+        bf16x8 o;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { v[t] += c0[t]; v[4 + t] += c1[t]; }
+        for (int t = 0; t < 8; ++t) o[t] = (__bf16)v[t];
+        *reinterpret_cast<bf16x8*>(p.C16 + row * p.ldc16 + col) = o;
       }
-    }
-    if (C) {
-      *reinterpret_cast<f32x4*>(C + row * p.ldc32 + col) = *reinterpret_cast<const f32x4*>(v);
-      *reinterpret_cast<f32x4*>(C + row * p.ldc32 + col + 4) = *reinterpret_cast<const f32x4*>(v + 4);
-    }
-    if (p.C16 && !split) {
-      bf16x8 o;
-#pragma unroll
-      for (int t = 0; t < 8; ++t) o[t] = (__bf16)v[t];
-      *reinterpret_cast<bf16x8*>(p.C16 + row * p.ldc16 + col) = o;
-    }
-    if (NT % C8 == 0) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) cs[t] += v[t];
     }
-  }
-  if constexpr (NT % C8 == 0) {
-    if (p.colpart && !split) {  // (uniform) per-tile column sums: lanes sharing a column group are NT / C8 apart in rows
-      constexpr int G = NT / C8;
+    if (p.colpart && !split) {  // (uniform) per-pass column sums, combined over the G row groups in fixed order
+      static_assert(G * BN <= EPR * LDE, "the partial sums reuse the epilogue image");
       __syncthreads();
+      if (tid < G * C8) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) smem[(tid / C8) * BN + (tid % C8) * 8 + t] = cs[t];
+        for (int t = 0; t < 8; ++t) smem[(tid / C8) * BN + c + t] = cs[t];
+      }
       __syncthreads();
-      for (int c = tid; c < BN; c += NT) {
-        float s = 0.f;
+      for (int cc = tid; cc < BN; cc += NT) {
+        float sacc = 0.f;
 #pragma unroll
-        for (int gq = 0; gq < G; ++gq) s += smem[gq * BN + c];
-        p.colpart[(long)(m0 / BM) * p.N + n0 + c] = s;
+        for (int gq = 0; gq < G; ++gq) sacc += smem[gq * BN + cc];
+        p.colpart[(long)(m0 / EPR + pass) * p.N + n0 + cc] = sacc;
       }
     }
   }
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE>
 static int launch_x(const GemmArgsX& a, dim3 grid, hipStream_t st) {
   size_t smem = (size_t)NSTAGE * (BM + BN) * 128;
-  smem = std::max(smem, (size_t)BM * (BN + 4) * sizeof(float));  // epilogue image
+  smem = std::max(smem, (size_t)128 * (BN + 4) * sizeof(float));  // epilogue image (one 128-row pass)
   auto kern = gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE>;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
@@ -384,8 +398,12 @@ static int launch_stages(const GemmArgsX& a, int stages, dim3 grid, hipStream_t 
 
 template <bool A_KM, bool B_KM>
 static int launch_layout(const GemmArgsX& a, int bm, int bn, int stages, dim3 grid, hipStream_t st) {
-  if (bm == 256) {  // 8 waves (two per SIMD), one block per CU: half the L2 -> LDS bytes per flop of the 128-row tiles
+  if (bm == 256 && bn == 128) {  // 8 waves (two per SIMD), one block per CU: half the L2 -> LDS bytes per flop of the 128-row tiles
     if constexpr (!A_KM) return launch_stages<256, 128, 4, 2, A_KM, B_KM>(a, stages > 3 ? 3 : stages, grid, st);
+    return MTVAF_ERR_SHAPE;
+  }
+  if (bn == 192) {  // 8 waves, one block per CU: 0.57x the L2 -> LDS bytes per flop of the 128x128 tile (2-stage ring: 112 KB)
+    if constexpr (!A_KM) return launch_x<256, 192, 4, 2, A_KM, B_KM, 2>(a, grid, st);
     return MTVAF_ERR_SHAPE;
   }
   if (bn == 128) return launch_stages<128, 128, 2, 2, A_KM, B_KM>(a, stages, grid, st);
@@ -406,7 +424,8 @@ extern "C" {
 //   colpart [M/128][N] (optional, 128x128 tiles): per-tile column sums of the result for mtvaf_colsum_small.
 //   allow_split: deterministic split-K (fp32 slabs in workspace + ordered reduction; fp32 result only, epi 0).
 // Requirements (MTVAF_ERR_SHAPE / _ALIGN otherwise; no fallback): M % 128 == 0, K % 64 == 0, N % 128 == 0 or N % 96 == 0, leading dimensions % 8 == 0, 16-byte aligned pointers.  tile: 0 auto, 1 128x96,
-// 2 128x128, 3 256x128 (8 waves; layout_a 0, M % 256 == 0, no colpart).  stages: 0 auto, 2, 3.
+// 2 128x128, 3 256x128 (8 waves; layout_a 0, M % 256 == 0, no colpart), 4 256x192 (8 waves; layout_a 0, M % 256 == 0, N % 192 == 0).
+// stages: 0 auto, 2 .. 5 (256x192: always 2).
 int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
                      void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
                      int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
@@ -423,9 +442,11 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
     return MTVAF_ERR_ALIGN;
   const bool can128 = N % 128 == 0, can96 = N % 96 == 0 && !colpart;
   const bool can256 = can128 && M % 256 == 0 && layout_a == 0 && !colpart;
-  int bn = tile == 1 ? 96 : ((tile == 2 || tile == 3) ? 128 : 0);
-  int bm = tile == 3 ? 256 : 128;
-  if ((bn == 96 && !can96) || (bn == 128 && !can128) || (bm == 256 && !can256)) return MTVAF_ERR_SHAPE;
+  const bool can192 = N % 192 == 0 && M % 256 == 0 && layout_a == 0;
+  int bn = tile == 1 ? 96 : ((tile == 2 || tile == 3) ? 128 : (tile == 4 ? 192 : 0));
+  int bm = (tile == 3 || tile == 4) ? 256 : 128;
+  if ((bn == 96 && !can96) || (bn == 128 && !can128) || (bm == 256 && bn == 128 && !can256) || (bn == 192 && !can192))
+    return MTVAF_ERR_SHAPE;
   if (bn == 0) {
     const long t128 = can128 ? (long)(M / 128) * (N / 128) : 0;
     if (!can96) bn = 128;
@@ -435,6 +456,11 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
     // (measured, tools/bf16x_bench.py at M = 65536: +6..10 % on the KC x KC products with the 3-deep ring; no gain with a
     // k-major B operand)
     if (can256 && layout_b == 0 && (long)(M / 256) * (N / 128) >= 1024) { bm = 256; bn = 128; }
+    // wide outputs at one tile per CU: the 256x192 tile moves 0.57x the operand bytes of 128x128 through the L2 -> LDS
+    // path (measured at M = 4096: QKV forward 32 -> 29 us, FFN-1 forward 39 -> 36, FFN-2 dX 45 -> 39; with two rounds of
+    // tiles -- M = 8192 -- its single co-resident block per CU gives the gain back)
+    const long t192 = can192 ? (long)(M / 256) * (N / 192) : 0;
+    if (t192 >= 192 && t192 <= 256) { bm = 256; bn = 192; }
   }
   const long tiles = (long)(M / bm) * (N / bn);
   const bool split_ok = allow_split && epi == EPI_NONE && C32 && !C16 && !colpart;
@@ -465,8 +491,9 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
   // measured (tools/bf16x_bench.py): with 4-wave blocks two co-resident blocks beat the deeper ring on every shape of the
   // path; the 8-wave 256x128 block (one per CU) wants the 3-deep ring
   if (stages < 2 || stages > 5) stages = bm == 256 ? 3 : 2;
+  if (bn == 192) stages = 2;  // (the only ring that fits: 2 x 56 KB)
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
-  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages >= 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256), layout_a, layout_b, 2, M, N, K, splits};
+  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages >= 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256) + 32 * (bn == 192), layout_a, layout_b, 2, M, N, K, splits};
   const int rec = prof_begin(key, stream);
   int rc;
   if (layout_a == 0 && layout_b == 0) rc = launch_layout<false, false>(a, bm, bn, stages, grid, stream);

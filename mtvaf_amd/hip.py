@@ -202,7 +202,7 @@ def kernel_symbol(cfg, la, lb, fast):
     b = lambda x: "true" if x else "false"
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE>
         c = cfg - 300
-        t = "256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1")
+        t = "256, 192, 4, 2" if c & 32 else ("256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"))
         return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}>"
     if cfg >= 100:
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]

@@ -656,7 +656,8 @@ def test_gemm_splitk_with_tanh_epilogues(hip):
     close(lg, F.linear(xs.double(), ws.double(), bs.double()), rtol=3e-4, name="auto split skinny")
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 96, 64), (256, 384, 192), (512, 768, 768), (384, 128, 4096), (128, 128, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 96, 64), (256, 384, 192), (512, 768, 768), (384, 128, 4096), (128, 128, 64),
+                                   (512, 192, 128)])
 def test_gemm_bf16_operands(hip, M, N, K):
     """bf16-OPERAND kernel (gemm_bf16x.hip): exact model = fp64 products of the bf16-rounded operands.  All three operand
     layout pairs of the path (forward KCxKC, dX KCxKM, dW KMxKM: the SAME row-major tensors read in both roles through
@@ -676,7 +677,8 @@ def test_gemm_bf16_operands(hip, M, N, K):
     for name, a_, la, b_, lb in layouts:
         for stages in (2, 3):
             for tile in ([0] + ([1] if N % 96 == 0 else []) + ([2] if N % 128 == 0 else []) +
-                         ([3] if (N % 128 == 0 and M % 256 == 0 and la == hip.KC) else [])):
+                         ([3] if (N % 128 == 0 and M % 256 == 0 and la == hip.KC) else []) +
+                         ([4] if (N % 192 == 0 and M % 256 == 0 and la == hip.KC and stages == 2) else [])):
                 out.fill_(float("nan"))
                 hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, bias=bd, tile=tile, stages=stages)
                 close(out, ref + b.double(), rtol=2e-5, name=f"{name} bias tile {tile} stages {stages}")
@@ -699,15 +701,22 @@ def test_gemm_bf16_operands(hip, M, N, K):
     pre = rnd(M, N, seed=5).to(torch.bfloat16)
     pd = pre.double().requires_grad_(True)
     F.gelu(pd).sum().backward()
-    if N % 128 == 0:
+    for tile in ([0] if N % 128 == 0 else []) + ([4] if (N % 192 == 0 and M % 256 == 0) else []):
         part = torch.full((M // 128, N), float("nan"), device=DEV)
-        hip.gemm_bf16x(xh, hip.KC, wt, hip.KM, M, N, K, out32=out, out16=o16, epi=hip.EPI_DGELU, aux16=pre.to(DEV), colpart=part)
-        close(out, ref * pd.grad, rtol=3e-5, atol=3e-6 * float(ref.abs().max()), name="dgelu")
+        hip.gemm_bf16x(xh, hip.KC, wt, hip.KM, M, N, K, out32=out, out16=o16, epi=hip.EPI_DGELU, aux16=pre.to(DEV), colpart=part,
+                       tile=tile)
+        close(out, ref * pd.grad, rtol=3e-5, atol=3e-6 * float(ref.abs().max()), name=f"dgelu tile {tile}")
+        assert torch.equal(o16, out.to(torch.bfloat16))
         cs = torch.empty(N, device=DEV)
         hip.colsum_small(part, cs)
         close(cs, out.double().sum(0), rtol=1e-5, atol=1e-5 * float(out.abs().sum(0).max()), name="colsum")
         hip.colsum_small(part, cs, accumulate=True)
         close(cs, 2 * out.double().sum(0), rtol=1e-5, atol=2e-5 * float(out.abs().sum(0).max()), name="colsum acc")
+    if N % 192 == 0 and M % 256 == 0:  # the 256x192 tile with the GELU epilogue (two 128-row epilogue passes)
+        hip.gemm_bf16x(xh, hip.KC, wh, hip.KC, M, N, K, out32=out, out16=o16, bias=bd, epi=hip.EPI_GELU, aux16=pre16, tile=4)
+        assert (pre16.cpu() != pre_ref).float().mean() < 2e-3
+        close(out, F.gelu(pre16.double().cpu()), rtol=2e-5, atol=2e-6 * float(ref.abs().max()), name="gelu tile 4")
+        assert torch.equal(o16, out.to(torch.bfloat16))
     acc0 = rnd(M, N, seed=6)
     out.copy_(acc0)
     hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, accumulate=True)

@@ -41,11 +41,11 @@ def main():
             aux = bf(m, n)
             bias = torch.randn(n, device=dev)
             best = None
-            for tile in (1, 2, 3):
-                if (tile == 1 and n % 96) or (tile == 3 and (la == 1 or m % 256 or kw.get("dgelu"))):
+            for tile in (1, 2, 3, 4):
+                if (tile == 1 and n % 96) or (tile == 3 and (la == 1 or m % 256 or kw.get("dgelu"))) or (tile == 4 and (la == 1 or m % 256 or n % 192)):
                     continue
-                for stages in (2, 3, 4, 5):
-                    if (tile == 3 and stages > 3) or (tile == 2 and stages > 4):
+                for stages in (2, 3):
+                    if (tile == 3 and stages > 3) or (tile == 2 and stages > 4) or (tile == 4 and stages != 2):
                         continue
                     def run():
                         if kw.get("split"):
@@ -58,7 +58,7 @@ def main():
                             hip.gemm_bf16x(a, la, b, lb, m, n, k, out32=out32, bias=bias, tile=tile, stages=stages)
                     us = t(run)
                     tf = 2.0 * m * n * k / us / 1e6
-                    print(f"M={M:6d} {name:14s} [{m:5d}x{n:5d}x{k:5d}] tile {['', '128x96 ', '128x128', '256x128'][tile]} stages {stages}: {us:8.1f} us {tf:7.1f} TF", flush=True)
+                    print(f"M={M:6d} {name:14s} [{m:5d}x{n:5d}x{k:5d}] tile {['', '128x96 ', '128x128', '256x128', '256x192'][tile]} stages {stages}: {us:8.1f} us {tf:7.1f} TF", flush=True)
                     if best is None or us < best[0]:
                         best = (us, tile, stages)
             us_auto = t(lambda: (hip.gemm_bf16x(a, la, b, lb, m, n, k, out32=out32, allow_split=bool(kw.get("split")))
