@@ -218,7 +218,9 @@ int mtvaf_mask_mul(const float* x, const float* row_keep, const float* col_keep,
  * 1 bias + erf-GELU (pre-activation saved to aux16 as bf16), 3 multiply by GELU'(aux16).  colpart [M/128][N] (optional):
  * per-tile column sums of the result, finished by mtvaf_colsum_small (the bias gradient of the layer that produced the
  * operand).  Deterministic split-K as mtvaf_gemm_f32 (fp32 result only).  Aligned shapes only (M % 128, N % 128 or N % 96, K % 64, ld % 8, 16-byte aligned pointers): MTVAF_ERR_SHAPE / _ALIGN otherwise.
- * tile: 0 auto, 1 128x96, 2 128x128; stages: 0 auto, 2 (two blocks per CU), 3 (one block, two k-tiles in flight).
+ * tile: 0 auto, 1 128x96, 2 128x128, 3 256x128 (8 waves; layout_a 0, M % 256 == 0, no colpart), 4 256x192 (8 waves;
+ * layout_a 0, M % 256 == 0, N % 192 == 0); stages: 0 auto, 2 (two blocks per CU), 3..5 (one block, stages - 1 k-tiles
+ * in flight; the 256x192 tile always runs its 2-stage ring).
  * mtvaf_cast_bf16 makes the bf16 copies of the fp32 master weights. */
 int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
                      void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
