@@ -137,17 +137,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const float* kfrag = Ks + lq * LDK + 4 * g;
   const float* vcol = Vs + 4 * g * LDT + lq;
 
-  for (int t0 = 0; t0 < T; t0 += KT) {
-    f32x4 kreg[4], vreg[4];
+  // The next key tile travels global -> registers while the current one is being multiplied: its loads are issued
+  // right behind the barrier that publishes the current tile and are first needed at the top of the next iteration.
+  f32x4 kreg[4], vreg[4];
+  float mreg = NEG_BIG;
+  auto fetch = [&](int t0) {
     kv_load(kreg, ksrc, a.P, T, ldt, t0);
     kv_load(vreg, vsrc, a.P, T, ldt, t0);
-    float mreg = NEG_BIG;
     if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
+  };
+  fetch(0);
+  for (int t0 = 0; t0 < T; t0 += KT) {
     __syncthreads();
     kv_store<LDK>(Ks, kreg);
     kv_store<LDT>(Vs, vreg);
     if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? mreg * LOG2E : NEG_BIG;
     __syncthreads();
+    if (t0 + KT < T) fetch(t0 + KT);
     const int nsub = min(4, (T - t0 + 15) >> 4);  // 16-key sub-tiles of this tile that hold real keys
     f32x4 s[4];
     float tmax = NEG_BIG;
@@ -263,17 +269,21 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
   const float* vfrag = Vs + lq * LDK + 4 * g;
   const float* kcol = Ks + 4 * g * LDT + lq;
 
-  for (int t0 = 0; t0 < T; t0 += KT) {
-    f32x4 kreg[4], vreg[4];
+  f32x4 kreg[4], vreg[4];  // (the next key tile is fetched while the current one is multiplied, as in the forward)
+  float mreg = NEG_BIG;
+  auto fetch = [&](int t0) {
     kv_load(kreg, ksrc, a.P, T, ldt, t0);
     kv_load(vreg, vsrc, a.P, T, ldt, t0);
-    float mreg = NEG_BIG;
     if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
+  };
+  fetch(0);
+  for (int t0 = 0; t0 < T; t0 += KT) {
     __syncthreads();
     kv_store<LDT>(Ks, kreg);
     kv_store<LDK>(Vs, vreg);
     if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? mreg * LOG2E : NEG_BIG;
     __syncthreads();
+    if (t0 + KT < T) fetch(t0 + KT);
     const int nsub = min(4, (T - t0 + 15) >> 4);
     const uint32_t cterm0 = (uint32_t)(t0 + 4 * g) * ATTN_DROP_C2;
 #pragma unroll
@@ -382,17 +392,25 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
   const float* ocol = dOs + 4 * g * LDT + lk;
   const uint32_t row_base = (uint32_t)((b * a.NH + h) * a.S);
 
-  for (int q0 = 0; q0 < a.S; q0 += KT) {
-    f32x4 qr[4], orr[4];
-    float dsum[4];
+  // the next query tile (Q, dO, O rows, lse) is fetched while the current one is multiplied
+  f32x4 qr[4], orr[4], ofw[4];
+  float lreg = 1.0e30f;
+  auto fetch = [&](int q0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int qq = min(q0 + r0 + 16 * i, a.S - 1);
       qr[i] = *reinterpret_cast<const f32x4*>(qsrc + (long)qq * 3 * a.H);
       orr[i] = *reinterpret_cast<const f32x4*>(dosrc + (long)qq * a.H);
-      const f32x4 o = *reinterpret_cast<const f32x4*>(osrc + (long)qq * a.H);
-      dsum[i] = o.x * orr[i].x + o.y * orr[i].y + o.z * orr[i].z + o.w * orr[i].w;
+      ofw[i] = *reinterpret_cast<const f32x4*>(osrc + (long)qq * a.H);
     }
+    if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, a.S - 1)] * LOG2E;
+  };
+  fetch(0);
+  for (int q0 = 0; q0 < a.S; q0 += KT) {
+    float dsum[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      dsum[i] = ofw[i].x * orr[i].x + ofw[i].y * orr[i].y + ofw[i].z * orr[i].z + ofw[i].w * orr[i].w;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {  // the 16 threads of a row are 16 consecutive lanes
       dsum[i] += __shfl_xor(dsum[i], 1, 64);
@@ -400,8 +418,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
       dsum[i] += __shfl_xor(dsum[i], 4, 64);
       dsum[i] += __shfl_xor(dsum[i], 8, 64);
     }
-    float lreg = 1.0e30f;
-    if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, a.S - 1)] * LOG2E;
+    const float lcur = lreg;
     __syncthreads();
     kv_store<LDT>(Qs, qr);
     kv_store<LDT>(dOs, orr);
@@ -411,10 +428,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
     }
     if (threadIdx.x < KT) {
       const int qq = q0 + threadIdx.x;
-      lse_s[threadIdx.x] = qq < a.S ? lreg : 1.0e30f;
+      lse_s[threadIdx.x] = qq < a.S ? lcur : 1.0e30f;
       rh_s[threadIdx.x] = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), row_base + (uint32_t)qq);
     }
     __syncthreads();
+    if (q0 + KT < a.S) fetch(q0 + KT);
     // a wave whose 16 keys all lie beyond T (last key tile) only takes part in the staging and the barriers
     const int nsub = wave_live ? min(4, (a.S - q0 + 15) >> 4) : 0;
 #pragma unroll
