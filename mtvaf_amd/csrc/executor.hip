@@ -149,7 +149,7 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
   MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, cx, H, L->wo, H, L->a, H, M, H, H, L->bo, X_EPI_NONE, nullptr, 0, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
   MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden, L->seed,
                                      L->offset + 1, nullptr, st));
-  MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, L->h1, H, L->w1, H, act, I, M, I, H, L->bi1, X_EPI_GELU, pre, I, 0, 0, nullptr, 0, -1, -1, st));
+  MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, L->h1, H, L->w1, H, act, I, M, I, H, L->bi1, X_EPI_GELU, pre, I, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
   MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, act, I, L->w2, I, L->f, H, M, H, I, L->bi2, X_EPI_NONE, nullptr, 0, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
   MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->f, L->h1, L->g2, L->b2, L->h2, L->mean2, L->rstd2, M, H, L->eps, L->p_hidden, L->seed,
                                      L->offset + 2, nullptr, st));
@@ -207,7 +207,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, df, H, act, I, g->dw2, I, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, side));
-    MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, df, H, L->w2, I, dpre, I, M, I, H, nullptr, X_EPI_DGELU, pre, I, 0, 0, nullptr, 0, -1, -1, mainS));
+    MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, df, H, L->w2, I, dpre, I, M, I, H, nullptr, X_EPI_DGELU, pre, I, 0, 1, g->ws_main, g->ws_main_bytes, -1, -1,
+                             mainS));
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, dpre, I, L->h1, H, g->dw1, H, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,

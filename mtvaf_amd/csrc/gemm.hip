@@ -518,11 +518,12 @@ __global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma
   }
 }
 
-// dst[r][c] (ld ldd) = (accumulate ? dst : 0) + epi(sum_z slabs[z][r][c] + bias[c]);  epi: none, tanh, or
-// multiply by 1 - aux^2 (the two element-wise epilogues that may follow a split product)
+// dst[r][c] (ld ldd) = (accumulate ? dst : 0) + epi(sum_z slabs[z][r][c] + bias[c]);  every element-wise epilogue of the
+// main kernels (tanh, erf-GELU with the pre-activation saved to aux, multiply by GELU'(aux) or by 1 - aux^2): the
+// few-token products (bs 4: M = 256) are worth splitting whatever follows them
 __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits, long slab_stride, float* dst,
                                      int rows, int cols, int ldd, const float* bias, int accumulate, int epi,
-                                     const float* __restrict__ aux, int ldaux) {
+                                     float* aux, int ldaux) {
   const long n = (long)rows * cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols), c = (int)(i % cols);
@@ -531,6 +532,11 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
     if (bias) s += bias[c];
     if (epi == EPI_TANH) {
       s = tanhf(s);
+    } else if (epi == EPI_GELU) {
+      aux[(long)r * ldaux + c] = s;
+      s = gelu_erf(s);
+    } else if (epi == EPI_DGELU) {
+      s *= gelu_erf_grad(aux[(long)r * ldaux + c]);
     } else if (epi == EPI_DTANH) {
       const float t = aux[(long)r * ldaux + c];
       s *= (1.f - t * t);
@@ -542,7 +548,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
 }
 
 // epilogues that commute with the ordered slab reduction (applied by splitk_reduce_kernel)
-static inline bool splittable(int epi) { return epi == EPI_NONE || epi == EPI_TANH || epi == EPI_DTANH; }
+static inline bool splittable(int epi) { return epi >= EPI_NONE && epi <= EPI_DTANH; }
 
 struct TileCfg { int bm, bn, bk; };
 static const TileCfg kCfgs[] = {{128, 128, 16}, {128, 96, 16}, {128, 288, 16}, {64, 64, 16}, {128, 64, 16},
@@ -609,7 +615,7 @@ int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, boo
 
 // ordered split-K slab reduction (+ bias / tanh / dtanh epilogue), shared with gemm_bf16kc.hip
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
-                         int epi, const float* aux, int ldaux, hipStream_t stream) {
+                         int epi, float* aux, int ldaux, hipStream_t stream) {
   const long n = (long)M * N;
   const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, splits, n, C, M, N, ldc, bias,
@@ -844,7 +850,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     const long n = (long)M * N;
     int blocks = (int)std::min<long>(cdiv(n, 256), 2048);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, splits,
-                       (long)M * N, C, M, N, ldc, bias, accumulate, epi, (const float*)aux, ldaux);
+                       (long)M * N, C, M, N, ldc, bias, accumulate, epi, aux, ldaux);
     MTVAF_LAUNCH_CHECK();
   }
   return MTVAF_OK;

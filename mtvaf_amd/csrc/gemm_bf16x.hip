@@ -29,7 +29,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
-                         int epi, const float* aux, int ldaux, hipStream_t stream);  // gemm.hip
+                         int epi, float* aux, int ldaux, hipStream_t stream);  // gemm.hip
 int prof_begin(const int key[8], hipStream_t stream);                                // gemm.hip (launch profiler)
 void prof_end(int rec, hipStream_t stream);
 

@@ -268,9 +268,9 @@ def linear_fwd(x, w, bias, out, epi=EPI_NONE, aux=None):
     """out[M,N] = x[M,K] . w[N,K]^T + bias  (nn.Linear)."""
     M, K = x.shape
     N = w.shape[0]
-    # plain bias epilogues may use the deterministic split-K (few output tiles, long K: e.g. the projector
-    # logits [288, 48] x K = 6144); the planner only splits when the tile grid underfills the chip
-    return gemm(x, KC, w, KC, out, M, N, K, bias=bias, epi=epi, aux=aux, allow_split=(epi in (EPI_NONE, EPI_TANH)))
+    # every epilogue may follow the deterministic split-K (few output tiles, long K: e.g. the projector logits
+    # [288, 48] x K = 6144, every product of a bs-4 step); the planner only splits when the tile grid underfills the chip
+    return gemm(x, KC, w, KC, out, M, N, K, bias=bias, epi=epi, aux=aux, allow_split=True)
 
 
 def linear_bwd_input(dy, w, dx, accumulate=False, epi=EPI_NONE, aux=None):
@@ -278,7 +278,7 @@ def linear_bwd_input(dy, w, dx, accumulate=False, epi=EPI_NONE, aux=None):
     M, N = dy.shape
     K = w.shape[1]
     return gemm(dy, KC, w, KM, dx, M, K, N, accumulate=accumulate, epi=epi, aux=aux,
-                allow_split=(epi in (EPI_NONE, EPI_DTANH)))
+                allow_split=True)
 
 
 def linear_bwd_weight(dy, x, dw, accumulate=False):
