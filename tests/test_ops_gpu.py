@@ -466,6 +466,43 @@ def test_crf(hip, B, S, C, scale):
     assert all(int((row[int(n):] != -1).sum()) == 0 for row, n in zip(tg.cpu(), ln.cpu()))
 
 
+def test_crf_random_shapes(hip):
+    """Thirty random (B, S, C, lengths, holes) draws: loss, all gradients and Viterbi paths of the hand-scheduled kernels
+    against the oracle -- S crosses the 8-step unroll groups and the 64-step mask words at arbitrary offsets."""
+    gnr = torch.Generator().manual_seed(2024)
+    g = lambda t: t.to(DEV)
+    for it in range(30):
+        B = int(torch.randint(1, 7, (1,), generator=gnr))
+        S = int(torch.randint(1, 200, (1,), generator=gnr))
+        C = int(torch.randint(2, 17, (1,), generator=gnr))
+        em, tags, mask, start, end, trans = _crf_inputs(B, S, C, 1000 + it)
+        if it % 3 == 0 and S > 2:
+            holes = torch.rand(B, S, generator=gnr) < 0.15
+            holes[:, 0] = False
+            mask = mask * (~holes).to(mask.dtype)
+        emd, sd_, ed, td = (t.double().requires_grad_(True) for t in (em, start, end, trans))
+        ref = -O.crf_log_likelihood(emd, tags, mask, sd_, ed, td, "mean")
+        ref.backward()
+        ws, wsb = hip.crf_workspace(B, S, C, DEV)
+        loss = torch.empty(1, device=DEV)
+        args = (g(em), g(tags), g(mask), g(start), g(end), g(trans))
+        hip.crf_nll_fwd(*args, loss, ws, wsb)
+        tag = f"draw {it}: B={B} S={S} C={C}"
+        close(loss, ref.reshape(1), rtol=2e-5, name="crf loss " + tag)
+        dem = torch.empty(B, S, C, device=DEV)
+        ds, de, dt = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, C, device=DEV)
+        hip.crf_nll_bwd(None, *args, dem, ds, de, dt, False, ws, wsb)
+        close(dem, emd.grad, rtol=1e-4, atol=2e-6, name="crf dem " + tag)
+        close(ds, sd_.grad, rtol=1e-4, atol=2e-6, name="crf dstart " + tag)
+        close(de, ed.grad, rtol=1e-4, atol=2e-6, name="crf dend " + tag)
+        close(dt, td.grad if td.grad is not None else torch.zeros_like(td), rtol=1e-4, atol=2e-6, name="crf dtrans " + tag)
+        tg, ln = torch.empty(B, S, dtype=torch.int32, device=DEV), torch.empty(B, dtype=torch.int32, device=DEV)
+        hip.crf_viterbi(g(em), g(mask), g(start), g(end), g(trans), tg, ln)
+        want = O.crf_decode(em, mask, start, end, trans)
+        got = [[int(t) for t in row[: int(n)]] for row, n in zip(tg.cpu(), ln.cpu())]
+        assert got == want, tag
+
+
 def test_crf_bruteforce_known_answer(hip):
     em, tags, mask, start, end, trans = _crf_inputs(3, 5, 11, 77, lengths=[4, 3, 1])
     logZ, best = O.crf_bruteforce(em, mask, start, end, trans)
