@@ -93,6 +93,21 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
                           float* dpk, float* dpv, int B, int S, int P, int NH, int head_dim, float p_drop,
                           uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
 
+/* The same attention over PACKED token rows (padding-free execution): cu [B+1] int32 -- sentence b owns rows
+ * cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / dqkv (its unmasked tokens in order, at most S).  Every kept key is unmasked,
+ * so no additive mask is read (a masked key contributes exp(-10000) = 0 in the padded form: dropping it is exact);
+ * lse / delta stay [B,NH,S].  Rows outside every sentence are not written. */
+int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, float* ctx, float* lse, int B,
+                                 int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                 mtvaf_stream_t stream);
+int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu,
+                                 const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
+                                 int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
+/* dst[r][:] = map[r] >= 0 ? src[map[r]][:] : 0  (rows_dst rows of H floats): packs / unpacks token rows. */
+int mtvaf_gather_rows(const float* src, const int* map, float* dst, int rows_dst, int H, mtvaf_stream_t stream);
+/* p[0..n) = 0 (a kernel, not hipMemsetAsync: usable inside captured graphs, see rowops.hip). */
+int mtvaf_zero_f32(float* p, long n, mtvaf_stream_t stream);
+
 /* ---- embeddings + LayerNorm + dropout -----------------------------------------------------------------
  * replaces BertEmbeddings.forward (modeling_bert.py:212-222) / RobertaEmbeddings.forward
  * (modeling_roberta.py:102-140) and create_position_ids_from_input_ids (:1706-1719).  pos_ids == NULL
@@ -271,6 +286,11 @@ typedef struct {
   void* h2_h;
   float *mean2, *rstd2;
   void* ws; size_t ws_bytes;
+  /* padding-free execution (fp32 mode): cu != NULL -> the token tensors (x, qkv ... h2, and the gradient buffers) hold Mp
+   * PACKED rows -- the Mv unmasked tokens sentence by sentence (cu [B+1] int32 row offsets), then Mp - Mv zero rows that
+   * pad the image to whole 128-row tiles; lse / delta keep [B,NH,S].  cu == NULL: the padded [B*S] layout. */
+  const int* cu;
+  int Mv, Mp;
 } mtvaf_layer_t;
 
 typedef struct {

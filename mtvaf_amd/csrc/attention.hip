@@ -45,7 +45,26 @@ struct AttnArgs {
   float scale, p_drop;
   uint32_t drop_key, drop_thr;
   const uint64_t* epoch;  // device-side dropout epoch (captured launches), or NULL
+  // PACKED token rows (padding-free execution): sentence b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / dqkv (its
+  // unmasked tokens, in order), every kept key is unmasked (addmask is not read), queries beyond the sentence do not
+  // exist.  NULL: the padded [B, S] layout.  lse / delta / the dropout row ids keep the [B, NH, S] indexing either way.
+  const int* cu;
 };
+
+struct Sent {
+  long tok0;  // first token row of the sentence
+  int n;      // its text tokens (queries; text keys)
+};
+__device__ __forceinline__ Sent sentence(const AttnArgs& a, int b) {
+  if (a.cu) {
+    const int c0 = a.cu[b];
+    return Sent{(long)c0, a.cu[b + 1] - c0};
+  }
+  return Sent{(long)b * a.S, a.S};
+}
+__device__ __forceinline__ float mask_at(const AttnArgs& a, int b, int Tf, int t) {
+  return a.cu ? 0.f : a.addmask[(long)b * Tf + t];
+}
 
 
 // Keys behind the LAST unmasked text position of a sentence (trailing padding: additive mask -10000) contribute exactly 0
@@ -108,10 +127,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 64 + wave * 16 + lq;
+  const Sent sn = sentence(a, b);
+  const int Sb = sn.n;
+  if ((int)blockIdx.x * 64 >= Sb) return;  // (block-uniform; packed rows: a query tile beyond the sentence)
   const int Tf = a.P + a.S;  // row length of the additive mask
   __shared__ int t_eff_slot;
-  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
-  const bool qok = q < a.S;
+  const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
+  const bool qok = q < Sb;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;  // scores are kept in the log2 domain: one v_exp_f32 per probability
@@ -120,13 +142,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   KvSrc ksrc, vsrc;
   ksrc.pre = a.pk + ((long)b * a.P * a.NH + (long)h * a.P) * D + c4;
   vsrc.pre = a.pv + ((long)b * a.P * a.NH + (long)h * a.P) * D + c4;
-  ksrc.txt = a.qkv + (long)b * a.S * 3 * a.H + a.H + h * D + c4;
+  ksrc.txt = a.qkv + sn.tok0 * 3 * a.H + a.H + h * D + c4;
   vsrc.txt = ksrc.txt + a.H;
   const int ldt = 3 * a.H;
 
   f32x4 qreg[4];
   {
-    const float* qp = a.qkv + ((long)b * a.S + min(q, a.S - 1)) * 3 * a.H + h * D + 4 * g;
+    const float* qp = a.qkv + (sn.tok0 + min(q, Sb - 1)) * 3 * a.H + h * D + 4 * g;
 #pragma unroll
     for (int db = 0; db < 4; ++db) qreg[db] = *reinterpret_cast<const f32x4*>(qp + 16 * db);
   }
@@ -144,7 +166,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   auto fetch = [&](int t0) {
     kv_load(kreg, ksrc, a.P, T, ldt, t0);
     kv_load(vreg, vsrc, a.P, T, ldt, t0);
-    if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
+    if (threadIdx.x < KT) mreg = mask_at(a, b, Tf, min(t0 + (int)threadIdx.x, T - 1));
   };
   fetch(0);
   for (int t0 = 0; t0 < T; t0 += KT) {
@@ -212,7 +234,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const float inv_l = 1.f / l_run;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<f32x4*>(a.ctx + ((long)b * a.S + q) * a.H + h * D + 16 * dt + 4 * g) = oacc[dt] * inv_l;
+      *reinterpret_cast<f32x4*>(a.ctx + (sn.tok0 + q) * a.H + h * D + 16 * dt + 4 * g) = oacc[dt] * inv_l;
     if (g == 0) a.lse[((long)b * a.NH + h) * a.S + q] = (m_run + log2f(l_run)) * LN2;
   }
 }
@@ -226,9 +248,12 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = qtile * 64 + wave * 16 + lq;
+  const Sent sn = sentence(a, b);
+  const int Sb = sn.n;
+  if (qtile * 64 >= Sb) return;  // (block-uniform)
   const int Tf = a.P + a.S;
-  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
-  const bool qok = q < a.S;
+  const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
+  const bool qok = q < Sb;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
@@ -237,14 +262,14 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
   KvSrc ksrc, vsrc;
   ksrc.pre = a.pk + ((long)b * a.P * a.NH + (long)h * a.P) * D + c4;
   vsrc.pre = a.pv + ((long)b * a.P * a.NH + (long)h * a.P) * D + c4;
-  ksrc.txt = a.qkv + (long)b * a.S * 3 * a.H + a.H + h * D + c4;
+  ksrc.txt = a.qkv + sn.tok0 * 3 * a.H + a.H + h * D + c4;
   vsrc.txt = ksrc.txt + a.H;
   const int ldt = 3 * a.H;
 
   f32x4 qreg[4], doreg[4];
   float dl = 0.f;
   {
-    const long qrow = (long)b * a.S + min(q, a.S - 1);
+    const long qrow = sn.tok0 + min(q, Sb - 1);
     const float* qp = a.qkv + qrow * 3 * a.H + h * D + 4 * g;
     const float* dop = a.dctx + qrow * a.H + h * D + 4 * g;
     const float* op = a.ctx + qrow * a.H + h * D + 4 * g;
@@ -274,7 +299,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
   auto fetch = [&](int t0) {
     kv_load(kreg, ksrc, a.P, T, ldt, t0);
     kv_load(vreg, vsrc, a.P, T, ldt, t0);
-    if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
+    if (threadIdx.x < KT) mreg = mask_at(a, b, Tf, min(t0 + (int)threadIdx.x, T - 1));
   };
   fetch(0);
   for (int t0 = 0; t0 < T; t0 += KT) {
@@ -322,7 +347,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
   if (qok) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<f32x4*>(a.dqkv + ((long)b * a.S + q) * 3 * a.H + h * D + 16 * dt + 4 * g) = dq[dt];
+      *reinterpret_cast<f32x4*>(a.dqkv + (sn.tok0 + q) * 3 * a.H + h * D + 16 * dt + 4 * g) = dq[dt];
   }
 }
 
@@ -339,12 +364,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lk = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int Tf = a.P + a.S;
-  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);  // keys >= T: trailing padding, dK = dV = 0
+  const Sent sn = sentence(a, b);
+  const int Sb = sn.n;
+  const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * (a.P + a.S), a.P, a.S, t_eff_slot);  // keys >= T: trailing padding, dK = dV = 0
+  const int Tf = a.cu ? T : a.P + a.S;  // (packed rows: keys beyond the sentence do not exist)
   const int key = ktile * 64 + wave * 16 + lk;
   if (ktile * 64 >= T) {  // (block-uniform) a key tile of trailing padding only: exact zeros, no query loop
     if (key < Tf) {
-      float* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+      float* dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -359,14 +386,14 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
   const int keyc = min(key, T - 1);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   // keys beyond T: mask -1e30 makes their probabilities exactly 0
-  const float mval2 = kok ? a.addmask[(long)b * Tf + key] * LOG2E : NEG_BIG;
+  const float mval2 = kok ? mask_at(a, b, Tf, key) * LOG2E : NEG_BIG;
   const float sc2 = a.scale * LOG2E;
   const uint32_t cterm = (uint32_t)key * ATTN_DROP_C2;
 
   KvSrc ksrc, vsrc;
   ksrc.pre = a.pk + ((long)b * a.P * a.NH + (long)h * a.P) * D + 4 * g;
   vsrc.pre = a.pv + ((long)b * a.P * a.NH + (long)h * a.P) * D + 4 * g;
-  ksrc.txt = a.qkv + (long)b * a.S * 3 * a.H + a.H + h * D + 4 * g;
+  ksrc.txt = a.qkv + sn.tok0 * 3 * a.H + a.H + h * D + 4 * g;
   vsrc.txt = ksrc.txt + a.H;
   f32x4 kreg[4], vreg[4];
   {
@@ -383,9 +410,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
   for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int c4 = (threadIdx.x & 15) * 4, r0 = threadIdx.x >> 4;
-  const float* qsrc = a.qkv + (long)b * a.S * 3 * a.H + h * D + c4;
-  const float* dosrc = a.dctx + (long)b * a.S * a.H + h * D + c4;
-  const float* osrc = a.ctx + (long)b * a.S * a.H + h * D + c4;
+  const float* qsrc = a.qkv + sn.tok0 * 3 * a.H + h * D + c4;
+  const float* dosrc = a.dctx + sn.tok0 * a.H + h * D + c4;
+  const float* osrc = a.ctx + sn.tok0 * a.H + h * D + c4;
   const float* qfrag = Qs + lk * LDT + 4 * g;
   const float* ofrag = dOs + lk * LDT + 4 * g;
   const float* qcol = Qs + 4 * g * LDT + lk;
@@ -398,15 +425,15 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
   auto fetch = [&](int q0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int qq = min(q0 + r0 + 16 * i, a.S - 1);
+      const int qq = min(q0 + r0 + 16 * i, Sb - 1);
       qr[i] = *reinterpret_cast<const f32x4*>(qsrc + (long)qq * 3 * a.H);
       orr[i] = *reinterpret_cast<const f32x4*>(dosrc + (long)qq * a.H);
       ofw[i] = *reinterpret_cast<const f32x4*>(osrc + (long)qq * a.H);
     }
-    if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, a.S - 1)] * LOG2E;
+    if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, Sb - 1)] * LOG2E;
   };
-  fetch(0);
-  for (int q0 = 0; q0 < a.S; q0 += KT) {
+  if (Sb > 0) fetch(0);
+  for (int q0 = 0; q0 < Sb; q0 += KT) {
     float dsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -428,13 +455,13 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
     }
     if (threadIdx.x < KT) {
       const int qq = q0 + threadIdx.x;
-      lse_s[threadIdx.x] = qq < a.S ? lcur : 1.0e30f;
+      lse_s[threadIdx.x] = qq < Sb ? lcur : 1.0e30f;
       rh_s[threadIdx.x] = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), row_base + (uint32_t)qq);
     }
     __syncthreads();
-    if (q0 + KT < a.S) fetch(q0 + KT);
+    if (q0 + KT < Sb) fetch(q0 + KT);
     // a wave whose 16 keys all lie beyond T (last key tile) only takes part in the staging and the barriers
-    const int nsub = wave_live ? min(4, (a.S - q0 + 15) >> 4) : 0;
+    const int nsub = wave_live ? min(4, (Sb - q0 + 15) >> 4) : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nsub) {
@@ -480,7 +507,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
     }
   }
   if (!kok && key < Tf) {  // trailing padding inside a partially valid tile
-    float* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+    float* dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -495,7 +522,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
       dkrow = a.dpk + ((long)b * a.P * a.NH + (long)h * a.P + key) * D;
       dvrow = a.dpv + ((long)b * a.P * a.NH + (long)h * a.P + key) * D;
     } else {
-      dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D;
+      dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D;
       dvrow = dkrow + a.H;
     }
 #pragma unroll
@@ -536,22 +563,24 @@ using namespace mtvaf;
 
 extern "C" {
 
-// ctx[B*S,H], lse[B,NH,S] <- attention over [prefix ; text] keys.  head_dim must be 64.
-int mtvaf_prefix_attn_fwd(const float* qkv, const float* pk, const float* pv, const float* addmask, float* ctx,
-                          float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
-                          uint64_t offset, hipStream_t st) {
-  if (head_dim != D) return MTVAF_ERR_SHAPE;
-  AttnArgs a{};
-  a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.ctx = ctx; a.lse = lse;
+static void fill_common(AttnArgs& a, int B, int S, int P, int NH, float p_drop, uint64_t seed, uint64_t offset) {
   a.B = B; a.S = S; a.P = P; a.NH = NH; a.H = NH * D;
   a.scale = 0.125f; a.p_drop = p_drop;
   a.drop_thr = p_drop > 0.f ? (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f) : 0u;
-  {
-    // host-side replica of attn_dropout_key
-    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
-    a.drop_key = mix((uint32_t)seed ^ mix((uint32_t)(seed >> 32) ^ mix((uint32_t)offset ^ 0x9E3779B9u)));
-  }
+  // host-side replica of attn_dropout_key
+  auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
+  a.drop_key = mix((uint32_t)seed ^ mix((uint32_t)(seed >> 32) ^ mix((uint32_t)offset ^ 0x9E3779B9u)));
   a.epoch = rng_epoch_ptr();
+}
+
+static int attn_fwd_launch(const float* qkv, const float* pk, const float* pv, const float* addmask, const int* cu, float* ctx,
+                           float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                           hipStream_t st) {
+  if (head_dim != D) return MTVAF_ERR_SHAPE;
+  if (!cu && !addmask) return MTVAF_ERR_ARG;
+  AttnArgs a{};
+  a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.ctx = ctx; a.lse = lse;
+  fill_common(a, B, S, P, NH, p_drop, seed, offset);
   int rc = check(a);
   if (rc) return rc;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, NH, B), dim3(256), 0, st, a);
@@ -559,23 +588,15 @@ int mtvaf_prefix_attn_fwd(const float* qkv, const float* pk, const float* pv, co
   return MTVAF_OK;
 }
 
-// dqkv[B*S,3H] (all three column blocks overwritten), dpk/dpv[B,P*H] <- gradients; delta[B,NH,S] scratch.
-int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv,
-                          const float* addmask, const float* ctx, const float* lse, float* delta, float* dqkv,
-                          float* dpk, float* dpv, int B, int S, int P, int NH, int head_dim, float p_drop,
-                          uint64_t seed, uint64_t offset, hipStream_t st) {
+static int attn_bwd_launch(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
+                           const int* cu, const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv,
+                           int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
   if (head_dim != D) return MTVAF_ERR_SHAPE;
+  if (!cu && !addmask) return MTVAF_ERR_ARG;
   AttnArgs a{};
-  a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.ctx = const_cast<float*>(ctx);
+  a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.ctx = const_cast<float*>(ctx);
   a.lse = const_cast<float*>(lse); a.dctx = dctx; a.delta = delta; a.dqkv = dqkv; a.dpk = dpk; a.dpv = dpv;
-  a.B = B; a.S = S; a.P = P; a.NH = NH; a.H = NH * D;
-  a.scale = 0.125f; a.p_drop = p_drop;
-  a.drop_thr = p_drop > 0.f ? (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f) : 0u;
-  {
-    auto mix = [](uint32_t x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; };
-    a.drop_key = mix((uint32_t)seed ^ mix((uint32_t)(seed >> 32) ^ mix((uint32_t)offset ^ 0x9E3779B9u)));
-  }
-  a.epoch = rng_epoch_ptr();
+  fill_common(a, B, S, P, NH, p_drop, seed, offset);
   int rc = check(a);
   if (rc) return rc;
   if (P > 0 && (!dpk || !dpv)) return MTVAF_ERR_ARG;
@@ -583,6 +604,38 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(nq + (P + S + 63) / 64, NH, B), dim3(256), 0, st, a, nq);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
+}
+
+// ctx[B*S,H], lse[B,NH,S] <- attention over [prefix ; text] keys.  head_dim must be 64.
+int mtvaf_prefix_attn_fwd(const float* qkv, const float* pk, const float* pv, const float* addmask, float* ctx,
+                          float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                          uint64_t offset, hipStream_t st) {
+  return attn_fwd_launch(qkv, pk, pv, addmask, nullptr, ctx, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+}
+
+// dqkv[B*S,3H] (all three column blocks overwritten), dpk/dpv[B,P*H] <- gradients; delta[B,NH,S] scratch.
+int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv,
+                          const float* addmask, const float* ctx, const float* lse, float* delta, float* dqkv,
+                          float* dpk, float* dpv, int B, int S, int P, int NH, int head_dim, float p_drop,
+                          uint64_t seed, uint64_t offset, hipStream_t st) {
+  return attn_bwd_launch(dctx, qkv, pk, pv, addmask, nullptr, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed,
+                         offset, st);
+}
+
+// The same attention over PACKED token rows (padding-free execution): cu [B+1] int32 row offsets -- sentence b owns rows
+// cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / dqkv (its unmasked tokens, at most S of them).  Every kept key is unmasked, so
+// no additive mask is read; lse / delta stay [B,NH,S].  Rows of ctx / dqkv outside every sentence are not written.
+int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, float* ctx, float* lse, int B,
+                                 int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+  if (!cu) return MTVAF_ERR_ARG;
+  return attn_fwd_launch(qkv, pk, pv, nullptr, cu, ctx, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+}
+
+int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu,
+                                 const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
+                                 int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+  if (!cu) return MTVAF_ERR_ARG;
+  return attn_bwd_launch(dctx, qkv, pk, pv, nullptr, cu, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed, offset, st);
 }
 
 }  // extern "C"

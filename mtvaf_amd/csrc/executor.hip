@@ -37,6 +37,12 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
                                const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
                                float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
                                float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
+int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, float* ctx, float* lse, int B,
+                                 int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
+int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu,
+                                 const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
+                                 int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
+int mtvaf_zero_f32(float* p, long n, hipStream_t st);
 int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                              float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
                              uint64_t offset, void* out_bf16, hipStream_t st);
@@ -103,6 +109,8 @@ struct mtvaf_layer_t {
   void* h2_h;
   float *mean2, *rstd2;
   void* ws; size_t ws_bytes;                   // main-stream scratch of the forward pass (split-K slabs of small-M products)
+  const int* cu;                               // padding-free execution: [B+1] row offsets of the PACKED token tensors, or NULL
+  int Mv, Mp;                                  // valid rows, rows of the packed image (Mv rounded up to whole 128-row tiles)
 };
 
 struct mtvaf_layer_grads_t {
@@ -119,7 +127,9 @@ struct mtvaf_layer_grads_t {
 
 int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
   if (!L) return MTVAF_ERR_ARG;
-  const int M = L->B * L->S, H = L->H, I = L->I;
+  // padding-free execution: the row-wise kernels simply see Mp packed rows; only attention knows about sentences
+  if (L->cu && (L->bf16 || L->Mp <= 0 || L->Mp % 128 || L->Mv <= 0 || L->Mv > L->Mp)) return MTVAF_ERR_ARG;
+  const int M = L->cu ? L->Mp : L->B * L->S, H = L->H, I = L->I;
   if (L->bf16) {
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KC, L->x_h, H, L->wqkv_h, H, nullptr, 0, L->qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE,
                                nullptr, 0, 0, nullptr, 0, nullptr, 0, 0, -1, 0, st));
@@ -144,8 +154,15 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
   // (plain-bias products may use the deterministic split-K: the planner only splits when the tile grid underfills the chip)
   MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, L->x, H, L->wqkv, H, qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE, nullptr, 0, 0, 1, L->ws,
                            L->ws_bytes, -1, -1, st));
-  MTVAF_TRY(mtvaf_prefix_attn_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx, L->lse,
-                                  L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
+  if (L->cu) {
+    MTVAF_TRY(mtvaf_prefix_attn_varlen_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu, cx, L->lse,
+                                           L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
+    // the rows that pad the packed image belong to no sentence: zero them (0 x NaN of an unwritten row would poison dW)
+    MTVAF_TRY(mtvaf_zero_f32(cx + (long)L->Mv * H, (long)(L->Mp - L->Mv) * H, st));
+  } else {
+    MTVAF_TRY(mtvaf_prefix_attn_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx, L->lse,
+                                    L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
+  }
   MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, cx, H, L->wo, H, L->a, H, M, H, H, L->bo, X_EPI_NONE, nullptr, 0, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
   MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden, L->seed,
                                      L->offset + 1, nullptr, st));
@@ -161,7 +178,8 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
 // behind every product that still reads the weights).
 int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g, hipStream_t mainS, hipStream_t side, int settle) {
   if (!L || !g) return MTVAF_ERR_ARG;
-  const int M = L->B * L->S, H = L->H, I = L->I, B = L->B, S = L->S, P = L->P, NH = L->NH;
+  if (L->cu && (L->bf16 || L->Mp <= 0 || L->Mp % 128 || L->Mv <= 0 || L->Mv > L->Mp)) return MTVAF_ERR_ARG;
+  const int M = L->cu ? L->Mp : L->B * L->S, H = L->H, I = L->I, B = L->B, S = L->S, P = L->P, NH = L->NH;
   if (L->bf16) {
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0,
                                        M, H, L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, g->df, mainS));
@@ -222,8 +240,15 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
                              g->ws_side_bytes, -1, -1, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, da, H, L->wo, H, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_main,
                              g->ws_main_bytes, -1, -1, mainS));
-    MTVAF_TRY(mtvaf_prefix_attn_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx,
-                                    L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+    if (L->cu) {
+      MTVAF_TRY(mtvaf_prefix_attn_varlen_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu, cx,
+                                             L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset,
+                                             mainS));
+      MTVAF_TRY(mtvaf_zero_f32(dqkv + (long)L->Mv * 3 * H, (long)(L->Mp - L->Mv) * 3 * H, mainS));
+    } else {
+      MTVAF_TRY(mtvaf_prefix_attn_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx,
+                                      L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+    }
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, dqkv, 3 * H, L->x, H, g->dwqkv, H, 3 * H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1,

@@ -472,6 +472,38 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
   return MTVAF_OK;
 }
 
+// dst[r][:] = map[r] >= 0 ? src[map[r]][:] : 0   -- packs the unmasked token rows of a padded [B*S, H] tensor (map = the
+// kept rows, -1 for the rows that pad the packed image to a whole tile) and, with the inverse map, unpacks them again
+// (zeros at the padded positions).  H % 4 == 0.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ map,
+                                                         float* __restrict__ dst, int rows, int h4) {
+  const long n = (long)rows * h4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / h4), c = (int)(i % h4);
+    const int sr = map[r];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (sr >= 0) v = reinterpret_cast<const f32x4*>(src)[(long)sr * h4 + c];
+    reinterpret_cast<f32x4*>(dst)[i] = v;
+  }
+}
+
+int mtvaf_zero_f32(float* p, long n, hipStream_t st) {
+  if (n < 0 || (n && !p)) return MTVAF_ERR_ARG;
+  if (n) zero_f32(p, n, st);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+int mtvaf_gather_rows(const float* src, const int* map, float* dst, int rows_dst, int H, hipStream_t st) {
+  if (rows_dst <= 0 || H <= 0 || H % 4) return MTVAF_ERR_SHAPE;
+  if (!src || !map || !dst) return MTVAF_ERR_ARG;
+  const long n4 = (long)rows_dst * (H / 4);
+  const int blocks = (int)std::min<long>((n4 + 255) / 256, 4096);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, st, src, map, dst, rows_dst, H / 4);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
 size_t mtvaf_colsum_workspace_bytes(int rows, int cols) { return (size_t)64 * cols * sizeof(float); }
 
 // few rows (the bs-4 configuration: M = 256 tokens): one launch -- 64 columns x 4 row groups per block, combined in fixed

@@ -197,7 +197,52 @@ NATIVE_EXEC = os.environ.get("MTVAF_NATIVE_EXEC", "1") != "0"
 # `torch.autograd.grad(loss, encoder_params)` wants the gradients RETURNED instead: set MTVAF_DIRECT_GRADS=0 (or
 # engine.DIRECT_GRADS = False) for such callers.
 DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
+# Padding-free execution (opt-in: MTVAF_UNPAD=1 / engine.UNPAD = True; fp32 mode, native executor):
+# the encoder layers run on the PACKED unmasked token rows -- every kernel of a layer treats token rows independently
+# except attention (which gets per-sentence row offsets) -- and the last hidden state is scattered back to [B,S,H] with
+# zeros at the masked positions.  Loss, decoded tags and every parameter gradient are those of the padded run (a masked
+# key contributes exp(-10000) = 0 there, a masked query feeds nothing); hidden states AT masked positions are zeros
+# instead of the reference's don't-care values, and the intermediate hidden states are handed out lazily / detached.
+UNPAD = os.environ.get("MTVAF_UNPAD", "0") == "1"
+LAST_PACK = None  # the Packing of the most recent native forward (None: it ran padded)
 _layouts = {}
+
+
+class Packing:
+    """Token packing of one forward pass: rowmap [Mp] packed row -> flat token (b*S + s), -1 for the rows that pad the
+    image to whole 128-row tiles; inv [B*S] flat token -> packed row or -1; cu [B+1] row offsets of the sentences."""
+    __slots__ = ("rowmap", "inv", "cu", "Mv", "Mp", "B", "S")
+
+    @staticmethod
+    def build(addmask: torch.Tensor, Pn: int, B: int, S: int) -> Optional["Packing"]:
+        valid = addmask[:, Pn:] > -5000.0
+        idx = torch.nonzero(valid.reshape(-1)).squeeze(1)  # (host sync: the packed row count sizes every launch)
+        Mv = int(idx.numel())
+        Mp = max(128, (Mv + 127) // 128 * 128)
+        if Mv == 0 or Mp > B * S - 128:
+            return None  # nothing to gain (or nothing to compute): stay padded
+        pk = Packing()
+        dev = addmask.device
+        pk.rowmap = torch.full((Mp,), -1, dtype=torch.int32, device=dev)
+        pk.rowmap[:Mv] = idx.to(torch.int32)
+        pk.inv = torch.full((B * S,), -1, dtype=torch.int32, device=dev)
+        pk.inv[idx] = torch.arange(Mv, dtype=torch.int32, device=dev)
+        pk.cu = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+        pk.cu[1:] = valid.sum(1).cumsum(0).to(torch.int32)
+        pk.Mv, pk.Mp, pk.B, pk.S = Mv, Mp, B, S
+        return pk
+
+    def pack(self, x2d: torch.Tensor) -> torch.Tensor:
+        out = _empty(self.Mp, x2d.shape[1], like=x2d)
+        hip._ck(hip.lib().mtvaf_gather_rows(hip._p(x2d), hip._p(self.rowmap), hip._p(out), self.Mp, x2d.shape[1], hip._st()),
+                "mtvaf_gather_rows")
+        return out
+
+    def unpack(self, xp: torch.Tensor) -> torch.Tensor:
+        out = _empty(self.B * self.S, xp.shape[1], like=xp)
+        hip._ck(hip.lib().mtvaf_gather_rows(hip._p(xp), hip._p(self.inv), hip._p(out), self.B * self.S, xp.shape[1], hip._st()),
+                "mtvaf_gather_rows")
+        return out
 
 
 def _layout(fields):
@@ -270,6 +315,10 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
     x = h0.contiguous().view(M, H)
     seed = RNG.seed()
     dev = x.device
+    pack = Packing.build(addmask, Pn, B, S) if (UNPAD and not use_h) else None
+    if pack is not None:
+        x = pack.pack(x)
+        M = pack.Mp
     x0_h = _cast(x) if use_h else None
     pkv_k = pkv
     if Pn:
@@ -297,6 +346,7 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
         base = arena.data_ptr()
         st = _layer_struct(w, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed)
         st.offset = off
+        st.cu, st.Mv, st.Mp = (pack.cu.data_ptr(), pack.Mv, pack.Mp) if pack is not None else (None, 0, 0)
         st.x, st.x_h, st.addmask = x_ptr, xh_ptr, am_ptr
         st.pk = (pk_ptr + li * pk_layer) if Pn else None
         st.pv = (pk_ptr + li * pk_layer + pk_step) if Pn else None
@@ -304,7 +354,13 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
             setattr(st, name, base + o if o >= 0 else None)
         st.ws, st.ws_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
         hip._ck(fn(ctypes.byref(st), stream), "mtvaf_encoder_layer_fwd")
-        outs.append(arena[o_h2:o_h2 + M * H * 4].view(torch.float32).view(B, S, H))
+        h2 = arena[o_h2:o_h2 + M * H * 4].view(torch.float32)
+        if pack is None:
+            outs.append(h2.view(B, S, H))
+        elif li < L - 1:
+            outs.append(h2.view(M, H))  # packed rows (detached below): modeling_bert wraps them into lazy [B,S,H] views
+        else:
+            outs.append(pack.unpack(h2.view(M, H)).view(B, S, H))
         arenas.append(arena)
         offs.append(off)
         x_ptr, xh_ptr = base + o_h2, (base + o_h2h if use_h else 0)
@@ -312,6 +368,11 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
     ctx.save_for_backward(*saved)
     ctx.stash = (offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
     ctx.native = (use_h, pkv_k if (use_h and Pn) else None)
+    ctx.pack = pack
+    global LAST_PACK
+    LAST_PACK = pack
+    if pack is not None and L > 1:
+        ctx.mark_non_differentiable(*outs[:-1])
     if grad_sink is not None:
         grad_sink.node_created()
     ctx.set_materialize_grads(False)
@@ -326,7 +387,8 @@ def _native_backward(ctx, douts):
     x0_h = saved[1] if use_h else None
     arenas = saved[2:] if use_h else saved[1:]
     NH, eps, p_hidden, p_attn = cfg[:4]
-    L, M = len(weights), B * S
+    pack = ctx.pack
+    L, M = len(weights), (pack.Mp if pack is not None else B * S)
     I = weights[0].w1.shape[0]
     dev = x0.device
     dpkv = torch.empty_like(pkv) if Pn else None
@@ -367,9 +429,12 @@ def _native_backward(ctx, douts):
                 if Pn:
                     dpkv[li].zero_()  # layers above the last used hidden state get no gradient
                 continue
-            dh = g_out.contiguous().view(M, H)
-            if dh.data_ptr() == g_out.data_ptr():
-                dh = dh.clone()  # we modify / free it
+            if pack is not None:
+                dh = pack.pack(g_out.contiguous().view(B * S, H))  # (a fresh buffer; zero rows pad the image)
+            else:
+                dh = g_out.contiguous().view(M, H)
+                if dh.data_ptr() == g_out.data_ptr():
+                    dh = dh.clone()  # we modify / free it
         elif g_out is not None:
             dh = dh + g_out.reshape(M, H)
         base_i = li * N_LAYER_PARAMS
@@ -381,6 +446,7 @@ def _native_backward(ctx, douts):
             dwqkv, dbqkv = _empty(3 * H, H, like=x0), _empty(3 * H, like=x0)
         st = _layer_struct(w, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed)
         st.offset = offs[li]
+        st.cu, st.Mv, st.Mp = (pack.cu.data_ptr(), pack.Mv, pack.Mp) if pack is not None else (None, 0, 0)
         base = arenas[li].data_ptr()
         for name, o in flay:
             setattr(st, name, base + o if o >= 0 else None)
@@ -435,6 +501,8 @@ def _native_backward(ctx, douts):
     if side is not None:
         main.wait_stream(side)  # join: gradients (and every buffer the second stream read) are settled from here on
     del keep
+    if dh is not None and pack is not None:
+        dh = pack.unpack(dh)
     dh0_out = dh.view(B, S, H) if dh is not None else None
     if not need_param_grads:
         pgrads = [None] * len(params)

@@ -35,6 +35,10 @@ _SIGS = {
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_varlen_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_varlen_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_gather_rows": (c_int, [P, P, P, I, I, P]),
+    "mtvaf_zero_f32": (c_int, [P, L, P]),
     "mtvaf_prefix_attn_bf16_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bf16_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_ln_bwd_workspace_bytes": (SZ, [I, I]),
@@ -87,7 +91,7 @@ class LayerStruct(ctypes.Structure):
                 [(n, c_void_p) for n in ("wqkv", "wo", "w1", "w2", "wqkv_h", "wo_h", "w1_h", "w2_h", "bqkv", "bo", "g1", "b1",
                                          "bi1", "bi2", "g2", "b2", "x", "x_h", "pk", "pv", "addmask", "qkv", "cx", "lse", "a",
                                          "h1", "h1_h", "mean1", "rstd1", "pre", "act", "f", "h2", "h2_h", "mean2", "rstd2",
-                                         "ws")] + [("ws_bytes", c_size_t)])
+                                         "ws")] + [("ws_bytes", c_size_t), ("cu", c_void_p), ("Mv", c_int), ("Mp", c_int)])
 
 
 class LayerGradsStruct(ctypes.Structure):

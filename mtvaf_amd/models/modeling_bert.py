@@ -295,11 +295,38 @@ class BertEncoder(nn.Module):
         outs = engine.EncoderFunction.apply(hidden_states, pkv, addmask, ecfg, [st.weights for st in stores],
                                             sink if torch.is_grad_enabled() else None, *params)
         all_hidden = (hidden_states,) + tuple(outs) if output_hidden_states else None
+        if all_hidden is not None and len(outs) > 1 and outs[0].dim() == 2:
+            all_hidden = _LazyHiddenStates(all_hidden, engine.LAST_PACK)  # padding-free run: intermediate states are packed
         if not return_dict:
             return tuple(v for v in [outs[-1], all_hidden] if v is not None)
         return BaseModelOutputWithPastAndCrossAttentions(last_hidden_state=outs[-1], past_key_values=None,
                                                          hidden_states=all_hidden, attentions=None,
                                                          cross_attentions=None)
+
+
+class _LazyHiddenStates(tuple):
+    """``hidden_states`` of a padding-free run (engine.UNPAD): the intermediate layers' outputs exist as PACKED rows of the
+    unmasked tokens; an entry is scattered to [B,S,H] (zeros at masked positions, detached) when it is first read --
+    the MTVAF path itself only reads ``last_hidden_state``, which is always materialised."""
+
+    def __new__(cls, items, pack):
+        obj = super().__new__(cls, items)
+        obj._pack, obj._cache = pack, {}
+        return obj
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return tuple(self[j] for j in range(*i.indices(len(self))))
+        v = super().__getitem__(i)
+        if v.dim() == 2:
+            i = i % len(self)
+            if i not in self._cache:
+                self._cache[i] = self._pack.unpack(v).view(self._pack.B, self._pack.S, v.shape[1])
+            v = self._cache[i]
+        return v
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
 
 
 class PrefixKV(list):

