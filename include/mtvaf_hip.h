@@ -255,6 +255,15 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
                                const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
                                float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
                                float p_drop, uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
+/* ... over PACKED token rows (padding-free execution, see mtvaf_prefix_attn_varlen_fwd): cu [B+1] int32, no mask read;
+ * partq / partkv keep their padded row counts (blocks beyond a sentence write zeros). */
+int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, void* ctx16, float* lse,
+                                      int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                      mtvaf_stream_t stream);
+int mtvaf_prefix_attn_bf16_varlen_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const int* cu,
+                                      const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                                      float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                      uint64_t offset, mtvaf_stream_t stream);
 int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int ldt, int R, int C,
                     mtvaf_stream_t stream);
 
@@ -286,7 +295,7 @@ typedef struct {
   void* h2_h;
   float *mean2, *rstd2;
   void* ws; size_t ws_bytes;
-  /* padding-free execution (fp32 mode): cu != NULL -> the token tensors (x, qkv ... h2, and the gradient buffers) hold Mp
+  /* padding-free execution: cu != NULL -> the token tensors (x, qkv ... h2, and the gradient buffers) hold Mp
    * PACKED rows -- the Mv unmasked tokens sentence by sentence (cu [B+1] int32 row offsets), then Mp - Mv zero rows that
    * pad the image to whole 128-row tiles; lse / delta keep [B,NH,S].  cu == NULL: the padded [B*S] layout. */
   const int* cu;

@@ -54,7 +54,23 @@ struct Args {
   float scale, p_drop;
   uint32_t drop_key, drop_thr;
   const uint64_t* epoch;  // device-side dropout epoch (captured launches), or NULL
+  const int* cu;          // PACKED token rows (see attention.hip): [B+1] row offsets of the sentences, or NULL
 };
+
+struct Sent {
+  long tok0;
+  int n;
+};
+__device__ __forceinline__ Sent sentence(const Args& a, int b) {
+  if (a.cu) {
+    const int c0 = a.cu[b];
+    return Sent{(long)c0, a.cu[b + 1] - c0};
+  }
+  return Sent{(long)b * a.S, a.S};
+}
+__device__ __forceinline__ float mask_at(const Args& a, int b, int Tf, int t) {
+  return a.cu ? 0.f : a.addmask[(long)b * Tf + t];
+}
 
 // byte offset of 16-byte chunk c (0..7) of row r in a [64][64] bf16 tile image
 __device__ __forceinline__ int tile_off(int r, int c) { return r * 128 + ((c ^ (((r >> 1) & 3) << 1)) << 4); }
@@ -137,10 +153,13 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 64 + wave * 16 + lq;
+  const Sent sn = sentence(a, b);
+  const int Sb = sn.n;
+  if ((int)blockIdx.x * 64 >= Sb) return;  // (block-uniform; packed rows: a query tile beyond the sentence)
   const int Tf = a.P + a.S;  // row length of the additive mask
   __shared__ int t_eff_slot;
-  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
-  const bool qok = q < a.S;
+  const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
+  const bool qok = q < Sb;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
@@ -148,13 +167,13 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
   KvSrc ksrc, vsrc;
   ksrc.pre = a.pk + ((long)b * a.P * a.NH + (long)h * a.P) * D;
   vsrc.pre = a.pv + ((long)b * a.P * a.NH + (long)h * a.P) * D;
-  ksrc.txt = a.qkv + (long)b * a.S * 3 * a.H + a.H + h * D;
+  ksrc.txt = a.qkv + sn.tok0 * 3 * a.H + a.H + h * D;
   vsrc.txt = ksrc.txt + a.H;
   const int ldt = 3 * a.H;
 
   bf16x8 qf[2];
   {
-    const __bf16* qp = a.qkv + ((long)b * a.S + min(q, a.S - 1)) * 3 * a.H + h * D + 8 * g;
+    const __bf16* qp = a.qkv + (sn.tok0 + min(q, Sb - 1)) * 3 * a.H + h * D + 8 * g;
     qf[0] = *reinterpret_cast<const bf16x8*>(qp);
     qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
   }
@@ -169,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
     tile_load_kv(kreg, ksrc, a.P, T, ldt, t0);
     tile_load_kv(vreg, vsrc, a.P, T, ldt, t0);
     float mreg = NEG_BIG;
-    if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
+    if (threadIdx.x < KT) mreg = mask_at(a, b, Tf, min(t0 + (int)threadIdx.x, T - 1));
     __syncthreads();
     tile_store(Ks, kreg);
     tile_store(Vs, vreg);
@@ -224,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
   }
   if (qok) {
     const float inv_l = 1.f / l_run;
-    __bf16* op = a.ctx + ((long)b * a.S + q) * a.H + h * D + 4 * g;
+    __bf16* op = a.ctx + (sn.tok0 + q) * a.H + h * D + 4 * g;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const f32x4 o = oacc[dt] * inv_l;
@@ -243,9 +262,15 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = qtile * 64 + wave * 16 + lq;
+  const Sent sn = sentence(a, b);
+  const int Sb = sn.n;
+  if (qtile * 64 >= Sb) {  // (block-uniform) a query tile beyond the sentence: its column-sum partial is zero
+    if (threadIdx.x < 64) a.partq[((long)b * ((a.S + 63) / 64) + qtile) * a.H + h * D + threadIdx.x] = 0.f;
+    return;
+  }
   const int Tf = a.P + a.S;
-  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
-  const bool qok = q < a.S;
+  const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
+  const bool qok = q < Sb;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
@@ -253,14 +278,14 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
   KvSrc ksrc, vsrc;
   ksrc.pre = a.pk + ((long)b * a.P * a.NH + (long)h * a.P) * D;
   vsrc.pre = a.pv + ((long)b * a.P * a.NH + (long)h * a.P) * D;
-  ksrc.txt = a.qkv + (long)b * a.S * 3 * a.H + a.H + h * D;
+  ksrc.txt = a.qkv + sn.tok0 * 3 * a.H + a.H + h * D;
   vsrc.txt = ksrc.txt + a.H;
   const int ldt = 3 * a.H;
 
   bf16x8 qf[2], dof[2];
   float dl = 0.f;
   {
-    const long qrow = (long)b * a.S + min(q, a.S - 1);
+    const long qrow = sn.tok0 + min(q, Sb - 1);
     const __bf16* qp = a.qkv + qrow * 3 * a.H + h * D + 8 * g;
     const __bf16* dop = a.dctx + qrow * a.H + h * D + 8 * g;
     const __bf16* op = a.ctx + qrow * a.H + h * D + 8 * g;
@@ -287,7 +312,7 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
   auto fetch = [&](int t0) {
     tile_load_kv(kreg, ksrc, a.P, T, ldt, t0);
     tile_load_kv(vreg, vsrc, a.P, T, ldt, t0);
-    if (threadIdx.x < KT) mreg = a.addmask[(long)b * Tf + min(t0 + (int)threadIdx.x, T - 1)];
+    if (threadIdx.x < KT) mreg = mask_at(a, b, Tf, min(t0 + (int)threadIdx.x, T - 1));
   };
   fetch(0);
   for (int t0 = 0; t0 < T; t0 += KT) {
@@ -331,7 +356,7 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
     }
   }
   if (qok) {
-    __bf16* dqp = a.dqkv + ((long)b * a.S + q) * 3 * a.H + h * D + 4 * g;
+    __bf16* dqp = a.dqkv + (sn.tok0 + q) * 3 * a.H + h * D + 4 * g;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
       *reinterpret_cast<bf16x4*>(dqp + 16 * dt) = bf16x4{(__bf16)dq[dt].x, (__bf16)dq[dt].y, (__bf16)dq[dt].z, (__bf16)dq[dt].w};
@@ -362,12 +387,15 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lk = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int Tf = a.P + a.S;
-  const int T = effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);  // keys >= T: trailing padding, dK = dV = 0
+  const Sent sn = sentence(a, b);
+  const int Sb = sn.n;
+  const int nkt = (a.P + a.S + 63) / 64;  // rows of partkv per sentence (allocation: the padded key count)
+  const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * (a.P + a.S), a.P, a.S, t_eff_slot);  // keys >= T: trailing padding, dK = dV = 0
+  const int Tf = a.cu ? T : a.P + a.S;  // (packed rows: keys beyond the sentence do not exist)
   const int key = ktile * 64 + wave * 16 + lk;
   if (ktile * 64 >= T) {  // (block-uniform) a key tile of trailing padding only: exact zeros, no query loop
     if (key < Tf) {
-      __bf16* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+      __bf16* dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
       const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -375,17 +403,15 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
         *reinterpret_cast<bf16x4*>(dkrow + a.H + 16 * dt) = z;
       }
     }
-    if (threadIdx.x < 128) {
-      const int nkt = (Tf + 63) / 64;
+    if (threadIdx.x < 128)
       a.partkv[((long)b * nkt + ktile) * 2 * a.H + (threadIdx.x >> 6) * a.H + h * D + (threadIdx.x & 63)] = 0.f;
-    }
     return;
   }
   const bool kok = key < T;
   const bool wave_live = (int)(ktile * 64 + wave * 16) < T;
   const int keyc = min(key, T - 1);
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
-  const float mval2 = kok ? a.addmask[(long)b * Tf + key] * LOG2E : NEG_BIG;  // keys beyond T: probability exactly 0
+  const float mval2 = kok ? mask_at(a, b, Tf, key) * LOG2E : NEG_BIG;  // keys beyond T: probability exactly 0
   const float sc2 = a.scale * LOG2E;
   const uint32_t cterm = (uint32_t)key * ATTN_DROP_C2;
 
@@ -394,7 +420,7 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
     KvSrc ksrc, vsrc;
     ksrc.pre = a.pk + ((long)b * a.P * a.NH + (long)h * a.P) * D;
     vsrc.pre = a.pv + ((long)b * a.P * a.NH + (long)h * a.P) * D;
-    ksrc.txt = a.qkv + (long)b * a.S * 3 * a.H + a.H + h * D;
+    ksrc.txt = a.qkv + sn.tok0 * 3 * a.H + a.H + h * D;
     vsrc.txt = ksrc.txt + a.H;
     const __bf16* krow = kv_row_ptr(ksrc, keyc, a.P, 3 * a.H) + 8 * g;
     const __bf16* vrow = kv_row_ptr(vsrc, keyc, a.P, 3 * a.H) + 8 * g;
@@ -409,9 +435,9 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
   for (int i = 0; i < 4; ++i) dk[i] = dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int c8 = threadIdx.x & 7, r0 = threadIdx.x >> 3;  // staging: rows r0, r0 + 32; 16-byte chunk c8
-  const __bf16* qsrc = a.qkv + (long)b * a.S * 3 * a.H + h * D + c8 * 8;
-  const __bf16* dosrc = a.dctx + (long)b * a.S * a.H + h * D + c8 * 8;
-  const __bf16* osrc = a.ctx + (long)b * a.S * a.H + h * D + c8 * 8;
+  const __bf16* qsrc = a.qkv + sn.tok0 * 3 * a.H + h * D + c8 * 8;
+  const __bf16* dosrc = a.dctx + sn.tok0 * a.H + h * D + c8 * 8;
+  const __bf16* osrc = a.ctx + sn.tok0 * a.H + h * D + c8 * 8;
   const uint32_t row_base = (uint32_t)((b * a.NH + h) * a.S);
 
   // the next query tile (Q, dO, O rows, lse) is fetched while the current one is multiplied
@@ -420,15 +446,15 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
   auto fetch = [&](int q0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int qq = min(q0 + r0 + 32 * i, a.S - 1);
+      const int qq = min(q0 + r0 + 32 * i, Sb - 1);
       qr[i] = *reinterpret_cast<const bf16x8*>(qsrc + (long)qq * 3 * a.H);
       orr[i] = *reinterpret_cast<const bf16x8*>(dosrc + (long)qq * a.H);
       ofw[i] = *reinterpret_cast<const bf16x8*>(osrc + (long)qq * a.H);
     }
-    if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, a.S - 1)] * LOG2E;
+    if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, Sb - 1)] * LOG2E;
   };
-  fetch(0);
-  for (int q0 = 0; q0 < a.S; q0 += KT) {
+  if (Sb > 0) fetch(0);
+  for (int q0 = 0; q0 < Sb; q0 += KT) {
     float dsum[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) dsum[i] = dot8(orr[i], ofw[i]);
@@ -448,13 +474,13 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
     }
     if (threadIdx.x < KT) {
       const int qq = q0 + threadIdx.x;
-      lse_s[threadIdx.x] = qq < a.S ? lcur : 1.0e30f;
+      lse_s[threadIdx.x] = qq < Sb ? lcur : 1.0e30f;
       rh_s[threadIdx.x] = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), row_base + (uint32_t)qq);
     }
     __syncthreads();
-    if (q0 + KT < a.S) fetch(q0 + KT);
+    if (q0 + KT < Sb) fetch(q0 + KT);
     // a wave whose 16 keys all lie beyond T (last key tile) only takes part in the staging and the barriers
-    const int nsub = wave_live ? min(4, (a.S - q0 + 15) >> 4) : 0;
+    const int nsub = wave_live ? min(4, (Sb - q0 + 15) >> 4) : 0;
     f32x4 pd[4], ds[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -498,7 +524,7 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
   }
   const bool is_text = kok && key >= a.P;
   if (!kok && key < Tf) {  // trailing padding inside a partially valid tile
-    __bf16* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+    __bf16* dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
     const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
@@ -516,7 +542,7 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
         *reinterpret_cast<f32x4*>(dvrow + 16 * dt) = dv[dt];
       }
     } else {
-      __bf16* dkrow = a.dqkv + ((long)b * a.S + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
+      __bf16* dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
       __bf16* dvrow = dkrow + a.H;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
@@ -540,7 +566,6 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
   __syncthreads();
   if (threadIdx.x < 128) {
     const int which = threadIdx.x >> 6, d = threadIdx.x & 63;
-    const int nkt = (Tf + 63) / 64;
     const float* rr = red + which * 256 + d;
     a.partkv[((long)b * nkt + ktile) * 2 * a.H + which * a.H + h * D + d] = rr[0] + rr[64] + rr[128] + rr[192];
   }
@@ -580,14 +605,13 @@ using namespace mtvaf;
 
 extern "C" {
 
-// ctx16 [B*S,H] bf16, lse [B,NH,S] <- attention over [prefix ; text] keys; qkv16 [B*S,3H] / pk16, pv16 [B,P*H] bf16.
-int mtvaf_prefix_attn_bf16_fwd(const void* qkv16, const void* pk16, const void* pv16, const float* addmask, void* ctx16,
-                               float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
-                               uint64_t offset, hipStream_t st) {
+static int attn16_fwd_launch(const void* qkv16, const void* pk16, const void* pv16, const float* addmask, const int* cu, void* ctx16,
+                             float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                             hipStream_t st) {
   if (head_dim != ab::D) return MTVAF_ERR_SHAPE;
   ab::Args a{};
   a.qkv = static_cast<const __bf16*>(qkv16); a.pk = static_cast<const __bf16*>(pk16); a.pv = static_cast<const __bf16*>(pv16);
-  a.addmask = addmask; a.ctx = static_cast<__bf16*>(ctx16); a.lse = lse;
+  a.addmask = addmask; a.cu = cu; a.ctx = static_cast<__bf16*>(ctx16); a.lse = lse;
   a.B = B; a.S = S; a.P = P; a.NH = NH; a.H = NH * ab::D;
   a.scale = 0.125f; a.p_drop = p_drop;
   a.drop_thr = p_drop > 0.f ? (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f) : 0u;
@@ -595,23 +619,20 @@ int mtvaf_prefix_attn_bf16_fwd(const void* qkv16, const void* pk16, const void* 
   a.epoch = rng_epoch_ptr();
   int rc = ab::check(a);
   if (rc) return rc;
-  if (!ctx16 || !lse || !addmask) return MTVAF_ERR_ARG;
+  if (!ctx16 || !lse || (!addmask && !cu)) return MTVAF_ERR_ARG;
   hipLaunchKernelGGL(ab::attn_bf16_fwd_kernel, dim3((S + 63) / 64, NH, B), dim3(256), 0, st, a);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
 
-// dqkv16 [B*S,3H] bf16 (all three column blocks overwritten), dpk / dpv [B,P*H] fp32 <- gradients.
-// partq [B*ceil(S/64), H] and partkv [B*ceil((P+S)/64), 2H] fp32: per-block column sums of dQ and of dK | dV (text keys):
-// summed over their rows they are the Q / K / V bias gradients.
-int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16,
-                               const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
-                               float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
-                               float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+static int attn16_bwd_launch(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const float* addmask,
+                             const int* cu, const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                             float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                             hipStream_t st) {
   if (head_dim != ab::D) return MTVAF_ERR_SHAPE;
   ab::Args a{};
   a.qkv = static_cast<const __bf16*>(qkv16); a.pk = static_cast<const __bf16*>(pk16); a.pv = static_cast<const __bf16*>(pv16);
-  a.addmask = addmask; a.ctx = static_cast<__bf16*>(const_cast<void*>(ctx16)); a.lse = const_cast<float*>(lse);
+  a.addmask = addmask; a.cu = cu; a.ctx = static_cast<__bf16*>(const_cast<void*>(ctx16)); a.lse = const_cast<float*>(lse);
   a.dctx = static_cast<const __bf16*>(dctx16); a.dqkv = static_cast<__bf16*>(dqkv16); a.dpk = dpk; a.dpv = dpv;
   a.partq = partq; a.partkv = partkv;
   a.B = B; a.S = S; a.P = P; a.NH = NH; a.H = NH * ab::D;
@@ -621,13 +642,51 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
   a.epoch = rng_epoch_ptr();
   int rc = ab::check(a);
   if (rc) return rc;
-  if (!dctx16 || !ctx16 || !lse || !dqkv16 || !partq || !partkv || !addmask) return MTVAF_ERR_ARG;
+  if (!dctx16 || !ctx16 || !lse || !dqkv16 || !partq || !partkv || (!addmask && !cu)) return MTVAF_ERR_ARG;
   if (P > 0 && (!dpk || !dpv)) return MTVAF_ERR_ARG;
   if (((uintptr_t)dctx16 | (uintptr_t)ctx16 | (uintptr_t)dqkv16) & 15) return MTVAF_ERR_ALIGN;
   const int nq = (S + 63) / 64;
   hipLaunchKernelGGL(ab::attn_bf16_bwd_kernel, dim3(nq + (P + S + 63) / 64, NH, B), dim3(256), 0, st, a, nq);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
+}
+
+// ctx16 [B*S,H] bf16, lse [B,NH,S] <- attention over [prefix ; text] keys; qkv16 [B*S,3H] / pk16, pv16 [B,P*H] bf16.
+int mtvaf_prefix_attn_bf16_fwd(const void* qkv16, const void* pk16, const void* pv16, const float* addmask, void* ctx16,
+                               float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                               uint64_t offset, hipStream_t st) {
+  if (!addmask) return MTVAF_ERR_ARG;
+  return attn16_fwd_launch(qkv16, pk16, pv16, addmask, nullptr, ctx16, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+}
+
+// dqkv16 [B*S,3H] bf16 (all three column blocks overwritten), dpk / dpv [B,P*H] fp32 <- gradients.
+// partq [B*ceil(S/64), H] and partkv [B*ceil((P+S)/64), 2H] fp32: per-block column sums of dQ and of dK | dV (text keys):
+// summed over their rows they are the Q / K / V bias gradients.
+int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16,
+                               const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
+                               float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
+                               float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+  if (!addmask) return MTVAF_ERR_ARG;
+  return attn16_bwd_launch(dctx16, qkv16, pk16, pv16, addmask, nullptr, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, P, NH,
+                           head_dim, p_drop, seed, offset, st);
+}
+
+// PACKED token rows (padding-free execution; see mtvaf_prefix_attn_varlen_fwd): cu [B+1] int32 row offsets, no mask read;
+// partq / partkv keep their padded row counts (blocks beyond a sentence write zeros).
+int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, void* ctx16, float* lse,
+                                      int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                      hipStream_t st) {
+  if (!cu) return MTVAF_ERR_ARG;
+  return attn16_fwd_launch(qkv16, pk16, pv16, nullptr, cu, ctx16, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+}
+
+int mtvaf_prefix_attn_bf16_varlen_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const int* cu,
+                                      const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                                      float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                      uint64_t offset, hipStream_t st) {
+  if (!cu) return MTVAF_ERR_ARG;
+  return attn16_bwd_launch(dctx16, qkv16, pk16, pv16, nullptr, cu, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, P, NH, head_dim,
+                           p_drop, seed, offset, st);
 }
 
 }  // extern "C"

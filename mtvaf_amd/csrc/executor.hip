@@ -43,6 +43,13 @@ int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const floa
                                  const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
 int mtvaf_zero_f32(float* p, long n, hipStream_t st);
+int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, void* ctx16, float* lse,
+                                      int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                      hipStream_t st);
+int mtvaf_prefix_attn_bf16_varlen_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const int* cu,
+                                      const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                                      float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                      uint64_t offset, hipStream_t st);
 int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                              float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
                              uint64_t offset, void* out_bf16, hipStream_t st);
@@ -128,13 +135,21 @@ struct mtvaf_layer_grads_t {
 int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
   if (!L) return MTVAF_ERR_ARG;
   // padding-free execution: the row-wise kernels simply see Mp packed rows; only attention knows about sentences
-  if (L->cu && (L->bf16 || L->Mp <= 0 || L->Mp % 128 || L->Mv <= 0 || L->Mv > L->Mp)) return MTVAF_ERR_ARG;
+  if (L->cu && (L->Mp <= 0 || L->Mp % 128 || L->Mv <= 0 || L->Mv > L->Mp)) return MTVAF_ERR_ARG;
   const int M = L->cu ? L->Mp : L->B * L->S, H = L->H, I = L->I;
   if (L->bf16) {
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KC, L->x_h, H, L->wqkv_h, H, nullptr, 0, L->qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE,
                                nullptr, 0, 0, nullptr, 0, nullptr, 0, 0, -1, 0, st));
-    MTVAF_TRY(mtvaf_prefix_attn_bf16_fwd(L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn,
-                                         L->seed, L->offset, st));
+    if (L->cu) {
+      MTVAF_TRY(mtvaf_prefix_attn_bf16_varlen_fwd(L->qkv, L->pk, L->pv, L->cu, L->cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn,
+                                                  L->seed, L->offset, st));
+      // (bf16 rows: H / 2 floats each) the rows that pad the packed image belong to no sentence
+      MTVAF_TRY(mtvaf_zero_f32(reinterpret_cast<float*>(static_cast<unsigned char*>(L->cx) + (size_t)L->Mv * H * 2),
+                               (long)(L->Mp - L->Mv) * H / 2, st));
+    } else {
+      MTVAF_TRY(mtvaf_prefix_attn_bf16_fwd(L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn,
+                                           L->seed, L->offset, st));
+    }
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KC, L->cx, H, L->wo_h, H, L->a, H, nullptr, 0, M, H, H, L->bo, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 0, nullptr, 0, 0, -1, 0, st));
     MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden, L->seed,
@@ -178,7 +193,7 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
 // behind every product that still reads the weights).
 int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g, hipStream_t mainS, hipStream_t side, int settle) {
   if (!L || !g) return MTVAF_ERR_ARG;
-  if (L->cu && (L->bf16 || L->Mp <= 0 || L->Mp % 128 || L->Mv <= 0 || L->Mv > L->Mp)) return MTVAF_ERR_ARG;
+  if (L->cu && (L->Mp <= 0 || L->Mp % 128 || L->Mv <= 0 || L->Mv > L->Mp)) return MTVAF_ERR_ARG;
   const int M = L->cu ? L->Mp : L->B * L->S, H = L->H, I = L->I, B = L->B, S = L->S, P = L->P, NH = L->NH;
   if (L->bf16) {
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0,
@@ -201,8 +216,15 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
                                nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->da, H, L->wo_h, H, nullptr, 0, g->dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
-    MTVAF_TRY(mtvaf_prefix_attn_bf16_bwd(g->dctx, L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, g->dqkv, g->dpk, g->dpv, g->partq,
-                                         g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+    if (L->cu) {
+      MTVAF_TRY(mtvaf_prefix_attn_bf16_varlen_bwd(g->dctx, L->qkv, L->pk, L->pv, L->cu, L->cx, L->lse, g->dqkv, g->dpk, g->dpv,
+                                                  g->partq, g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+      MTVAF_TRY(mtvaf_zero_f32(reinterpret_cast<float*>(static_cast<unsigned char*>(g->dqkv) + (size_t)L->Mv * 3 * H * 2),
+                               (long)(L->Mp - L->Mv) * 3 * H / 2, mainS));
+    } else {
+      MTVAF_TRY(mtvaf_prefix_attn_bf16_bwd(g->dctx, L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, g->dqkv, g->dpk, g->dpv, g->partq,
+                                           g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+    }
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum_small(g->partq, B * ((S + 63) / 64), H, g->dbqkv, 0, side));
     MTVAF_TRY(mtvaf_colsum_small(g->partkv, B * ((P + S + 63) / 64), 2 * H, g->dbqkv + H, 0, side));

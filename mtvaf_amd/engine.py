@@ -197,7 +197,7 @@ NATIVE_EXEC = os.environ.get("MTVAF_NATIVE_EXEC", "1") != "0"
 # `torch.autograd.grad(loss, encoder_params)` wants the gradients RETURNED instead: set MTVAF_DIRECT_GRADS=0 (or
 # engine.DIRECT_GRADS = False) for such callers.
 DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
-# Padding-free execution (opt-in: MTVAF_UNPAD=1 / engine.UNPAD = True; fp32 mode, native executor):
+# Padding-free execution (opt-in: MTVAF_UNPAD=1 / engine.UNPAD = True; native executor):
 # the encoder layers run on the PACKED unmasked token rows -- every kernel of a layer treats token rows independently
 # except attention (which gets per-sentence row offsets) -- and the last hidden state is scattered back to [B,S,H] with
 # zeros at the masked positions.  Loss, decoded tags and every parameter gradient are those of the padded run (a masked
@@ -315,7 +315,7 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
     x = h0.contiguous().view(M, H)
     seed = RNG.seed()
     dev = x.device
-    pack = Packing.build(addmask, Pn, B, S) if (UNPAD and not use_h) else None
+    pack = Packing.build(addmask, Pn, B, S) if UNPAD else None
     if pack is not None:
         x = pack.pack(x)
         M = pack.Mp

@@ -37,6 +37,8 @@ _SIGS = {
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_varlen_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_varlen_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_bf16_varlen_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_bf16_varlen_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_gather_rows": (c_int, [P, P, P, I, I, P]),
     "mtvaf_zero_f32": (c_int, [P, L, P]),
     "mtvaf_prefix_attn_bf16_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),

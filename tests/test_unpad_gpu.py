@@ -78,3 +78,33 @@ def test_unpadded_training_step_with_dropout_is_finite_and_deterministic():
     for r in res:
         assert r[4]
         assert all(torch.isfinite(g).all() for g in r[3].values())
+
+
+def test_unpadded_run_in_bf16_mode_tracks_the_padded_bf16_run():
+    """Mixed-precision mode: the packed run uses the same bf16 kernels on fewer rows; tile plans (and with them the fp32
+    summation order in front of a bf16 rounding) depend on the row count, so the comparison carries the bf16 tolerance."""
+    from mtvaf_amd import hip
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=4, max_pos=512)
+    hip.set_compute_dtype("bf16")
+    try:
+        m = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+        B, S = 16, 128
+        ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 95, B, S, lo_id=1000))
+        feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(96, B, 8))
+        kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+        l0, t0, h0, g0, p0, _ = _run(m, kw, False)
+        l1, t1, h1, g1, p1, _ = _run(m, kw, True)
+        assert not p0 and p1
+        assert abs(l0 - l1) <= 5e-3 * abs(l0), (l0, l1)
+        agree = sum(a == b for x, y in zip(t0, t1) for a, b in zip(x, y)) / sum(len(x) for x in t0)
+        assert agree > 0.97, agree
+        valid = mask.bool()
+        close(h1[valid], h0[valid], rtol=3e-2, atol=3e-2 * float(h0[valid].abs().max()), name="last hidden state (bf16)")
+        assert float(h1[~valid].abs().max()) == 0.0
+        for n in ("bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.3.output.dense.weight",
+                  "bert.encoder.layer.1.intermediate.dense.bias", "bert.encoder.layer.2.attention.self.key.bias", "fc.weight"):
+            assert torch.isfinite(g1[n]).all()
+            rel = float((g1[n] - g0[n]).norm() / g0[n].norm())
+            assert rel < 5e-2, (n, rel)
+    finally:
+        hip.set_compute_dtype("fp32")
