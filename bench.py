@@ -166,6 +166,10 @@ def main():
                     help="replay forward + backward as ONE HIP graph (mtvaf_amd.graph.GraphedTrainStep: device-side dropout "
                          "epoch, eager optimizer step) -- for the launch-bound shapes (bs 4 / S 64, bf16 at bs 32)")
     ap.add_argument("--no-overlap-optimizer", action="store_true", help="HIP AdamW launched by step() only (after the backward)")
+    ap.add_argument("--unpad", action="store_true",
+                    help="padding-free execution (mtvaf_amd.engine.UNPAD): the encoder layers run on the packed unmasked "
+                         "token rows; loss / tags / gradients are those of the padded run.  Without the flag the padded run "
+                         "is the timed one and the padding-free rate is reported beside it (key `padding_free`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     a = ap.parse_args()
@@ -197,6 +201,8 @@ def main():
     hip.set_compute_dtype(a.dtype)
 
     B, S, P = a.batch, a.seq, 4 * (1 + a.aux)
+    from mtvaf_amd import engine
+    engine.UNPAD = bool(a.unpad)
     model, cfg = build_model(device, a.model, S)
     model.train()
     sync = None
@@ -310,6 +316,36 @@ def main():
         if hasattr(opt, "suspended"):
             opt.suspended = False
 
+    # flops of the rows that are real tokens (what a padding-free run executes): per sentence with its own length
+    lens_host = mask.sum(1).tolist()
+    f_exec = 3 * sum(f_fwd(int(n), P) for n in lens_host) / B
+    real_rows = sum(lens_host) / float(B * S)
+    padding_free = None
+    if not a.unpad and not a.graph and real_rows < 0.97:
+        # secondary figure: the SAME K steps (optimizer included) with the encoder on the packed unmasked token rows
+        engine.UNPAD = True
+        try:
+            for _ in range(2):
+                step()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            barrier()
+            dt2 = time.perf_counter() - t2
+        finally:
+            engine.UNPAD = False
+        if world > 1:
+            t = torch.tensor([dt2], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t)
+        v2 = world * B * a.steps / dt2
+        padding_free = {"value": round(v2, 2), "ms_per_step": round(1e3 * dt2 / a.steps, 3),
+                        "mfma_fraction_of_step_executed_flops": round(v2 / world * f_exec / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
+                        "note": "same workload and results (loss, tags, parameter gradients equal the padded run: "
+                                "tests/test_unpad_gpu.py); masked token rows are not computed; opt-in (`--unpad` / "
+                                "MTVAF_UNPAD=1), not the headline"}
+
     res = {"metric": "training sentences/sec (fwd+bwd)", "value": round(value, 2), "unit": "sentences/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype if a.dtype == "fp32" else "bf16 MFMA / fp32 accumulate+storage",
@@ -323,7 +359,13 @@ def main():
            "median_ms_per_step": round(med_ms, 3), "value_median": round(world * B / (med_ms * 1e-3), 2),
            "loss": round(loss_val, 4),
            "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
-           "flop_per_sentence_train": ftrain, "fwd_bwd_without_optimizer": fwd_bwd_only}
+           "flop_per_sentence_train": ftrain, "fwd_bwd_without_optimizer": fwd_bwd_only,
+           "real_token_rows": round(real_rows, 4), "flop_per_sentence_train_real_rows": round(f_exec),
+           "padding": "skipped (--unpad): the fraction below counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
+           "padding_free": padding_free}
+    if a.unpad:
+        res["mfma_fraction_of_step"] = round(per_gpu * f_exec / (PEAK_TFLOPS[a.dtype] * 1e12), 4)
+        res["config"]["workload"] += ", padding-free execution (masked token rows not computed)"
 
     # ---- roofline of the dominant kernel (fp32 MFMA GEMM), measured live with HIP events recorded by the
     # library on the launch stream, directly around each main GEMM kernel of 3 further identical steps ----

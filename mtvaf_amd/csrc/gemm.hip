@@ -554,8 +554,10 @@ struct TileCfg { int bm, bn, bk; };
 static const TileCfg kCfgs[] = {{128, 128, 16}, {128, 96, 16}, {128, 288, 16}, {64, 64, 16}, {128, 64, 16},
                                 {128, 128, 32}, {128, 96, 32}, {128, 192, 16}, {128, 192, 32},
                                 {128, 96, 32}, {128, 128, 32}, {128, 192, 32},   // 9..11: LDS-DMA pipeline (FAST only)
-                                {128, 96, 32}, {128, 128, 32}};  // 12..13: 2-stage LDS-DMA ring, two blocks per CU
-constexpr int kNumCfgs = 14;
+                                {128, 96, 32}, {128, 128, 32},   // 12..13: 2-stage LDS-DMA ring, two blocks per CU
+                                {128, 64, 32}, {128, 64, 32}};   // 14..15: 128x64 LDS-DMA tile (3-stage / 2-stage): row counts
+                                                                 // that leave 128x96 tiles on half the CUs (padding-free runs)
+constexpr int kNumCfgs = 16;
 constexpr int kFirstDma = 9;
 
 template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
@@ -654,7 +656,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
   //                                  128x128 128x96 128x288 64x64 128x64 128x128x32 128x96x32 128x192 128x192x32
   static const double eff_base[kNumCfgs] = {0.80, 0.86, 0.72, 0.45, 0.80, 0.70, 1.00, 0.92, 0.78,
                                             1.18, 1.00, 0.85,   // 9..11: LDS-DMA pipeline
-                                            1.18, 1.00};        // 12..13: same tiles, 2-stage ring, two blocks per CU
+                                            1.18, 1.00,         // 12..13: same tiles, 2-stage ring, two blocks per CU
+                                            1.08, 1.08};        // 14..15: 128x64 (measured with tools/gemm_sweep.py --rows 2432)
   double eff[kNumCfgs];
   for (int c = 0; c < kNumCfgs; ++c) {
     eff[c] = eff_base[c];
@@ -683,7 +686,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       // two co-resident blocks hide each other's prologue / epilogue / barrier stalls once every CU holds two
       // (measured +8..9 % at >= 2 tiles per CU, -3..5 % with a single tile per CU: the 2-stage ring is shallower;
       // preferring it there anyway for its smaller footprint measured 0.5 % slower on the whole step)
-      const double occ2 = c >= 12 ? (tiles * s >= 512 ? 1.08 : 0.95) : 1.0;
+      const bool two_blocks = c == 12 || c == 13 || c == 15;
+      const double occ2 = two_blocks ? (tiles * s >= 384 ? 1.08 : 0.95) : 1.0;  // (>= 1.5 blocks per CU: M = 2432 rows measured)
       double cost = (double)rounds * bm * bn * kc / 128.0 / (eff[c] * occ2);
       cost += 3000.0;  // fill/drain + launch
       if (s > 1) {
@@ -814,7 +818,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
            (a.slab_stride % 4 == 0);
   if (cfg >= kFirstDma && !(aligned && !(layout_a == 1 && layout_b == 0))) {
     if (cfg_forced) return MTVAF_ERR_SHAPE;
-    static const int staged_twin[5] = {6, 5, 8, 6, 5};  // same tile, register-staged kernel (handles any alignment)
+    static const int staged_twin[7] = {6, 5, 8, 6, 5, 4, 4};  // same tile, register-staged kernel (handles any alignment)
     cfg = staged_twin[cfg - kFirstDma];
   }
   ProfRec* pr = nullptr;
@@ -834,6 +838,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     case 11: rc = launch_dma<128, 192, 2, 2>(a, layout_a, layout_b, grid, stream); break;
     case 12: rc = launch_dma<128, 96, 4, 1, 2>(a, layout_a, layout_b, grid, stream); break;
     case 13: rc = launch_dma<128, 128, 2, 2, 2>(a, layout_a, layout_b, grid, stream); break;
+    case 14: rc = launch_dma<128, 64, 4, 1>(a, layout_a, layout_b, grid, stream); break;
+    case 15: rc = launch_dma<128, 64, 4, 1, 2>(a, layout_a, layout_b, grid, stream); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 16>(a, layout_a, layout_b, grid, mode, stream); break;
     case 1: rc = launch_cfg<128, 96, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
     case 2: rc = launch_cfg<128, 288, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
