@@ -105,6 +105,11 @@ int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const floa
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
 /* dst[r][:] = map[r] >= 0 ? src[map[r]][:] : 0  (rows_dst rows of H floats): packs / unpacks token rows. */
 int mtvaf_gather_rows(const float* src, const int* map, float* dst, int rows_dst, int H, mtvaf_stream_t stream);
+/* Token packing of a batch from its additive mask [B, T = P + S] (text keys at columns P..; kept: > -5000): cu [B+1] row
+ * offsets of the sentences, inv [B*S] flat token -> packed row (-1 masked), rowmap [B*S] packed row -> flat token (-1 beyond
+ * the kept rows), mv_out[0] = number of kept rows.  All int32, device. */
+int mtvaf_build_packing(const float* addmask, int B, int T, int P, int S, int* cu, int* inv, int* rowmap, int* mv_out,
+                        mtvaf_stream_t stream);
 /* p[0..n) = 0 (a kernel, not hipMemsetAsync: usable inside captured graphs, see rowops.hip). */
 int mtvaf_zero_f32(float* p, long n, mtvaf_stream_t stream);
 

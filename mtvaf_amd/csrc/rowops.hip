@@ -487,6 +487,51 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   }
 }
 
+// Token packing of a batch from its additive mask [B, T] (T = P + S; text keys at columns P..): cu [B+1] row offsets of
+// the sentences, inv [B*S] flat token -> packed row (-1: masked), rowmap [B*S] packed row -> flat token (-1 beyond the
+// mv_out[0] = cu[B] kept rows).  One block: a thread counts / numbers the tokens of a sentence, thread 0 scans the counts.
+__global__ __launch_bounds__(1024) void build_packing_kernel(const float* __restrict__ addmask, int B, int T, int P, int S,
+                                                            int* __restrict__ cu, int* __restrict__ inv, int* __restrict__ rowmap,
+                                                            int* __restrict__ mv_out) {
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float* m = addmask + (long)b * T + P;
+    int n = 0;
+    for (int t = 0; t < S; ++t) n += m[t] > -5000.f ? 1 : 0;
+    cu[b + 1] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    cu[0] = 0;
+    for (int b = 0; b < B; ++b) {
+      acc += cu[b + 1];
+      cu[b + 1] = acc;
+    }
+    mv_out[0] = acc;
+  }
+  __syncthreads();
+  const int mv = cu[B];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float* m = addmask + (long)b * T + P;
+    int pos = cu[b];
+    for (int t = 0; t < S; ++t) {
+      const bool keep = m[t] > -5000.f;
+      inv[b * S + t] = keep ? pos : -1;
+      if (keep) rowmap[pos++] = b * S + t;
+    }
+  }
+  for (int r = mv + threadIdx.x; r < B * S; r += blockDim.x) rowmap[r] = -1;
+}
+
+int mtvaf_build_packing(const float* addmask, int B, int T, int P, int S, int* cu, int* inv, int* rowmap, int* mv_out,
+                        hipStream_t st) {
+  if (B <= 0 || S <= 0 || P < 0 || T != P + S || (long)B * S >= (1L << 31)) return MTVAF_ERR_SHAPE;
+  if (!addmask || !cu || !inv || !rowmap || !mv_out) return MTVAF_ERR_ARG;
+  hipLaunchKernelGGL(build_packing_kernel, dim3(1), dim3(1024), 0, st, addmask, B, T, P, S, cu, inv, rowmap, mv_out);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
 int mtvaf_zero_f32(float* p, long n, hipStream_t st) {
   if (n < 0 || (n && !p)) return MTVAF_ERR_ARG;
   if (n) zero_f32(p, n, st);

@@ -205,6 +205,8 @@ DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
 # instead of the reference's don't-care values, and the intermediate hidden states are handed out lazily / detached.
 UNPAD = os.environ.get("MTVAF_UNPAD", "0") == "1"
 LAST_PACK = None  # the Packing of the most recent native forward (None: it ran padded)
+_PENDING_PACK = None  # packing started by Packing.begin, consumed by the next Packing.build
+_PACK_HOST = {}
 _layouts = {}
 
 
@@ -214,7 +216,47 @@ class Packing:
     __slots__ = ("rowmap", "inv", "cu", "Mv", "Mp", "B", "S")
 
     @staticmethod
+    def begin(addmask: torch.Tensor, Pn: int, S: int):
+        """Start the packing of a batch as early as its mask exists (BertModel.forward calls this before the embeddings):
+        one kernel builds the maps, the kept-row count travels to pinned host memory asynchronously, and `build` waits for
+        it only after the host has enqueued the prompt generator and the embeddings -- the one host sync padding-free
+        execution needs (the row count sizes every launch) then costs no GPU idle time."""
+        global _PENDING_PACK
+        _PENDING_PACK = None
+        if not (UNPAD and addmask.is_cuda and addmask.dtype == torch.float32 and addmask.is_contiguous()):
+            return
+        B, T = addmask.shape
+        dev = addmask.device
+        cu = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        inv = torch.empty(B * S, dtype=torch.int32, device=dev)
+        rowmap = torch.empty(B * S, dtype=torch.int32, device=dev)
+        mv = torch.empty(1, dtype=torch.int32, device=dev)
+        hip._ck(hip.lib().mtvaf_build_packing(hip._p(addmask), B, T, Pn, S, hip._p(cu), hip._p(inv), hip._p(rowmap), hip._p(mv),
+                                              hip._st()), "mtvaf_build_packing")
+        key = dev.index or 0
+        host = _PACK_HOST.get(key)
+        if host is None:
+            host = _PACK_HOST[key] = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(mv, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        _PENDING_PACK = (addmask.data_ptr(), B, S, Pn, cu, inv, rowmap, host, ev)
+
+    @staticmethod
     def build(addmask: torch.Tensor, Pn: int, B: int, S: int) -> Optional["Packing"]:
+        global _PENDING_PACK
+        pend, _PENDING_PACK = _PENDING_PACK, None
+        if pend is not None and pend[:4] == (addmask.data_ptr(), B, S, Pn):
+            _, _, _, _, cu, inv, rowmap, host, ev = pend
+            ev.synchronize()
+            Mv = int(host[0])
+            Mp = max(128, (Mv + 127) // 128 * 128)
+            if Mv == 0 or Mp > B * S - 128:
+                return None
+            pk = Packing()
+            pk.rowmap, pk.inv, pk.cu = rowmap[:Mp], inv, cu
+            pk.Mv, pk.Mp, pk.B, pk.S = Mv, Mp, B, S
+            return pk
         valid = addmask[:, Pn:] > -5000.0
         idx = torch.nonzero(valid.reshape(-1)).squeeze(1)  # (host sync: the packed row count sizes every launch)
         Mv = int(idx.numel())

@@ -501,6 +501,8 @@ class BertModel(nn.Module):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         ext = self.get_extended_attention_mask(attention_mask)
+        if engine.UNPAD:  # padding-free execution: the packing maps are built while the host enqueues the embeddings
+            engine.Packing.begin(ext.view(B, -1), ext.shape[-1] - S, S)
         emb = self.embeddings(input_ids=input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
                               inputs_embeds=inputs_embeds, past_key_values_length=0)
         enc = self.encoder(emb, attention_mask=ext, past_key_values=past_key_values,
