@@ -43,6 +43,9 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep needs the batch on the MI355X (no CPU fallback)")
         if "labels" not in tens:
             raise ValueError("a training step needs labels (loss.backward() is part of the graph)")
+        if engine.UNPAD:
+            raise RuntimeError("padding-free execution (engine.UNPAD) reads the packed row count on the host once per step: "
+                               "it cannot be captured into a HIP graph -- use the eager model")
         self.model = model
         self.static = {k: v.clone() for k, v in tens.items()}
         self.const = {k: v for k, v in batch.items() if not torch.is_tensor(v)}
