@@ -493,11 +493,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 __global__ __launch_bounds__(1024) void build_packing_kernel(const float* __restrict__ addmask, int B, int T, int P, int S,
                                                             int* __restrict__ cu, int* __restrict__ inv, int* __restrict__ rowmap,
                                                             int* __restrict__ mv_out) {
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+  // one wave per sentence (16 waves take the sentences in turn): 64 mask values per coalesced read, counted / numbered
+  // with a ballot; thread 0 scans the B counts in between
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int b = wave; b < B; b += nw) {
     const float* m = addmask + (long)b * T + P;
     int n = 0;
-    for (int t = 0; t < S; ++t) n += m[t] > -5000.f ? 1 : 0;
-    cu[b + 1] = n;
+    for (int t0 = 0; t0 < S; t0 += 64) n += __popcll(__ballot(t0 + lane < S && m[t0 + lane] > -5000.f));
+    if (lane == 0) cu[b + 1] = n;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -511,13 +514,17 @@ __global__ __launch_bounds__(1024) void build_packing_kernel(const float* __rest
   }
   __syncthreads();
   const int mv = cu[B];
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+  for (int b = wave; b < B; b += nw) {
     const float* m = addmask + (long)b * T + P;
-    int pos = cu[b];
-    for (int t = 0; t < S; ++t) {
-      const bool keep = m[t] > -5000.f;
-      inv[b * S + t] = keep ? pos : -1;
-      if (keep) rowmap[pos++] = b * S + t;
+    int base = cu[b];
+    for (int t0 = 0; t0 < S; t0 += 64) {
+      const bool in = t0 + lane < S;
+      const bool keep = in && m[t0 + lane] > -5000.f;
+      const unsigned long long bal = __ballot(keep);
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      if (in) inv[b * S + t0 + lane] = keep ? pos : -1;
+      if (keep) rowmap[pos] = b * S + t0 + lane;
+      base += __popcll(bal);
     }
   }
   for (int r = mv + threadIdx.x; r < B * S; r += blockDim.x) rowmap[r] = -1;
