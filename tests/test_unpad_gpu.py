@@ -108,3 +108,23 @@ def test_unpadded_run_in_bf16_mode_tracks_the_padded_bf16_run():
             assert rel < 5e-2, (n, rel)
     finally:
         hip.set_compute_dtype("fp32")
+
+
+def test_unpadded_encoder_entry_without_the_early_packing_hook():
+    """`BertModel.get_bert_output` (the Cutoff augmentation entry, reference models/modeling_bert.py:1127-1157) reaches the
+    encoder without `Packing.begin`: the maps are then built on the spot (the fallback with a plain host sync)."""
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=2, max_pos=512)
+    m = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+    ids, mask, tt, _ = (t.to(DEV) for t in P.text_batch(cfg, 97, 8, 128, lo_id=1000))
+    with torch.no_grad():
+        emb = m.bert.get_embedding_output(ids, tt)
+        seq0, _ = m.bert.get_bert_output(emb, attention_mask=mask)
+        engine.UNPAD = True
+        try:
+            seq1, _ = m.bert.get_bert_output(emb, attention_mask=mask)
+            assert engine.LAST_PACK is not None
+        finally:
+            engine.UNPAD = False
+    valid = mask.bool()
+    close(seq1[valid], seq0[valid], rtol=2e-5, name="get_bert_output, unpadded")
+    assert float(seq1[~valid].abs().max()) == 0.0

@@ -20,9 +20,12 @@ python bench.py --steps 20 --warmup 5 > $O/${T}_bench_line.json 2> $O/bench_fp32
 python bench.py --steps 20 --warmup 5 --dtype bf16 --model roberta --no-cpu-baseline > $O/${T}_bench_line_bf16_c3.json 2> $O/bench_c3.err
 python bench.py --steps 20 --warmup 5 --dtype bf16 --batch 64 --no-cpu-baseline > $O/${T}_bench_line_bf16_c4.json 2> $O/bench_c4.err
 python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/${T}_bench_line_bf16_c2shape.json 2> $O/bench_c2b.err
+python bench.py --steps 20 --warmup 5 --unpad --no-cpu-baseline > $O/${T}_bench_line_unpad.json 2> $O/bench_unpad.err
+python bench.py --steps 20 --warmup 5 --unpad --dtype bf16 --batch 64 --no-cpu-baseline --no-roofline > $O/${T}_bench_line_unpad_bf16_c4.json 2> $O/bench_unpad_c4.err
 echo "== kernel stats"; date
 stats fp32 MTVAF_DW_STREAM=1
 stats fp32_serial MTVAF_DW_STREAM=0
+stats fp32_unpad_serial MTVAF_DW_STREAM=0 --unpad
 stats bf16_c3_serial MTVAF_DW_STREAM=0 --dtype bf16 --model roberta
 stats bf16_c4_serial MTVAF_DW_STREAM=0 --dtype bf16 --batch 64
 stats bf16_c4 MTVAF_DW_STREAM=1 --dtype bf16 --batch 64
