@@ -25,7 +25,7 @@ def _run(m, kw, unpad):
         torch.cuda.synchronize()
         packed = engine.LAST_PACK is not None
         hs = cap["out"]["hidden_states"]
-        return (float(out.loss), list(out.logits), cap["out"]["last_hidden_state"].detach().clone(),
+        return (float(out.loss.detach()), list(out.logits), cap["out"]["last_hidden_state"].detach().clone(),
                 {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, packed,
                 hs[1].detach().clone())
     finally:
@@ -128,3 +128,21 @@ def test_unpadded_encoder_entry_without_the_early_packing_hook():
     valid = mask.bool()
     close(seq1[valid], seq0[valid], rtol=2e-5, name="get_bert_output, unpadded")
     assert float(seq1[~valid].abs().max()) == 0.0
+
+
+def test_unpadded_steps_with_changing_batches():
+    """Consecutive steps with different batch shapes and masks (the packed row count changes every step: arenas, layouts
+    and tile plans follow it) -- each step against its padded twin."""
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=2, max_pos=512)
+    m = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+    for i, (B, S) in enumerate([(8, 128), (24, 64), (5, 200), (8, 128)]):
+        ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 200 + i, B, S, lo_id=1000))
+        feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(300 + i, B, 3))
+        kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+        l0, t0, h0, g0, _, _ = _run(m, kw, False)
+        l1, t1, h1, g1, packed, _ = _run(m, kw, True)
+        assert abs(l0 - l1) <= 2e-6 * abs(l0), (i, l0, l1)
+        assert t0 == t1
+        for n in ("bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.1.output.dense.bias",
+                  "bert.embeddings.position_embeddings.weight", "encoder_conv.2.weight"):
+            close(g1[n], g0[n], rtol=2e-5, atol=1e-6 * float(g0[n].abs().max()) + 1e-9, name=f"step {i} {n}")
