@@ -13,3 +13,9 @@ run --optimizer reference
 run --batch 4 --seq 64 --aux 3 --graph
 run --dtype bf16 --graph
 run --batch 4 --seq 64 --aux 3 --dtype bf16
+run --unpad
+run --unpad --batch 64
+run --unpad --dtype bf16 --model roberta
+run --unpad --dtype bf16 --batch 64
+run --unpad --batch 128 --seq 512 --steps 5 --warmup 4
+run --unpad --batch 128 --seq 512 --dtype bf16 --steps 5 --warmup 4
