@@ -146,3 +146,30 @@ def test_unpadded_steps_with_changing_batches():
         for n in ("bert.encoder.layer.0.attention.self.query.weight", "bert.encoder.layer.1.output.dense.bias",
                   "bert.embeddings.position_embeddings.weight", "encoder_conv.2.weight"):
             close(g1[n], g0[n], rtol=2e-5, atol=1e-6 * float(g0[n].abs().max()) + 1e-9, name=f"step {i} {n}")
+
+
+def test_unpadded_bench_workload_against_the_cpu_oracle():
+    """BASELINE configs[1] (the bench workload: BERT-base 12 layers, bs 32, S = 128, 8 aux crops -> P = 36) with the encoder
+    on packed rows, directly against the CPU oracle: loss 1e-3, decoded tags identical, emissions at unmasked positions,
+    the gradients the padded parity test checks."""
+    from test_configs_gpu import GRADS, _assembled_case, _oracle, _run_model
+    from test_model_gpu import build_tvnet2, make_args
+    cfg = P.BASE_BERT
+    B, S, n_aux = 32, 128, 8
+    sde, sdh, sdp, text, vis = _assembled_case(cfg, B, S, n_aux, seed=41)
+    oloss, oem, otags, ograds = _oracle(cfg, sde, sdh, sdp, text, vis, GRADS)
+    m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
+    m.eval()
+    engine.UNPAD = True
+    try:
+        out, em = _run_model(m, text, vis)
+        assert engine.LAST_PACK is not None
+    finally:
+        engine.UNPAD = False
+    valid = text[1].bool()
+    close(em.cpu()[valid], torch.as_tensor(oem)[valid], name="emissions at unmasked positions")
+    assert abs(float(out.loss) - oloss) <= 1e-3 * abs(oloss), (float(out.loss), oloss)
+    assert list(out.logits) == otags, "decoded tags differ from the oracle"
+    named = dict(m.named_parameters())
+    for n in GRADS:
+        close(named[n].grad, ograds[n], rtol=3e-3, name=n)
