@@ -200,7 +200,8 @@ DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
 # Padding-free execution (opt-in: MTVAF_UNPAD=1 / engine.UNPAD = True; native executor):
 # the encoder layers run on the PACKED unmasked token rows -- every kernel of a layer treats token rows independently
 # except attention (which gets per-sentence row offsets) -- and the last hidden state is scattered back to [B,S,H] with
-# zeros at the masked positions.  Loss, decoded tags and every parameter gradient are those of the padded run (a masked
+# zeros at the masked positions (only for callers that set BertModel.allow_unpad: TVNetSAModel2, whose CRF head is
+# masked; the span model's position softmax reads every position, so it stays padded).  Loss, decoded tags and every parameter gradient are those of the padded run (a masked
 # key contributes exp(-10000) = 0 there, a masked query feeds nothing); hidden states AT masked positions are zeros
 # instead of the reference's don't-care values, and the intermediate hidden states are handed out lazily / detached.
 UNPAD = os.environ.get("MTVAF_UNPAD", "0") == "1"
@@ -349,7 +350,7 @@ def _layer_struct(w: LayerWeights, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_a
 
 def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
     B, S, H = h0.shape
-    NH, eps, p_hidden, p_attn, pkv_ready = cfg
+    NH, eps, p_hidden, p_attn, pkv_ready = cfg[:5]
     M, L = B * S, len(weights)
     Pn = 0 if pkv is None else pkv.shape[3] // H
     I = weights[0].w1.shape[0]
@@ -357,7 +358,8 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
     x = h0.contiguous().view(M, H)
     seed = RNG.seed()
     dev = x.device
-    pack = Packing.build(addmask, Pn, B, S) if UNPAD else None
+    # (the caller vouches that nothing downstream reads hidden states at masked positions: cfg[5], BertModel.allow_unpad)
+    pack = Packing.build(addmask, Pn, B, S) if (UNPAD and len(cfg) > 5 and cfg[5]) else None
     if pack is not None:
         x = pack.pack(x)
         M = pack.Mp
@@ -565,7 +567,7 @@ class EncoderFunction(torch.autograd.Function):
         if NATIVE_EXEC and len(weights):
             return _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params)
         B, S, H = h0.shape
-        NH, eps, p_hidden, p_attn, pkv_ready = cfg
+        NH, eps, p_hidden, p_attn, pkv_ready = cfg[:5]
         L = len(weights)
         M = B * S
         Pn = 0 if pkv is None else pkv.shape[3] // H

@@ -126,6 +126,9 @@ class TVNetSAModel2(nn.Module):
         else:
             self.bert = enc_cls.from_pretrained(args.bert_name)
         self.bert.skip_pooler = True  # pooler_output is unused on this path
+        # this head reads hidden states through the mask only (fc -> CRF with mask=attention_mask): padding-free execution
+        # (engine.UNPAD) may leave zeros at masked positions.  TVNetSAModel's position softmax reads every position: no flag.
+        self.bert.allow_unpad = True
         hidden = self.bert.config.hidden_size
         self.num_labels = len(label_list) + 1
 

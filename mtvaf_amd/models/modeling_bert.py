@@ -271,8 +271,9 @@ class BertEncoder(nn.Module):
 
     def forward(self, hidden_states, attention_mask=None, head_mask=None, encoder_hidden_states=None,
                 encoder_attention_mask=None, past_key_values=None, use_cache=None, output_attentions=False,
-                output_hidden_states=False, return_dict=True):
-        """``attention_mask`` is the additive extended mask [B,1,1,T] (or [B,T]) as in the reference."""
+                output_hidden_states=False, return_dict=True, unpad_ok=False):
+        """``attention_mask`` is the additive extended mask [B,1,1,T] (or [B,T]) as in the reference.  ``unpad_ok``: the
+        caller does not read hidden states at masked positions (padding-free execution may zero them, engine.UNPAD)."""
         if encoder_hidden_states is not None or (head_mask is not None and any(h is not None for h in head_mask)):
             raise NotImplementedError("cross-attention / head_mask are not on the MTVAF path")
         if not hidden_states.is_cuda:
@@ -290,7 +291,7 @@ class BertEncoder(nn.Module):
             raise ValueError(f"attention mask covers {addmask.shape[1]} keys, expected prefix {Pn} + text {S}")
         tr = self.training
         ecfg = (cfg.num_attention_heads, cfg.layer_norm_eps, cfg.hidden_dropout_prob if tr else 0.0,
-                cfg.attention_probs_dropout_prob if tr else 0.0, getattr(past_key_values, "ready_event", None))
+                cfg.attention_probs_dropout_prob if tr else 0.0, getattr(past_key_values, "ready_event", None), bool(unpad_ok))
         params = [p for l in self.layer for p in l.ordered_params()]
         outs = engine.EncoderFunction.apply(hidden_states, pkv, addmask, ecfg, [st.weights for st in stores],
                                             sink if torch.is_grad_enabled() else None, *params)
@@ -501,12 +502,13 @@ class BertModel(nn.Module):
         if token_type_ids is None:
             token_type_ids = torch.zeros_like(input_ids)
         ext = self.get_extended_attention_mask(attention_mask)
-        if engine.UNPAD:  # padding-free execution: the packing maps are built while the host enqueues the embeddings
+        unpad_ok = bool(getattr(self, "allow_unpad", False))
+        if engine.UNPAD and unpad_ok:  # padding-free execution: the packing maps are built while the host enqueues the embeddings
             engine.Packing.begin(ext.view(B, -1), ext.shape[-1] - S, S)
         emb = self.embeddings(input_ids=input_ids, token_type_ids=token_type_ids, position_ids=position_ids,
                               inputs_embeds=inputs_embeds, past_key_values_length=0)
         enc = self.encoder(emb, attention_mask=ext, past_key_values=past_key_values,
-                           output_hidden_states=output_hidden_states, return_dict=True)
+                           output_hidden_states=output_hidden_states, return_dict=True, unpad_ok=unpad_ok)
         seq = enc.last_hidden_state
         # the pooler output is consumed only by the span model's DualGCN head; TVNetSAModel2 never reads it
         # (models/bert_model.py:496-506) and sets `skip_pooler` so the [B,H]x[H,H] product is not launched
@@ -526,7 +528,8 @@ class BertModel(nn.Module):
         """reference: models/modeling_bert.py:1127-1157"""
         assert attention_mask.dim() == 2
         ext = self.get_extended_attention_mask(attention_mask)
-        enc = self.encoder(embedding_output, attention_mask=ext, past_key_values=past_key_values, return_dict=True)
+        enc = self.encoder(embedding_output, attention_mask=ext, past_key_values=past_key_values, return_dict=True,
+                           unpad_ok=bool(getattr(self, "allow_unpad", False)))
         seq = enc.last_hidden_state
         pooled = self.pooler(seq) if (self.pooler is not None and not getattr(self, "skip_pooler", False)) else None
         return (seq, pooled)
