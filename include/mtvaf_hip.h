@@ -96,11 +96,12 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
 /* The same attention over PACKED token rows (padding-free execution): cu [B+1] int32 -- sentence b owns rows
  * cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / dqkv (its unmasked tokens in order, at most S).  Every kept key is unmasked,
  * so no additive mask is read (a masked key contributes exp(-10000) = 0 in the padded form: dropping it is exact);
- * lse / delta stay [B,NH,S].  Rows outside every sentence are not written. */
-int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, float* ctx, float* lse, int B,
-                                 int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+ * lse / delta stay [B,NH,S].  pad_rows: the rows behind the last sentence that pad the packed image to whole tiles; an
+ * extra slice of the launch zero-fills them in ctx / dqkv (an unwritten row could hold a NaN: 0 x NaN would poison dW). */
+int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows, float* ctx,
+                                 float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
                                  mtvaf_stream_t stream);
-int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu,
+int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows,
                                  const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
 /* dst[r][:] = map[r] >= 0 ? src[map[r]][:] : 0  (rows_dst rows of H floats): packs / unpacks token rows. */
@@ -262,11 +263,11 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
                                float p_drop, uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
 /* ... over PACKED token rows (padding-free execution, see mtvaf_prefix_attn_varlen_fwd): cu [B+1] int32, no mask read;
  * partq / partkv keep their padded row counts (blocks beyond a sentence write zeros). */
-int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, void* ctx16, float* lse,
-                                      int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
-                                      mtvaf_stream_t stream);
+int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, int pad_rows, void* ctx16,
+                                      float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                      uint64_t offset, mtvaf_stream_t stream);
 int mtvaf_prefix_attn_bf16_varlen_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const int* cu,
-                                      const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                                      int pad_rows, const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
                                       float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
                                       uint64_t offset, mtvaf_stream_t stream);
 int mtvaf_cast_bf16(const float* x, int ldx, void* out, int ldo, void* outT, int ldt, int R, int C,

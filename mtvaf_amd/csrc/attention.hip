@@ -49,6 +49,7 @@ struct AttnArgs {
   // unmasked tokens, in order), every kept key is unmasked (addmask is not read), queries beyond the sentence do not
   // exist.  NULL: the padded [B, S] layout.  lse / delta / the dropout row ids keep the [B, NH, S] indexing either way.
   const int* cu;
+  int pad_rows;  // packed rows: this many rows behind the last sentence pad the image; the z-slice b == B zero-fills them
 };
 
 struct Sent {
@@ -127,6 +128,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 64 + wave * 16 + lq;
+  if (a.cu && b == a.B) {  // (block-uniform) the rows that pad the packed image: zeros (0 x NaN of an unwritten row would poison dW)
+    const int r0 = a.cu[a.B];
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < a.pad_rows; r += gridDim.x * 16)
+      *reinterpret_cast<f32x4*>(a.ctx + (long)(r0 + r) * a.H + h * D + (threadIdx.x & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
   if ((int)blockIdx.x * 64 >= Sb) return;  // (block-uniform; packed rows: a query tile beyond the sentence)
@@ -542,6 +549,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(AttnArgs a, int nq) { 
   __shared__ __attribute__((aligned(16))) float tile1[KT * LDK];
   __shared__ __attribute__((aligned(16))) float small[3 * KT];
   __shared__ int t_eff_slot;
+  if (a.cu && (int)blockIdx.z == a.B) {  // (block-uniform) zero dQ | dK | dV of the rows that pad the packed image
+    const int r0 = a.cu[a.B], h = blockIdx.y;
+    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < a.pad_rows; r += gridDim.x * 16)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        *reinterpret_cast<f32x4*>(a.dqkv + (long)(r0 + r) * 3 * a.H + c * a.H + h * D + (threadIdx.x & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
+  }
   if ((int)blockIdx.x < nq) {
     attn_bwd_dq_body(a, blockIdx.x, tile0, tile1, small, &t_eff_slot);
   } else {
@@ -573,35 +588,37 @@ static void fill_common(AttnArgs& a, int B, int S, int P, int NH, float p_drop, 
   a.epoch = rng_epoch_ptr();
 }
 
-static int attn_fwd_launch(const float* qkv, const float* pk, const float* pv, const float* addmask, const int* cu, float* ctx,
-                           float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
-                           hipStream_t st) {
+static int attn_fwd_launch(const float* qkv, const float* pk, const float* pv, const float* addmask, const int* cu, int pad_rows,
+                           float* ctx, float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                           uint64_t offset, hipStream_t st) {
   if (head_dim != D) return MTVAF_ERR_SHAPE;
   if (!cu && !addmask) return MTVAF_ERR_ARG;
   AttnArgs a{};
-  a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.ctx = ctx; a.lse = lse;
+  a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.pad_rows = pad_rows; a.ctx = ctx; a.lse = lse;
   fill_common(a, B, S, P, NH, p_drop, seed, offset);
   int rc = check(a);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, NH, B), dim3(256), 0, st, a);
+  if (pad_rows < 0 || (pad_rows && !cu)) return MTVAF_ERR_ARG;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, NH, B + (pad_rows > 0 ? 1 : 0)), dim3(256), 0, st, a);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
 
 static int attn_bwd_launch(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
-                           const int* cu, const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv,
+                           const int* cu, int pad_rows, const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv,
                            int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
   if (head_dim != D) return MTVAF_ERR_SHAPE;
   if (!cu && !addmask) return MTVAF_ERR_ARG;
   AttnArgs a{};
-  a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.ctx = const_cast<float*>(ctx);
+  a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.pad_rows = pad_rows; a.ctx = const_cast<float*>(ctx);
   a.lse = const_cast<float*>(lse); a.dctx = dctx; a.delta = delta; a.dqkv = dqkv; a.dpk = dpk; a.dpv = dpv;
   fill_common(a, B, S, P, NH, p_drop, seed, offset);
   int rc = check(a);
   if (rc) return rc;
   if (P > 0 && (!dpk || !dpv)) return MTVAF_ERR_ARG;
+  if (pad_rows < 0 || (pad_rows && !cu)) return MTVAF_ERR_ARG;
   const int nq = (S + 63) / 64;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nq + (P + S + 63) / 64, NH, B), dim3(256), 0, st, a, nq);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nq + (P + S + 63) / 64, NH, B + (pad_rows > 0 ? 1 : 0)), dim3(256), 0, st, a, nq);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -610,7 +627,7 @@ static int attn_bwd_launch(const float* dctx, const float* qkv, const float* pk,
 int mtvaf_prefix_attn_fwd(const float* qkv, const float* pk, const float* pv, const float* addmask, float* ctx,
                           float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
                           uint64_t offset, hipStream_t st) {
-  return attn_fwd_launch(qkv, pk, pv, addmask, nullptr, ctx, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+  return attn_fwd_launch(qkv, pk, pv, addmask, nullptr, 0, ctx, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
 }
 
 // dqkv[B*S,3H] (all three column blocks overwritten), dpk/dpv[B,P*H] <- gradients; delta[B,NH,S] scratch.
@@ -618,24 +635,27 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
                           const float* addmask, const float* ctx, const float* lse, float* delta, float* dqkv,
                           float* dpk, float* dpv, int B, int S, int P, int NH, int head_dim, float p_drop,
                           uint64_t seed, uint64_t offset, hipStream_t st) {
-  return attn_bwd_launch(dctx, qkv, pk, pv, addmask, nullptr, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed,
+  return attn_bwd_launch(dctx, qkv, pk, pv, addmask, nullptr, 0, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed,
                          offset, st);
 }
 
 // The same attention over PACKED token rows (padding-free execution): cu [B+1] int32 row offsets -- sentence b owns rows
 // cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / dqkv (its unmasked tokens, at most S of them).  Every kept key is unmasked, so
-// no additive mask is read; lse / delta stay [B,NH,S].  Rows of ctx / dqkv outside every sentence are not written.
-int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, float* ctx, float* lse, int B,
-                                 int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+// no additive mask is read; lse / delta stay [B,NH,S].  The pad_rows rows behind the last sentence (they pad the packed
+// image to whole tiles) are zero-filled in ctx / dqkv by an extra slice of the same launch.
+int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows, float* ctx,
+                                 float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                 hipStream_t st) {
   if (!cu) return MTVAF_ERR_ARG;
-  return attn_fwd_launch(qkv, pk, pv, nullptr, cu, ctx, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+  return attn_fwd_launch(qkv, pk, pv, nullptr, cu, pad_rows, ctx, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
 }
 
-int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu,
+int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows,
                                  const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
   if (!cu) return MTVAF_ERR_ARG;
-  return attn_bwd_launch(dctx, qkv, pk, pv, nullptr, cu, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+  return attn_bwd_launch(dctx, qkv, pk, pv, nullptr, cu, pad_rows, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed,
+                         offset, st);
 }
 
 }  // extern "C"

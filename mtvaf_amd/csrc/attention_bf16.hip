@@ -55,6 +55,7 @@ struct Args {
   uint32_t drop_key, drop_thr;
   const uint64_t* epoch;  // device-side dropout epoch (captured launches), or NULL
   const int* cu;          // PACKED token rows (see attention.hip): [B+1] row offsets of the sentences, or NULL
+  int pad_rows;           // rows behind the last sentence that pad the packed image: zero-filled by the z-slice b == B
 };
 
 struct Sent {
@@ -153,6 +154,13 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
   const int lq = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 64 + wave * 16 + lq;
+  if (a.cu && b == a.B) {  // (block-uniform) the rows that pad the packed image: zeros
+    const int r0 = a.cu[a.B];
+    const bf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    for (int r = blockIdx.x * 32 + (threadIdx.x >> 3); r < a.pad_rows; r += gridDim.x * 32)
+      *reinterpret_cast<bf16x8*>(a.ctx + (long)(r0 + r) * a.H + h * D + (threadIdx.x & 7) * 8) = z;
+    return;
+  }
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
   if ((int)blockIdx.x * 64 >= Sb) return;  // (block-uniform; packed rows: a query tile beyond the sentence)
@@ -578,6 +586,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_bwd_kernel(Args a, int nq) {
   __shared__ __attribute__((aligned(16))) float small[3 * KT];
   __shared__ __attribute__((aligned(16))) float red[8 * 64];
   __shared__ int t_eff_slot;
+  if (a.cu && (int)blockIdx.z == a.B) {  // (block-uniform) zero dQ | dK | dV of the rows that pad the packed image
+    const int r0 = a.cu[a.B], h = blockIdx.y;
+    const bf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    for (int r = blockIdx.x * 32 + (threadIdx.x >> 3); r < a.pad_rows; r += gridDim.x * 32)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        *reinterpret_cast<bf16x8*>(a.dqkv + (long)(r0 + r) * 3 * a.H + c * a.H + h * D + (threadIdx.x & 7) * 8) = z;
+    return;
+  }
   if ((int)blockIdx.x < nq) {
     bwd_dq_body(a, blockIdx.x, tile0, tile1, small, red, &t_eff_slot);
   } else {
@@ -605,13 +622,13 @@ using namespace mtvaf;
 
 extern "C" {
 
-static int attn16_fwd_launch(const void* qkv16, const void* pk16, const void* pv16, const float* addmask, const int* cu, void* ctx16,
-                             float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+static int attn16_fwd_launch(const void* qkv16, const void* pk16, const void* pv16, const float* addmask, const int* cu, int pad_rows,
+                             void* ctx16, float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
                              hipStream_t st) {
   if (head_dim != ab::D) return MTVAF_ERR_SHAPE;
   ab::Args a{};
   a.qkv = static_cast<const __bf16*>(qkv16); a.pk = static_cast<const __bf16*>(pk16); a.pv = static_cast<const __bf16*>(pv16);
-  a.addmask = addmask; a.cu = cu; a.ctx = static_cast<__bf16*>(ctx16); a.lse = lse;
+  a.addmask = addmask; a.cu = cu; a.pad_rows = pad_rows; a.ctx = static_cast<__bf16*>(ctx16); a.lse = lse;
   a.B = B; a.S = S; a.P = P; a.NH = NH; a.H = NH * ab::D;
   a.scale = 0.125f; a.p_drop = p_drop;
   a.drop_thr = p_drop > 0.f ? (uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f) : 0u;
@@ -619,20 +636,20 @@ static int attn16_fwd_launch(const void* qkv16, const void* pk16, const void* pv
   a.epoch = rng_epoch_ptr();
   int rc = ab::check(a);
   if (rc) return rc;
-  if (!ctx16 || !lse || (!addmask && !cu)) return MTVAF_ERR_ARG;
-  hipLaunchKernelGGL(ab::attn_bf16_fwd_kernel, dim3((S + 63) / 64, NH, B), dim3(256), 0, st, a);
+  if (!ctx16 || !lse || (!addmask && !cu) || pad_rows < 0 || (pad_rows && !cu)) return MTVAF_ERR_ARG;
+  hipLaunchKernelGGL(ab::attn_bf16_fwd_kernel, dim3((S + 63) / 64, NH, B + (pad_rows > 0 ? 1 : 0)), dim3(256), 0, st, a);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
 
 static int attn16_bwd_launch(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const float* addmask,
-                             const int* cu, const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                             const int* cu, int pad_rows, const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
                              float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
                              hipStream_t st) {
   if (head_dim != ab::D) return MTVAF_ERR_SHAPE;
   ab::Args a{};
   a.qkv = static_cast<const __bf16*>(qkv16); a.pk = static_cast<const __bf16*>(pk16); a.pv = static_cast<const __bf16*>(pv16);
-  a.addmask = addmask; a.cu = cu; a.ctx = static_cast<__bf16*>(const_cast<void*>(ctx16)); a.lse = const_cast<float*>(lse);
+  a.addmask = addmask; a.cu = cu; a.pad_rows = pad_rows; a.ctx = static_cast<__bf16*>(const_cast<void*>(ctx16)); a.lse = const_cast<float*>(lse);
   a.dctx = static_cast<const __bf16*>(dctx16); a.dqkv = static_cast<__bf16*>(dqkv16); a.dpk = dpk; a.dpv = dpv;
   a.partq = partq; a.partkv = partkv;
   a.B = B; a.S = S; a.P = P; a.NH = NH; a.H = NH * ab::D;
@@ -645,8 +662,9 @@ static int attn16_bwd_launch(const void* dctx16, const void* qkv16, const void* 
   if (!dctx16 || !ctx16 || !lse || !dqkv16 || !partq || !partkv || (!addmask && !cu)) return MTVAF_ERR_ARG;
   if (P > 0 && (!dpk || !dpv)) return MTVAF_ERR_ARG;
   if (((uintptr_t)dctx16 | (uintptr_t)ctx16 | (uintptr_t)dqkv16) & 15) return MTVAF_ERR_ALIGN;
+  if (pad_rows < 0 || (pad_rows && !cu)) return MTVAF_ERR_ARG;
   const int nq = (S + 63) / 64;
-  hipLaunchKernelGGL(ab::attn_bf16_bwd_kernel, dim3(nq + (P + S + 63) / 64, NH, B), dim3(256), 0, st, a, nq);
+  hipLaunchKernelGGL(ab::attn_bf16_bwd_kernel, dim3(nq + (P + S + 63) / 64, NH, B + (pad_rows > 0 ? 1 : 0)), dim3(256), 0, st, a, nq);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -656,7 +674,7 @@ int mtvaf_prefix_attn_bf16_fwd(const void* qkv16, const void* pk16, const void* 
                                float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
                                uint64_t offset, hipStream_t st) {
   if (!addmask) return MTVAF_ERR_ARG;
-  return attn16_fwd_launch(qkv16, pk16, pv16, addmask, nullptr, ctx16, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+  return attn16_fwd_launch(qkv16, pk16, pv16, addmask, nullptr, 0, ctx16, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
 }
 
 // dqkv16 [B*S,3H] bf16 (all three column blocks overwritten), dpk / dpv [B,P*H] fp32 <- gradients.
@@ -667,26 +685,26 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
                                float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
                                float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
   if (!addmask) return MTVAF_ERR_ARG;
-  return attn16_bwd_launch(dctx16, qkv16, pk16, pv16, addmask, nullptr, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, P, NH,
+  return attn16_bwd_launch(dctx16, qkv16, pk16, pv16, addmask, nullptr, 0, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, P, NH,
                            head_dim, p_drop, seed, offset, st);
 }
 
 // PACKED token rows (padding-free execution; see mtvaf_prefix_attn_varlen_fwd): cu [B+1] int32 row offsets, no mask read;
 // partq / partkv keep their padded row counts (blocks beyond a sentence write zeros).
-int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, void* ctx16, float* lse,
-                                      int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
-                                      hipStream_t st) {
+int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, int pad_rows, void* ctx16,
+                                      float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                      uint64_t offset, hipStream_t st) {
   if (!cu) return MTVAF_ERR_ARG;
-  return attn16_fwd_launch(qkv16, pk16, pv16, nullptr, cu, ctx16, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
+  return attn16_fwd_launch(qkv16, pk16, pv16, nullptr, cu, pad_rows, ctx16, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st);
 }
 
 int mtvaf_prefix_attn_bf16_varlen_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const int* cu,
-                                      const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                                      int pad_rows, const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
                                       float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
                                       uint64_t offset, hipStream_t st) {
   if (!cu) return MTVAF_ERR_ARG;
-  return attn16_bwd_launch(dctx16, qkv16, pk16, pv16, nullptr, cu, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, P, NH, head_dim,
-                           p_drop, seed, offset, st);
+  return attn16_bwd_launch(dctx16, qkv16, pk16, pv16, nullptr, cu, pad_rows, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, P, NH,
+                           head_dim, p_drop, seed, offset, st);
 }
 
 }  // extern "C"

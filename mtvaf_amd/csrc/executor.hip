@@ -37,17 +37,18 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
                                const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
                                float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
                                float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
-int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, float* ctx, float* lse, int B,
-                                 int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
-int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu,
+int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows, float* ctx,
+                                 float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                 hipStream_t st);
+int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows,
                                  const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
 int mtvaf_zero_f32(float* p, long n, hipStream_t st);
-int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, void* ctx16, float* lse,
-                                      int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
-                                      hipStream_t st);
+int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, int pad_rows, void* ctx16,
+                                      float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                      uint64_t offset, hipStream_t st);
 int mtvaf_prefix_attn_bf16_varlen_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const int* cu,
-                                      const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                                      int pad_rows, const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
                                       float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
                                       uint64_t offset, hipStream_t st);
 int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
@@ -141,11 +142,9 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KC, L->x_h, H, L->wqkv_h, H, nullptr, 0, L->qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE,
                                nullptr, 0, 0, nullptr, 0, nullptr, 0, 0, -1, 0, st));
     if (L->cu) {
-      MTVAF_TRY(mtvaf_prefix_attn_bf16_varlen_fwd(L->qkv, L->pk, L->pv, L->cu, L->cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn,
-                                                  L->seed, L->offset, st));
-      // (bf16 rows: H / 2 floats each) the rows that pad the packed image belong to no sentence
-      MTVAF_TRY(mtvaf_zero_f32(reinterpret_cast<float*>(static_cast<unsigned char*>(L->cx) + (size_t)L->Mv * H * 2),
-                               (long)(L->Mp - L->Mv) * H / 2, st));
+      // (the rows that pad the packed image belong to no sentence: an extra slice of the launch zero-fills them)
+      MTVAF_TRY(mtvaf_prefix_attn_bf16_varlen_fwd(L->qkv, L->pk, L->pv, L->cu, L->Mp - L->Mv, L->cx, L->lse, L->B, L->S, L->P, L->NH, 64,
+                                                  L->p_attn, L->seed, L->offset, st));
     } else {
       MTVAF_TRY(mtvaf_prefix_attn_bf16_fwd(L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn,
                                            L->seed, L->offset, st));
@@ -170,10 +169,10 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
   MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, L->x, H, L->wqkv, H, qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE, nullptr, 0, 0, 1, L->ws,
                            L->ws_bytes, -1, -1, st));
   if (L->cu) {
-    MTVAF_TRY(mtvaf_prefix_attn_varlen_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu, cx, L->lse,
-                                           L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
-    // the rows that pad the packed image belong to no sentence: zero them (0 x NaN of an unwritten row would poison dW)
-    MTVAF_TRY(mtvaf_zero_f32(cx + (long)L->Mv * H, (long)(L->Mp - L->Mv) * H, st));
+    // the rows that pad the packed image belong to no sentence: an extra slice of the launch zero-fills them (0 x NaN of an
+    // unwritten row would poison dW)
+    MTVAF_TRY(mtvaf_prefix_attn_varlen_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
+                                           L->Mp - L->Mv, cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
   } else {
     MTVAF_TRY(mtvaf_prefix_attn_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx, L->lse,
                                     L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
@@ -217,10 +216,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->da, H, L->wo_h, H, nullptr, 0, g->dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
     if (L->cu) {
-      MTVAF_TRY(mtvaf_prefix_attn_bf16_varlen_bwd(g->dctx, L->qkv, L->pk, L->pv, L->cu, L->cx, L->lse, g->dqkv, g->dpk, g->dpv,
-                                                  g->partq, g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
-      MTVAF_TRY(mtvaf_zero_f32(reinterpret_cast<float*>(static_cast<unsigned char*>(g->dqkv) + (size_t)L->Mv * 3 * H * 2),
-                               (long)(L->Mp - L->Mv) * 3 * H / 2, mainS));
+      MTVAF_TRY(mtvaf_prefix_attn_bf16_varlen_bwd(g->dctx, L->qkv, L->pk, L->pv, L->cu, L->Mp - L->Mv, L->cx, L->lse, g->dqkv, g->dpk,
+                                                  g->dpv, g->partq, g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
     } else {
       MTVAF_TRY(mtvaf_prefix_attn_bf16_bwd(g->dctx, L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, g->dqkv, g->dpk, g->dpv, g->partq,
                                            g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
@@ -263,10 +260,9 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, da, H, L->wo, H, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_main,
                              g->ws_main_bytes, -1, -1, mainS));
     if (L->cu) {
-      MTVAF_TRY(mtvaf_prefix_attn_varlen_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu, cx,
-                                             L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset,
-                                             mainS));
-      MTVAF_TRY(mtvaf_zero_f32(dqkv + (long)L->Mv * 3 * H, (long)(L->Mp - L->Mv) * 3 * H, mainS));
+      MTVAF_TRY(mtvaf_prefix_attn_varlen_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
+                                             L->Mp - L->Mv, cx, L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn,
+                                             L->seed, L->offset, mainS));
     } else {
       MTVAF_TRY(mtvaf_prefix_attn_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx,
                                       L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
