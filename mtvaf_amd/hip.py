@@ -362,6 +362,30 @@ def prefix_attn_bwd(dctx, qkv, pk, pv, addmask, ctx, lse, delta, dqkv, dpk, dpv,
         "mtvaf_prefix_attn_bwd")
 
 
+def prefix_attn_varlen_fwd(qkv, pk, pv, cu, pad_rows, ctx, lse, B, S, Pn, NH, p, seed, offset):
+    """PACKED token rows: cu [B+1] int32 row offsets; the pad_rows rows behind the last sentence are zero-filled."""
+    _ck(lib().mtvaf_prefix_attn_varlen_fwd(_p(qkv), _p(pk), _p(pv), _p(cu), int(pad_rows), _p(ctx), _p(lse), B, S, Pn, NH, 64,
+                                           float(p), seed, offset, _st()), "mtvaf_prefix_attn_varlen_fwd")
+
+
+def prefix_attn_varlen_bwd(dctx, qkv, pk, pv, cu, pad_rows, ctx, lse, delta, dqkv, dpk, dpv, B, S, Pn, NH, p, seed, offset):
+    _ck(lib().mtvaf_prefix_attn_varlen_bwd(_p(dctx), _p(qkv), _p(pk), _p(pv), _p(cu), int(pad_rows), _p(ctx), _p(lse), _p(delta),
+                                           _p(dqkv), _p(dpk), _p(dpv), B, S, Pn, NH, 64, float(p), seed, offset, _st()),
+        "mtvaf_prefix_attn_varlen_bwd")
+
+
+def prefix_attn_bf16_varlen_fwd(qkv16, pk16, pv16, cu, pad_rows, ctx16, lse, B, S, Pn, NH, p, seed, offset):
+    _ck(lib().mtvaf_prefix_attn_bf16_varlen_fwd(_p(qkv16), _p(pk16), _p(pv16), _p(cu), int(pad_rows), _p(ctx16), _p(lse), B, S, Pn,
+                                                NH, 64, float(p), seed, offset, _st()), "mtvaf_prefix_attn_bf16_varlen_fwd")
+
+
+def prefix_attn_bf16_varlen_bwd(dctx16, qkv16, pk16, pv16, cu, pad_rows, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, Pn, NH,
+                                p, seed, offset):
+    _ck(lib().mtvaf_prefix_attn_bf16_varlen_bwd(_p(dctx16), _p(qkv16), _p(pk16), _p(pv16), _p(cu), int(pad_rows), _p(ctx16),
+                                                _p(lse), _p(dqkv16), _p(dpk), _p(dpv), _p(partq), _p(partkv), B, S, Pn, NH, 64,
+                                                float(p), seed, offset, _st()), "mtvaf_prefix_attn_bf16_varlen_bwd")
+
+
 def prefix_attn_bf16_fwd(qkv16, pk16, pv16, addmask, ctx16, lse, B, S, Pn, NH, p, seed, offset):
     _ck(lib().mtvaf_prefix_attn_bf16_fwd(_p(qkv16), _p(pk16), _p(pv16), _p(addmask), _p(ctx16), _p(lse), B, S, Pn, NH, 64,
                                          float(p), seed, offset, _st()), "mtvaf_prefix_attn_bf16_fwd")

@@ -307,6 +307,87 @@ def test_prefix_attention_bf16(hip, B, S, Pn, NH):
     close(bsum, dqkv.double().cpu().sum(0), rtol=2e-2, atol=2e-2 * float(dqkv.double().cpu().sum(0).abs().max()), name="partials vs stored")
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,S,Pn,NH,p", [(5, 128, 36, 12, 0.0), (4, 200, 16, 3, 0.0), (3, 64, 0, 2, 0.0), (6, 128, 36, 4, 0.1)])
+def test_varlen_attention_is_the_padded_attention_on_packed_rows(hip, dtype, B, S, Pn, NH, p):
+    """Padding-free execution at kernel level: the varlen launch on PACKED rows against the padded launch on the same
+    sentences with trailing padding.  Same keys in the same order through the same tiles, and the dropout hash is
+    indexed by (sentence, head, query, key) in both layouts: every kept row must come out BIT-identical (context, lse,
+    dQ|dK|dV), the prefix gradients too; the rows that pad the packed image are zeros; the bf16 column-sum partials add
+    up to the same bias gradients."""
+    H, T = NH * 64, Pn + S
+    bf16 = dtype == "bf16"
+    cast = (lambda t: t.to(torch.bfloat16)) if bf16 else (lambda t: t)
+    lens = [S] + [max(1, (S * (i + 1)) // (B + 1)) for i in range(B - 1)]
+    Mv = sum(lens)
+    Mp = (Mv + 127) // 128 * 128 + 128  # (one whole tile of padding rows as well)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    qkv = cast(rnd(B * S, 3 * H, seed=1))
+    pk, pv = cast(rnd(B, max(Pn, 1) * H, seed=2)), cast(rnd(B, max(Pn, 1) * H, seed=3))
+    dctx = cast(rnd(B * S, H, seed=4))
+    mask = torch.zeros(B, T)
+    rows = []
+    for b, Lb in enumerate(lens):
+        mask[b, : Pn + Lb] = 1
+        rows += [b * S + s_ for s_ in range(Lb)]
+    rows = torch.tensor(rows)
+    keep = torch.zeros(B * S, dtype=torch.bool)
+    keep[rows] = True
+    dctx = dctx * keep[:, None].to(dctx.dtype)  # (nothing downstream reads a padded query: its upstream gradient is zero)
+    addmask = (1 - mask) * -10000.0
+    g = lambda t: t.to(DEV)
+    gk, gv = (g(pk), g(pv)) if Pn else (None, None)
+    odt = torch.bfloat16 if bf16 else torch.float32
+    # ---- padded launch
+    ctx0, lse0 = torch.zeros(B * S, H, dtype=odt, device=DEV), torch.zeros(B, NH, S, device=DEV)
+    dq0 = torch.zeros(B * S, 3 * H, dtype=odt, device=DEV)
+    dpk0, dpv0 = (torch.zeros(B, Pn * H, device=DEV), torch.zeros(B, Pn * H, device=DEV)) if Pn else (None, None)
+    nqt, nkt = (S + 63) // 64, (T + 63) // 64
+    if bf16:
+        pq0, pkv0 = torch.zeros(B * nqt, H, device=DEV), torch.zeros(B * nkt, 2 * H, device=DEV)
+        hip.prefix_attn_bf16_fwd(g(qkv), gk, gv, g(addmask), ctx0, lse0, B, S, Pn, NH, p, 11, 5)
+        hip.prefix_attn_bf16_bwd(g(dctx), g(qkv), gk, gv, g(addmask), ctx0, lse0, dq0, dpk0, dpv0, pq0, pkv0, B, S, Pn, NH, p, 11, 5)
+    else:
+        delta0 = torch.zeros(B, NH, S, device=DEV)
+        hip.prefix_attn_fwd(g(qkv), gk, gv, g(addmask), ctx0, lse0, B, S, Pn, NH, p, 11, 5)
+        hip.prefix_attn_bwd(g(dctx), g(qkv), gk, gv, g(addmask), ctx0, lse0, delta0, dq0, dpk0, dpv0, B, S, Pn, NH, p, 11, 5)
+    # ---- packed launch
+    def packed(t, width):
+        out = torch.zeros(Mp, width, dtype=t.dtype)
+        out[:Mv] = t[rows]
+        return g(out)
+    qp, dcp = packed(qkv, 3 * H), packed(dctx, H)
+    ctx1 = torch.full((Mp, H), float("nan"), dtype=odt, device=DEV)
+    lse1 = torch.zeros(B, NH, S, device=DEV)
+    dq1 = torch.full((Mp, 3 * H), float("nan"), dtype=odt, device=DEV)
+    dpk1, dpv1 = (torch.zeros(B, Pn * H, device=DEV), torch.zeros(B, Pn * H, device=DEV)) if Pn else (None, None)
+    if bf16:
+        pq1, pkv1 = torch.full((B * nqt, H), float("nan"), device=DEV), torch.full((B * nkt, 2 * H), float("nan"), device=DEV)
+        hip.prefix_attn_bf16_varlen_fwd(qp, gk, gv, g(cu), Mp - Mv, ctx1, lse1, B, S, Pn, NH, p, 11, 5)
+        hip.prefix_attn_bf16_varlen_bwd(dcp, qp, gk, gv, g(cu), Mp - Mv, ctx1, lse1, dq1, dpk1, dpv1, pq1, pkv1, B, S, Pn, NH, p, 11, 5)
+    else:
+        delta1 = torch.zeros(B, NH, S, device=DEV)
+        hip.prefix_attn_varlen_fwd(qp, gk, gv, g(cu), Mp - Mv, ctx1, lse1, B, S, Pn, NH, p, 11, 5)
+        hip.prefix_attn_varlen_bwd(dcp, qp, gk, gv, g(cu), Mp - Mv, ctx1, lse1, delta1, dq1, dpk1, dpv1, B, S, Pn, NH, p, 11, 5)
+    torch.cuda.synchronize()
+    rd = rows.to(DEV)
+    assert torch.equal(ctx1[:Mv], ctx0[rd]), "context rows"
+    assert torch.equal(dq1[:Mv], dq0[rd]), "dQ | dK | dV rows"
+    assert float(ctx1[Mv:].float().abs().max()) == 0.0 and float(dq1[Mv:].float().abs().max()) == 0.0, "padding rows of the image"
+    for b, Lb in enumerate(lens):
+        assert torch.equal(lse1[b, :, :Lb], lse0[b, :, :Lb]), "lse"
+    if Pn:
+        assert torch.equal(dpk1, dpk0) and torch.equal(dpv1, dpv0), "prefix gradients"
+    if bf16:
+        assert torch.isfinite(pq1).all() and torch.isfinite(pkv1).all()
+        # the padded launch also sums the (exactly zero) gradients of padded keys / the garbage-free padded queries:
+        close(pkv1.sum(0), pkv0.sum(0), rtol=1e-5, atol=1e-5 * float(pkv0.sum(0).abs().max()), name="dK | dV column sums")
+        valid_q = torch.zeros(B * S, dtype=torch.bool, device=DEV)
+        valid_q[rd] = True
+        want_q = dq0[:, :H].float()[valid_q].sum(0)
+        close(pq1.sum(0), want_q, rtol=2e-2, atol=2e-2 * float(want_q.abs().max()), name="dQ column sums over the kept rows")
+
+
 def test_prefix_attention_bf16_dropout(hip):
     """Dropout in the bf16 kernels: keep fraction, the forward mask regenerated identically by both backward sides
     (directional derivative by central differences under the same mask)."""
