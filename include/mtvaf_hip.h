@@ -111,6 +111,18 @@ int mtvaf_gather_rows(const float* src, const int* map, float* dst, int rows_dst
  * the kept rows), mv_out[0] = number of kept rows.  All int32, device. */
 int mtvaf_build_packing(const float* addmask, int B, int T, int P, int S, int* cu, int* inv, int* rowmap, int* mv_out,
                         mtvaf_stream_t stream);
+/* k-tile list for mtvaf_gemm_f32_ktiles: the bk-row tiles of the [B*S] token axis that hold at least one unmasked token
+ * (additive mask [B, T = P + S], kept: > -5000), in order; kcnt[0] = how many.  (B*S) % bk == 0.  Device int32 arrays. */
+int mtvaf_build_ktiles(const float* addmask, int B, int T, int P, int S, int bk, int* klist, int* kcnt,
+                       mtvaf_stream_t stream);
+/* mtvaf_gemm_f32 for a weight-gradient product (layouts KM x KM, the reduction index is the token row) whose operand A is
+ * EXACTLY ZERO outside the listed 32-row k-tiles: the reduction runs over klist[0 .. *kcnt) only (no host sync).  Gradients
+ * of token rows that nothing downstream reads -- padded positions -- are exact zeros, so skipping their k-tiles changes
+ * nothing but time; plans that cannot use the list reduce over the whole range (same result). */
+int mtvaf_gemm_f32_ktiles(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                          int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                          int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits, const int* klist,
+                          const int* kcnt, mtvaf_stream_t stream);
 /* p[0..n) = 0 (a kernel, not hipMemsetAsync: usable inside captured graphs, see rowops.hip). */
 int mtvaf_zero_f32(float* p, long n, mtvaf_stream_t stream);
 
@@ -318,6 +330,9 @@ typedef struct {
   float *dpk, *dpv;
   void* ws_main; size_t ws_main_bytes;
   void* ws_side; size_t ws_side_bytes;
+  /* fp32 mode, optional: 32-row k-tile list of the token axis for the weight-gradient products (mtvaf_build_ktiles) */
+  const int* klist;
+  const int* kcnt;
 } mtvaf_layer_grads_t;
 
 int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* layer, mtvaf_stream_t stream);

@@ -44,6 +44,10 @@ int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const floa
                                  const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
 int mtvaf_zero_f32(float* p, long n, hipStream_t st);
+int mtvaf_gemm_f32_ktiles(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                          int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                          int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits, const int* klist,
+                          const int* kcnt, hipStream_t stream);
 int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, int pad_rows, void* ctx16,
                                       float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
                                       uint64_t offset, hipStream_t st);
@@ -131,6 +135,8 @@ struct mtvaf_layer_grads_t {
   float *dpk, *dpv;                            // [B, P*H] or NULL
   void* ws_main; size_t ws_main_bytes;         // scratch of the main stream (LayerNorm partials, split-K slabs)
   void* ws_side; size_t ws_side_bytes;         // scratch of the second stream (split-K slabs, column-sum partials)
+  const int* klist;                            // fp32 mode, optional: k-tile list of the token axis for the dW products
+  const int* kcnt;
 };
 
 int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
@@ -242,21 +248,21 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0, M, H,
                                        L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, nullptr, mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, df, H, act, I, g->dw2, I, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
-                             g->ws_side_bytes, -1, -1, side));
+    MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, df, H, act, I, g->dw2, I, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+                             g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, df, H, L->w2, I, dpre, I, M, I, H, nullptr, X_EPI_DGELU, pre, I, 0, 1, g->ws_main, g->ws_main_bytes, -1, -1,
                              mainS));
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
-    MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, dpre, I, L->h1, H, g->dw1, H, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
-                             g->ws_side_bytes, -1, -1, side));
+    MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dpre, I, L->h1, H, g->dw1, H, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+                             g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dpre, I, L->w1, H, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, 1, g->ws_main,
                              g->ws_main_bytes, -1, -1, mainS));
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, 0, g->dg1, g->db1, g->dbo, 0, M, H,
                                        L->p_hidden, L->seed, L->offset + 1, g->ws_main, g->ws_main_bytes, nullptr, mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, da, H, cx, H, g->dwo, H, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
-                             g->ws_side_bytes, -1, -1, side));
+    MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, da, H, cx, H, g->dwo, H, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+                             g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, da, H, L->wo, H, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_main,
                              g->ws_main_bytes, -1, -1, mainS));
     if (L->cu) {
@@ -269,8 +275,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     }
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
-    MTVAF_TRY(mtvaf_gemm_f32(X_KM, X_KM, dqkv, 3 * H, L->x, H, g->dwqkv, H, 3 * H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1,
-                             g->ws_side, g->ws_side_bytes, -1, -1, side));
+    MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dqkv, 3 * H, L->x, H, g->dwqkv, H, 3 * H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1,
+                             g->ws_side, g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dqkv, 3 * H, L->wqkv, H, g->dh, H, M, H, 3 * H, nullptr, X_EPI_NONE, nullptr, 0, 1, 1,
                              g->ws_main, g->ws_main_bytes, -1, -1, mainS));
   }

@@ -258,8 +258,9 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE = 3>
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE = 3, bool KLIST = false>
 __global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma_kernel(GemmArgs p) {
+  static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
   constexpr int BK = 32;
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -278,9 +279,17 @@ __global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
-  const int kbeg = blockIdx.z * p.k_chunk;
+  int kbeg = blockIdx.z * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
-  const int nk = (kend - kbeg) / BK;
+  int nk = (kend - kbeg) / BK;
+  int lbeg = 0;
+  if constexpr (KLIST) {  // this split's share of the listed k-tiles (the count lives on the device)
+    const int cnt = *p.kcnt;
+    const int per = (cnt + (int)gridDim.z - 1) / (int)gridDim.z;
+    lbeg = blockIdx.z * per;
+    nk = max(0, min(cnt - lbeg, per));
+    kbeg = 0;
+  }
 
   // per-lane source pointers of this wave's DMA pieces (advance by one k-tile per issue)
   const float* pa[IA];
@@ -311,9 +320,22 @@ __global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma
   stepA = A_KM ? (long)BK * p.lda : BK;
   stepB = B_KM ? (long)BK * p.ldb : BK;
 
+  int issued = 0;   // (k-tile list) ordinal of the next tile to issue ...
+  int kt_next = 0;  // ... and its k-tile index, fetched one issue ahead (a uniform scalar load)
+  if constexpr (KLIST) kt_next = nk > 0 ? p.klist[lbeg] : 0;
   auto issue = [&](int stage) {
     float* sa = smem + stage * STAGE + wave * IA * 256;
     float* sb = smem + stage * STAGE + A_SZ + wave * IB * 256;
+    if constexpr (KLIST) {
+      const long oa = (long)kt_next * stepA, ob = (long)kt_next * stepB;
+      ++issued;
+      kt_next = p.klist[lbeg + min(issued, nk - 1)];
+#pragma unroll
+      for (int i = 0; i < IA; ++i) glds16(pa[i] + oa, sa + i * 256);
+#pragma unroll
+      for (int i = 0; i < IB; ++i) glds16(pb[i] + ob, sb + i * 256);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       glds16(pa[i], sa + i * 256);
@@ -448,6 +470,7 @@ __global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma
     __builtin_amdgcn_sched_barrier(0);
   };
 
+  if (!KLIST || nk > 0) {  // (a split of an almost empty list has nothing to add: its slab is zeros)
   issue(0);
   if (NSTAGE == 3 && nk > 1) {
     issue(1);
@@ -481,6 +504,7 @@ __global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma
     }
   }
   if (kt < nk) tile_body(std::integral_constant<int, 0>{}, st_c, 0, 0);
+  }
 
   if (p.wide) {
     epilogue_wide<BM, BN, WM, WN, TM, TN, NW * 64>(p, acc, smem, m0, n0, wm, wn, li, h, tid);
@@ -578,8 +602,20 @@ static int launch_dma(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t 
   } while (0)
   if (la == 0 && lb == 0) MTVAF_DMA_LAUNCH(false, false);
   else if (la == 0 && lb == 1) MTVAF_DMA_LAUNCH(false, true);
-  else if (la == 1 && lb == 1) MTVAF_DMA_LAUNCH(true, true);
-  else return MTVAF_ERR_ARG;
+  else if (la == 1 && lb == 1) {
+    if (a.klist) {
+      auto kern = gemm_f32_dma_kernel<BM, BN, WM, WN, true, true, NSTAGE, true>;
+      static bool attr_set_l = false;
+      if (smem > 64 * 1024 && !attr_set_l) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set_l = true;
+      }
+      hipLaunchKernelGGL(kern, grid, block, smem, st, a);
+    } else {
+      MTVAF_DMA_LAUNCH(true, true);
+    }
+  } else return MTVAF_ERR_ARG;
 #undef MTVAF_DMA_LAUNCH
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
@@ -767,7 +803,7 @@ int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi
 static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
                          int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
-                         hipStream_t stream) {
+                         hipStream_t stream, const int* klist = nullptr, const int* kcnt = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_SHAPE;
   if (compute == 1) {
     // the bf16 kernels need k-aligned, vector-loadable operands; anything else runs the fp32 kernels
@@ -791,6 +827,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     if (splits < 1) splits = 1;
   }
   GemmArgs a;
+  a.klist = nullptr; a.kcnt = nullptr;
   a.A = A; a.B = B; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldaux = ldaux;
   a.epi = epi; a.accumulate = accumulate;
@@ -820,6 +857,12 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     if (cfg_forced) return MTVAF_ERR_SHAPE;
     static const int staged_twin[7] = {6, 5, 8, 6, 5, 4, 4};  // same tile, register-staged kernel (handles any alignment)
     cfg = staged_twin[cfg - kFirstDma];
+  }
+  // the k-tile list only reaches the LDS-DMA kernels (32-row k-tiles of k-major operands); any other plan reduces over
+  // the whole range, which gives the same result (the skipped k-tiles are exact zeros by the caller's contract)
+  if (klist && kcnt && compute == 0 && cfg >= kFirstDma && layout_a == 1 && layout_b == 1 && K % 32 == 0) {
+    a.klist = klist;
+    a.kcnt = kcnt;
   }
   ProfRec* pr = nullptr;
   if (g_prof && g_prof_n < g_prof_cap) {
@@ -868,6 +911,19 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
                    hipStream_t stream) {
   return gemm_dispatch(0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
                        allow_split, workspace, workspace_bytes, cfg, splits, stream);
+}
+
+// mtvaf_gemm_f32 for a weight-gradient product (layouts KM x KM: C[M,N] = A[K,M]^T . B[K,N], the reduction index is the
+// token row) whose operand A is known to be EXACTLY ZERO outside the listed 32-row k-tiles: the reduction runs over
+// klist[0 .. *kcnt) only (device arrays: no host sync; k-tile t = rows 32 t .. 32 t + 31).  Gradients of token rows that
+// nothing downstream reads -- padded positions -- are exact zeros, so skipping their k-tiles changes nothing but time.
+// Plans that cannot use the list (unaligned shapes, other layouts) reduce over the whole range: same result.
+int mtvaf_gemm_f32_ktiles(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                          int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                          int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits, const int* klist,
+                          const int* kcnt, hipStream_t stream) {
+  return gemm_dispatch(0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
+                       allow_split, workspace, workspace_bytes, cfg, splits, stream, klist, kcnt);
 }
 
 // Same contract as mtvaf_gemm_f32 (fp32 operands and results in memory), but the products run on the bf16

@@ -20,6 +20,11 @@ struct GemmArgs {
   int epi, a_vec, b_vec, accumulate;
   int tiles_n;
   int wide;  // wide (LDS-transposed, dwordx4) epilogue allowed: ldc/ldaux % 4 == 0, 16-B aligned C/aux/bias
+  // k-tile list (weight-gradient products, k-major operands): the reduction runs over the 32-row k-tiles klist[0 .. *kcnt)
+  // only -- the caller vouches that every other k-tile of one operand is exactly zero (token rows whose gradient is zero:
+  // padded positions).  NULL: the whole reduction range.  Both live on the device: no host sync.
+  const int* klist;
+  const int* kcnt;
 };
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so

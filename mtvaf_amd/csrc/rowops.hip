@@ -539,6 +539,50 @@ int mtvaf_build_packing(const float* addmask, int B, int T, int P, int S, int* c
   return MTVAF_OK;
 }
 
+// k-tile list of the weight-gradient products (mtvaf_gemm_f32_ktiles): the bk-row tiles of the [B*S] token axis that hold at
+// least one unmasked token, in order; kcnt[0] = how many.  One block; 64 tiles per wave pass, compacted with ballots.
+__global__ __launch_bounds__(1024) void build_ktiles_kernel(const float* __restrict__ addmask, int B, int T, int P, int S, int bk,
+                                                           int* __restrict__ klist, int* __restrict__ kcnt) {
+  __shared__ int chunk_base[1025];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int ntiles = (B * S) / bk, nchunks = (ntiles + 63) / 64;
+  auto live = [&](int t) {
+    bool any = false;
+    for (int r = t * bk; r < (t + 1) * bk && !any; ++r) any = addmask[(long)(r / S) * T + P + (r % S)] > -5000.f;
+    return any;
+  };
+  for (int c = wave; c < nchunks; c += nw) {
+    const int t = c * 64 + lane;
+    const unsigned long long bal = __ballot(t < ntiles && live(t));
+    if (lane == 0) chunk_base[c + 1] = __popcll(bal);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    chunk_base[0] = 0;
+    for (int c = 0; c < nchunks; ++c) {
+      acc += chunk_base[c + 1];
+      chunk_base[c + 1] = acc;
+    }
+    kcnt[0] = acc;
+  }
+  __syncthreads();
+  for (int c = wave; c < nchunks; c += nw) {
+    const int t = c * 64 + lane;
+    const bool keep = t < ntiles && live(t);
+    const unsigned long long bal = __ballot(keep);
+    if (keep) klist[chunk_base[c] + __popcll(bal & ((1ull << lane) - 1ull))] = t;
+  }
+}
+
+int mtvaf_build_ktiles(const float* addmask, int B, int T, int P, int S, int bk, int* klist, int* kcnt, hipStream_t st) {
+  if (B <= 0 || S <= 0 || P < 0 || T != P + S || bk <= 0 || ((long)B * S) % bk || (long)B * S / bk > 64 * 1024) return MTVAF_ERR_SHAPE;
+  if (!addmask || !klist || !kcnt) return MTVAF_ERR_ARG;
+  hipLaunchKernelGGL(build_ktiles_kernel, dim3(1), dim3(1024), 0, st, addmask, B, T, P, S, bk, klist, kcnt);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
 int mtvaf_zero_f32(float* p, long n, hipStream_t st) {
   if (n < 0 || (n && !p)) return MTVAF_ERR_ARG;
   if (n) zero_f32(p, n, st);

@@ -205,6 +205,11 @@ DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
 # key contributes exp(-10000) = 0 there, a masked query feeds nothing); hidden states AT masked positions are zeros
 # instead of the reference's don't-care values, and the intermediate hidden states are handed out lazily / detached.
 UNPAD = os.environ.get("MTVAF_UNPAD", "0") == "1"
+# Padded run, fp32: the weight-gradient products skip the 32-row k-tiles of the token axis that hold only masked tokens.
+# The gradient of a token row nothing downstream reads is EXACTLY zero (a masked key has probability exp(-10000) = 0, a
+# masked query feeds only itself, the CRF is masked), so the skipped terms of dW = sum_rows dY[r]^T X[r] are zeros: every
+# output of the step is unchanged.  Only for callers that vouch for it (cfg[5], BertModel.allow_unpad).
+SKIP_PAD_DW = os.environ.get("MTVAF_SKIP_PAD_DW", "1") != "0"
 LAST_PACK = None  # the Packing of the most recent native forward (None: it ran padded)
 _PENDING_PACK = None  # packing started by Packing.begin, consumed by the next Packing.build
 _PACK_HOST = {}
@@ -463,6 +468,16 @@ def _native_backward(ctx, douts):
     dpk_step, dpk_layer = ((dpkv.stride(1) * 4, dpkv.stride(0) * 4) if Pn else (0, 0))
     am_ptr = addmask.data_ptr()
     settle = int(grad_sink is not None and side is not None and grad_sink.on_layer_done is not None and grad_sink.settle_params)
+    klist = kcnt = None
+    if (SKIP_PAD_DW and pack is None and not use_h and need_param_grads and len(cfg) > 5 and cfg[5] and (B * S) % 32 == 0
+            and addmask.dtype == torch.float32 and addmask.is_contiguous()):
+        klist = torch.empty(B * S // 32, dtype=torch.int32, device=dev)
+        kcnt = torch.empty(1, dtype=torch.int32, device=dev)
+        hip._ck(hip.lib().mtvaf_build_ktiles(hip._p(addmask), B, addmask.shape[1], Pn, S, 32, hip._p(klist), hip._p(kcnt), main_h),
+                "mtvaf_build_ktiles")
+        if side is not None:
+            klist.record_stream(side)
+            kcnt.record_stream(side)
     keep = []  # temporaries the second stream still reads: alive until the join below
     dh = None
     for li in range(L - 1, -1, -1):
@@ -517,6 +532,7 @@ def _native_backward(ctx, douts):
         gs.dpv = (dpk_ptr + li * dpk_layer + dpk_step) if Pn else None
         gs.ws_main, gs.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()
         gs.ws_side, gs.ws_side_bytes = ws_side.data_ptr(), ws_side.numel()
+        gs.klist, gs.kcnt = (klist.data_ptr(), kcnt.data_ptr()) if klist is not None else (None, None)
         hip._ck(fn(ctypes.byref(st), ctypes.byref(gs), main_h, side_h, settle), "mtvaf_encoder_layer_bwd")
         if gviews is None:
             G[0], G[2], G[4] = dwqkv[:H], dwqkv[H:2 * H], dwqkv[2 * H:]
@@ -688,6 +704,14 @@ class EncoderFunction(torch.autograd.Function):
             for t in reads:  # temporaries freed before the join below: the allocator must wait for the side stream
                 t.record_stream(side)
 
+        ktiles = None  # (the native executor's k-tile list: the two paths must stay bit-identical)
+        if (SKIP_PAD_DW and not use_h and need_param_grads and len(cfg) > 5 and cfg[5] and M % 32 == 0
+                and addmask.dtype == torch.float32 and addmask.is_contiguous()):
+            ktiles = hip.build_ktiles(addmask, Pn, S)
+            if side is not None:
+                for t_ in ktiles:
+                    t_.record_stream(side)
+
         dh = None  # gradient wrt the current layer's OUTPUT, [M,H], owned by us
         for li in range(L - 1, -1, -1):
             x, qkv, cx, lse, a, h1, mean1, rstd1, pre, act, f, mean2, rstd2 = flat[13 * li:13 * li + 13]
@@ -737,12 +761,12 @@ class EncoderFunction(torch.autograd.Function):
                 hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, df, dh1, False, G[14], G[15], False, p_hidden, seed,
                                        off + 2, dbias_x=G[13])
                 dpre = _empty(M, I, like=dev_like)
-                on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12]))
+                on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12], ktiles=ktiles))
                 hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
 
                 def ffn1_grads():
                     hip.colsum(dpre, G[11])
-                    hip.linear_bwd_weight(dpre, h1, G[10])
+                    hip.linear_bwd_weight(dpre, h1, G[10], ktiles=ktiles)
                 on_side((dpre,), ffn1_grads)
                 hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
             # ---- attention block ----
@@ -771,7 +795,7 @@ class EncoderFunction(torch.autograd.Function):
                 da = df if side is None else _empty(M, H, like=dev_like)  # df is still being read on the side stream
                 hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
                                        off + 1, dbias_x=G[7])
-                on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6]))
+                on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6], ktiles=ktiles))
                 hip.linear_bwd_input(da, w.wo, dctx)
                 dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
                 hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
@@ -780,7 +804,7 @@ class EncoderFunction(torch.autograd.Function):
 
                 def qkv_grads():
                     hip.colsum(dqkv, dbqkv)
-                    hip.linear_bwd_weight(dqkv, x, dwqkv)
+                    hip.linear_bwd_weight(dqkv, x, dwqkv, ktiles=ktiles)
                 on_side((dqkv,), qkv_grads)
                 hip.linear_bwd_input(dqkv, w.wqkv, dh0, accumulate=True)
             dh = dh0

@@ -41,6 +41,8 @@ _SIGS = {
     "mtvaf_prefix_attn_bf16_varlen_bwd": (c_int, [P, P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_gather_rows": (c_int, [P, P, P, I, I, P]),
     "mtvaf_build_packing": (c_int, [P, I, I, I, I, P, P, P, P, P]),
+    "mtvaf_build_ktiles": (c_int, [P, I, I, I, I, I, P, P, P]),
+    "mtvaf_gemm_f32_ktiles": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P, P, P]),
     "mtvaf_zero_f32": (c_int, [P, L, P]),
     "mtvaf_prefix_attn_bf16_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bf16_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -102,7 +104,8 @@ class LayerGradsStruct(ctypes.Structure):
     _fields_ = ([(n, c_void_p) for n in ("dh", "dh1", "df", "dpre", "da", "dctx", "dqkv", "part", "partq", "partkv", "delta",
                                          "dwqkv", "dbqkv", "dwo", "dbo", "dg1", "db1", "dw1", "dbi1", "dw2", "dbi2", "dg2",
                                          "db2", "dpk", "dpv", "ws_main")] + [("ws_main_bytes", c_size_t), ("ws_side", c_void_p),
-                                                                            ("ws_side_bytes", c_size_t)])
+                                                                            ("ws_side_bytes", c_size_t), ("klist", c_void_p),
+                                                                            ("kcnt", c_void_p)])
 
 
 _lib = None
@@ -271,6 +274,24 @@ def gemm(a: torch.Tensor, layout_a: int, b: torch.Tensor, layout_b: int, out: to
     return out
 
 
+def gemm_ktiles(a, b, out, M, N, K, klist, kcnt, accumulate=False, cfg=-1, splits=-1):
+    """out[M,N] (+)= a[K,M]^T . b[K,N] over the listed 32-row k-tiles only (a is exactly zero elsewhere): klist / kcnt int32."""
+    wsb = lib().mtvaf_gemm_f32_workspace_bytes(M, N, K, 1)
+    ws = workspace(wsb, out.device)
+    _ck(lib().mtvaf_gemm_f32_ktiles(KM, KM, _p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, None,
+                                    EPI_NONE, None, 0, int(accumulate), 1, _p(ws), wsb, cfg, splits, _p(klist), _p(kcnt), _st()),
+        "mtvaf_gemm_f32_ktiles")
+    return out
+
+
+def build_ktiles(addmask, Pn, S, bk=32):
+    B, T = addmask.shape
+    klist = torch.empty(B * S // bk, dtype=torch.int32, device=addmask.device)
+    kcnt = torch.empty(1, dtype=torch.int32, device=addmask.device)
+    _ck(lib().mtvaf_build_ktiles(_p(addmask), B, T, Pn, S, bk, _p(klist), _p(kcnt), _st()), "mtvaf_build_ktiles")
+    return klist, kcnt
+
+
 def linear_fwd(x, w, bias, out, epi=EPI_NONE, aux=None):
     """out[M,N] = x[M,K] . w[N,K]^T + bias  (nn.Linear)."""
     M, K = x.shape
@@ -288,10 +309,13 @@ def linear_bwd_input(dy, w, dx, accumulate=False, epi=EPI_NONE, aux=None):
                 allow_split=True)
 
 
-def linear_bwd_weight(dy, x, dw, accumulate=False):
-    """dw[N,K] (+)= dy[M,N]^T . x[M,K]   (deterministic split-K over M)"""
+def linear_bwd_weight(dy, x, dw, accumulate=False, ktiles=None):
+    """dw[N,K] (+)= dy[M,N]^T . x[M,K]   (deterministic split-K over M).  ktiles = (klist, kcnt): dy is exactly zero outside
+    the listed 32-row k-tiles of the token axis (mtvaf_build_ktiles): the reduction skips the others."""
     M, N = dy.shape
     K = x.shape[1]
+    if ktiles is not None and COMPUTE == "fp32":
+        return gemm_ktiles(dy, x, dw, N, K, M, ktiles[0], ktiles[1], accumulate=accumulate)
     return gemm(dy, KM, x, KM, dw, N, K, M, accumulate=accumulate, allow_split=True)
 
 

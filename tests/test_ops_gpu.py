@@ -774,6 +774,47 @@ def test_gemm_splitk_with_tanh_epilogues(hip):
     close(lg, F.linear(xs.double(), ws.double(), bs.double()), rtol=3e-4, name="auto split skinny")
 
 
+@pytest.mark.parametrize("B,S,Pn", [(32, 128, 36), (8, 96, 4), (5, 64, 0)])
+def test_weight_gradient_over_listed_k_tiles(hip, B, S, Pn):
+    """mtvaf_build_ktiles + mtvaf_gemm_f32_ktiles: dW = dY^T . X over the 32-row k-tiles that hold an unmasked token, dY exactly
+    zero at masked rows -- against the full fp64 product; every DMA tile, forced split counts (more splits than listed
+    tiles included), an EMPTY-but-for-one list, accumulate; a plan that cannot use the list gives the same result."""
+    T, Mtok = Pn + S, B * S
+    gnr = torch.Generator().manual_seed(7)
+    lens = [S] + [int(x) for x in torch.randint(1, S + 1, (B - 1,), generator=gnr)]
+    mask = torch.zeros(B, T)
+    for b, Lb in enumerate(lens):
+        mask[b, : Pn + Lb] = 1
+    mask[1, Pn + 3] = 0  # (a hole)
+    addmask = ((1 - mask) * -10000.0).to(DEV)
+    valid = mask[:, Pn:].reshape(-1).bool()
+    NO, KI = 768, 384
+    dy = rnd(Mtok, NO, seed=1) * valid[:, None]
+    x = rnd(Mtok, KI, seed=2)
+    ref = dy.double().t() @ x.double()
+    klist, kcnt = hip.build_ktiles(addmask, Pn, S)
+    n = int(kcnt.item())
+    tiles = sorted(set(int(r) // 32 for r in torch.nonzero(valid).flatten()))
+    assert klist[:n].tolist() == tiles
+    out = torch.empty(NO, KI, device=DEV)
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    for cfg in (-1, 9, 12, 14, 10, 6):  # (6: a register-staged plan -- ignores the list)
+        for sp in (-1, 1, 3, 16):
+            out.fill_(float("nan"))
+            hip.gemm_ktiles(dyd, xd, out, NO, KI, Mtok, klist, kcnt, cfg=cfg, splits=sp)
+            close(out, ref, rtol=2e-5, name=f"dW over listed k-tiles, cfg {cfg} splits {sp}")
+    acc0 = rnd(NO, KI, seed=3)
+    out.copy_(acc0)
+    hip.gemm_ktiles(dyd, xd, out, NO, KI, Mtok, klist, kcnt, accumulate=True)
+    close(out, ref + acc0.double(), rtol=2e-5, name="accumulate")
+    one = torch.tensor([tiles[-1]], dtype=torch.int32, device=DEV)
+    cnt1 = torch.ones(1, dtype=torch.int32, device=DEV)
+    dy1 = torch.zeros_like(dy)
+    dy1[tiles[-1] * 32:(tiles[-1] + 1) * 32] = dy[tiles[-1] * 32:(tiles[-1] + 1) * 32]
+    hip.gemm_ktiles(dy1.to(DEV), xd, out, NO, KI, Mtok, one, cnt1, splits=4)
+    close(out, dy1.double().t() @ x.double(), rtol=2e-5, name="one listed tile, four splits")
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 96, 64), (256, 384, 192), (512, 768, 768), (384, 128, 4096), (128, 128, 64),
                                    (512, 192, 128)])
 def test_gemm_bf16_operands(hip, M, N, K):

@@ -173,3 +173,33 @@ def test_unpadded_bench_workload_against_the_cpu_oracle():
     named = dict(m.named_parameters())
     for n in GRADS:
         close(named[n].grad, ograds[n], rtol=3e-3, name=n)
+
+
+def test_weight_gradients_skip_padded_k_tiles_without_changing_anything():
+    """Padded run (the default): the dW products skip the 32-row k-tiles of the token axis that hold only masked tokens
+    (engine.SKIP_PAD_DW) -- their dY rows are exact zeros, so every parameter gradient must equal the full reduction up
+    to the order in which split-K slabs are cut; loss, tags and hidden states are untouched (forward is identical)."""
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=3, max_pos=512)
+    m = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+    B, S = 32, 128
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 98, B, S, lo_id=1000))
+    g = torch.Generator().manual_seed(4)
+    drop = (torch.rand(B, S, generator=g) < 0.1).to(DEV)
+    drop[:, 0] = False
+    mask = mask * (~drop).to(mask.dtype)  # (holes as well as trailing padding)
+    feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(99, B, 8))
+    kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+    res = []
+    for skip in (False, True):
+        engine.SKIP_PAD_DW = skip
+        try:
+            res.append(_run(m, kw, False))
+        finally:
+            engine.SKIP_PAD_DW = True
+    (l0, t0, h0, g0, _, _), (l1, t1, h1, g1, _, _) = res
+    assert l0 == l1 and t0 == t1 and torch.equal(h0, h1)
+    for n in g0:
+        if "word_embeddings" in n:
+            close(g1[n], g0[n], rtol=1e-4, atol=2e-6 * float(g0[n].abs().max()), name=n)
+        else:
+            close(g1[n], g0[n], rtol=1e-5, atol=1e-6 * float(g0[n].abs().max()) + 1e-9, name=n)
