@@ -259,6 +259,12 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
                      void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
                      int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
                      int splits, int stages, mtvaf_stream_t stream);
+/* ... for a weight-gradient product (KM x KM) whose operand A is exactly zero outside the listed 64-row k-tiles of the token
+ * axis (mtvaf_build_ktiles with bk = 64): see mtvaf_gemm_f32_ktiles. */
+int mtvaf_gemm_bf16x_ktiles(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
+                            void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
+                            int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
+                            int splits, int stages, const int* klist, const int* kcnt, mtvaf_stream_t stream);
 int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, mtvaf_stream_t stream);
 
 /* Prefix attention of the mixed-precision mode: the algorithm of mtvaf_prefix_attn_fwd / _bwd (same key order, mask,
@@ -330,7 +336,8 @@ typedef struct {
   float *dpk, *dpv;
   void* ws_main; size_t ws_main_bytes;
   void* ws_side; size_t ws_side_bytes;
-  /* fp32 mode, optional: 32-row k-tile list of the token axis for the weight-gradient products (mtvaf_build_ktiles) */
+  /* optional: k-tile list of the token axis for the weight-gradient products (mtvaf_build_ktiles; 32-row tiles in fp32
+   * mode, 64-row tiles in bf16 mode) */
   const int* klist;
   const int* kcnt;
 } mtvaf_layer_grads_t;

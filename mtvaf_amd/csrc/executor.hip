@@ -21,6 +21,10 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
                      void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
                      int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
                      int splits, int stages, hipStream_t stream);
+int mtvaf_gemm_bf16x_ktiles(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
+                            void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
+                            int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
+                            int splits, int stages, const int* klist, const int* kcnt, hipStream_t stream);
 int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, hipStream_t stream);
 int mtvaf_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* workspace,
                  size_t workspace_bytes, hipStream_t st);
@@ -135,7 +139,7 @@ struct mtvaf_layer_grads_t {
   float *dpk, *dpv;                            // [B, P*H] or NULL
   void* ws_main; size_t ws_main_bytes;         // scratch of the main stream (LayerNorm partials, split-K slabs)
   void* ws_side; size_t ws_side_bytes;         // scratch of the second stream (split-K slabs, column-sum partials)
-  const int* klist;                            // fp32 mode, optional: k-tile list of the token axis for the dW products
+  const int* klist;                            // optional: k-tile list of the token axis for the dW products (32-row tiles in fp32 mode, 64 in bf16)
   const int* kcnt;
 };
 
@@ -204,21 +208,21 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0,
                                        M, H, L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, g->df, mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_gemm_bf16x(X_KM, X_KM, g->df, H, L->act, I, g->dw2, I, nullptr, 0, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
-                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->df, H, L->act, I, g->dw2, I, nullptr, 0, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->df, H, L->w2_h, I, nullptr, 0, g->dpre, I, M, I, H, nullptr, X_EPI_DGELU, L->pre, I, 0,
                                g->part, 0, nullptr, 0, 0, -1, 0, mainS));
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum_small(g->part, M / 128, I, g->dbi1, 0, side));
-    MTVAF_TRY(mtvaf_gemm_bf16x(X_KM, X_KM, g->dpre, I, L->h1_h, H, g->dw1, H, nullptr, 0, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
-                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->dpre, I, L->h1_h, H, g->dw1, H, nullptr, 0, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->dpre, I, L->w1_h, H, g->dh1, H, nullptr, 0, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1,
                                nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, nullptr, g->dh, 0, g->dg1, g->db1, g->dbo, 0, M,
                                        H, L->p_hidden, L->seed, L->offset + 1, g->ws_main, g->ws_main_bytes, g->da, mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_gemm_bf16x(X_KM, X_KM, g->da, H, L->cx, H, g->dwo, H, nullptr, 0, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
-                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->da, H, L->cx, H, g->dwo, H, nullptr, 0, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+                               nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->da, H, L->wo_h, H, nullptr, 0, g->dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
     if (L->cu) {
@@ -231,8 +235,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum_small(g->partq, B * ((S + 63) / 64), H, g->dbqkv, 0, side));
     MTVAF_TRY(mtvaf_colsum_small(g->partkv, B * ((P + S + 63) / 64), 2 * H, g->dbqkv + H, 0, side));
-    MTVAF_TRY(mtvaf_gemm_bf16x(X_KM, X_KM, g->dqkv, 3 * H, L->x_h, H, g->dwqkv, H, nullptr, 0, 3 * H, H, M, nullptr, X_EPI_NONE,
-                               nullptr, 0, 0, nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, side));
+    MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->dqkv, 3 * H, L->x_h, H, g->dwqkv, H, nullptr, 0, 3 * H, H, M, nullptr, X_EPI_NONE,
+                               nullptr, 0, 0, nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->dqkv, 3 * H, L->wqkv_h, H, g->dh, H, nullptr, 0, M, H, 3 * H, nullptr, X_EPI_NONE,
                                nullptr, 0, 1, nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
   } else {

@@ -46,6 +46,8 @@ struct GemmArgsX {
   int k_chunk;
   long slab_stride;
   int epi, accumulate, tiles_n;
+  const int* klist;  // k-tile list (weight-gradient products, k-major operands): reduce over the 64-row k-tiles
+  const int* kcnt;   // klist[0 .. *kcnt) only -- the rest of operand A is exactly zero (gemm_common.h); or NULL
 };
 
 __device__ __forceinline__ void glds16x(const void* src, void* lds_wave_base) {
@@ -91,9 +93,18 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
-  const int kbeg = blockIdx.z * p.k_chunk;
+  int kbeg = blockIdx.z * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
-  const int nk = (kend - kbeg) / BK;
+  int nk = (kend - kbeg) / BK;
+  const bool klist_mode = A_KM && B_KM && p.klist != nullptr;  // (uniform)
+  int lbeg = 0;
+  if (klist_mode) {  // this split's share of the listed k-tiles (the count lives on the device)
+    const int cnt = *p.kcnt;
+    const int per = (cnt + (int)gridDim.z - 1) / (int)gridDim.z;
+    lbeg = blockIdx.z * per;
+    nk = max(0, min(cnt - lbeg, per));
+    kbeg = 0;
+  }
 
   // ---- per-lane DMA source addresses: LDS position (row, chunk position cp) receives source chunk cp ^ swizzle(row)
   const unsigned char* pa[IA];
@@ -125,9 +136,21 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
   }
   const long stepA = A_KM ? (long)BK * p.lda * 2 : BK * 2;
   const long stepB = B_KM ? (long)BK * p.ldb * 2 : BK * 2;
+  int issued = 0;
+  int kt_next = (klist_mode && nk > 0) ? p.klist[lbeg] : 0;  // fetched one issue ahead (a uniform scalar load)
   auto issue = [&](int stage) {
     unsigned char* sa = smem_b + stage * STAGE_B + wave * IA * 1024;
     unsigned char* sb = smem_b + stage * STAGE_B + A_B + wave * IB * 1024;
+    if (klist_mode) {
+      const long oa = (long)kt_next * stepA, ob = (long)kt_next * stepB;
+      ++issued;
+      kt_next = p.klist[lbeg + min(issued, nk - 1)];
+#pragma unroll
+      for (int i = 0; i < IA; ++i) glds16x(pa[i] + oa, sa + i * 1024);
+#pragma unroll
+      for (int i = 0; i < IB; ++i) glds16x(pb[i] + ob, sb + i * 1024);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       glds16x(pa[i], sa + i * 1024);
@@ -426,10 +449,10 @@ extern "C" {
 // Requirements (MTVAF_ERR_SHAPE / _ALIGN otherwise; no fallback): M % 128 == 0, K % 64 == 0, N % 128 == 0 or N % 96 == 0, leading dimensions % 8 == 0, 16-byte aligned pointers.  tile: 0 auto, 1 128x96,
 // 2 128x128, 3 256x128 (8 waves; layout_a 0, M % 256 == 0, no colpart), 4 256x192 (8 waves; layout_a 0, M % 256 == 0, N % 192 == 0).
 // stages: 0 auto, 2 .. 5 (256x192: always 2).
-int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
-                     void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
-                     int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
-                     int splits, int stages, hipStream_t stream) {
+static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
+                           void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
+                           int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
+                           int splits, int stages, const int* klist, const int* kcnt, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_SHAPE;
   if (!A || !B || (!C32 && !C16)) return MTVAF_ERR_ARG;
   if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1 || (layout_a == 1 && layout_b == 0)) return MTVAF_ERR_ARG;
@@ -471,6 +494,8 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
   if (!split_ok) splits = 1;
   while (splits > 1 && ((size_t)splits * M * N * sizeof(float) > workspace_bytes || (K / 64) / splits < 4)) --splits;
   GemmArgsX a;
+  a.klist = (klist && kcnt && layout_a == 1 && layout_b == 1) ? klist : nullptr;
+  a.kcnt = a.klist ? kcnt : nullptr;
   a.A = static_cast<const __bf16*>(A);
   a.B = static_cast<const __bf16*>(B);
   a.C16 = static_cast<__bf16*>(C16);
@@ -503,6 +528,24 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
   if (rc != MTVAF_OK) return rc;
   if (splits > 1) return launch_splitk_reduce((const float*)workspace, splits, C32, M, N, ldc32, bias, accumulate, EPI_NONE, nullptr, 0, stream);
   return MTVAF_OK;
+}
+
+int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
+                     void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
+                     int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
+                     int splits, int stages, hipStream_t stream) {
+  return gemm_bf16x_core(layout_a, layout_b, A, lda, B, ldb, C32, ldc32, C16, ldc16, M, N, K, bias, epi, aux16, ldaux, accumulate,
+                         colpart, allow_split, workspace, workspace_bytes, tile, splits, stages, nullptr, nullptr, stream);
+}
+
+// mtvaf_gemm_bf16x for a weight-gradient product (layouts KM x KM) whose operand A is exactly zero outside the listed 64-row
+// k-tiles of the reduction (token) axis: see mtvaf_gemm_f32_ktiles.  klist / kcnt: device int32 (mtvaf_build_ktiles, bk = 64).
+int mtvaf_gemm_bf16x_ktiles(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
+                            void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
+                            int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
+                            int splits, int stages, const int* klist, const int* kcnt, hipStream_t stream) {
+  return gemm_bf16x_core(layout_a, layout_b, A, lda, B, ldb, C32, ldc32, C16, ldc16, M, N, K, bias, epi, aux16, ldaux, accumulate,
+                         colpart, allow_split, workspace, workspace_bytes, tile, splits, stages, klist, kcnt, stream);
 }
 
 // out[c] (+)= sum over rows of part[rows][cols] (fixed order): finishes the epilogue column sums of mtvaf_gemm_bf16x

@@ -205,11 +205,12 @@ DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
 # key contributes exp(-10000) = 0 there, a masked query feeds nothing); hidden states AT masked positions are zeros
 # instead of the reference's don't-care values, and the intermediate hidden states are handed out lazily / detached.
 UNPAD = os.environ.get("MTVAF_UNPAD", "0") == "1"
-# Padded run, fp32: the weight-gradient products skip the 32-row k-tiles of the token axis that hold only masked tokens.
+# Padded run: the weight-gradient products skip the k-tiles (32 token rows in fp32 mode, 64 in bf16 mode) of the token axis that hold only masked tokens.
 # The gradient of a token row nothing downstream reads is EXACTLY zero (a masked key has probability exp(-10000) = 0, a
 # masked query feeds only itself, the CRF is masked), so the skipped terms of dW = sum_rows dY[r]^T X[r] are zeros: every
 # output of the step is unchanged.  Only for callers that vouch for it (cfg[5], BertModel.allow_unpad).
 SKIP_PAD_DW = os.environ.get("MTVAF_SKIP_PAD_DW", "1") != "0"
+SKIP_PAD_DW_BF16 = os.environ.get("MTVAF_SKIP_PAD_DW", "1") == "2"
 LAST_PACK = None  # the Packing of the most recent native forward (None: it ran padded)
 _PENDING_PACK = None  # packing started by Packing.begin, consumed by the next Packing.build
 _PACK_HOST = {}
@@ -469,11 +470,15 @@ def _native_backward(ctx, douts):
     am_ptr = addmask.data_ptr()
     settle = int(grad_sink is not None and side is not None and grad_sink.on_layer_done is not None and grad_sink.settle_params)
     klist = kcnt = None
-    if (SKIP_PAD_DW and pack is None and not use_h and need_param_grads and len(cfg) > 5 and cfg[5] and (B * S) % 32 == 0
+    bk = 64 if use_h else 32  # k-tile of the dW kernels
+    # (mixed-precision mode: measured SLOWER with the list -- 7.90 vs 7.71 ms at C3, 11.80 vs 11.72 at C4: 64-row tiles skip
+    # only ~19 % of a 33-us product and the device-side count delays its first loads -- so the list is an fp32-mode lever;
+    # MTVAF_SKIP_PAD_DW=2 forces it for the bf16 kernels too)
+    if (SKIP_PAD_DW and (not use_h or SKIP_PAD_DW_BF16) and pack is None and need_param_grads and len(cfg) > 5 and cfg[5] and (B * S) % bk == 0
             and addmask.dtype == torch.float32 and addmask.is_contiguous()):
-        klist = torch.empty(B * S // 32, dtype=torch.int32, device=dev)
+        klist = torch.empty(B * S // bk, dtype=torch.int32, device=dev)
         kcnt = torch.empty(1, dtype=torch.int32, device=dev)
-        hip._ck(hip.lib().mtvaf_build_ktiles(hip._p(addmask), B, addmask.shape[1], Pn, S, 32, hip._p(klist), hip._p(kcnt), main_h),
+        hip._ck(hip.lib().mtvaf_build_ktiles(hip._p(addmask), B, addmask.shape[1], Pn, S, bk, hip._p(klist), hip._p(kcnt), main_h),
                 "mtvaf_build_ktiles")
         if side is not None:
             klist.record_stream(side)
@@ -705,9 +710,9 @@ class EncoderFunction(torch.autograd.Function):
                 t.record_stream(side)
 
         ktiles = None  # (the native executor's k-tile list: the two paths must stay bit-identical)
-        if (SKIP_PAD_DW and not use_h and need_param_grads and len(cfg) > 5 and cfg[5] and M % 32 == 0
+        if (SKIP_PAD_DW and (not use_h or SKIP_PAD_DW_BF16) and need_param_grads and len(cfg) > 5 and cfg[5] and M % (64 if use_h else 32) == 0
                 and addmask.dtype == torch.float32 and addmask.is_contiguous()):
-            ktiles = hip.build_ktiles(addmask, Pn, S)
+            ktiles = hip.build_ktiles(addmask, Pn, S, bk=64 if use_h else 32)
             if side is not None:
                 for t_ in ktiles:
                     t_.record_stream(side)
@@ -747,13 +752,13 @@ class EncoderFunction(torch.autograd.Function):
                 df_h = _bf16(M, H, like=dev_like)
                 hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, None, dh1, False, G[14], G[15], False, p_hidden, seed,
                                        off + 2, dbias_x=G[13], dx16=df_h)
-                on_side((df_h,), lambda: hip.gemm_bf16x(df_h, KM, act, KM, H, I, M, out32=G[12], allow_split=True))
+                on_side((df_h,), lambda: hip.gemm_bf16x(df_h, KM, act, KM, H, I, M, out32=G[12], allow_split=True, ktiles=ktiles))
                 dpre_h, part = _bf16(M, I, like=dev_like), _empty(M // 128, I, like=dev_like)
                 hip.gemm_bf16x(df_h, KC, w2_h, KM, M, I, H, out16=dpre_h, epi=hip.EPI_DGELU, aux16=pre, colpart=part)
 
                 def ffn1_grads():
                     hip.colsum_small(part, G[11])
-                    hip.gemm_bf16x(dpre_h, KM, h1_h, KM, I, H, M, out32=G[10], allow_split=True)
+                    hip.gemm_bf16x(dpre_h, KM, h1_h, KM, I, H, M, out32=G[10], allow_split=True, ktiles=ktiles)
                 on_side((dpre_h, part), ffn1_grads)
                 hip.gemm_bf16x(dpre_h, KC, w1_h, KM, M, H, I, out32=dh1, accumulate=True)
             else:
@@ -775,7 +780,7 @@ class EncoderFunction(torch.autograd.Function):
                 da_h, dctx = _bf16(M, H, like=dev_like), _bf16(M, H, like=dev_like)
                 hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, None, dh0, False, G[8], G[9], False, p_hidden, seed,
                                        off + 1, dbias_x=G[7], dx16=da_h)
-                on_side((da_h,), lambda: hip.gemm_bf16x(da_h, KM, cx, KM, H, H, M, out32=G[6], allow_split=True))
+                on_side((da_h,), lambda: hip.gemm_bf16x(da_h, KM, cx, KM, H, H, M, out32=G[6], allow_split=True, ktiles=ktiles))
                 hip.gemm_bf16x(da_h, KC, wo_h, KM, M, H, H, out16=dctx)
                 dqkv = _bf16(M, 3 * H, like=dev_like)
                 nqt, nkt = (S + 63) // 64, (Pn + S + 63) // 64
@@ -787,7 +792,7 @@ class EncoderFunction(torch.autograd.Function):
                 def qkv_grads():
                     (hip.colsum_small if partq.shape[0] <= 256 else hip.colsum)(partq, dbqkv[:H])
                     (hip.colsum_small if partkv.shape[0] <= 256 else hip.colsum)(partkv, dbqkv[H:])
-                    hip.gemm_bf16x(dqkv, KM, x_h, KM, 3 * H, H, M, out32=dwqkv, allow_split=True)
+                    hip.gemm_bf16x(dqkv, KM, x_h, KM, 3 * H, H, M, out32=dwqkv, allow_split=True, ktiles=ktiles)
                 on_side((dqkv, partq, partkv), qkv_grads)
                 hip.gemm_bf16x(dqkv, KC, wqkv_h, KM, M, H, 3 * H, out32=dh0, accumulate=True)
             else:

@@ -80,6 +80,7 @@ _SIGS = {
     "mtvaf_ce_bwd": (c_int, [P, P, P, P, P, I, I, P]),
     "mtvaf_mask_mul": (c_int, [P, P, P, P, I, I, I, P]),
     "mtvaf_gemm_bf16x": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P]),
+    "mtvaf_gemm_bf16x_ktiles": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P, P, P]),
     "mtvaf_colsum_small": (c_int, [P, I, I, P, I, P]),
     "mtvaf_cast_bf16": (c_int, [P, I, P, I, P, I, I, I, P]),
     "mtvaf_adamw": (c_int, [P, P, P, P, L, F, c_double, c_double, F, F, F, F, F, P, P]),
@@ -511,7 +512,7 @@ def cast_bf16(x, out=None, out_t=None):
 
 
 def gemm_bf16x(a, layout_a, b, layout_b, M, N, K, out32=None, out16=None, bias=None, epi=EPI_NONE, aux16=None,
-               accumulate=False, colpart=None, allow_split=False, tile=0, splits=-1, stages=0):
+               accumulate=False, colpart=None, allow_split=False, tile=0, splits=-1, stages=0, ktiles=None):
     """out[M,N] = opA[M,K] . opB[K,N], bf16 operands, fp32 accumulation.  KC: a is [M,K] / b is [N,K]; KM: a is [K,M] /
     b is [K,N] (the same row-major tensors read in their other role).  out32 fp32 and / or out16 bf16; aux16: bf16
     pre-activation (written by EPI_GELU, read by EPI_DGELU); colpart [M/128, N] fp32 per-tile column sums of the result."""
@@ -519,6 +520,14 @@ def gemm_bf16x(a, layout_a, b, layout_b, M, N, K, out32=None, out16=None, bias=N
     if allow_split:
         wsb = 8 * M * N * 4
         ws = workspace(wsb, a.device)
+    if ktiles is not None:  # (a, KM) is exactly zero outside the listed 64-row k-tiles (mtvaf_build_ktiles, bk = 64)
+        _ck(lib().mtvaf_gemm_bf16x_ktiles(layout_a, layout_b, _p(a), a.stride(0), _p(b), b.stride(0), _p(out32),
+                                          out32.stride(0) if out32 is not None else 0, _p(out16),
+                                          out16.stride(0) if out16 is not None else 0, M, N, K, _p(bias), epi, _p(aux16),
+                                          aux16.stride(0) if aux16 is not None else 0, int(accumulate), _p(colpart),
+                                          int(allow_split), _p(ws), wsb, tile, splits, stages, _p(ktiles[0]), _p(ktiles[1]),
+                                          _st()), "mtvaf_gemm_bf16x_ktiles")
+        return
     _ck(lib().mtvaf_gemm_bf16x(layout_a, layout_b, _p(a), a.stride(0), _p(b), b.stride(0), _p(out32),
                                out32.stride(0) if out32 is not None else 0, _p(out16),
                                out16.stride(0) if out16 is not None else 0, M, N, K, _p(bias), epi, _p(aux16),
