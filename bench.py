@@ -361,6 +361,9 @@ def main():
            "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
            "flop_per_sentence_train": ftrain, "fwd_bwd_without_optimizer": fwd_bwd_only,
            "real_token_rows": round(real_rows, 4), "flop_per_sentence_train_real_rows": round(f_exec),
+           "note_flops": "mfma_fraction_of_step credits the algorithmic 3 x F_fwd per sentence (SURVEY 8d); in the fp32 mode the "
+                         "weight-gradient products skip the k-tiles of masked token rows (exact zeros, DESIGN 4.5b): the roofline "
+                         "object below counts the flops those launches execute",
            "padding": "skipped (--unpad): the fraction below counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
            "padding_free": padding_free}
     if a.unpad:
@@ -392,13 +395,17 @@ def main():
         recs = hip.prof_stop(8192)
         _engine.DW_SIDE_STREAM = side_was
         by_sym, by_shape = {}, {}
+        # weight-gradient launches that walk the k-tile list execute 32 rows per LISTED tile of the token axis:
+        # their flops are counted from the list, not from the padded token count
+        k_listed = 32 * int(((mask.view(-1, 32).sum(1) > 0).sum()).item()) if (B * S) % 32 == 0 else B * S
         for k, ms in recs:
             sym = hip.kernel_symbol(k["cfg"], k["la"], k["lb"], k["fast"])
             d = by_sym.setdefault(sym, [0.0, 0, 0.0])
             d[0] += ms
             d[1] += 1
-            d[2] += 2.0 * k["M"] * k["N"] * k["K"]
-            sk = (sym, k["M"], k["N"], k["K"], k["splits"])
+            kk = min(k["K"], k_listed) if (k["fast"] & 8) else k["K"]
+            d[2] += 2.0 * k["M"] * k["N"] * kk
+            sk = (sym, k["M"], k["N"], kk, k["splits"])
             e = by_shape.setdefault(sk, [0.0, 0])
             e[0] += ms
             e[1] += 1
@@ -407,7 +414,8 @@ def main():
         sym, (ms, cnt, fl) = max(by_sym.items(), key=lambda kv: kv[1][0])
         avg_us = 1e3 * ms / cnt
         ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
-        traffic, traffic_src = pmc_traffic(sym, a.dtype, B, S)
+        # (no PMC passes were collected for the padding-free workload: its row counts differ from the committed files')
+        traffic, traffic_src = (None, None) if a.unpad else pmc_traffic(sym, a.dtype, B, S)
         res["roofline"] = {
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[a.dtype], "unit": "TFLOP/s",
             "frac": round(ach / PEAK_TFLOPS[a.dtype], 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": sym,

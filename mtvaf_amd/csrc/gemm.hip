@@ -867,7 +867,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   ProfRec* pr = nullptr;
   if (g_prof && g_prof_n < g_prof_cap) {
     pr = &g_prof[g_prof_n++];
-    const int key[8] = {compute == 1 ? 100 + cfg : cfg, layout_a, layout_b, mode, M, N, K, splits};
+    // (key[3]: alignment mode 0..2, +8 when the launch walks a k-tile list: its flops are 2 M N 32 (*kcnt), not 2 M N K)
+    const int key[8] = {compute == 1 ? 100 + cfg : cfg, layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
     hipEventRecord(pr->e0, stream);
   }

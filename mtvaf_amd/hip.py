@@ -211,6 +211,7 @@ def kernel_symbol(cfg, la, lb, fast):
             8: (128, 192, 2, 2, 32), 9: (128, 96, 4, 1), 10: (128, 128, 2, 2), 11: (128, 192, 2, 2),
             12: (128, 96, 4, 1), 13: (128, 128, 2, 2), 14: (128, 64, 4, 1), 15: (128, 64, 4, 1)}.get(cfg)
     b = lambda x: "true" if x else "false"
+    klist, fast = bool(fast & 8), fast & 7  # (+8: the launch walked a k-tile list)
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE>
         c = cfg - 300
         t = "256, 192, 4, 2" if c & 32 else ("256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"))
@@ -219,7 +220,8 @@ def kernel_symbol(cfg, la, lb, fast):
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
         return f"gemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(fast == 2)}>"
     if cfg >= 9:
-        return f"gemm_f32_dma_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {b(la)}, {b(lb)}, {2 if cfg in (12, 13, 15) else 3}>"
+        return (f"gemm_f32_dma_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {b(la)}, {b(lb)}, "
+                f"{2 if cfg in (12, 13, 15) else 3}, {b(klist)}>")
     return (f"gemm_f32_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {dims[4]}, {b(la)}, {b(lb)}, "
             f"{b(fast >= 1)}, {b(fast == 2)}>")
 TILE_NAMES = {0: "128x128x16", 1: "128x96x16", 2: "128x288x16", 3: "64x64x16", 4: "128x64x16", 5: "128x128x32",
