@@ -297,6 +297,31 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
   f32x4 dq[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  {
+    // A query tile whose upstream gradient is all zeros (padded positions: nothing downstream reads them) has dP = dO.V^T = 0
+    // and delta = 0, hence dS = 0 and dQ = 0 EXACTLY: write the zeros and skip the key loop.  Detected, not assumed: one
+    // LDS flag (Ms[0] is free until the first key tile is staged), no vote primitive.  (The same test on the key side --
+    // skipping all-zero query tiles in the dK / dV loop -- measured 3 % SLOWER on the whole step, with a vote primitive
+    // and with plain LDS flags alike: the loop is at its register limit.)
+    bool nz = false;
+#pragma unroll
+    for (int db = 0; db < 4; ++db) nz = nz || doreg[db].x != 0.f || doreg[db].y != 0.f || doreg[db].z != 0.f || doreg[db].w != 0.f;
+    int* flag = reinterpret_cast<int*>(Ms);
+    if (threadIdx.x == 0) *flag = 0;
+    __syncthreads();
+    if (qok && nz) *flag = 1;  // (benign race: every writer stores the same value)
+    __syncthreads();
+    const bool live = *flag != 0;
+    __syncthreads();  // (the flag word is the mask tile's first entry: nobody may still read it when staging starts)
+    if (!live) {
+      if (qok) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<f32x4*>(a.dqkv + (sn.tok0 + q) * 3 * a.H + h * D + 16 * dt + 4 * g) = dq[dt];
+      }
+      return;
+    }
+  }
   const float* kfrag = Ks + lq * LDT + 4 * g;
   const float* vfrag = Vs + lq * LDK + 4 * g;
   const float* kcol = Ks + 4 * g * LDT + lq;
