@@ -233,3 +233,50 @@ def test_bf16_weight_gradients_skip_padded_k_tiles():
                 close(g1[n], g0[n], rtol=1e-5, atol=2e-6 * float(g0[n].abs().max()) + 1e-9, name=n)
     finally:
         hip.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_gradients_of_masked_token_rows_are_exact_zeros(dtype):
+    """The premise of DESIGN 4.5b, checked on its own with the lever switched OFF: in the padded run the gradient that
+    reaches a masked token row is exactly 0.0 at the encoder output AND after twelve... (here four) layers at the encoder
+    input -- trailing padding and holes, dropout live -- so the terms the weight-gradient products skip are zeros."""
+    from mtvaf_amd import hip
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=4, max_pos=512)
+    hip.set_compute_dtype(dtype)
+    engine.SKIP_PAD_DW = False
+    try:
+        m = _props_model(cfg, "bert-base-uncased", dropout=0.1).train()
+        B, S = 16, 128
+        ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 111, B, S, lo_id=1000))
+        g = torch.Generator().manual_seed(9)
+        drop = (torch.rand(B, S, generator=g) < 0.1).to(DEV)
+        drop[:, 0] = False
+        mask = mask * (~drop).to(mask.dtype)
+        feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(112, B, 8))
+        grads = {}
+        def grab(name):
+            def hook(gr):
+                grads[name] = gr.detach().clone()
+            return hook
+
+        def on_embeddings(mod, inp, out):  # (a forward hook must return None, or it replaces the output)
+            out.register_hook(grab("encoder input"))
+
+        def on_encoder(mod, inp, out):
+            out.last_hidden_state.register_hook(grab("encoder output"))
+
+        h_in = m.bert.embeddings.register_forward_hook(on_embeddings)
+        h_out = m.bert.encoder.register_forward_hook(on_encoder)
+        out = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+        out.loss.backward()
+        h_in.remove()
+        h_out.remove()
+        torch.cuda.synchronize()
+        masked = ~mask.bool()
+        assert set(grads) == {"encoder input", "encoder output"}
+        for name, gr in grads.items():
+            assert float(gr[mask.bool()].abs().max()) > 0.0
+            assert float(gr[masked].abs().max()) == 0.0, f"{name}: a masked token row carries a nonzero gradient"
+    finally:
+        engine.SKIP_PAD_DW = True
+        hip.set_compute_dtype("fp32")
