@@ -71,7 +71,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
   return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE>
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE, bool KLIST = false>
 __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 : 2))) void gemm_bf16x_kernel(GemmArgsX p) {
   constexpr int BK = 64;  // bf16 elements per k-tile
   constexpr int NW = WM * WN, NT = NW * 64;
@@ -96,9 +96,10 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
   int kbeg = blockIdx.z * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
   int nk = (kend - kbeg) / BK;
-  const bool klist_mode = A_KM && B_KM && p.klist != nullptr;  // (uniform)
+  static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
+  constexpr bool klist_mode = KLIST;
   int lbeg = 0;
-  if (klist_mode) {  // this split's share of the listed k-tiles (the count lives on the device)
+  if constexpr (klist_mode) {  // this split's share of the listed k-tiles (the count lives on the device)
     const int cnt = *p.kcnt;
     const int per = (cnt + (int)gridDim.z - 1) / (int)gridDim.z;
     lbeg = blockIdx.z * per;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
   auto issue = [&](int stage) {
     unsigned char* sa = smem_b + stage * STAGE_B + wave * IA * 1024;
     unsigned char* sb = smem_b + stage * STAGE_B + A_B + wave * IB * 1024;
-    if (klist_mode) {
+    if constexpr (klist_mode) {
       const long oa = (long)kt_next * stepA, ob = (long)kt_next * stepB;
       ++issued;
       kt_next = p.klist[lbeg + min(issued, nk - 1)];
@@ -391,11 +392,14 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE>
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE, bool KLIST = false>
 static int launch_x(const GemmArgsX& a, dim3 grid, hipStream_t st) {
+  if constexpr (A_KM && B_KM && !KLIST && NSTAGE == 2) {  // (the k-tile list: 2-stage weight-gradient kernels only)
+    if (a.klist) return launch_x<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, true>(a, grid, st);
+  }
   size_t smem = (size_t)NSTAGE * (BM + BN) * 128;
   smem = std::max(smem, (size_t)128 * (BN + 4) * sizeof(float));  // epilogue image (one 128-row pass)
-  auto kern = gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE>;
+  auto kern = gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -517,6 +521,7 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
   // path; the 8-wave 256x128 block (one per CU) wants the 3-deep ring
   if (stages < 2 || stages > 5) stages = bm == 256 ? 3 : 2;
   if (bn == 192) stages = 2;  // (the only ring that fits: 2 x 56 KB)
+  if (a.klist && stages != 2) a.klist = a.kcnt = nullptr;  // (list mode exists for the 2-stage kernels: otherwise reduce over everything)
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
   const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages >= 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256) + 32 * (bn == 192), layout_a, layout_b, 2, M, N, K, splits};
   const int rec = prof_begin(key, stream);
