@@ -471,7 +471,7 @@ def _native_backward(ctx, douts):
     settle = int(grad_sink is not None and side is not None and grad_sink.on_layer_done is not None and grad_sink.settle_params)
     klist = kcnt = None
     bk = 64 if use_h else 32  # k-tile of the dW kernels
-    # (mixed-precision mode: measured SLOWER with the list -- 7.90 vs 7.71 ms at C3, 11.80 vs 11.72 at C4: 64-row tiles skip
+    # (mixed-precision mode: measured SLOWER with the list -- 7.85 vs 7.56 ms at C3, 11.71 vs 11.60 at C4: 64-row tiles skip
     # only ~19 % of a 33-us product and the device-side count delays its first loads -- so the list is an fp32-mode lever;
     # MTVAF_SKIP_PAD_DW=2 forces it for the bf16 kernels too)
     if (SKIP_PAD_DW and (not use_h or SKIP_PAD_DW_BF16) and pack is None and need_param_grads and len(cfg) > 5 and cfg[5] and (B * S) % bk == 0
