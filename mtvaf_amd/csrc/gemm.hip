@@ -245,6 +245,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32_kernel(GemmArgs p) {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) MTVAF_WAIT_VMCNT(0);
+  else if constexpr (N == 4) MTVAF_WAIT_VMCNT(4);
   else if constexpr (N == 5) MTVAF_WAIT_VMCNT(5);
   else if constexpr (N == 6) MTVAF_WAIT_VMCNT(6);
   else if constexpr (N == 7) MTVAF_WAIT_VMCNT(7);
@@ -571,6 +572,37 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slabs, int splits
   }
 }
 
+// the same reduction four columns per thread (cols, ldd, ldaux multiples of 4 and 16-byte aligned pointers: every product
+// of the encoder): one dwordx4 per slab, all slab loads of a thread in flight together
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float* __restrict__ slabs, int splits, long slab_stride,
+                                                             float* dst, int rows, int cols, int ldd, const float* bias,
+                                                             int accumulate, int epi, float* aux, int ldaux) {
+  const int c4n = cols >> 2;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * c4n) return;
+  const int r = (int)(i / c4n), c = (int)(i % c4n) << 2;
+  const float* src = slabs + (long)r * cols + c;
+  f32x4 s = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll 4
+  for (int z = 1; z < splits; ++z) s += *reinterpret_cast<const f32x4*>(src + z * slab_stride);
+  if (bias) s += *reinterpret_cast<const f32x4*>(bias + c);
+  if (epi == EPI_TANH) {
+    s = f32x4{tanhf(s.x), tanhf(s.y), tanhf(s.z), tanhf(s.w)};
+  } else if (epi == EPI_GELU) {
+    *reinterpret_cast<f32x4*>(aux + (long)r * ldaux + c) = s;
+    s = f32x4{gelu_erf(s.x), gelu_erf(s.y), gelu_erf(s.z), gelu_erf(s.w)};
+  } else if (epi == EPI_DGELU) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(aux + (long)r * ldaux + c);
+    s = f32x4{s.x * gelu_erf_grad(a.x), s.y * gelu_erf_grad(a.y), s.z * gelu_erf_grad(a.z), s.w * gelu_erf_grad(a.w)};
+  } else if (epi == EPI_DTANH) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(aux + (long)r * ldaux + c);
+    s = s * (1.f - t * t);
+  }
+  float* d = dst + (long)r * ldd + c;
+  if (accumulate) s += *reinterpret_cast<const f32x4*>(d);
+  *reinterpret_cast<f32x4*>(d) = s;
+}
+
 // epilogues that commute with the ordered slab reduction (applied by splitk_reduce_kernel)
 static inline bool splittable(int epi) { return epi >= EPI_NONE && epi <= EPI_DTANH; }
 
@@ -579,9 +611,11 @@ static const TileCfg kCfgs[] = {{128, 128, 16}, {128, 96, 16}, {128, 288, 16}, {
                                 {128, 128, 32}, {128, 96, 32}, {128, 192, 16}, {128, 192, 32},
                                 {128, 96, 32}, {128, 128, 32}, {128, 192, 32},   // 9..11: LDS-DMA pipeline (FAST only)
                                 {128, 96, 32}, {128, 128, 32},   // 12..13: 2-stage LDS-DMA ring, two blocks per CU
-                                {128, 64, 32}, {128, 64, 32}};   // 14..15: 128x64 LDS-DMA tile (3-stage / 2-stage): row counts
+                                {128, 64, 32}, {128, 64, 32},    // 14..15: 128x64 LDS-DMA tile (3-stage / 2-stage): row counts
                                                                  // that leave 128x96 tiles on half the CUs (padding-free runs)
-constexpr int kNumCfgs = 16;
+                                {64, 64, 32}, {64, 64, 32}};     // 16..17: 64x64 LDS-DMA tile (3-stage / 2-stage): few-token
+                                                                 // products (bs 4: M = 256), where the wave count is the limit
+constexpr int kNumCfgs = 18;
 constexpr int kFirstDma = 9;
 
 template <int BM, int BN, int WM, int WN, int NSTAGE = 3>
@@ -655,9 +689,16 @@ int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, boo
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
                          int epi, float* aux, int ldaux, hipStream_t stream) {
   const long n = (long)M * N;
-  const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, splits, n, C, M, N, ldc, bias,
-                     accumulate, epi, aux, ldaux);
+  const bool vec = (N % 4 == 0) && (ldc % 4 == 0) && (((uintptr_t)slabs & 15) == 0) && (((uintptr_t)C & 15) == 0) &&
+                   (!bias || (((uintptr_t)bias & 15) == 0)) && (!aux || ((ldaux % 4 == 0) && (((uintptr_t)aux & 15) == 0)));
+  if (vec) {
+    hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, slabs, splits, n, C,
+                       M, N, ldc, bias, accumulate, epi, aux, ldaux);
+  } else {
+    const int blocks = (int)std::min<long>((n + 255) / 256, 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, splits, n, C, M, N, ldc, bias,
+                       accumulate, epi, aux, ldaux);
+  }
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -693,7 +734,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
   static const double eff_base[kNumCfgs] = {0.80, 0.86, 0.72, 0.45, 0.80, 0.70, 1.00, 0.92, 0.78,
                                             1.18, 1.00, 0.85,   // 9..11: LDS-DMA pipeline
                                             1.18, 1.00,         // 12..13: same tiles, 2-stage ring, two blocks per CU
-                                            1.08, 1.08};        // 14..15: 128x64 (measured with tools/gemm_sweep.py --rows 2432)
+                                            1.08, 1.08,         // 14..15: 128x64 (measured with tools/gemm_sweep.py --rows 2432)
+                                            0.60, 0.60};        // 16..17: 64x64
   double eff[kNumCfgs];
   for (int c = 0; c < kNumCfgs; ++c) {
     eff[c] = eff_base[c];
@@ -722,9 +764,12 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       // two co-resident blocks hide each other's prologue / epilogue / barrier stalls once every CU holds two
       // (measured +8..9 % at >= 2 tiles per CU, -3..5 % with a single tile per CU: the 2-stage ring is shallower;
       // preferring it there anyway for its smaller footprint measured 0.5 % slower on the whole step)
-      const bool two_blocks = c == 12 || c == 13 || c == 15;
+      const bool two_blocks = c == 12 || c == 13 || c == 15 || c == 17;
       const double occ2 = two_blocks ? (tiles * s >= 384 ? 1.08 : 0.95) : 1.0;  // (>= 1.5 blocks per CU: M = 2432 rows measured)
-      double cost = (double)rounds * bm * bn * kc / 128.0 / (eff[c] * occ2);
+      // the 64x64 tile re-reads operands twice as often as 128x64 (its 0.60), which only costs once the CUs are full:
+      // with at most one block per CU -- few-token products -- a wave's own MFMA chain is the limit and the small tile wins
+      const double e = (c >= 16 && tiles * s <= 256) ? 1.0 : eff[c];
+      double cost = (double)rounds * bm * bn * kc / 128.0 / (e * occ2);
       cost += 3000.0;  // fill/drain + launch
       if (s > 1) {
         // slabs: s*M*N floats written then read once (plus the final write) at ~4 TB/s ~ 1.7 KB/clk chip-wide
@@ -855,7 +900,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
            (a.slab_stride % 4 == 0);
   if (cfg >= kFirstDma && !(aligned && !(layout_a == 1 && layout_b == 0))) {
     if (cfg_forced) return MTVAF_ERR_SHAPE;
-    static const int staged_twin[7] = {6, 5, 8, 6, 5, 4, 4};  // same tile, register-staged kernel (handles any alignment)
+    static const int staged_twin[9] = {6, 5, 8, 6, 5, 4, 4, 3, 3};  // same tile, register-staged kernel (handles any alignment)
     cfg = staged_twin[cfg - kFirstDma];
   }
   // the k-tile list only reaches the LDS-DMA kernels (32-row k-tiles of k-major operands); any other plan reduces over
@@ -884,6 +929,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     case 13: rc = launch_dma<128, 128, 2, 2, 2>(a, layout_a, layout_b, grid, stream); break;
     case 14: rc = launch_dma<128, 64, 4, 1>(a, layout_a, layout_b, grid, stream); break;
     case 15: rc = launch_dma<128, 64, 4, 1, 2>(a, layout_a, layout_b, grid, stream); break;
+    case 16: rc = launch_dma<64, 64, 2, 2>(a, layout_a, layout_b, grid, stream); break;
+    case 17: rc = launch_dma<64, 64, 2, 2, 2>(a, layout_a, layout_b, grid, stream); break;
     case 0: rc = launch_cfg<128, 128, 2, 2, 16>(a, layout_a, layout_b, grid, mode, stream); break;
     case 1: rc = launch_cfg<128, 96, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
     case 2: rc = launch_cfg<128, 288, 4, 1, 16>(a, layout_a, layout_b, grid, mode, stream); break;
@@ -896,13 +943,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   }
   if (pr) hipEventRecord(pr->e1, stream);
   if (rc != MTVAF_OK) return rc;
-  if (splits > 1) {
-    const long n = (long)M * N;
-    int blocks = (int)std::min<long>(cdiv(n, 256), 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)workspace, splits,
-                       (long)M * N, C, M, N, ldc, bias, accumulate, epi, aux, ldaux);
-    MTVAF_LAUNCH_CHECK();
-  }
+  if (splits > 1)
+    return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
   return MTVAF_OK;
 }
 

@@ -602,17 +602,34 @@ int mtvaf_gather_rows(const float* src, const int* map, float* dst, int rows_dst
 
 size_t mtvaf_colsum_workspace_bytes(int rows, int cols) { return (size_t)64 * cols * sizeof(float); }
 
-// few rows (the bs-4 configuration: M = 256 tokens): one launch -- 64 columns x 4 row groups per block, combined in fixed
+// few rows (the bs-4 configuration: M = 256 tokens): one launch -- 32 columns x 32 row groups per block (every thread
+// has its <= 16 loads in flight at once: the kernel is one memory round trip, not a chain of them), combined in fixed
 // order through LDS.  The two-stage form pays a second launch (~5 us on a stream of ~5-us kernels) for nothing here.
-__global__ __launch_bounds__(256) void colsum_direct_kernel(const float* __restrict__ x, int rows, int cols, long ld,
-                                                           float* __restrict__ out, int accumulate) {
-  __shared__ float red[4][64];
-  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+__global__ __launch_bounds__(1024) void colsum_direct_kernel(const float* __restrict__ x, int rows, int cols, long ld,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ float red[32][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  if (c < cols)
-    for (int r = rg; r < rows; r += 4) s += x[(long)r * ld + c];
+  if (c < cols) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = rg + 32 * i;
+      v[i] = r < rows ? x[(long)r * ld + c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+  }
   red[rg][cl] = s;
+  __syncthreads();
+  float t4 = 0.f;  // 32 partials per column: four threads add eight each, then one adds the four
+  if (rg < 4) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t4 += red[rg * 8 + i][cl];
+  }
+  __syncthreads();
+  if (rg < 4) red[rg][cl] = t4;
   __syncthreads();
   if (rg == 0 && c < cols) {
     const float t = ((red[0][cl] + red[1][cl]) + red[2][cl]) + red[3][cl];
@@ -625,7 +642,7 @@ int mtvaf_colsum(const float* x, int rows, int cols, int ld, float* out, int acc
                  size_t workspace_bytes, hipStream_t st) {
   if (rows <= 0 || cols <= 0) return MTVAF_ERR_SHAPE;
   if (rows <= 512) {
-    hipLaunchKernelGGL(colsum_direct_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, x, rows, cols, (long)ld, out, accumulate);
+    hipLaunchKernelGGL(colsum_direct_kernel, dim3((cols + 31) / 32), dim3(1024), 0, st, x, rows, cols, (long)ld, out, accumulate);
     MTVAF_LAUNCH_CHECK();
     return MTVAF_OK;
   }

@@ -209,7 +209,8 @@ def kernel_symbol(cfg, la, lb, fast):
     dims = {0: (128, 128, 2, 2, 16), 1: (128, 96, 4, 1, 16), 2: (128, 288, 4, 1, 16), 3: (64, 64, 2, 2, 16),
             4: (128, 64, 4, 1, 16), 5: (128, 128, 2, 2, 32), 6: (128, 96, 4, 1, 32), 7: (128, 192, 2, 2, 16),
             8: (128, 192, 2, 2, 32), 9: (128, 96, 4, 1), 10: (128, 128, 2, 2), 11: (128, 192, 2, 2),
-            12: (128, 96, 4, 1), 13: (128, 128, 2, 2), 14: (128, 64, 4, 1), 15: (128, 64, 4, 1)}.get(cfg)
+            12: (128, 96, 4, 1), 13: (128, 128, 2, 2), 14: (128, 64, 4, 1), 15: (128, 64, 4, 1),
+            16: (64, 64, 2, 2), 17: (64, 64, 2, 2)}.get(cfg)
     b = lambda x: "true" if x else "false"
     klist, fast = bool(fast & 8), fast & 7  # (+8: the launch walked a k-tile list)
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE>
@@ -221,12 +222,13 @@ def kernel_symbol(cfg, la, lb, fast):
         return f"gemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(fast == 2)}>"
     if cfg >= 9:
         return (f"gemm_f32_dma_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {b(la)}, {b(lb)}, "
-                f"{2 if cfg in (12, 13, 15) else 3}, {b(klist)}>")
+                f"{2 if cfg in (12, 13, 15, 17) else 3}, {b(klist)}>")
     return (f"gemm_f32_kernel<{dims[0]}, {dims[1]}, {dims[2]}, {dims[3]}, {dims[4]}, {b(la)}, {b(lb)}, "
             f"{b(fast >= 1)}, {b(fast == 2)}>")
 TILE_NAMES = {0: "128x128x16", 1: "128x96x16", 2: "128x288x16", 3: "64x64x16", 4: "128x64x16", 5: "128x128x32",
               6: "128x96x32", 7: "128x192x16", 8: "128x192x32", 9: "128x96x32dma", 10: "128x128x32dma",
-              11: "128x192x32dma", 12: "128x96x32dma2", 13: "128x128x32dma2", 14: "128x64x32dma", 15: "128x64x32dma2"}
+              11: "128x192x32dma", 12: "128x96x32dma2", 13: "128x128x32dma2", 14: "128x64x32dma", 15: "128x64x32dma2",
+              16: "64x64x32dma", 17: "64x64x32dma2"}
 
 
 def gemm_plan(M, N, K, allow_split, layout_a=0, layout_b=0, epi=0):

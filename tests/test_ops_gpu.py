@@ -674,11 +674,11 @@ def test_kl_logsoftmax(hip):
     close(dz, zd.grad, rtol=1e-4, atol=1e-8, name="kl dz")
 
 
-@pytest.mark.parametrize("cfg", [9, 10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [9, 10, 11, 12, 13, 14, 15, 16, 17])
 def test_gemm_dma_pipeline(hip, cfg):
     """LDS-DMA pipelined kernels (aligned shapes only): all three operand-layout combinations, short and
     long K (1, 2, 3 and many k-tiles exercise the 3-stage ring prologue/drain), split-K, epilogues."""
-    bn = {9: 96, 10: 128, 11: 192, 12: 96, 13: 128}[cfg]
+    bn = {9: 96, 10: 128, 11: 192, 12: 96, 13: 128, 14: 64, 15: 64, 16: 64, 17: 64}[cfg]
     for K in (32, 64, 96, 768):
         M, N = 256, 2 * bn
         x, w, b = rnd(M, K, seed=K), rnd(N, K, seed=K + 1), rnd(N, seed=3)
