@@ -354,10 +354,13 @@ size_t mtvaf_layer_struct_bytes(int which /* 0: mtvaf_layer_t, 1: mtvaf_layer_gr
  * (:621-625): decoupled weight decay, bias corrections passed in (bc1 = 1 - beta1^t, bc2_sqrt = sqrt(1 - beta2^t)).
  * mtvaf_adamw updates ONE flat fp32 tensor (an encoder layer's parameter buffer: all 16 parameters of a layer in one
  * launch, enqueued behind that layer's gradient all-reduce so the update overlaps the rest of the backward pass) and
- * optionally writes the updated parameters rounded to bf16 (the GEMM operand shadow of the bf16 compute mode).
+ * optionally writes the updated parameters rounded to bf16 (the GEMM operand shadow of the bf16 compute mode);
+ * max_blocks > 0 caps its grid (a background update that trickles under MFMA-bound kernels instead of taking the whole
+ * HBM rate from them for its duration; 0 = full width).
  * mtvaf_adamw_multi updates `count` tensors of one parameter group per launch (host arrays of device pointers). */
 int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, double beta1, double beta2, float eps,
-                float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, mtvaf_stream_t stream);
+                float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, int max_blocks,
+                mtvaf_stream_t stream);
 int mtvaf_adamw_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
                       const long* n, float lr, double beta1, double beta2, float eps, float weight_decay, float bc1,
                       float bc2_sqrt, float grad_scale, mtvaf_stream_t stream);

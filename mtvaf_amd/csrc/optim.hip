@@ -161,12 +161,19 @@ extern "C" {
 
 // One flat tensor (an encoder layer's parameter buffer).  bias corrections are passed in: bc1 = 1 - beta1^t,
 // bc2_sqrt = sqrt(1 - beta2^t).  p_bf16 (optional) receives the updated parameter rounded to bf16.
+// max_blocks > 0 caps the grid: a BACKGROUND update.  At full width (2048 blocks) the update streams at the HBM rate
+// (6.3 TB/s) and starves the operand fetches of the MFMA-bound products it runs beside for its 32 us; 128 blocks trickle
+// at ~1 TB/s under them instead (measured per step, same box: fp32 bs 32 18.95 -> 18.70 ms, bf16 bs 64 11.78 -> 11.56;
+// 64 blocks and fewer take longer than the layer's backward pass they hide behind and lose).  0: full width.
 int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, double beta1, double beta2, float eps,
-                float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, hipStream_t stream) {
+                float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, int max_blocks,
+                hipStream_t stream) {
   if (!p || !g || !m || !v || n <= 0) return MTVAF_ERR_ARG;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 3) return MTVAF_ERR_ALIGN;
   const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
-  hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid((n + 3) / 4)), dim3(256), 0, stream, p, g, m, v,
+  int grid = stream_grid((n + 3) / 4);
+  if (max_blocks > 0 && max_blocks < grid) grid = max_blocks;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v,
                      static_cast<__bf16*>(p_bf16), n, h);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;

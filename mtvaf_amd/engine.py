@@ -176,6 +176,7 @@ N_LAYER_PARAMS = 16  # q.w q.b k.w k.b v.w v.b ao.w ao.b ln1.w ln1.b i.w i.b o.w
 # already produced, so they run on a side stream and fill the bubbles of the chain's non-GEMM kernels (attention
 # backward, LayerNorm backward, split-K reductions) and the head / tail of its GEMMs.  MTVAF_DW_STREAM=0 serialises.
 DW_SIDE_STREAM = os.environ.get("MTVAF_DW_STREAM", "1") != "0"
+DW_STREAM_MIN_ROWS = int(os.environ.get("MTVAF_DW_STREAM_MIN_ROWS", "1024"))
 _side_streams = {}
 
 
@@ -444,10 +445,12 @@ def _native_backward(ctx, douts):
     dpkv = torch.empty_like(pkv) if Pn else None
     need_param_grads = any(p.requires_grad for p in params)
     gviews = grad_sink.acquire(params) if grad_sink is not None else None
+    if grad_sink is not None:
+        grad_sink.token_rows = M
     direct = gviews is not None and DIRECT_GRADS
     pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
     main = torch.cuda.current_stream()
-    side = _side_stream(dev) if (DW_SIDE_STREAM and need_param_grads and M >= 1024) else None
+    side = _side_stream(dev) if (DW_SIDE_STREAM and need_param_grads and M >= DW_STREAM_MIN_ROWS) else None
     main_h = hip._st()
     if side is not None:
         with torch.cuda.stream(side):
@@ -685,6 +688,8 @@ class EncoderFunction(torch.autograd.Function):
         # parameter-gradient destinations: the module's flat per-layer gradient buffers when they are
         # free (param.grad is None), otherwise fresh tensors that autograd accumulates.
         gviews = grad_sink.acquire(params) if grad_sink is not None else None
+        if grad_sink is not None:
+            grad_sink.token_rows = M
         pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
 
         wh = ctx.wh
@@ -694,7 +699,7 @@ class EncoderFunction(torch.autograd.Function):
         KC, KM = hip.KC, hip.KM
         main = torch.cuda.current_stream()
         # (small batches are host-bound: the extra events / stream switches cost more than the overlap returns)
-        side = _side_stream(dev_like.device) if (DW_SIDE_STREAM and need_param_grads and M >= 1024) else None
+        side = _side_stream(dev_like.device) if (DW_SIDE_STREAM and need_param_grads and M >= DW_STREAM_MIN_ROWS) else None
 
         def on_side(reads, fn):
             """Run `fn` (weight-gradient kernels that only read `reads`) behind everything enqueued so far."""

@@ -83,7 +83,7 @@ _SIGS = {
     "mtvaf_gemm_bf16x_ktiles": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P, P, P]),
     "mtvaf_colsum_small": (c_int, [P, I, I, P, I, P]),
     "mtvaf_cast_bf16": (c_int, [P, I, P, I, P, I, I, I, P]),
-    "mtvaf_adamw": (c_int, [P, P, P, P, L, F, c_double, c_double, F, F, F, F, F, P, P]),
+    "mtvaf_adamw": (c_int, [P, P, P, P, L, F, c_double, c_double, F, F, F, F, F, P, I, P]),
     "mtvaf_adamw_multi": (c_int, [I, P, P, P, P, P, F, c_double, c_double, F, F, F, F, F, P]),
     "mtvaf_grad_pack_bf16": (c_int, [P, P, L, L, P]),
     "mtvaf_grad_reduce_bf16": (c_int, [P, P, I, L, F, P]),
@@ -546,12 +546,13 @@ def colsum_small(part, out, accumulate=False):
 
 
 # ---- optimizer / gradient wire format (csrc/optim.hip) ------------------------------------------------------------
-def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, p_bf16=None):
-    """In-place AdamW update of one flat fp32 tensor (torch.optim.AdamW semantics); `step` is the 1-based step count."""
+def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, p_bf16=None, max_blocks=0):
+    """In-place AdamW update of one flat fp32 tensor (torch.optim.AdamW semantics); `step` is the 1-based step count;
+    max_blocks > 0: a background update on that many blocks (runs under MFMA-bound kernels without starving them)."""
     n = p.numel()
     bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
     _ck(lib().mtvaf_adamw(_p(p), _p(g), _p(m), _p(v), n, lr, beta1, beta2, eps, weight_decay, bc1, bc2 ** 0.5, grad_scale,
-                          _p(p_bf16), _st()), "mtvaf_adamw")
+                          _p(p_bf16), int(max_blocks), _st()), "mtvaf_adamw")
 
 
 def adamw_multi(ps, gs, ms, vs, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):

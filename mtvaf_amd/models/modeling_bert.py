@@ -213,6 +213,7 @@ class GradSink:
         self.fast = False
         self.settle_params = False  # set by an optimizer that updates parameters from the hook (mtvaf_amd.optim.AdamW)
         self.raw_stream_hook = False  # the hook only enqueues library kernels on hip._st() (no torch stream semantics needed)
+        self.token_rows = 0  # token rows of the backward pass in flight (how long a layer's backward is: optim.AdamW)
         self.live_nodes = 0
         self._reset_armed = False
 

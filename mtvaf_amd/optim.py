@@ -47,6 +47,7 @@ class AdamW(torch.optim.Optimizer):
         self._encoder = None
         self._layer_group: Dict[int, Optional[dict]] = {}
         self._early = set()
+        self._background_ok = True
         self.suspended = False    # True: the backward hook does nothing (backward passes that are not followed by step())
         if model is not None:
             self.attach(model, grad_sync)
@@ -58,6 +59,9 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("AdamW.attach needs a mtvaf_amd model (TVNetSAModel2 / TVNetSAModel / BertModel)")
         self._encoder = enc
         self._map_layers()
+        # under GradSync the hook runs on the communication stream, where a slow update would delay the next layer's
+        # all-reduce: full width there
+        self._background_ok = grad_sync is None
         if self.overlap:
             sink = enc.grad_sink
             sink.settle_params = True  # the hook's stream must also be behind the layer's last dX product (engine.py)
@@ -92,7 +96,13 @@ class AdamW(torch.optim.Optimizer):
                 ps["step"] = st["step_t"]  # (torch.optim keeps `step` as a tensor too)
         return st
 
-    def _update_layer_flat(self, li: int, group: dict, store):
+    # an update enqueued from inside the backward pass runs beside MFMA-bound products: on 128 blocks it trickles under
+    # them (csrc/optim.hip); below this many token rows a layer's backward is shorter than such an update and it would
+    # only pile up behind the pass
+    BACKGROUND_MIN_ROWS = 2048
+    BACKGROUND_BLOCKS = 128
+
+    def _update_layer_flat(self, li: int, group: dict, store, background: bool = False):
         st = self._layer_state(li, store)
         st["step"] += 1
         st["step_t"].fill_(st["step"])  # the 16 per-parameter state entries share this 0-dim tensor
@@ -100,7 +110,7 @@ class AdamW(torch.optim.Optimizer):
         from . import engine
         shadow = engine.shadow_for_update(store.weights)  # bf16 compute mode: the GEMM operand image, written in the same pass
         hip.adamw(store.flat, store.grad, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                  st["step"], p_bf16=shadow)
+                  st["step"], p_bf16=shadow, max_blocks=self.BACKGROUND_BLOCKS if background else 0)
         if shadow is not None:
             engine.shadow_written(store.weights)
 
@@ -112,7 +122,10 @@ class AdamW(torch.optim.Optimizer):
             return
         if li in self._early:
             raise RuntimeError("mtvaf_amd.optim.AdamW(overlap=True): a second backward pass ran before optimizer.step()")
-        self._update_layer_flat(li, group, stores[li])
+        rows = getattr(self._encoder.grad_sink, "token_rows", 0)
+        # (layer 0 is the last one of the pass: nothing left to hide behind)
+        background = self._background_ok and li > 0 and rows >= self.BACKGROUND_MIN_ROWS
+        self._update_layer_flat(li, group, stores[li], background=background)
         self._early.add(li)
 
     # -- the step ------------------------------------------------------------------------------------------------

@@ -100,6 +100,28 @@ def test_overlap_update_inside_backward_equals_the_plain_schedule():
         torch.testing.assert_close(p, outs[1][1][n], rtol=0, atol=atol, msg=n)
 
 
+def test_background_update_is_the_full_width_update():
+    """max_blocks caps the grid of the per-layer launch (a background update beside MFMA-bound kernels): element-wise
+    arithmetic, so parameters, moments and the bf16 shadow must be bit-identical for every grid, ragged tail included."""
+    from mtvaf_amd import hip
+    n = 7 * 1024 * 1024 + 13
+    g0 = torch.Generator(device="cpu").manual_seed(2)
+    base = [torch.randn(n, generator=g0).to(DEV) for _ in range(3)] + [torch.rand(n, generator=g0).to(DEV) * 1e-3]
+    outs = []
+    for blocks in (0, 128, 3):
+        p, g, m, v = (t.clone() for t in base)
+        sh = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        for step in (1, 2):
+            hip.adamw(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, p_bf16=sh, max_blocks=blocks)
+        outs.append((p, m, v, sh))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
+    # and the optimizer asks for it only where a layer's backward pass is long enough to hide it
+    from mtvaf_amd.optim import AdamW
+    assert AdamW.BACKGROUND_BLOCKS == 128 and AdamW.BACKGROUND_MIN_ROWS == 2048
+
+
 def test_overlap_contract_violation_raises():
     from mtvaf_amd.optim import AdamW
     m, cfg = _model(layers=2)
