@@ -63,9 +63,11 @@ def test_adamw_kernels_match_torch_adamw_on_the_reference_groups():
 
 
 
-def test_overlap_update_inside_backward_equals_the_plain_schedule():
+@pytest.mark.parametrize("B", [16, 32])
+def test_overlap_update_inside_backward_equals_the_plain_schedule(B):
     """overlap=True enqueues each layer's update from the backward hook (second stream, M >= 1024); parameters after
-    3 steps must equal the plain step() schedule, in train mode with dropout (same seeds)."""
+    3 steps must equal the plain step() schedule, in train mode with dropout (same seeds).  B = 32 (2048 token rows) is
+    where the in-backward updates become background launches (128 blocks)."""
     from mtvaf_amd import engine
     from mtvaf_amd.optim import AdamW, reference_param_groups
     outs = []
@@ -73,7 +75,7 @@ def test_overlap_update_inside_backward_equals_the_plain_schedule():
         m, cfg = _model(dropout=0.1)
         m.train()
         opt = AdamW(reference_param_groups(m, 1e-3), model=m, overlap=overlap)
-        batch = _batch(cfg)
+        batch = _batch(cfg, B=B)
         engine.RNG.offset = 0
         torch.manual_seed(3)
         losses = []
