@@ -172,6 +172,9 @@ def main():
                          "is the timed one and the padding-free rate is reported beside it (key `padding_free`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary figures (fwd+bwd without the optimizer, padding-free): profiler runs, so that "
+                         "every kernel launch in the trace belongs to the headline workload")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -290,7 +293,7 @@ def main():
     ftrain = 3 * f_fwd(S, P)
 
     fwd_bwd_only = None
-    if opt is not None and not a.graph:
+    if opt is not None and not a.graph and not a.no_secondary:
         # secondary figure: the same K steps without the optimizer update (the metric's literal "fwd+bwd")
         def step_nb():
             out = model(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None,
@@ -321,7 +324,7 @@ def main():
     f_exec = 3 * sum(f_fwd(int(n), P) for n in lens_host) / B
     real_rows = sum(lens_host) / float(B * S)
     padding_free = None
-    if not a.unpad and not a.graph and real_rows < 0.97:
+    if not a.unpad and not a.graph and not a.no_secondary and real_rows < 0.97:
         # secondary figure: the SAME K steps (optimizer included) with the encoder on the packed unmasked token rows
         engine.UNPAD = True
         try:

@@ -6,7 +6,7 @@ T=${1:-r02}
 R=$PWD
 O=$R/gpurun_out/$T
 mkdir -p $O
-S="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-optimizer"   # 7 model steps per process
+S="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-optimizer --no-secondary"   # 7 model steps per process
 stats() {  # <name> <env> <bench args...>
   local name=$1 envv=$2; shift 2
   env $envv TMPDIR=/tmp true
