@@ -69,7 +69,8 @@ def test_assembled_forward_on_the_timed_path_vs_oracle(B):
     B = 8 (1024 tokens) and B = 32 (the bench batch): prompt generator and Viterbi on the second stream, DeferredTags."""
     from mtvaf_amd import engine
     from mtvaf_amd.modules.crf import DeferredTags
-    assert engine.DW_SIDE_STREAM, "this test must run with the second stream enabled (MTVAF_DW_STREAM unset)"
+    if not engine.DW_SIDE_STREAM:
+        pytest.skip("covers the second stream: run without MTVAF_DW_STREAM=0")
     cfg = P.BASE_BERT
     S, n_aux = 128, 8
     sde, sdh, sdp, text, vis = _assembled_case(cfg, B, S, n_aux, seed=41)
@@ -263,7 +264,9 @@ def test_two_forwards_one_backward_accumulates_encoder_grads():
     m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss.backward()
     st = m.bert.encoder._stores[1]
     g = m.bert.encoder.layer[1].intermediate.dense.weight.grad
-    assert st.grad.data_ptr() <= g.data_ptr() < st.grad.data_ptr() + st.grad.numel() * 4
+    from mtvaf_amd import engine
+    if engine.NATIVE_EXEC and engine.DIRECT_GRADS:  # (the Python orchestration hands views to autograd, which may copy them)
+        assert st.grad.data_ptr() <= g.data_ptr() < st.grad.data_ptr() + st.grad.numel() * 4
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
