@@ -116,6 +116,36 @@ def test_config1_bs4_seq64_three_aux_fp32():
         close(named[n].grad, ograds[n], rtol=3e-3, name=n)
 
 
+@pytest.mark.parametrize("B,S,n_aux,lengths", [(3, 50, 2, [50, 1, 17]), (5, 33, 1, [33, 2, 33, 5, 16]), (2, 130, 8, [130, 64]),
+                                              (1, 7, 3, [7])])
+@pytest.mark.parametrize("unpad", [False, True])
+def test_ragged_odd_shapes_on_the_assembled_path_vs_oracle(B, S, n_aux, lengths, unpad):
+    """Shapes no tile divides (S = 50 / 33 / 130 / 7, B = 1 / 3 / 5, P = 8 / 12 / 16 / 36), one-token sentences beside full ones:
+    the assembled TVNetSAModel2 step against the oracle -- emissions, loss, tags, parameter gradients; padded and
+    padding-free (packed token rows: 68 / 89 / 194 / 7 of them)."""
+    from mtvaf_amd import engine
+    cfg = P.BASE_BERT
+    sde, sdh, sdp = P.encoder_params(cfg, 71, std=0.03), P.head_params(cfg, 72), P.prompt_params(73)
+    text = P.text_batch(cfg, 74, B, S, lengths=lengths, lo_id=1000)
+    text[3][:, 0] = 9
+    vis = _prompt_inputs(75, B, n_aux)
+    oloss, oem, otags, ograds = _oracle(cfg, sde, sdh, sdp, text, vis, GRADS)
+    m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
+    m.eval()
+    engine.UNPAD = unpad
+    try:
+        out, em = _run_model(m, text, vis)
+    finally:
+        engine.UNPAD = False
+    valid = text[1].bool()
+    close(em[valid.to(DEV)], oem[valid], name="emissions of the unmasked tokens")
+    assert abs(float(out.loss) - oloss) <= 1e-3 * abs(oloss)
+    assert list(out.logits) == otags
+    named = dict(m.named_parameters())
+    for n in GRADS:
+        close(named[n].grad, ograds[n], rtol=3e-3, name=n)
+
+
 ROBERTA_BASE = P.EncCfg(vocab_size=50265, hidden=768, heads=12, inter=3072, layers=12, max_pos=514, type_vocab=1, eps=1e-5,
                         roberta=True, pad_idx=1)
 
