@@ -4,6 +4,7 @@
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        # no launcher: this process (which has made no GPU call) starts the N ranks itself
 
 Workload (BASELINE.json configs[1]): TVNetSAModel2 (BERT-base, random init N(0,0.02)), fp32, per-GPU
 batch 32, seq_len 128, 36 visual prefix slots (main image + 8 aux crops through the prompt generator),
@@ -145,6 +146,61 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def launch_ranks(n, argv, script=None, timeout_s=3000.0, extra_env=None):
+    """`bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): start the N ranks as fresh child processes --
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set, as torch.distributed.run would -- wait for
+    them, forward rank 0's JSON line, and fail if any rank fails (the others are then stopped by PID: they would wait in
+    the rendezvous or a collective forever).  The parent never touches the GPU, and nothing is exec'ed from a process that
+    has.  -> (return code, rank 0's stdout)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, script, *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    # rank 0's stdout is drained by a thread (a full pipe must not block it); the ranks are polled so that one failure
+    # ends the job instead of hanging it
+    import threading
+    out0 = []
+    th = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    t_end = time.time() + timeout_s
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            c = procs[r].poll()
+            if c is not None:
+                alive.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    log(f"rank {r} exited with code {c}: stopping the other ranks")
+        if rc != 0 or time.time() > t_end:
+            if rc == 0:
+                rc = 124
+                log(f"ranks still running after {timeout_s:.0f} s: stopping them")
+            for r in alive:
+                procs[r].terminate()
+            for r in alive:
+                try:
+                    procs[r].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            alive = set()
+        else:
+            time.sleep(0.05)
+    th.join(10)
+    return rc, (out0[0] if out0 else "")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +226,10 @@ def main():
                     help="padding-free execution (mtvaf_amd.engine.UNPAD): the encoder layers run on the packed unmasked "
                          "token rows; loss / tags / gradients are those of the padded run.  Without the flag the padded run "
                          "is the timed one and the padding-free rate is reported beside it (key `padding_free`)")
+    ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
+                    help="N > 1: wire format of the gradient exchange (mtvaf_amd.parallel.GradSync): fp32 = RCCL all_reduce(AVG) in "
+                         "place; bf16 = pack -> all_to_all -> fp32 sum -> all_gather (mesh-shaped, half the bytes); auto = fp32 in "
+                         "fp32 compute mode, bf16 in bf16 compute mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -181,9 +241,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # started without a launcher: be the launcher (no GPU call has been made in this process)
+        rc, out = launch_ranks(a.gpus, sys.argv[1:])
+        line = [ln for ln in out.splitlines() if ln.startswith("{")]
+        if rc == 0 and line:
+            print(line[-1], flush=True)
+            return
+        raise SystemExit(rc or 1)
     if a.gpus != world:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N > 1 with `python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 bench.py --gpus {a.gpus} ...`")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher started {world} ranks; use "
+                         f"--nproc-per-node {a.gpus}, or start `python bench.py --gpus {a.gpus}` without a launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     # Launcher smoke test on a 1-GPU box: MTVAF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 over gloo (RCCL refuses
@@ -211,7 +279,7 @@ def main():
     sync = None
     if world > 1:
         from mtvaf_amd.parallel import GradSync
-        sync = GradSync(model)
+        sync = GradSync(model, compress={"auto": "auto", "fp32": None, "bf16": "bf16"}[a.grad_wire])
     sched = None
     if a.no_optimizer:
         opt = None
@@ -369,6 +437,21 @@ def main():
                          "object below counts the flops those launches execute",
            "padding": "skipped (--unpad): the fraction below counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
            "padding_free": padding_free}
+    res["n_ranks_seen"] = dist.get_world_size() if world > 1 else 1
+    res["backend"] = dist.get_backend() if world > 1 else None
+    if sync is not None:
+        # 3 further steps with an event pair around every exchange (outside the timed region: the events are not free)
+        sync.timing = True
+        for _ in range(3):
+            step()
+        tm = sync.take_timing()
+        sync.timing = False
+        res["grad_sync"] = {"wire": sync.compress or "fp32",
+                            "comm_stream_ms_per_step": round(tm["comm_stream_ms"] / max(1, tm["passes"]), 3),
+                            "exposed_tail_ms_per_step": round(tm["exposed_tail_ms"] / max(1, tm["passes"]), 3),
+                            "note": "rank 0, 3 extra steps: time the communication stream spent in exchanges (and the per-layer "
+                                    "optimizer updates queued behind them), and how long the last exchange ran past the "
+                                    "backward pass's own kernels"}
     if a.unpad:
         res["mfma_fraction_of_step"] = round(per_gpu * f_exec / (PEAK_TFLOPS[a.dtype] * 1e12), 4)
         res["config"]["workload"] += ", padding-free execution (masked token rows not computed)"

@@ -432,6 +432,13 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
     return tuple(outs)
 
 
+def _has_grad_hooks(params) -> bool:
+    for p in params:
+        if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return True
+    return False
+
+
 def _native_backward(ctx, douts):
     offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params = ctx.stash
     use_h, pkv16 = ctx.native
@@ -449,7 +456,9 @@ def _native_backward(ctx, douts):
     gviews = grad_sink.acquire(params) if grad_sink is not None else None
     if grad_sink is not None:
         grad_sink.token_rows = M
-    direct = gviews is not None and DIRECT_GRADS
+    # zero-copy gradients bypass AccumulateGrad: only when nobody listens there (tensor hooks, post-accumulate hooks -- which is
+    # also how torch DDP's reducer learns that a gradient is ready)
+    direct = gviews is not None and DIRECT_GRADS and not _has_grad_hooks(params)
     pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
     main = torch.cuda.current_stream()
     side = _side_stream(dev) if (DW_SIDE_STREAM and need_param_grads and M >= DW_STREAM_MIN_ROWS) else None
@@ -990,7 +999,7 @@ class PromptFunction(torch.autograd.Function):
             pg.append(dwp[4 * i:4 * i + 4])
             pg.append(dbp[4 * i:4 * i + 4])
         pp = ctx.proj_params
-        if DIRECT_GRADS and all(p.requires_grad and p.grad is None for p in pp):
+        if DIRECT_GRADS and all(p.requires_grad and p.grad is None for p in pp) and not _has_grad_hooks(pp):
             # the 2*NL slices of the packed gradients become .grad directly: handed to autograd they are VIEWS, which
             # AccumulateGrad deep-copies one by one (24 copies at the very tail of the step, behind the encoder backward)
             for p, g in zip(pp, pg):

@@ -46,6 +46,13 @@ class GraphedTrainStep:
         if engine.UNPAD:
             raise RuntimeError("padding-free execution (engine.UNPAD) reads the packed row count on the host once per step: "
                                "it cannot be captured into a HIP graph -- use the eager model")
+        enc = getattr(getattr(model, "bert", model), "encoder", None)
+        sink = getattr(enc, "_sink", None)
+        if sink is not None and sink.on_layer_done is not None:
+            # a backward-pass hook is attached: mtvaf_amd.optim.AdamW(overlap=True) would apply real updates during the
+            # warm-up passes below (and raise on the second), GradSync would enqueue collectives into the capture
+            raise RuntimeError("GraphedTrainStep: the encoder has a backward hook attached (AdamW(overlap=True) or GradSync); "
+                               "build the optimizer with overlap=False and capture single-GPU steps only")
         self.model = model
         self.static = {k: v.clone() for k, v in tens.items()}
         self.const = {k: v for k, v in batch.items() if not torch.is_tensor(v)}

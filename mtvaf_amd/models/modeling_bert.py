@@ -214,6 +214,7 @@ class GradSink:
         self.settle_params = False  # set by an optimizer that updates parameters from the hook (mtvaf_amd.optim.AdamW)
         self.raw_stream_hook = False  # the hook only enqueues library kernels on hip._st() (no torch stream semantics needed)
         self.token_rows = 0  # token rows of the backward pass in flight (how long a layer's backward is: optim.AdamW)
+        self.optimizer = None  # the mtvaf_amd.optim.AdamW attached to this encoder, if any (GradSync re-wires through it)
         self.live_nodes = 0
         self._reset_armed = False
 
@@ -264,6 +265,7 @@ class BertEncoder(nn.Module):
             if old is not None:
                 self._sink.on_layer_done, self._sink.settle_params = old.on_layer_done, old.settle_params
                 self._sink.raw_stream_hook = old.raw_stream_hook
+                self._sink.optimizer = old.optimizer
         return self._stores, self._sink
 
     @property

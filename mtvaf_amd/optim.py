@@ -35,8 +35,13 @@ class AdamW(torch.optim.Optimizer):
     ``overlap=True``: layers are updated from inside ``loss.backward()`` as soon as their gradients are final (after
     the all-reduce under data parallelism).  Contract: every backward pass is followed by exactly one ``step()`` before
     the next backward (the reference trainer's flow with gradient_accumulation_steps = 1, modules/train.py:620-625);
-    a second backward without a ``step()`` raises.  ``step()`` then only updates what is left (embeddings, heads,
-    prompt generator) and layers that could not take the fast path."""
+    a second backward without a ``step()`` raises -- with or without ``zero_grad`` in between, so gradient accumulation
+    (gradient_accumulation_steps > 1, train.py:616-625) cannot silently train the encoder on one micro-batch: use
+    ``overlap=False`` for it (``build_optimizer`` does).  ``step()`` then only updates what is left (embeddings, heads,
+    prompt generator) and layers that could not take the fast path.
+
+    Checkpoints: ``state_dict()`` / ``load_state_dict()`` are torch.optim's; the flat per-layer moment buffers are
+    rebuilt from the loaded per-parameter ``exp_avg`` / ``exp_avg_sq`` / ``step`` entries on the first update."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  model: Optional[torch.nn.Module] = None, overlap: bool = False, grad_sync=None):
@@ -47,6 +52,7 @@ class AdamW(torch.optim.Optimizer):
         self._encoder = None
         self._layer_group: Dict[int, Optional[dict]] = {}
         self._early = set()
+        self._param_layer: Dict[int, int] = {}  # id(parameter) -> encoder layer whose flat state its entries are views of
         self._background_ok = True
         self.suspended = False    # True: the backward hook does nothing (backward passes that are not followed by step())
         if model is not None:
@@ -62,15 +68,32 @@ class AdamW(torch.optim.Optimizer):
         # under GradSync the hook runs on the communication stream, where a slow update would delay the next layer's
         # all-reduce: full width there
         self._background_ok = grad_sync is None
+        sink = enc.grad_sink
+        sink.optimizer = self  # (a GradSync constructed later re-wires the hook through this, parallel.py)
         if self.overlap:
-            sink = enc.grad_sink
             sink.settle_params = True  # the hook's stream must also be behind the layer's last dX product (engine.py)
             if grad_sync is not None:
-                grad_sync.after_layer_reduced = self._early_layer_update
+                grad_sync.adopt_optimizer(self)
             else:
-                sink.on_layer_done = lambda li, flat: self._early_layer_update(li) if flat is not None else None
+                sink.on_layer_done = self._sink_hook
                 sink.raw_stream_hook = True  # the update is one library launch on hip._st()
         return self
+
+    def _sink_hook(self, li: int, flat):
+        """GradSink.on_layer_done without data parallelism.  flat is None: the pass could not use the flat gradient buffers
+        (some .grad pre-existed: gradient accumulation, or two encoder nodes under one backward) -- that layer is left to
+        step(); but if an earlier pass has ALREADY updated layers from inside its backward, this pass accumulates on top of
+        weights that moved mid-accumulation: refuse."""
+        self.layer_pass_check(li, flat)
+        if flat is not None:
+            self._early_layer_update(li)
+
+    def layer_pass_check(self, li: int, flat):
+        if self.suspended or not self.overlap:
+            return
+        if flat is None and self._early:
+            raise RuntimeError("mtvaf_amd.optim.AdamW(overlap=True): a second backward pass ran before optimizer.step() "
+                               "(gradient accumulation needs overlap=False)")
 
     def _map_layers(self):
         group_of = {id(p): g for g in self.param_groups for p in g["params"]}
@@ -88,13 +111,31 @@ class AdamW(torch.optim.Optimizer):
             st = {"m": torch.zeros_like(store.flat), "v": torch.zeros_like(store.flat), "step": 0,
                   "step_t": torch.zeros((), dtype=torch.float32)}
             self._flat_state[key] = st
+            steps = set()
             for i, p in enumerate(self._encoder.layer[li].ordered_params()):
                 off, n = store.offsets[i], p.numel()
                 ps = self.state[p]
-                ps["exp_avg"] = st["m"][off:off + n].view(p.shape)
-                ps["exp_avg_sq"] = st["v"][off:off + n].view(p.shape)
+                m_v, v_v = st["m"][off:off + n].view(p.shape), st["v"][off:off + n].view(p.shape)
+                if "exp_avg" in ps:  # per-parameter state that exists already (load_state_dict, or earlier per-tensor updates)
+                    m_v.copy_(ps["exp_avg"])
+                    v_v.copy_(ps["exp_avg_sq"])
+                    steps.add(int(ps.get("step", 0)))
+                ps["exp_avg"], ps["exp_avg_sq"] = m_v, v_v
                 ps["step"] = st["step_t"]  # (torch.optim keeps `step` as a tensor too)
+                self._param_layer[id(p)] = li
+            if len(steps) > 1:
+                raise RuntimeError(f"AdamW: the parameters of encoder layer {li} carry different step counts {sorted(steps)}")
+            if steps:
+                st["step"] = steps.pop()
+                st["step_t"].fill_(st["step"])
         return st
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # the flat per-layer buffers are rebuilt from the loaded per-parameter entries by the next _layer_state()
+        self.__dict__["_flat_state"] = {}
+        self._param_layer = {}
+        self._early = set()
 
     # an update enqueued from inside the backward pass runs beside MFMA-bound products: on 128 blocks it trickles under
     # them (csrc/optim.hip); below this many token rows a layer's backward is shorter than such an update and it would
@@ -154,6 +195,8 @@ class AdamW(torch.optim.Optimizer):
                     self._update_layer_flat(li, group, store)
                     done.update(id(p) for p in ps)
         self._early = set()
+        touched = set()  # layers updated tensor by tensor this step: ONE step counter per layer, shared with the flat path
+        flat_state = self.__dict__.get("_flat_state", {})
         for group in self.param_groups:
             b1, b2 = group["betas"]
             buckets: Dict[int, list] = {}
@@ -165,16 +208,28 @@ class AdamW(torch.optim.Optimizer):
                 stt = self.state[p]
                 if "exp_avg" not in stt:
                     stt["exp_avg"], stt["exp_avg_sq"], stt["step"] = torch.zeros_like(p), torch.zeros_like(p), 0
-                if torch.is_tensor(stt["step"]):  # was updated through a layer-flat launch before: own counter from here on
-                    stt["step"] = int(stt["step"])
-                stt["step"] += 1
+                li = self._param_layer.get(id(p))
+                fst = flat_state.get(("layer", li)) if li is not None else None
+                if fst is not None and stt["step"] is fst["step_t"]:
+                    # moments live in the layer's flat buffers (views): this tensor-by-tensor update advances the layer's counter
+                    step_no = fst["step"] + 1
+                    touched.add(li)
+                else:
+                    if torch.is_tensor(stt["step"]):
+                        stt["step"] = int(stt["step"])
+                    stt["step"] += 1
+                    step_no = stt["step"]
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.is_contiguous():
                     raise RuntimeError("non-contiguous parameter")
-                buckets.setdefault(stt["step"], []).append((p, g, stt["exp_avg"], stt["exp_avg_sq"]))
+                buckets.setdefault(step_no, []).append((p, g, stt["exp_avg"], stt["exp_avg_sq"]))
             for step_no, items in buckets.items():
                 hip.adamw_multi([i[0] for i in items], [i[1] for i in items], [i[2] for i in items], [i[3] for i in items],
                                 float(group["lr"]), b1, b2, group["eps"], group["weight_decay"], step_no)
+        for li in touched:
+            fst = flat_state[("layer", li)]
+            fst["step"] += 1
+            fst["step_t"].fill_(fst["step"])
         return loss
 
 
@@ -212,9 +267,12 @@ def build_optimizer(model: torch.nn.Module, args, train_num_steps: int):
             if "image_model" in n:
                 p.requires_grad = False
     on_gpu = any(p.is_cuda for g in groups for p in g["params"])
-    if on_gpu:  # the path's own optimizer kernels; overlap: the reference trainer steps after every backward (:620-625)
-        opt = AdamW(groups, lr=args.lr, model=model, overlap=bool(getattr(args, "overlap_optimizer", True)),
-                    grad_sync=getattr(args, "grad_sync", None))
+    if on_gpu:
+        # the path's own optimizer kernels.  Updates from inside the backward pass only when every backward is followed by a
+        # step (gradient_accumulation_steps == 1: train.py:616-625 steps every `accum` backward passes)
+        accum = int(getattr(args, "gradient_accumulation_steps", 1) or 1)
+        overlap = bool(getattr(args, "overlap_optimizer", True)) and accum == 1
+        opt = AdamW(groups, lr=args.lr, model=model, overlap=overlap, grad_sync=getattr(args, "grad_sync", None))
     else:
         opt = torch.optim.AdamW(groups, lr=args.lr)
     sched = linear_schedule_with_warmup(opt, getattr(args, "warmup_ratio", 0.01) * train_num_steps, train_num_steps)

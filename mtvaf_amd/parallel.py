@@ -22,7 +22,7 @@ Two wire formats:
   deterministic), scales by 1/world, rounds ONCE to bf16 and ``all_gather``s the reduced chunk; the result is
   unpacked into the fp32 gradient buffer.  Half the bytes of the fp32 ring on every link, one rounding per phase
   instead of one per ring hop, and every rank ends with bit-identical gradients.  Pack / reduce / unpack are HIP
-  kernels (``csrc/comm.hip``) on the communication stream.
+  kernels (``mtvaf_grad_pack_bf16`` / ``_reduce_bf16`` / ``_unpack_bf16`` in ``csrc/optim.hip``) on the communication stream.
 
 Dropout under data parallelism: ``engine.RNG`` derives its seed from ``torch.initial_seed()``; launchers that seed
 every rank alike would make all ranks draw the same masks for the same (site, row).  GradSync therefore folds the
@@ -54,7 +54,12 @@ class GradSync:
             raise ValueError(f"compress must be None, 'bf16' or 'auto', got {compress!r}")
         self.compress = compress
         self.encoder = model.bert.encoder if hasattr(model, "bert") else model.encoder
-        self.encoder.grad_sink.on_layer_done = self._layer_done
+        sink = self.encoder.grad_sink
+        sink.on_layer_done = self._layer_done
+        # this hook records events and switches to the communication stream with torch's stream context: it must be
+        # called under torch.cuda.stream(side), never through the raw-stream shortcut an optimizer attached EARLIER may
+        # have asked for (engine._native_backward; otherwise the all-reduce could start before the layer's dW kernels end)
+        sink.raw_stream_hook = False
         self._enc_param_ids = {id(p) for l in self.encoder.layer for p in l.ordered_params()}
         self._comm = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._pending: List = []
@@ -65,6 +70,16 @@ class GradSync:
         self.force = force  # run the collectives even with world_size == 1 (single-GPU test of the N > 1 path)
         self._bufs = {}     # persistent staging: tail bucket, bf16 send / receive / shard
         self.after_layer_reduced = None  # callable(layer_index) run on the comm stream behind a layer's all-reduce
+        self.before_layer = None         # callable(layer_index, flat_grad or None): the optimizer's contract check
+        # timing = True: every collective is bracketed by events on the communication stream and the join at the end of the
+        # backward pass by one event on each stream; take_timing() -> ms of communication-stream work and the part of it
+        # the backward pass did not cover.  Off in timed regions (an event pair per collective is not free).
+        self.timing = False
+        self._tev: List = []
+        self._ttail: List = []
+        opt = getattr(sink, "optimizer", None)
+        if opt is not None and getattr(opt, "overlap", False):  # AdamW(overlap=True) attached before this object existed
+            self.adopt_optimizer(opt)
         # Large non-encoder gradients (94 MB word table, encoder_conv weights) are reduced the moment autograd has
         # accumulated them, so e.g. the word-table all-reduce overlaps the prompt generator's backward instead of
         # sitting in the un-overlapped tail bucket.
@@ -75,6 +90,39 @@ class GradSync:
         if seed_per_rank:
             from . import engine
             engine.RNG.set_stream(self.rank)
+
+    def adopt_optimizer(self, opt):
+        """mtvaf_amd.optim.AdamW(overlap=True): its per-layer update runs on the communication stream right behind the
+        layer's reduction (full width: the stream must not wait), whichever of the two objects was constructed first."""
+        self.after_layer_reduced = opt._early_layer_update
+        self.before_layer = opt.layer_pass_check
+        opt._background_ok = False
+        sink = self.encoder.grad_sink
+        sink.on_layer_done = self._layer_done
+        sink.raw_stream_hook = False
+
+    def _timed(self, fn, *a):
+        if not self.timing or self._comm is None:
+            return fn(*a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a)
+        e1.record()
+        self._tev.append((e0, e1))
+        return r
+
+    def take_timing(self):
+        """-> {"comm_stream_ms": time the communication stream spent in exchanges (+ the optimizer updates queued behind
+        them), "exposed_tail_ms": time from the end of the backward pass's own kernels to the end of the last exchange},
+        summed over the passes since the last call.  Synchronises the device."""
+        if self._comm is None:
+            return None
+        torch.cuda.synchronize()
+        comm = sum(a.elapsed_time(b) for a, b in self._tev)
+        tail = sum(max(0.0, a.elapsed_time(b)) for a, b in self._ttail)
+        n = len(self._ttail)
+        self._tev, self._ttail = [], []
+        return {"comm_stream_ms": comm, "exposed_tail_ms": tail, "passes": n}
 
     # -- wire formats ------------------------------------------------------------------------------------------
     def _buf(self, name: str, numel: int, dtype, device) -> torch.Tensor:
@@ -119,6 +167,8 @@ class GradSync:
 
     # -- called from inside EncoderFunction.backward, newest layer first ---------------------------------
     def _layer_done(self, li: int, flat_grad: Optional[torch.Tensor]):
+        if self.before_layer is not None:
+            self.before_layer(li, flat_grad)
         if not self.enabled or (self.world == 1 and not self.force):
             return
         self._arm()
@@ -138,7 +188,7 @@ class GradSync:
         ev.record()
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ev)
-            self._allreduce_mean(flat_grad)
+            self._timed(self._allreduce_mean, flat_grad)
             if self.after_layer_reduced is not None:
                 self.after_layer_reduced(li)
 
@@ -162,7 +212,7 @@ class GradSync:
             ev.record()
             with torch.cuda.stream(self._comm):
                 self._comm.wait_event(ev)
-                self._allreduce_mean(g)
+                self._timed(self._allreduce_mean, g)
         self._early_done.add(id(p))
 
     # -- runs once when the autograd pass is complete ---------------------------------------------------------
@@ -189,9 +239,16 @@ class GradSync:
             rest.extend(p for p in self.encoder.layer[li].ordered_params() if p.grad is not None)
         self._slow_layers, self._fast_layers = [], []
         if self._comm is not None:
+            if self.timing:
+                t_main = torch.cuda.Event(enable_timing=True)
+                t_main.record()  # the backward pass's own kernels end here
             self._comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._comm):
-                self._reduce_bucket(rest)
+                self._timed(self._reduce_bucket, rest)
+                if self.timing:
+                    t_comm = torch.cuda.Event(enable_timing=True)
+                    t_comm.record()
+                    self._ttail.append((t_main, t_comm))
             torch.cuda.current_stream().wait_stream(self._comm)
         else:
             hooks = []

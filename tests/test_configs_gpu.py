@@ -47,16 +47,38 @@ def _oracle(cfg, sde, sdh, sdp, text, vis, grad_names):
 
 
 def _run_model(m, text, vis):
+    """-> (output, emissions).  The emissions are the tensor the HIP `fc` product (engine.LinearFunction: skinny GEMM behind
+    the head dropout) handed to the CRF kernels, captured where the model passes it to the Viterbi decode -- not a
+    recomputation from the hidden state."""
     ids, mask, tt, labels = (t.to(DEV) for t in text)
     feats, aux, lab = (t.to(DEV) for t in vis)
     cap = {}
-    hb = m.bert.register_forward_hook(lambda mod, inp, out: cap.update(out=out))
+    decode = m.crf.decode_deferred
+
+    def spy(em, mask_u8):
+        cap["em"] = em.detach().clone()
+        return decode(em, mask_u8)
+    m.crf.decode_deferred = spy
     m.zero_grad(set_to_none=True)
-    out = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=lab, images=feats, aux_imgs=aux)
-    hb.remove()
+    try:
+        out = m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=lab, images=feats, aux_imgs=aux)
+    finally:
+        del m.crf.decode_deferred  # (the instance attribute shadowing the method)
     out.loss.backward()
-    em = torch.nn.functional.linear(cap["out"]["last_hidden_state"].detach(), m.fc.weight, m.fc.bias)
-    return out, em
+    torch.cuda.synchronize()  # (the capture may have run on the second stream)
+    return out, cap["em"]
+
+
+def _bf16_report(tag, em, oem, loss, oloss, tags, otags, grads=None):
+    """Measured deviation of a mixed-precision run from the fp32 oracle, printed (pytest -s / the captured log) so that the
+    bounds asserted next to it are the observed figures plus a margin, not a guess."""
+    rel = float((em - oem).norm() / oem.norm())
+    lrel = abs(loss - oloss) / abs(oloss)
+    agree = sum(a == b for ta, tb in zip(tags, otags) for a, b in zip(ta, tb)) / max(1, sum(len(t) for t in otags))
+    g = {n: float((a - b).norm() / b.norm()) for n, (a, b) in (grads or {}).items()}
+    print(f"[bf16 deviation] {tag}: emissions {rel:.3e}  loss {lrel:.3e}  tag agreement {agree:.4f}  "
+          + "  ".join(f"{n.split('.')[-2] if '.' in n else n} {v:.3e}" for n, v in g.items()), flush=True)
+    return rel, lrel, agree, g
 
 
 GRADS = ["encoder_conv.2.weight", "projectors.0.weight", "bert.encoder.layer.5.intermediate.dense.weight",
@@ -163,34 +185,39 @@ def _bf16(fn):
         hip.set_compute_dtype("fp32")
 
 
-def test_config3_roberta_base_bf16_vs_fp32_oracle():
+# Mixed-precision bounds against the fp32 oracle = the deviations measured on MI355X (printed by _bf16_report; round 3:
+# emissions 2.7-5.9e-3, loss 0.3-4.3e-4, tags 99.1-99.4 % at the C3 shapes (97.8-100 % on the 68 .. 194-token odd shapes),
+# gradient norms 0.3-3.3e-2 -- the largest on the prompt generator's weights, whose gradient sums over every layer's prefix
+# slots) plus a margin.  bf16 operands carry 2^-9 relative rounding, so north_star's 1e-3 / bit-exact tags cannot hold by
+# construction in this mode.
+BF16_EM, BF16_LOSS, BF16_TAGS, BF16_GRAD = 1e-2, 2e-3, 0.97, 5e-2
+
+
+@pytest.mark.parametrize("B", [8, 32])
+def test_config3_roberta_base_bf16_vs_fp32_oracle(B):
     """BASELINE configs[2]: RoBERTa-base (12 layers, vocab 50265, 514 positions, eps 1e-5, pad id 1), S = 128, P = 36,
-    bf16 compute, B = 8, against the fp32 oracle.  bf16 operands carry 2^-9 relative rounding, so north_star's 1e-3 /
-    bit-exact tags cannot hold by construction in this mode: the bound here is 2e-2 on emissions / loss and > 90 % tag
-    agreement (stated wherever a C3 / C4 number is quoted)."""
+    bf16 compute, at B = 8 and at the configuration's own B = 32, against the fp32 oracle."""
     cfg = ROBERTA_BASE
-    B, S, n_aux = 8, 128, 8
+    S, n_aux = 128, 8
     sde, sdh, sdp, text, vis = _assembled_case(cfg, B, S, n_aux, seed=61)
     oloss, oem, otags, ograds = _oracle(cfg, sde, sdh, sdp, text, vis, GRADS[:3])
     m = build_tvnet2(cfg, make_args(alpha=0.0, bert_name="roberta-base"), sde=sde, sdh=sdh, sdp=sdp)
     m.eval()
     out, em = _bf16(lambda: _run_model(m, text, vis))
-    rel = float((em.cpu() - oem).norm() / oem.norm())
-    assert rel < 2e-2, rel
-    assert abs(float(out.loss) - oloss) <= 2e-2 * abs(oloss), (float(out.loss), oloss)
-    agree = sum(a == b for ta, tb in zip(list(out.logits), otags) for a, b in zip(ta, tb)) / sum(len(t) for t in otags)
-    assert agree > 0.9, agree
     named = dict(m.named_parameters())
-    for n in GRADS[:3]:
-        g, go = named[n].grad.cpu(), ograds[n]
-        assert float((g - go).norm() / go.norm()) < 5e-2, n
+    valid = text[1].bool()
+    rel, lrel, agree, g = _bf16_report(f"C3 RoBERTa-base B={B}", em.cpu()[valid], oem[valid], float(out.loss), oloss,
+                                       list(out.logits), otags, {n: (named[n].grad.cpu(), ograds[n]) for n in GRADS[:3]})
+    assert rel < BF16_EM and lrel < BF16_LOSS and agree >= BF16_TAGS, (rel, lrel, agree)
+    assert all(v < BF16_GRAD for v in g.values()), g
 
 
 @pytest.mark.parametrize("B,S,n_aux,lengths", [(3, 50, 2, [50, 1, 17]), (5, 33, 1, [33, 2, 33, 5, 16]), (2, 130, 8, [130, 64])])
 @pytest.mark.parametrize("unpad", [False, True])
 def test_ragged_odd_shapes_in_bf16_mode_track_the_fp32_oracle(B, S, n_aux, lengths, unpad):
     """The same odd shapes in the mixed-precision mode (bf16 kernels need 8-element operand rows and fall back where a shape
-    breaks that): 2e-2 of the fp32 oracle, > 90 % of the tags, gradients 5e-2 in norm."""
+    breaks that), within the measured mixed-precision bounds of the fp32 oracle (a handful of tokens: tag agreement is
+    counted over 7 .. 194 of them, so one flipped tag is 0.5 .. 1.5 %: bound 95 %)."""
     from mtvaf_amd import engine
     cfg = P.BASE_BERT
     sde, sdh, sdp = P.encoder_params(cfg, 71, std=0.03), P.head_params(cfg, 72), P.prompt_params(73)
@@ -206,15 +233,11 @@ def test_ragged_odd_shapes_in_bf16_mode_track_the_fp32_oracle(B, S, n_aux, lengt
     finally:
         engine.UNPAD = False
     valid = text[1].bool()
-    rel = float((em.cpu()[valid] - oem[valid]).norm() / oem[valid].norm())
-    assert rel < 2e-2, rel
-    assert abs(float(out.loss) - oloss) <= 2e-2 * abs(oloss), (float(out.loss), oloss)
-    agree = sum(a == b for ta, tb in zip(list(out.logits), otags) for a, b in zip(ta, tb)) / sum(len(t) for t in otags)
-    assert agree > 0.9, agree
     named = dict(m.named_parameters())
-    for n in GRADS[:3]:
-        g, go = named[n].grad.cpu(), ograds[n]
-        assert float((g - go).norm() / go.norm()) < 5e-2, n
+    rel, lrel, agree, g = _bf16_report(f"odd shape B={B} S={S} unpad={unpad}", em.cpu()[valid], oem[valid], float(out.loss), oloss,
+                                       list(out.logits), otags, {n: (named[n].grad.cpu(), ograds[n]) for n in GRADS[:3]})
+    assert rel < BF16_EM and lrel < BF16_LOSS and agree >= 0.95, (rel, lrel, agree)
+    assert all(v < BF16_GRAD for v in g.values()), g
 
 
 def _props_model(cfg, bert_name, dropout=0.0):
@@ -371,3 +394,90 @@ def test_native_executor_equals_python_orchestration(dtype):
                 assert torch.equal(g1[n], g0[n]), n
     finally:
         hip.set_compute_dtype("fp32")
+
+
+# ---- BASELINE configs[4] (C5): S = 512, 36 visual regions ------------------------------------------------------------------
+def test_config5_assembled_seq512_vs_oracle():
+    """C5 shape on the ASSEMBLED model: TVNetSAModel2, BERT-base 12 layers, S = 512, 8 aux crops (P = 36), B = 4, fp32, against
+    the oracle: prompt generator on the second stream, CRF / Viterbi at S = 512, weight-gradient k-tile lists (half the rows
+    of a ragged S = 512 batch are padding), second stream in backward."""
+    cfg = P.BASE_BERT
+    B, S, n_aux = 4, 512, 8
+    sde, sdh, sdp, text, vis = _assembled_case(cfg, B, S, n_aux, seed=91)
+    oloss, oem, otags, ograds = _oracle(cfg, sde, sdh, sdp, text, vis, GRADS)
+    m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
+    m.eval()
+    out, em = _run_model(m, text, vis)
+    valid = text[1].bool()
+    close(em[valid.to(DEV)], oem[valid], name="emissions of the unmasked tokens")
+    assert abs(float(out.loss) - oloss) <= 1e-3 * abs(oloss), (float(out.loss), oloss)
+    assert list(out.logits) == otags, "decoded tags differ from the oracle"
+    named = dict(m.named_parameters())
+    for n in GRADS:
+        close(named[n].grad, ograds[n], rtol=3e-3, name=n)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_config5_full_size_properties(dtype):
+    """C5 at its full size (B = 128, S = 512, P = 36: 65 536 token rows), assembled forward, fp32 and mixed precision:
+    repeated calls bit-identical, batch permutation permutes rows bit for bit, junk under the padding never reaches a valid
+    token."""
+    from mtvaf_amd import hip
+    cfg = P.BASE_BERT
+    B, S, n_aux = 128, 512, 8
+    m = _props_model(cfg, "bert-base-uncased").eval()
+    ids, mask, tt, _ = (t.to(DEV) for t in P.text_batch(cfg, 73, B, S, lo_id=5))
+    feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(74, B, n_aux))
+    hip.set_compute_dtype(dtype)
+    try:
+        h, tags = _emissions(m, ids, mask, tt, feats, aux)
+        h2, tags2 = _emissions(m, ids, mask, tt, feats, aux)
+        assert torch.equal(h, h2) and tags == tags2, "repeated forward differs"
+        del h2
+        perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).to(DEV)
+        hp, tagsp = _emissions(m, ids[perm], mask[perm], tt[perm], feats[perm], aux[perm])
+        assert torch.equal(hp, h[perm]), "batch permutation changes rows"
+        assert tagsp == [tags[int(i)] for i in perm]
+        del hp
+        junk = ids.clone()
+        junk[mask == 0] = 7
+        hj, tagsj = _emissions(m, junk, mask, tt, feats, aux)
+        valid = mask.bool()
+        assert torch.equal(hj[valid], h[valid]), "padding leaks into valid tokens"
+        assert tagsj == tags
+    finally:
+        hip.set_compute_dtype("fp32")
+
+
+def test_word_table_gradient_reproducibility_contract():
+    """What is and is not bit-reproducible in a training step.  Every gradient except the word table's is bit-identical from
+    run to run (deterministic split-K, ordered reductions: asserted by the determinism tests above).  The word-table
+    gradient is a scatter-add of 4096 token rows into 30522 table rows with float atomics: rows that a single token touches
+    (the common case) ARE bit-identical; rows shared by several tokens ([CLS], [SEP], repeated words) see their addends in
+    arbitrary order and may differ in the last bits -- never by more than a few ulp of the row's largest addend.  Under
+    data parallelism every rank holds the bit-identical REDUCED gradient either way (GradSync's ordered fp32 sum)."""
+    cfg = P.BASE_BERT
+    B, S, n_aux = 32, 128, 8
+    m = _props_model(cfg, "bert-base-uncased").eval()
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 83, B, S, lo_id=1000))
+    feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(84, B, n_aux))
+    w = m.bert.embeddings.word_embeddings.weight
+    runs = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux).loss.backward()
+        torch.cuda.synchronize()
+        runs.append(w.grad.detach().clone())
+    valid_ids = ids[mask.bool()]
+    uniq, counts = torch.unique(valid_ids, return_counts=True)
+    single = uniq[counts == 1]
+    shared = uniq[counts > 1]
+    assert len(single) > 1000 and len(shared) >= 2
+    untouched = torch.ones(w.shape[0], dtype=torch.bool, device=DEV)
+    untouched[uniq] = False
+    for r in runs[1:]:
+        assert torch.equal(r[single], runs[0][single]), "rows touched by one token must be bit-reproducible"
+        assert not r[untouched].any() and not runs[0][untouched].any(), "rows no token touches have exact-zero gradient"
+        scale = runs[0][shared].abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+        assert float(((r[shared] - runs[0][shared]).abs() / scale).max()) < 1e-5
+    assert not runs[0][0].any(), "padding_idx row gets no gradient (nn.Embedding(padding_idx=0), modeling_bert.py:171)"

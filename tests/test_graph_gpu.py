@@ -160,3 +160,34 @@ def test_graphed_training_trajectory_equals_eager(dtype):
             g.close()
     finally:
         hip.set_compute_dtype("fp32")
+
+
+def test_padding_free_execution_refuses_graph_capture():
+    """engine.UNPAD reads the packed row count on the host once per step, which a capture cannot contain: the documented
+    error, before anything is captured."""
+    import pytest as _pt
+    from mtvaf_amd import engine
+    from mtvaf_amd.graph import GraphedTrainStep
+    engine_unpad = engine.UNPAD
+    engine.UNPAD = True
+    try:
+        with _pt.raises(RuntimeError, match="cannot be captured"):
+            GraphedTrainStep(torch.nn.Linear(2, 2).to("cuda"), {"input_ids": torch.zeros(2, 8, dtype=torch.long, device="cuda"),
+                                                                "labels": torch.zeros(2, 8, dtype=torch.long, device="cuda")})
+    finally:
+        engine.UNPAD = engine_unpad
+
+
+def test_graph_capture_refuses_an_attached_backward_hook():
+    """AdamW(overlap=True) (build_optimizer's default) would apply real updates during the capture's warm-up passes."""
+    import pytest as _pt
+    from mtvaf_amd.graph import GraphedTrainStep
+    from mtvaf_amd.optim import AdamW
+    from test_optim_gpu import _batch, _model
+    m, cfg = _model(layers=2)
+    m.train()
+    AdamW(m.parameters(), lr=1e-3, model=m, overlap=True)
+    before = m.bert.encoder.layer[0].output.dense.weight.detach().clone()
+    with _pt.raises(RuntimeError, match="backward hook"):
+        GraphedTrainStep(m, _batch(cfg))
+    assert torch.equal(before, m.bert.encoder.layer[0].output.dense.weight)

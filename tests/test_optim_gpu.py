@@ -137,6 +137,104 @@ def test_overlap_contract_violation_raises():
     opt.step()
 
 
+def test_second_backward_without_zero_grad_raises_under_overlap():
+    """Gradient accumulation (backward, backward, step -- no zero_grad in between, train.py:616-625) under overlap=True:
+    the first pass updates the encoder from inside its backward, so the second must refuse instead of accumulating on top
+    of moved weights."""
+    from mtvaf_amd.optim import AdamW
+    m, cfg = _model(layers=2)
+    m.eval()
+    opt = AdamW(m.parameters(), lr=1e-3, model=m, overlap=True)
+    batch = _batch(cfg)
+    m(**batch).loss.backward()
+    with pytest.raises(RuntimeError, match="second backward"):
+        m(**batch).loss.backward()
+    opt.step()
+
+
+def test_build_optimizer_with_gradient_accumulation_equals_torch_adamw():
+    """build_optimizer(gradient_accumulation_steps=2) must not update from inside the backward pass: two accumulated
+    micro-batches then one step, twice, equal torch.optim.AdamW on the same groups."""
+    from mtvaf_amd.optim import build_optimizer, reference_param_groups
+    m, cfg = _model(layers=2)
+    m.eval()
+    ref = copy.deepcopy(m)
+    args = types.SimpleNamespace(lr=1e-3, warmup_ratio=0.0, use_prefix=True, gradient_accumulation_steps=2)
+    opt, _ = build_optimizer(m, args, 100)
+    assert opt.overlap is False and m.bert.encoder.grad_sink.on_layer_done is None
+    topt = torch.optim.AdamW(reference_param_groups(ref, 1e-3), lr=1e-3)
+    batches = [_batch(cfg, seed=5), _batch(cfg, seed=9)]
+    for mod, o in ((m, opt), (ref, topt)):
+        for _ in range(2):
+            for b in batches:
+                (mod(**b).loss / 2).backward()
+            o.step()
+            o.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        if "key.bias" in n or "word_embeddings" in n:
+            continue  # pure-noise gradient whose sign Adam amplifies / float-atomic scatter-add
+        atol = 2.5e-4 if (n.startswith("crf") or n.startswith("fc")) else 5e-6
+        torch.testing.assert_close(p, q, rtol=0, atol=atol, msg=n)
+    # and with accumulation 1 the in-backward updates are on
+    m2, _ = _model(layers=2)
+    args.gradient_accumulation_steps = 1
+    opt2, _ = build_optimizer(m2, args, 100)
+    assert opt2.overlap is True and m2.bert.encoder.grad_sink.on_layer_done is not None
+
+
+def test_state_dict_round_trip_keeps_the_flat_moments_and_step():
+    """load_state_dict into a fresh optimizer: the encoder's Adam moments and bias-correction step survive (the flat
+    per-layer buffers are rebuilt from the loaded per-parameter entries); a resumed run equals the uninterrupted one."""
+    from mtvaf_amd.optim import AdamW
+    batch = None
+    finals = []
+    for resume in (False, True):
+        m, cfg = _model(layers=2)
+        m.eval()
+        batch = batch or _batch(cfg)
+        opt = AdamW(m.parameters(), lr=1e-3, model=m, overlap=True)
+        for it in range(4):
+            if resume and it == 2:
+                sd_o, sd_m = copy.deepcopy(opt.state_dict()), copy.deepcopy(m.state_dict())
+                m, _ = _model(layers=2)
+                m.eval()
+                m.load_state_dict(sd_m)
+                opt = AdamW(m.parameters(), lr=1e-3, model=m, overlap=True)
+                opt.load_state_dict(sd_o)
+            m(**batch).loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        p0 = m.bert.encoder.layer[1].intermediate.dense.weight
+        assert int(opt.state[p0]["step"]) == 4
+        finals.append({n: p.detach().clone() for n, p in m.named_parameters()})
+    for n, p in finals[0].items():
+        if "key.bias" in n or "word_embeddings" in n:
+            continue
+        atol = 2.5e-4 if (n.startswith("crf") or n.startswith("fc")) else 5e-6
+        torch.testing.assert_close(finals[1][n], p, rtol=0, atol=atol, msg=n)
+
+
+def test_tensor_hooks_on_encoder_parameters_still_fire():
+    """The zero-copy gradient path assigns .grad itself and bypasses AccumulateGrad; with a hook registered on an encoder
+    parameter the backward must go through autograd so that the hook runs (torch DDP's reducer relies on that)."""
+    m, cfg = _model(layers=2)
+    m.eval()
+    batch = _batch(cfg)
+    m(**batch).loss.backward()
+    w = m.bert.encoder.layer[0].output.dense.weight
+    want = w.grad.detach().clone()
+    m.zero_grad(set_to_none=True)
+    seen = []
+    h = w.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.detach().clone()))
+    m(**batch).loss.backward()
+    torch.cuda.synchronize()
+    h.remove()
+    assert len(seen) == 1
+    torch.testing.assert_close(seen[0], want, rtol=1e-5, atol=1e-7)
+
+
 def test_grad_wire_format_kernels():
     """pack / reduce / unpack of the bf16 gradient exchange against torch arithmetic (bit-exact: RNE casts, fp32 sums
     in rank order)."""

@@ -409,3 +409,75 @@ def test_gradsync_two_ranks_real_model_one_gpu():
     for rank, worst, aliased, n in out:
         assert n >= 40 and aliased
         assert worst < 2e-4, f"rank {rank}: synced gradients differ from the mean of the per-rank gradients by {worst:.2e}"
+
+
+@pytest.mark.gpu
+def test_optimizer_attached_before_gradsync_is_rewired():
+    """AdamW(overlap=True) constructed BEFORE GradSync (a natural order): GradSync must take the hook over -- no raw-stream
+    shortcut (its events belong on the second stream), the layer updates behind the reductions -- and the step must equal
+    the order optimizer-after-GradSync."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import params as P
+    from transformers import BertConfig
+    from mtvaf_amd.models.bert_model import TVNetSAModel2
+    from mtvaf_amd.optim import AdamW
+    from mtvaf_amd.parallel import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        cfg = BertConfig(vocab_size=500, hidden_size=128, num_hidden_layers=3, num_attention_heads=2,
+                         intermediate_size=256, max_position_embeddings=64, hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0)
+        args = types.SimpleNamespace(bert_name="bert-base-uncased", bert_config=cfg, use_prefix=False, vao=False,
+                                     noauxloss=True, use_probe=False, n_gpu=1, alpha=0.0, prefix_len=4, prefix_dim=768,
+                                     device="cuda", resnet_root=None, use_152=False)
+        labels_list = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
+        ids, mask, tt, labels = (t.to("cuda") for t in P.text_batch(P.EncCfg(vocab_size=500), 3, 32, 64, lo_id=5))
+        res = []
+        for opt_first in (False, True):
+            torch.manual_seed(0)
+            m = TVNetSAModel2(labels_list, None, args).to("cuda").eval()
+            if opt_first:
+                opt = AdamW(m.parameters(), lr=1e-3, model=m, overlap=True)
+                assert m.bert.encoder.grad_sink.raw_stream_hook
+                sync = GradSync(m, force=True, seed_per_rank=False)
+            else:
+                sync = GradSync(m, force=True, seed_per_rank=False)
+                opt = AdamW(m.parameters(), lr=1e-3, model=m, overlap=True, grad_sync=sync)
+            sink = m.bert.encoder.grad_sink
+            assert not sink.raw_stream_hook and sink.on_layer_done == sync._layer_done
+            assert sync.after_layer_reduced == opt._early_layer_update and not opt._background_ok
+            for _ in range(2):
+                m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels).loss.backward()
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            res.append({n: p.detach().clone() for n, p in m.named_parameters()})
+        for n, p in res[0].items():
+            if "word_embeddings" in n or "key.bias" in n:
+                continue
+            torch.testing.assert_close(res[1][n], p, rtol=0, atol=2e-6, msg=n)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with NO launcher: the parent spawns the two ranks itself (bench.launch_ranks).  On the
+    one-GPU box both ranks sit on cuda:0 over gloo (MTVAF_BENCH_ONE_DEVICE=1: RCCL refuses two ranks per device) -- a
+    rehearsal of the rendezvous, GradSync, the barriers, the rank-0 JSON line; not a measurement."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MTVAF_BENCH_ONE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "8", "--seq", "64", "--aux", "3", "--no-cpu-baseline", "--no-roofline", "--no-secondary",
+                        "--grad-wire", "fp32"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["backend"] == "gloo" and d["value"] > 0
+    assert d["config"]["global_batch"] == 16 and d["grad_sync"]["wire"] == "fp32"
+    assert d["grad_sync"]["comm_stream_ms_per_step"] > 0
