@@ -18,58 +18,11 @@
 // Epilogue (tile transposed through LDS, 8 columns per lane, 16-byte stores): bias, erf-GELU (pre-activation saved as
 // bf16), * GELU'(pre), accumulate into fp32 C, fp32 and / or bf16 result, and per-tile column sums of the result (the
 // bias gradient of the producing layer, finished by mtvaf_colsum_small) -- or fp32 split-K slabs + ordered reduction.
-#include "gemm_common.h"
+#include "gemm_bf16x.h"
 
 #include <algorithm>
 
 namespace mtvaf {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
-                         int epi, float* aux, int ldaux, hipStream_t stream);  // gemm.hip
-int prof_begin(const int key[8], hipStream_t stream);                                // gemm.hip (launch profiler)
-void prof_end(int rec, hipStream_t stream);
-
-struct GemmArgsX {
-  const __bf16* A;
-  const __bf16* B;
-  float* C32;        // fp32 result (or split-K slabs), may be NULL when C16 is given
-  __bf16* C16;       // bf16 result, may be NULL
-  const float* bias;
-  __bf16* aux16;     // EPI_GELU: pre-activation out; EPI_DGELU: pre-activation in
-  float* colpart;    // [M / BM][N] column sums of the result, or NULL
-  int M, N, K;
-  int lda, ldb, ldc32, ldc16, ldaux;  // elements
-  int k_chunk;
-  long slab_stride;
-  int epi, accumulate, tiles_n;
-  const int* klist;  // k-tile list (weight-gradient products, k-major operands): reduce over the 64-row k-tiles
-  const int* kcnt;   // klist[0 .. *kcnt) only -- the rest of operand A is exactly zero (gemm_common.h); or NULL
-};
-
-__device__ __forceinline__ void glds16x(const void* src, void* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {  // counted wait: the N most recent DMA instructions of this wave may stay in flight
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-__device__ __forceinline__ int km_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
-
-// two transposing reads -> the 8 consecutive reduction values of this lane's output row / column
-__device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsigned char* p1) {
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
-  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_bit_cast(bf16x8, v);
-}
 
 template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE, bool KLIST = false>
 __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 : 2))) void gemm_bf16x_kernel(GemmArgsX p) {
@@ -451,7 +404,8 @@ extern "C" {
 //   colpart [M/128][N] (optional, 128x128 tiles): per-tile column sums of the result for mtvaf_colsum_small.
 //   allow_split: deterministic split-K (fp32 slabs in workspace + ordered reduction; fp32 result only, epi 0).
 // Requirements (MTVAF_ERR_SHAPE / _ALIGN otherwise; no fallback): M % 128 == 0, K % 64 == 0, N % 128 == 0 or N % 96 == 0, leading dimensions % 8 == 0, 16-byte aligned pointers.  tile: 0 auto, 1 128x96,
-// 2 128x128, 3 256x128 (8 waves; layout_a 0, M % 256 == 0, no colpart), 4 256x192 (8 waves; layout_a 0, M % 256 == 0, N % 192 == 0).
+// 2 128x128, 3 256x128 (8 waves; layout_a 0, M % 256 == 0, no colpart), 4 256x192 (8 waves; layout_a 0, M % 256 == 0, N % 192 == 0),
+// 5 256x256 eight-phase (gemm_bf16p.hip; any layout pair, M % 256 == 0, N % 256 == 0).
 // stages: 0 auto, 2 .. 5 (256x192: always 2).
 static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
                            void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
@@ -470,9 +424,11 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
   const bool can128 = N % 128 == 0, can96 = N % 96 == 0 && !colpart;
   const bool can256 = can128 && M % 256 == 0 && layout_a == 0 && !colpart;
   const bool can192 = N % 192 == 0 && M % 256 == 0 && layout_a == 0;
-  int bn = tile == 1 ? 96 : ((tile == 2 || tile == 3) ? 128 : (tile == 4 ? 192 : 0));
-  int bm = (tile == 3 || tile == 4) ? 256 : 128;
-  if ((bn == 96 && !can96) || (bn == 128 && !can128) || (bm == 256 && bn == 128 && !can256) || (bn == 192 && !can192))
+  const bool canp256 = M % 256 == 0 && N % 256 == 0;  // the eight-phase 256x256 kernel (gemm_bf16p.hip), all three layouts
+  int bn = tile == 1 ? 96 : ((tile == 2 || tile == 3) ? 128 : (tile == 4 ? 192 : (tile == 5 ? 256 : 0)));
+  int bm = (tile == 3 || tile == 4 || tile == 5) ? 256 : 128;
+  if ((bn == 96 && !can96) || (bn == 128 && !can128) || (bm == 256 && bn == 128 && !can256) || (bn == 192 && !can192) ||
+      (bn == 256 && !canp256))
     return MTVAF_ERR_SHAPE;
   if (bn == 0) {
     const long t128 = can128 ? (long)(M / 128) * (N / 128) : 0;
@@ -488,6 +444,23 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
     // tiles -- M = 8192 -- its single co-resident block per CU gives the gain back)
     const long t192 = can192 ? (long)(M / 256) * (N / 192) : 0;
     if (t192 >= 192 && t192 <= 256) { bm = 256; bn = 192; }
+    // the eight-phase 256x256 kernel (gemm_bf16p.hip): 1.5 us per 256x256x64 step per CU in the loop (5.4 TFLOP/s per CU
+    // against 2-3 of the rings above) but ~10 us of launch + pipeline fill + epilogue per tile round, and whole rounds of
+    // 256 tiles (measured, tools/p256_bench.py): it wins once a forward / dX product has two rounds of tiles (M = 65536:
+    // 0.78-1.19 PFLOP/s against 0.55-0.86), and on the weight-gradient products (long reductions over the tokens, few
+    // output tiles) once tiles x splits fill the chip with at least 12 k-tiles per split
+    const bool p256_epi = !(bias && (epi == EPI_DGELU || accumulate)) && !(colpart && epi != EPI_DGELU) && !(accumulate && epi != EPI_NONE) &&
+                          !(klist && kcnt);
+    if (canp256 && p256_epi) {
+      const long t256 = (long)(M / 256) * (N / 256);
+      if (layout_a == 0) {
+        if (t256 >= 512 && splits <= 1) { bm = 256; bn = 256; splits = 1; }
+      } else if (splits <= 0 && allow_split && epi == EPI_NONE && C32 && !C16 && !colpart) {
+        long sp = std::min<long>(32, std::max<long>(1, 256 / t256));
+        while (sp > 1 && ((K / 64) / sp < 12 || (size_t)sp * M * N * sizeof(float) > workspace_bytes)) --sp;
+        if (t256 * sp >= 160) { bm = 256; bn = 256; splits = (int)sp; }
+      }
+    }
   }
   const long tiles = (long)(M / bm) * (N / bn);
   const bool split_ok = allow_split && epi == EPI_NONE && C32 && !C16 && !colpart;
@@ -496,7 +469,7 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
     if (split_ok && tiles < 384) splits = (int)std::min<long>(std::max<long>(512 / tiles, 1), 8);
   }
   if (!split_ok) splits = 1;
-  while (splits > 1 && ((size_t)splits * M * N * sizeof(float) > workspace_bytes || (K / 64) / splits < 4)) --splits;
+  while (splits > 1 && ((size_t)splits * M * N * sizeof(float) > workspace_bytes || (K / 64) / splits < (bn == 256 ? 1 : 4))) --splits;
   GemmArgsX a;
   a.klist = (klist && kcnt && layout_a == 1 && layout_b == 1) ? klist : nullptr;
   a.kcnt = a.klist ? kcnt : nullptr;
@@ -521,12 +494,14 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
   // path; the 8-wave 256x128 block (one per CU) wants the 3-deep ring
   if (stages < 2 || stages > 5) stages = bm == 256 ? 3 : 2;
   if (bn == 192) stages = 2;  // (the only ring that fits: 2 x 56 KB)
+  if (bn == 256) { stages = 2; a.klist = a.kcnt = nullptr; }
   if (a.klist && stages != 2) a.klist = a.kcnt = nullptr;  // (list mode exists for the 2-stage kernels: otherwise reduce over everything)
   dim3 grid((unsigned)tiles, 1, (unsigned)splits);
-  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages >= 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256) + 32 * (bn == 192), layout_a, layout_b, 2, M, N, K, splits};
+  const int key[8] = {300 + (bn == 96 ? 0 : 1) + 2 * (stages >= 3) + 4 * layout_a + 8 * layout_b + 16 * (bm == 256) + 32 * (bn == 192) + 64 * (bn == 256), layout_a, layout_b, 2, M, N, K, splits};
   const int rec = prof_begin(key, stream);
   int rc;
-  if (layout_a == 0 && layout_b == 0) rc = launch_layout<false, false>(a, bm, bn, stages, grid, stream);
+  if (bn == 256) rc = launch_p256(a, layout_a, layout_b, grid, stream);
+  else if (layout_a == 0 && layout_b == 0) rc = launch_layout<false, false>(a, bm, bn, stages, grid, stream);
   else if (layout_a == 0) rc = launch_layout<false, true>(a, bm, bn, stages, grid, stream);
   else rc = launch_layout<true, true>(a, bm, bn, stages, grid, stream);
   prof_end(rec, stream);

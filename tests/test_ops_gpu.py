@@ -887,3 +887,65 @@ def test_gemm_bf16_operands(hip, M, N, K):
                 close(out, ref, rtol=2e-5, name=f"{name} split {sp}")
     with pytest.raises(RuntimeError):
         hip.gemm_bf16x(xh[:100], hip.KC, wh, hip.KC, 100, N, K, out32=out[:100])  # ragged M: no fallback inside the library
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 256, 192), (256, 768, 768), (768, 512, 3072),
+                                   (1024, 768, 4096)])
+def test_gemm_bf16_eight_phase_tile(hip, M, N, K):
+    """The 256x256 eight-wave / eight-phase kernel (gemm_bf16p.hip, tile 5) against the exact model (fp64 products of the
+    bf16-rounded operands): all three operand-layout pairs, one / two / three / many k-tiles per block (the pipeline's
+    prologue and drain paths), split-K (1 .. 6 k-tiles per split), every epilogue, fp32 / bf16 results, column sums,
+    accumulate.  Operands differ per row AND per column (random): a swapped or transposed fragment map cannot pass."""
+    x, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12), rnd(N, seed=13)
+    xh, wh = x.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV)
+    xt, wt = xh.t().contiguous(), wh.t().contiguous()
+    ref = xh.double().cpu() @ wh.double().cpu().t()
+    out = torch.empty(M, N, device=DEV)
+    bd = b.to(DEV)
+    layouts = [("KCxKC", xh, hip.KC, wh, hip.KC), ("KCxKM", xh, hip.KC, wt, hip.KM), ("KMxKM", xt, hip.KM, wt, hip.KM)]
+    for name, a_, la, b_, lb in layouts:
+        out.fill_(float("nan"))
+        hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, bias=bd, tile=5)
+        close(out, ref + b.double(), rtol=2e-5, name=f"{name} bias")
+        for _ in range(3):  # the same launch again: a race between DMA and reads would come and go
+            o2 = torch.full_like(out, float("nan"))
+            hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=o2, bias=bd, tile=5)
+            assert torch.equal(o2, out), f"{name}: repeated launch differs"
+        for sp in (2, 3, 8):
+            if K // 64 >= sp:
+                out.fill_(float("nan"))
+                hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, allow_split=True, splits=sp, tile=5)
+                close(out, ref, rtol=2e-5, name=f"{name} split {sp}")
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_bf16x(xt, hip.KM, wt, hip.KM, M, N, K, out32=out, out16=o16, bias=bd, tile=5)
+    assert torch.equal(o16, out.to(torch.bfloat16))
+    hip.gemm_bf16x(xh, hip.KC, wt, hip.KM, M, N, K, out16=o16.zero_(), bias=bd, tile=5)
+    assert torch.equal(o16, out.to(torch.bfloat16))
+    pre16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_bf16x(xh, hip.KC, wh, hip.KC, M, N, K, out32=out, out16=o16, bias=bd, epi=hip.EPI_GELU, aux16=pre16, tile=5)
+    pre_ref = (ref + b.double()).float().to(torch.bfloat16)
+    assert (pre16.cpu() != pre_ref).float().mean() < 2e-3  # fp32-sum rounding at a bf16 tie flips a few
+    close(out, F.gelu(pre16.double().cpu()), rtol=2e-5, atol=2e-6 * float(ref.abs().max()), name="gelu")
+    assert torch.equal(o16, out.to(torch.bfloat16))
+    pre = rnd(M, N, seed=15).to(torch.bfloat16)
+    pd = pre.double().requires_grad_(True)
+    F.gelu(pd).sum().backward()
+    part = torch.full((M // 128, N), float("nan"), device=DEV)
+    hip.gemm_bf16x(xh, hip.KC, wt, hip.KM, M, N, K, out32=out, out16=o16, epi=hip.EPI_DGELU, aux16=pre.to(DEV), colpart=part, tile=5)
+    close(out, ref * pd.grad, rtol=3e-5, atol=3e-6 * float(ref.abs().max()), name="dgelu")
+    assert torch.equal(o16, out.to(torch.bfloat16))
+    cs = torch.empty(N, device=DEV)
+    hip.colsum_small(part, cs)
+    close(cs, out.double().sum(0), rtol=1e-5, atol=1e-5 * float(out.abs().sum(0).max()), name="colsum")
+    acc0 = rnd(M, N, seed=16)
+    out.copy_(acc0)
+    hip.gemm_bf16x(xt, hip.KM, wt, hip.KM, M, N, K, out32=out, accumulate=True, tile=5)
+    close(out, ref + acc0.double(), rtol=2e-5, name="accumulate")
+    # strided operands (a column block of a wider tensor, as the QKV / FFN buffers are read): leading dimension != width
+    if K >= 128:
+        wide = torch.zeros(M, K + 64, dtype=torch.bfloat16, device=DEV)
+        wide[:, 64:] = xh
+        hip.gemm_bf16x(wide[:, 64:], hip.KC, wh, hip.KC, M, N, K, out32=out, tile=5)
+        close(out, ref, rtol=2e-5, name="strided A")
+    with pytest.raises(RuntimeError):
+        hip.gemm_bf16x(xh, hip.KC, wh[:N - 128], hip.KC, M, N - 128, K, out32=out[:, :N - 128], tile=5)  # N % 256 != 0
