@@ -266,6 +266,22 @@ int mtvaf_gemm_bf16x_ktiles(int layout_a, int layout_b, const void* A, int lda, 
                             int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
                             int splits, int stages, const int* klist, const int* kcnt, mtvaf_stream_t stream);
 int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, mtvaf_stream_t stream);
+/* Stream-K form of the 256x256 eight-phase bf16 kernel (csrc/gemm_bf16p.hip; tile 5 = tile-per-block, tile 6 = stream-K forced,
+ * tile 0 = the planner decides): one block per CU walks an equal run of the k-tile steps of all output tiles; a tile whose
+ * reduction is shared by several blocks is combined inside the launch (fp32 contributions in block order = k order, published
+ * with an agent-scope release and consumed behind an agent-scope acquire: deterministic for a given scratch size).  The
+ * contributions live in a caller-owned scratch attached per stream: at least mtvaf_streamk_scratch_bytes(256) bytes, 16-byte
+ * aligned, zero-initialised by the caller, alive until replaced or detached (scratch = NULL).  Replaces nothing in the
+ * reference (new functionality of the mixed-precision mode); the products are those of modeling_bert.py:266, 283-284, 353,
+ * 420-421, 433 and their autograd backward. */
+int mtvaf_streamk_attach(void* scratch, size_t bytes, mtvaf_stream_t stream);
+size_t mtvaf_streamk_scratch_bytes(int blocks);
+int mtvaf_streamk_attached(mtvaf_stream_t stream); /* -> blocks the attached scratch serves, 0: none */
+/* The (up to four) weight-gradient products of one encoder layer, dW_i[M_i,N_i] = A_i^T . B_i with A_i [K,M_i], B_i [K,N_i] bf16
+ * row-major and fp32 results, in ONE stream-K launch (autograd backward of modeling_bert.py:266, 283-284, 353, 420-421, 433).
+ * Needs an attached scratch (MTVAF_ERR_WORKSPACE otherwise); M_i % 256 == 0, N_i % 256 == 0, K % 64 == 0. */
+int mtvaf_gemm_bf16x_dw_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C32,
+                              const int* ldc32, const int* M, const int* N, int K, mtvaf_stream_t stream);
 
 /* Prefix attention of the mixed-precision mode: the algorithm of mtvaf_prefix_attn_fwd / _bwd (same key order, mask,
  * dropout hash) on bf16 operands with fp32 softmax statistics and accumulation.  qkv16 [B*S,3H], pk16 / pv16 [B,P*H],

@@ -21,6 +21,9 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
                      void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
                      int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
                      int splits, int stages, hipStream_t stream);
+int mtvaf_streamk_attached(hipStream_t stream);
+int mtvaf_gemm_bf16x_dw_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C32,
+                              const int* ldc32, const int* M, const int* N, int K, hipStream_t stream);
 int mtvaf_gemm_bf16x_ktiles(int layout_a, int layout_b, const void* A, int lda, const void* B, int ldb, float* C32, int ldc32,
                             void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
                             int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
@@ -205,23 +208,27 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
   if (L->cu && (L->Mp <= 0 || L->Mp % 128 || L->Mv <= 0 || L->Mv > L->Mp)) return MTVAF_ERR_ARG;
   const int M = L->cu ? L->Mp : L->B * L->S, H = L->H, I = L->I, B = L->B, S = L->S, P = L->P, NH = L->NH;
   if (L->bf16) {
+    // the four weight-gradient products of the layer as ONE launch (mtvaf_gemm_bf16x_dw_group: every tile's reduction over the
+    // tokens cut in two, combined inside the launch) when a stream-K scratch is attached to the second stream: 36 + 36 + 27 + 9
+    // output tiles fill 256 CUs together, not one product at a time.  Enqueued behind the last of their operands (dqkv).
+    const bool grp = mtvaf_streamk_attached(side) > 0 && !g->klist && M % 256 == 0 && H % 256 == 0 && I % 256 == 0;
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0,
                                        M, H, L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, g->df, mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->df, H, L->act, I, g->dw2, I, nullptr, 0, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+    if (!grp) MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->df, H, L->act, I, g->dw2, I, nullptr, 0, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->df, H, L->w2_h, I, nullptr, 0, g->dpre, I, M, I, H, nullptr, X_EPI_DGELU, L->pre, I, 0,
                                g->part, 0, nullptr, 0, 0, -1, 0, mainS));
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum_small(g->part, M / 128, I, g->dbi1, 0, side));
-    MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->dpre, I, L->h1_h, H, g->dw1, H, nullptr, 0, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+    if (!grp) MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->dpre, I, L->h1_h, H, g->dw1, H, nullptr, 0, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->dpre, I, L->w1_h, H, g->dh1, H, nullptr, 0, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1,
                                nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, nullptr, g->dh, 0, g->dg1, g->db1, g->dbo, 0, M,
                                        H, L->p_hidden, L->seed, L->offset + 1, g->ws_main, g->ws_main_bytes, g->da, mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->da, H, L->cx, H, g->dwo, H, nullptr, 0, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
+    if (!grp) MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->da, H, L->cx, H, g->dwo, H, nullptr, 0, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->da, H, L->wo_h, H, nullptr, 0, g->dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
@@ -235,8 +242,16 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum_small(g->partq, B * ((S + 63) / 64), H, g->dbqkv, 0, side));
     MTVAF_TRY(mtvaf_colsum_small(g->partkv, B * ((P + S + 63) / 64), 2 * H, g->dbqkv + H, 0, side));
-    MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->dqkv, 3 * H, L->x_h, H, g->dwqkv, H, nullptr, 0, 3 * H, H, M, nullptr, X_EPI_NONE,
+    if (!grp) MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->dqkv, 3 * H, L->x_h, H, g->dwqkv, H, nullptr, 0, 3 * H, H, M, nullptr, X_EPI_NONE,
                                nullptr, 0, 0, nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
+    if (grp) {
+      const void* const As[4] = {g->df, g->dpre, g->da, g->dqkv};
+      const void* const Bs[4] = {L->act, L->h1_h, L->cx, L->x_h};
+      float* const Cs[4] = {static_cast<float*>(g->dw2), static_cast<float*>(g->dw1), static_cast<float*>(g->dwo), static_cast<float*>(g->dwqkv)};
+      const int lda[4] = {H, I, H, 3 * H}, ldb[4] = {I, H, H, H}, ldc[4] = {I, H, H, H};
+      const int Ms[4] = {H, I, H, 3 * H}, Ns[4] = {I, H, H, H};
+      MTVAF_TRY(mtvaf_gemm_bf16x_dw_group(4, As, lda, Bs, ldb, Cs, ldc, Ms, Ns, M, side));
+    }
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->dqkv, 3 * H, L->wqkv_h, H, g->dh, H, nullptr, 0, M, H, 3 * H, nullptr, X_EPI_NONE,
                                nullptr, 0, 1, nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
   } else {

@@ -33,8 +33,29 @@
 // * The two wave rows run staggered by one barrier (wr = 1 takes one extra barrier before the loop, wr = 0 one after it): each
 //   SIMD holds one wave of either row, so while one of them issues its 16 MFMAs the other issues its LDS reads and DMA.
 // The tail (last two k-tiles) issues less and drains vmcnt 6 -> 0; a block with a single k-tile skips the pipeline.
+//
+// STREAM-K mode (template flag SK; launch_p256_streamk).  The products of the path are small against the chip -- a
+// [8192 x 3072] output is 384 tiles for 256 CUs (1.5 rounds), the four weight gradients of a layer are 36 + 36 + 27 + 9 tiles
+// with reductions of 64 .. 1024 k-tiles -- so a tile-per-block launch leaves most CUs idle for part of it.  In this mode the
+// grid is ONE block per CU and the unit of work is the k-tile STEP: all steps of all output tiles (of up to four products
+// that share a launch: the weight gradients of one layer) are laid out tile after tile and cut into `grid` equal runs; a
+// block walks its run, which may begin in the middle of a tile's reduction and end in the middle of another's.
+//   * a run's first piece that starts at k > 0 is a CONTRIBUTION: its accumulators go to this block's slab (256 KiB, in the
+//     register order of the kernel itself: lane-contiguous 16-byte stores, and the finisher's lanes read back exactly what
+//     the same lanes of the contributor wrote), then the slab is published: every wave drains its stores, the block's
+//     barrier, one lane's agent-scope release fence, a second drain, a relaxed agent-scope flag store;
+//   * the piece that holds a tile's k = 0 is its FINISHER (always the LAST piece of its block's run, so the contributions --
+//     first pieces of the following blocks -- are long there): one lane polls the following blocks' flags (relaxed, bounded),
+//     one agent-scope acquire fence + drain + the block's barrier, then every wave adds the slabs to its accumulators in
+//     block order (= k order: the result does not depend on arrival order, only on the grid size) and runs the ordinary
+//     epilogue; the finisher resets the flags it consumed, so a zero-initialised flag array stays zero between launches.
+// No block ever waits before it has published its own contribution, and waits only for HIGHER block ids: no cycle, whatever
+// the dispatch order or residency.  Slabs and flags live in a caller-owned scratch attached to the stream
+// (mtvaf_streamk_attach), never shared with the split-K workspaces.
 #include "gemm_bf16x.h"
 
+#include <algorithm>
+#include <climits>
 #include <type_traits>
 
 namespace mtvaf {
@@ -49,8 +70,10 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define P256_SB() __builtin_amdgcn_sched_barrier(0)
 #define P256_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-template <bool A_KM, bool B_KM>
-__global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p) {
+typedef __attribute__((address_space(1))) unsigned gu32;
+
+template <bool A_KM, bool B_KM, bool SK>
+__global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK sk) {
   constexpr int HALF = 16384, BUF = 4 * HALF;  // bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];  // the ONLY LDS object: 2 x 64 KiB
 
@@ -59,55 +82,57 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int g = lane >> 4, l15 = lane & 15;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / p.tiles_n) * 256;
-  const int n0 = (bid % p.tiles_n) * 256;
-  const int kbeg = blockIdx.z * p.k_chunk;
-  const int kend = min(p.K, kbeg + p.k_chunk);
-  const int nk = (kend - kbeg) >> 6;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);  // (stream-K: consecutive logical blocks -- which share tiles -- sit on one XCD)
 
-  // ---- DMA: per-lane source offsets (bytes from the block's operand base of k-tile 0, half 0) ----
+  // ---- the piece of work in hand: operands, output tile, k-range (bound by `bind`) ----
   const unsigned char* Abase;
   const unsigned char* Bbase;
   long stepA, stepB;   // bytes per k-tile
   int hstepA, hstepB;  // bytes from half 0 to half 1
   unsigned voffA[2], voffB[2];
-  if (!A_KM) {
-    Abase = reinterpret_cast<const unsigned char*>(p.A + (long)m0 * p.lda + kbeg);
-    stepA = 128;
-    hstepA = 64 * p.lda * 2;
-  } else {
-    Abase = reinterpret_cast<const unsigned char*>(p.A + (long)kbeg * p.lda + m0);
-    stepA = (long)64 * p.lda * 2;
-    hstepA = 128;
-  }
-  if (!B_KM) {
-    Bbase = reinterpret_cast<const unsigned char*>(p.B + (long)n0 * p.ldb + kbeg);
-    stepB = 128;
-    hstepB = 32 * p.ldb * 2;
-  } else {
-    Bbase = reinterpret_cast<const unsigned char*>(p.B + (long)kbeg * p.ldb + n0);
-    stepB = (long)64 * p.ldb * 2;
-    hstepB = 64;
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int f = (wave * 2 + i) * 64 + lane;  // 16-byte position inside the half-tile image
+  int m0, n0, nk;
+  float* Cout;         // fp32 result (or this split's slab)
+  int ldc32;
+  // DMA: per-lane source offsets (bytes from the piece's operand base of its first k-tile, half 0)
+  auto bind = [&](const __bf16* A, const __bf16* B, int lda, int ldb, int m0_, int n0_, int kbeg, int nk_) {
+    m0 = m0_; n0 = n0_; nk = nk_;
     if (!A_KM) {
-      const int r = f >> 3, cp = f & 7;
-      voffA[i] = (unsigned)(((r >> 6) * 128 + (r & 63)) * p.lda * 2 + ((cp ^ ((r >> 1) & 7)) << 4));
+      Abase = reinterpret_cast<const unsigned char*>(A + (long)m0 * lda + kbeg);
+      stepA = 128;
+      hstepA = 64 * lda * 2;
     } else {
-      const int r = f >> 4, cp = f & 15, o = (cp ^ km_swz(r)) * 8;  // o: first of the chunk's 8 outputs inside the half (0..127)
-      voffA[i] = (unsigned)(r * p.lda * 2 + ((o >> 6) * 128 + (o & 63)) * 2);
+      Abase = reinterpret_cast<const unsigned char*>(A + (long)kbeg * lda + m0);
+      stepA = (long)64 * lda * 2;
+      hstepA = 128;
     }
     if (!B_KM) {
-      const int r = f >> 3, cp = f & 7;
-      voffB[i] = (unsigned)(((r >> 5) * 64 + (r & 31)) * p.ldb * 2 + ((cp ^ ((r >> 1) & 7)) << 4));
+      Bbase = reinterpret_cast<const unsigned char*>(B + (long)n0 * ldb + kbeg);
+      stepB = 128;
+      hstepB = 32 * ldb * 2;
     } else {
-      const int r = f >> 4, cp = f & 15, o = (cp ^ km_swz(r)) * 8;
-      voffB[i] = (unsigned)(r * p.ldb * 2 + ((o >> 5) * 64 + (o & 31)) * 2);
+      Bbase = reinterpret_cast<const unsigned char*>(B + (long)kbeg * ldb + n0);
+      stepB = (long)64 * ldb * 2;
+      hstepB = 64;
     }
-  }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = (wave * 2 + i) * 64 + lane;  // 16-byte position inside the half-tile image
+      if (!A_KM) {
+        const int r = f >> 3, cp = f & 7;
+        voffA[i] = (unsigned)(((r >> 6) * 128 + (r & 63)) * lda * 2 + ((cp ^ ((r >> 1) & 7)) << 4));
+      } else {
+        const int r = f >> 4, cp = f & 15, o = (cp ^ km_swz(r)) * 8;  // o: first of the chunk's 8 outputs inside the half (0..127)
+        voffA[i] = (unsigned)(r * lda * 2 + ((o >> 6) * 128 + (o & 63)) * 2);
+      }
+      if (!B_KM) {
+        const int r = f >> 3, cp = f & 7;
+        voffB[i] = (unsigned)(((r >> 5) * 64 + (r & 31)) * ldb * 2 + ((cp ^ ((r >> 1) & 7)) << 4));
+      } else {
+        const int r = f >> 4, cp = f & 15, o = (cp ^ km_swz(r)) * 8;
+        voffB[i] = (unsigned)(r * ldb * 2 + ((o >> 5) * 64 + (o & 31)) * 2);
+      }
+    }
+  };
   unsigned char* const dma_dst = smem_b + wave * 2048;  // this wave's two 1-KiB pieces of a half-tile
   auto stage_A = [&](int buf, int h, int kt) {
     const unsigned char* s = Abase + (long)kt * stepA + h * hstepA;
@@ -174,10 +199,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p) {
   };
 
   f32x4v acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
   // 16 MFMAs of quadrant (mi, ni): D^T blocks -- the B fragment is the MFMA's A operand, so register r of a lane is output
   // column 16*J + 4*g + r of output row 16*I + (lane & 15)
@@ -192,9 +213,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p) {
     __builtin_amdgcn_s_setprio(0);                                                                              \
   } while (0)
 
-  // one k-tile (4 phases).  I1: issue (t+1).A-h1 in phase 1; I2: issue the three half-tiles of t+2 in phases 3 / 4;
-  // WAIT: 6 (steady state), 0 (the last DMA of the block is in flight), -1 (nothing in flight)
-#define P256_KTILE(I1, I2, WAIT)                                                  \
+  // one k-tile (4 phases).  I1: issue (t+1).A-h1 in phase 1; I2: issue the three half-tiles of t+2 in phases 3 / 4 and leave
+  // them in flight (vmcnt 6), else drain (vmcnt 0: the last DMA of the piece, or nothing, is in flight).  Wave-uniform
+  // run-time flags, ONE copy of the body: with the tail peeled into two further copies the three exits of the loop left the
+  // accumulators in different registers and the allocator permuted ~120 of them through scratch after every k-loop
+#define P256_KTILE(I1, I2)                                                        \
   do {                                                                            \
     const int cur = t & 1;                                                        \
     bf16x8 FA0[4][2], FA1[4][2], FB0[2][2], FB1[2][2];                            \
@@ -232,9 +255,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p) {
     P256_SB();                                                                    \
     P256_BAR();                                                                   \
     /* phase 4 */                                                                 \
-    if (I2) stage_B(cur, 1, t + 2);                                               \
-    if ((WAIT) == 6) wait_vm<6>();                                                \
-    else if ((WAIT) == 0) wait_vm<0>();                                           \
+    if (I2) {                                                                     \
+      stage_B(cur, 1, t + 2);                                                     \
+      wait_vm<6>();                                                               \
+    } else {                                                                      \
+      wait_vm<0>();                                                               \
+    }                                                                             \
     P256_SB();                                                                    \
     P256_BAR();                                                                   \
     P256_SB();                                                                    \
@@ -244,7 +270,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p) {
     P256_SB();                                                                    \
   } while (0)
 
-  // ---- prologue: all of tile 0, three half-tiles of tile 1 ----
+  // ---- the k-loop of the bound piece: accumulators <- sum over its nk k-tiles ----
+  auto mainloop = [&]() __attribute__((always_inline)) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  // prologue: all of tile 0, three half-tiles of tile 1
   stage_B(0, 0, 0);
   stage_A(0, 0, 0);
   stage_B(0, 1, 0);
@@ -262,136 +294,270 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p) {
   if (wr == 1) P256_BAR();  // stagger: this wave row runs one barrier behind the other (balanced after the loop)
   P256_SB();
 
-  int t = 0;
-  for (; t + 2 < nk; ++t) P256_KTILE(1, 1, 6);
-  if (nk >= 2) {
-    P256_KTILE(1, 0, 0);
-    ++t;
+  for (int t = 0; t < nk; ++t) {
+    const bool i1 = t + 1 < nk, i2 = t + 2 < nk;
+    P256_KTILE(i1, i2);
   }
-  P256_KTILE(0, 0, -1);
   if (wr == 0) P256_BAR();
-#undef P256_KTILE
-#undef P256_QUAD
+  };
 
   // ---- epilogue: straight from the registers (lane: row 16*I + l15, columns 16*J + 4*g .. +3 of the wave's block) ----
   // One straight-line body per epilogue KIND, chosen once: a runtime `if (epi == ..)` around each of the 32 loads of the
   // DGELU / accumulate forms makes hipcc branch around every load and drain vmcnt per element (32 dependent round trips:
   // measured 26 us per tile); inside a body the loads of half the tile are issued together, then consumed.
   typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-  const bool split = gridDim.z > 1;
-  float* const C = p.C32 ? p.C32 + (long)blockIdx.z * p.slab_stride : nullptr;
-  __bf16* const C16 = split ? nullptr : p.C16;
-  const int colw = n0 + wc * 64 + 4 * g;
-  const long row0 = m0 + wr * 128 + l15;
   // what the path combines (checked by the launcher): bias with the plain / GELU forms only, column sums with DGELU only
   enum { K_RAW = 0, K_PLAIN = 1, K_GELU = 2, K_DGELU = 3, K_ACC = 4 };
-  auto body = [&](auto kind_c) {
-    constexpr int KIND = decltype(kind_c)::value;
-    constexpr bool BIAS = KIND == K_PLAIN || KIND == K_GELU, SUMS = KIND == K_DGELU;
-    f32x4v cs[4], bias4[4];
-#pragma unroll
-    for (int J = 0; J < 4; ++J) {
-      cs[J] = f32x4v{0.f, 0.f, 0.f, 0.f};
-      bias4[J] = (BIAS && p.bias) ? *reinterpret_cast<const f32x4v*>(p.bias + colw + 16 * J) : f32x4v{0.f, 0.f, 0.f, 0.f};
-    }
-    constexpr int NB = KIND == K_ACC ? 2 : 4;  // 16-row blocks per batch of loads: 32 registers in flight either way
-#pragma unroll
-    for (int hI = 0; hI < 8 / NB; ++hI) {
-      bf16x4v pre[NB][4];
-      f32x4v old[NB][4];
-      if (KIND == K_DGELU) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-          for (int J = 0; J < 4; ++J)
-            pre[i][J] = *reinterpret_cast<const bf16x4v*>(p.aux16 + (row0 + 16 * (NB * hI + i)) * p.ldaux + colw + 16 * J);
-      }
-      if (KIND == K_ACC) {
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-#pragma unroll
-          for (int J = 0; J < 4; ++J)
-            old[i][J] = *reinterpret_cast<const f32x4v*>(C + (row0 + 16 * (NB * hI + i)) * p.ldc32 + colw + 16 * J);
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int I = NB * hI + i;
-        const long row = row0 + 16 * I;
-#pragma unroll
-        for (int J = 0; J < 4; ++J) {
-          const int col = colw + 16 * J;
-          f32x4v v = acc[I][J];
-          if (BIAS) v += bias4[J];
-          if (KIND == K_GELU) {
-            bf16x4v pr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) pr[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x4v*>(p.aux16 + row * p.ldaux + col) = pr;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf((float)pr[e]);  // of the SAVED (rounded) pre-activation: fwd/bwd consistent
-          } else if (KIND == K_DGELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad((float)pre[i][J][e]);
-          } else if (KIND == K_ACC) {
-            v += old[i][J];
-          }
-          if (C) *reinterpret_cast<f32x4v*>(C + row * p.ldc32 + col) = v;
-          if (C16) {
-            bf16x4v o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-            *reinterpret_cast<bf16x4v*>(C16 + row * p.ldc16 + col) = o;
-          }
-          if (SUMS) cs[J] += v;
-        }
-      }
-    }
-    if (SUMS && p.colpart) {  // column sums of this wave's 128 rows: over the 8 row blocks (above), then over the 16 row lanes
+  auto epilogue = [&](bool raw, __bf16* C16) __attribute__((always_inline)) {
+    // addresses = wave-uniform base (advanced per 16-row block on the scalar unit) + ONE 32-bit per-lane offset per array:
+    // per-element 64-bit address arithmetic in vector registers (8 row blocks x 3 arrays) pushed the epilogue into spills
+    unsigned char* const Cb = reinterpret_cast<unsigned char*>(Cout);
+    unsigned char* const C16b = reinterpret_cast<unsigned char*>(C16);
+    unsigned char* const auxb = reinterpret_cast<unsigned char*>(p.aux16);
+    const int colw = n0 + wc * 64 + 4 * g;
+    const int rowl = m0 + wr * 128 + l15;
+    const unsigned vo32 = (unsigned)rowl * (unsigned)ldc32 * 4u + (unsigned)colw * 4u;
+    const unsigned vo16 = (unsigned)rowl * (unsigned)p.ldc16 * 2u + (unsigned)colw * 2u;
+    const unsigned voax = (unsigned)rowl * (unsigned)p.ldaux * 2u + (unsigned)colw * 2u;
+    const long rs32 = (long)ldc32 * 64, rs16 = (long)p.ldc16 * 32, rsax = (long)p.ldaux * 32;  // bytes per 16 rows
+    auto body = [&](auto kind_c) __attribute__((always_inline)) {
+      constexpr int KIND = decltype(kind_c)::value;
+      constexpr bool BIAS = KIND == K_PLAIN || KIND == K_GELU, SUMS = KIND == K_DGELU;
+      f32x4v cs[4], bias4[4];
 #pragma unroll
       for (int J = 0; J < 4; ++J) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float sum = cs[J][e];
-#pragma unroll
-          for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-          cs[J][e] = sum;
-        }
-        if (l15 == 0) *reinterpret_cast<f32x4v*>(p.colpart + (long)(m0 / 128 + wr) * p.N + colw + 16 * J) = cs[J];
+        cs[J] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        bias4[J] = (BIAS && p.bias) ? *reinterpret_cast<const f32x4v*>(p.bias + colw + 16 * J) : f32x4v{0.f, 0.f, 0.f, 0.f};
       }
-    }
+      constexpr int NB = KIND == K_ACC ? 2 : 4;  // 16-row blocks per batch of loads: 32 registers in flight either way
+#pragma unroll
+      for (int hI = 0; hI < 8 / NB; ++hI) {
+        bf16x4v pre[NB][4];
+        f32x4v old[NB][4];
+        if (KIND == K_DGELU) {
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+              pre[i][J] = *reinterpret_cast<const bf16x4v*>(auxb + (NB * hI + i) * rsax + 32 * J + voax);
+        }
+        if (KIND == K_ACC) {
+#pragma unroll
+          for (int i = 0; i < NB; ++i)
+#pragma unroll
+            for (int J = 0; J < 4; ++J)
+              old[i][J] = *reinterpret_cast<const f32x4v*>(Cb + (NB * hI + i) * rs32 + 64 * J + vo32);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+          const int I = NB * hI + i;
+#pragma unroll
+          for (int J = 0; J < 4; ++J) {
+            f32x4v v = acc[I][J];
+            if (BIAS) v += bias4[J];
+            if (KIND == K_GELU) {
+              bf16x4v pr;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) pr[e] = (__bf16)v[e];
+              *reinterpret_cast<bf16x4v*>(auxb + I * rsax + 32 * J + voax) = pr;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf((float)pr[e]);  // of the SAVED (rounded) pre-activation: fwd/bwd consistent
+            } else if (KIND == K_DGELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad((float)pre[i][J][e]);
+            } else if (KIND == K_ACC) {
+              v += old[i][J];
+            }
+            if (Cb) *reinterpret_cast<f32x4v*>(Cb + I * rs32 + 64 * J + vo32) = v;
+            if (C16b) {
+              bf16x4v o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+              *reinterpret_cast<bf16x4v*>(C16b + I * rs16 + 32 * J + vo16) = o;
+            }
+            if (SUMS) cs[J] += v;
+          }
+        }
+      }
+      if (SUMS && p.colpart) {  // column sums of this wave's 128 rows: over the 8 row blocks (above), then over the 16 row lanes
+#pragma unroll
+        for (int J = 0; J < 4; ++J) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float sum = cs[J][e];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            cs[J][e] = sum;
+          }
+          if (l15 == 0) *reinterpret_cast<f32x4v*>(p.colpart + (long)(m0 / 128 + wr) * p.N + colw + 16 * J) = cs[J];
+        }
+      }
+    };
+    if (raw) body(std::integral_constant<int, K_RAW>{});
+    else if (p.epi == EPI_GELU) body(std::integral_constant<int, K_GELU>{});
+    else if (p.epi == EPI_DGELU) body(std::integral_constant<int, K_DGELU>{});
+    else if (p.accumulate) body(std::integral_constant<int, K_ACC>{});
+    else body(std::integral_constant<int, K_PLAIN>{});
   };
-  if (split) body(std::integral_constant<int, K_RAW>{});
-  else if (p.epi == EPI_GELU) body(std::integral_constant<int, K_GELU>{});
-  else if (p.epi == EPI_DGELU) body(std::integral_constant<int, K_DGELU>{});
-  else if (p.accumulate) body(std::integral_constant<int, K_ACC>{});
-  else body(std::integral_constant<int, K_PLAIN>{});
-}
 
-template <bool A_KM, bool B_KM>
-static int launch_p256_t(const GemmArgsX& a, dim3 grid, hipStream_t st) {
+  if (!SK) {  // one tile (and one split of its reduction) per block
+    const int kbeg = blockIdx.z * p.k_chunk;
+    const int kend = min(p.K, kbeg + p.k_chunk);
+    bind(p.A, p.B, p.lda, p.ldb, (bid / p.tiles_n) * 256, (bid % p.tiles_n) * 256, kbeg, (kend - kbeg) >> 6);
+    const bool split = gridDim.z > 1;
+    Cout = p.C32 ? p.C32 + (long)blockIdx.z * p.slab_stride : nullptr;
+    ldc32 = p.ldc32;
+    mainloop();
+    epilogue(split, split ? nullptr : p.C16);
+    return;
+  }
+
+  // ---- stream-K: ONE piece per block.  blockIdx.x -> run (reversed: later runs are dispatched first), blockIdx.y -> the
+  // y-th piece of the run.  Piece 0 starts at the run's first step (possibly inside a tile: a CONTRIBUTION); the following
+  // pieces start at the tile boundaries inside the run.  Every contribution is therefore a y = 0 piece of a LATER run than
+  // its finisher: with x reversed and y slowest in the dispatch order, contributions are handed to CUs before the pieces
+  // that wait for them (dispatch order is a speed matter only: waits are bounded and flagged) ----
+  const int KT = sk.KT;
+  const int run = (int)gridDim.x - 1 - bid;  // (bid: XCD-aware, so neighbouring runs -- which share operand panels -- share an L2)
+  const long rs = (long)run * sk.W, re = min(rs + (long)sk.W, sk.total);
+  long ps = rs;                                   // piece start
+  if (blockIdx.y > 0) ps = (rs / KT + blockIdx.y) * KT;
+  if (ps >= re) return;                           // (uniform: the run has fewer pieces)
+  const int tg = (int)(ps / KT);
+  const int k0 = (int)(ps - (long)tg * KT);
+  const int k1 = (int)min((long)KT, k0 + (re - ps));
+  {
+    // the product this tile belongs to (up to four share a launch).  The table is indexed at run time: it stays in the
+    // kernel-argument segment (scalar loads on demand) instead of occupying ~50 SGPRs for the whole kernel
+    const int q = (tg >= sk.tile_begin[1]) + (tg >= sk.tile_begin[2]) + (tg >= sk.tile_begin[3]);
+    const P256Prob& pb = sk.pr[q];
+    const int tl = tg - sk.tile_begin[q], tiles_n = pb.tiles_n;
+    Cout = pb.C32;
+    ldc32 = pb.ldc32;
+    bind(pb.A, pb.B, pb.lda, pb.ldb, (tl / tiles_n) * 256, (tl % tiles_n) * 256, k0 * 64, k1 - k0);
+  }
+  mainloop();
+  const unsigned tid16 = (unsigned)tid * 16u;
+  if (k0 > 0) {
+    // CONTRIBUTION: accumulators -> this run's slab, in register order (8 KiB per store instruction of the block)
+    unsigned char* const my_slab = reinterpret_cast<unsigned char*>(sk.slabs) + (long)run * (256 * 256 * 4);
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+      for (int J = 0; J < 4; ++J) *reinterpret_cast<f32x4v*>(my_slab + (I * 4 + J) * 8192 + tid16) = acc[I][J];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains ...
+    __syncthreads();                                    // ... before the one lane that publishes
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (keep: ROCm 7.2 can drop the fence's own wait)
+      __hip_atomic_store((gu32*)(sk.flags + run), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  if (k1 < KT) {
+    // FINISHER: the rest of this tile's reduction sits in the slabs of the following runs, in k order
+    const int ncon = (KT - k1 + sk.W - 1) / sk.W;
+    if (tid == 0) {
+      for (int c = 1; c <= ncon; ++c) {
+        unsigned spins = 0;
+        while (__hip_atomic_load((gu32*)(sk.flags + run + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > (1u << 24)) {  // bounded: ~ seconds.  Never in a healthy launch; the error word says so
+            __hip_atomic_store((gu32*)sk.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    const unsigned char* const slab1 = reinterpret_cast<const unsigned char*>(sk.slabs) + (long)(run + 1) * (256 * 256 * 4);
+    // eight 16-byte pieces per lane at a time: the run-time loop over the contributions carries 8 running sums, never the
+    // 32 accumulator blocks (a loop that updates all of them made the allocator permute them through scratch)
+#pragma unroll
+    for (int b8 = 0; b8 < 4; ++b8) {
+      f32x4v sum[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum[e] = acc[2 * b8 + (e >> 2)][e & 3];
+      for (int c = 0; c < ncon; ++c) {
+        const unsigned char* sl = slab1 + (long)c * (256 * 256 * 4) + b8 * 8 * 8192 + tid16;
+        f32x4v part[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part[e] = *reinterpret_cast<const f32x4v*>(sl + e * 8192);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum[e] += part[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[2 * b8 + (e >> 2)][e & 3] = sum[e];
+    }
+    if (tid == 0)
+      for (int c = 1; c <= ncon; ++c) __hip_atomic_store((gu32*)(sk.flags + run + c), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // consumed
+  }
+  epilogue(false, p.C16);
+}
+#undef P256_KTILE
+#undef P256_QUAD
+
+template <bool A_KM, bool B_KM, bool SK>
+static int launch_p256_t(const GemmArgsX& a, const P256SK& sk, dim3 grid, hipStream_t st) {
   constexpr size_t smem = 128 * 1024;
-  auto kern = gemm_bf16_p256_kernel<A_KM, B_KM>;
+  auto kern = gemm_bf16_p256_kernel<A_KM, B_KM, SK>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a, sk);
   MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+static int p256_check(const GemmArgsX& a) {
+  // 32-bit byte offsets inside the result / pre-activation arrays (the epilogue's per-lane offsets)
+  if ((double)a.M * std::max(std::max(a.ldc32 * 4, a.ldc16 * 2), a.ldaux * 2) >= 4294967296.0) return MTVAF_ERR_SHAPE;
+  // the epilogue bodies of the kernel cover the combinations the path uses
+  if (a.bias && (a.epi == EPI_DGELU || a.accumulate)) return MTVAF_ERR_ARG;
+  if (a.colpart && a.epi != EPI_DGELU) return MTVAF_ERR_ARG;
+  if (a.accumulate && a.epi != EPI_NONE) return MTVAF_ERR_ARG;
   return MTVAF_OK;
 }
 
 // 256 x 256 tile, any of the three operand-layout pairs of the path.  Requires M % 256 == 0, N % 256 == 0, K % 64 == 0 and
 // whole 64-element k-tiles per split (checked by the caller, gemm_bf16x_core).
 int launch_p256(const GemmArgsX& a, int layout_a, int layout_b, dim3 grid, hipStream_t st) {
-  // the epilogue bodies of the kernel cover the combinations the path uses
-  if (a.bias && (a.epi == EPI_DGELU || a.accumulate)) return MTVAF_ERR_ARG;
-  if (a.colpart && a.epi != EPI_DGELU) return MTVAF_ERR_ARG;
-  if (a.accumulate && a.epi != EPI_NONE) return MTVAF_ERR_ARG;
-  if (layout_a == 0 && layout_b == 0) return launch_p256_t<false, false>(a, grid, st);
-  if (layout_a == 0) return launch_p256_t<false, true>(a, grid, st);
-  return launch_p256_t<true, true>(a, grid, st);
+  if (int rc = p256_check(a)) return rc;
+  P256SK sk = {};
+  if (layout_a == 0 && layout_b == 0) return launch_p256_t<false, false, false>(a, sk, grid, st);
+  if (layout_a == 0) return launch_p256_t<false, true, false>(a, sk, grid, st);
+  return launch_p256_t<true, true, false>(a, sk, grid, st);
+}
+
+// Stream-K launch: `sk` describes the step space (sk.nprob = 0: the single product of `a`, any epilogue; 1..4: products that
+// share the launch, plain fp32 results); one block per CU of the scratch's grid.
+int launch_p256_streamk(const GemmArgsX& a, P256SK sk, int layout_a, int layout_b, int grid_blocks, int steps_per_run, hipStream_t st) {
+  if (int rc = p256_check(a)) return rc;
+  if (grid_blocks <= 0 || !sk.slabs || !sk.flags || sk.KT <= 0 || sk.total <= 0) return MTVAF_ERR_ARG;
+  if (sk.nprob == 0) {  // the single product of `a`
+    sk.pr[0] = P256Prob{a.A, a.B, a.C32, a.lda, a.ldb, a.ldc32, a.tiles_n};
+    sk.nprob = 1;
+    sk.tile_begin[0] = 0;
+  }
+  for (int q = sk.nprob; q < 4; ++q) sk.tile_begin[q] = INT_MAX;
+  // steps_per_run > 0: every tile's reduction is cut into KT / steps_per_run equal pieces (a divisor of KT: the planner's
+  // choice -- equal pieces in whole rounds of the CUs); 0: the step line is cut into grid_blocks equal runs wherever they fall
+  const long g = std::min<long>(grid_blocks, sk.total);
+  sk.W = steps_per_run > 0 ? steps_per_run : (int)((sk.total + g - 1) / g);
+  const long runs = (sk.total + sk.W - 1) / sk.W;
+  if (steps_per_run > 0 && sk.KT % steps_per_run) return MTVAF_ERR_ARG;
+  if (runs > grid_blocks && !(sk.W % sk.KT == 0)) return MTVAF_ERR_WORKSPACE;  // one slab / flag per run (runs of whole tiles need none)
+  // runs x (pieces per run: the piece from the run's start, then one per tile boundary inside the run; blocks beyond a
+  // run's last piece exit at once)
+  const dim3 grid((unsigned)runs, (unsigned)(sk.KT % sk.W == 0 ? 1 : (sk.W + sk.KT - 2) / sk.KT + 1));
+  if (layout_a == 0 && layout_b == 0) return launch_p256_t<false, false, true>(a, sk, grid, st);
+  if (layout_a == 0) return launch_p256_t<false, true, true>(a, sk, grid, st);
+  return launch_p256_t<true, true, true>(a, sk, grid, st);
 }
 
 }  // namespace mtvaf

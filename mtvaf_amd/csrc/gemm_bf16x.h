@@ -53,6 +53,26 @@ __device__ __forceinline__ bf16x8 tr_read8(const unsigned char* p0, const unsign
 }
 
 
+// stream-K description of a launch of the 256x256 kernel (gemm_bf16p.hip): the k-tile steps of all output tiles, tile after
+// tile, cut into equal runs of W steps per block
+struct P256Prob {
+  const __bf16* A;
+  const __bf16* B;
+  float* C32;
+  int lda, ldb, ldc32, tiles_n;
+};
+struct P256SK {
+  P256Prob pr[4];
+  int tile_begin[4];  // global index of each product's first tile (INT_MAX: unused slot)
+  int nprob;        // 0: the single product of the GemmArgsX; 1..4: products sharing the launch (same K, same layouts)
+  int KT;           // k-tiles per output tile
+  int W;            // steps per block (set by the launcher)
+  long total;       // tiles * KT
+  float* slabs;     // [blocks][256 * 256] fp32 contributions, in the kernel's register order
+  unsigned* flags;  // [blocks], zero between launches
+  unsigned* err;    // set if a bounded wait ran out
+};
 int launch_p256(const GemmArgsX& a, int layout_a, int layout_b, dim3 grid, hipStream_t st);  // gemm_bf16p.hip
+int launch_p256_streamk(const GemmArgsX& a, P256SK sk, int layout_a, int layout_b, int grid_blocks, int steps_per_run, hipStream_t st);
 
 }  // namespace mtvaf

@@ -21,6 +21,7 @@
 #include "gemm_bf16x.h"
 
 #include <algorithm>
+#include <mutex>
 
 namespace mtvaf {
 
@@ -390,6 +391,47 @@ static int launch_layout(const GemmArgsX& a, int bm, int bn, int stages, dim3 gr
   return launch_stages<128, 96, 4, 1, A_KM, B_KM>(a, stages, grid, st);
 }
 
+
+// ---- stream-K scratch: caller-owned, zero-initialised buffers attached per stream (mtvaf_streamk_attach) ----
+// [0, 4096): flags (one 32-bit word per block, zero between launches) and the error word (last word); then one 256-KiB slab
+// per block.  Never shared with the split-K workspaces, whose users scribble over their whole buffer.
+struct StreamKScratch { hipStream_t stream; unsigned char* ptr; size_t bytes; };
+static StreamKScratch g_sk[8];
+static int g_sk_n = 0;
+static std::mutex g_sk_mu;
+constexpr size_t SK_HEADER = 4096, SK_SLAB = 256 * 256 * sizeof(float);
+
+static bool streamk_lookup(hipStream_t stream, P256SK* sk, int* blocks) {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  for (int i = 0; i < g_sk_n; ++i)
+    if (g_sk[i].stream == stream) {
+      const long b = std::min<long>({256L, (long)((g_sk[i].bytes - SK_HEADER) / SK_SLAB), (long)(SK_HEADER / 4 - 1)});
+      if (b < 8) return false;
+      sk->flags = reinterpret_cast<unsigned*>(g_sk[i].ptr);
+      sk->err = sk->flags + SK_HEADER / 4 - 1;
+      sk->slabs = reinterpret_cast<float*>(g_sk[i].ptr + SK_HEADER);
+      *blocks = (int)b;
+      return true;
+    }
+  return false;
+}
+
+// Pieces per tile for the in-launch-combine form of the 256x256 kernel: S divides the KT k-tiles of a tile's reduction, all
+// tiles x S pieces are equal and run in ONE round of the `blocks` CUs (one contribution slab per piece).  Model calibrated with
+// tools/p256_bench.py: 1.55 us per 256x256x64 step, ~3.5 us of block start + pipeline fill per piece, ~7 us for a piece's
+// contribution (256-KiB slab out, flag) and the finisher's combine, ~3 us of epilogue.  -> microseconds, *S_out
+static double p256_plan(long tiles, int KT, int blocks, int* S_out) {
+  double best = 1e30;
+  *S_out = 1;
+  for (int S = 1; S <= KT; ++S) {
+    if (KT % S || (S > 1 && (tiles * S > blocks || KT / S < 3))) continue;
+    const double rounds = (double)((tiles * S + blocks - 1) / blocks);
+    const double t = rounds * (KT / S * 1.55 + 3.5) + (S > 1 ? 7.0 : 0.0) + 3.0;
+    if (t < best) { best = t; *S_out = S; }
+  }
+  return best;
+}
+
 }  // namespace mtvaf
 
 using namespace mtvaf;
@@ -425,8 +467,8 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
   const bool can256 = can128 && M % 256 == 0 && layout_a == 0 && !colpart;
   const bool can192 = N % 192 == 0 && M % 256 == 0 && layout_a == 0;
   const bool canp256 = M % 256 == 0 && N % 256 == 0;  // the eight-phase 256x256 kernel (gemm_bf16p.hip), all three layouts
-  int bn = tile == 1 ? 96 : ((tile == 2 || tile == 3) ? 128 : (tile == 4 ? 192 : (tile == 5 ? 256 : 0)));
-  int bm = (tile == 3 || tile == 4 || tile == 5) ? 256 : 128;
+  int bn = tile == 1 ? 96 : ((tile == 2 || tile == 3) ? 128 : (tile == 4 ? 192 : ((tile == 5 || tile == 6) ? 256 : 0)));
+  int bm = (tile == 3 || tile == 4 || tile == 5 || tile == 6) ? 256 : 128;
   if ((bn == 96 && !can96) || (bn == 128 && !can128) || (bm == 256 && bn == 128 && !can256) || (bn == 192 && !can192) ||
       (bn == 256 && !canp256))
     return MTVAF_ERR_SHAPE;
@@ -460,9 +502,46 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
         while (sp > 1 && ((K / 64) / sp < 12 || (size_t)sp * M * N * sizeof(float) > workspace_bytes)) --sp;
         if (t256 * sp >= 160) { bm = 256; bn = 256; splits = (int)sp; }
       }
+      // with a scratch attached to this stream (mtvaf_streamk_attach) the kernel can cut every tile's reduction into S equal
+      // pieces that fill one round of the CUs and combine them inside the launch: priced against what the rings above reach on
+      // these shapes (0.62 PFLOP/s, 0.78 at K >= 2048, 0.5 on weight gradients)
+      if (bn != 256 && splits <= 1) {
+        P256SK tmp = {};
+        int blocks = 0, S = 1;
+        if (streamk_lookup(stream, &tmp, &blocks)) {
+          const double t_new = p256_plan(t256, K / 64, blocks, &S) + ((epi == EPI_GELU || epi == EPI_DGELU) ? 7.0 : 0.0);
+          const double rate = layout_a == 1 ? 0.5e9 : (K >= 2048 ? 0.78e9 : 0.62e9);  // flop per microsecond
+          const double t_old = 2.0 * M * N * K / rate + 3.0;
+          if (S > 1 && t_new < 0.85 * t_old) { bm = 256; bn = 256; splits = 1; }
+        }
+      }
     }
   }
   const long tiles = (long)(M / bm) * (N / bn);
+  // ---- the 256x256 kernel with its in-launch combine: S equal pieces per tile in one round of the CUs (tile 6 forces the
+  // general stream-K cut: the step line in `blocks` equal runs wherever they fall) ----
+  if ((bn == 256 && tile != 5) || tile == 6) {
+    P256SK sk = {};
+    int blocks = 0, S = 1;
+    const int KT = K / 64;
+    const bool have = streamk_lookup(stream, &sk, &blocks);
+    if (tile == 6 && !have) return MTVAF_ERR_WORKSPACE;
+    if (have) p256_plan(tiles, KT, blocks, &S);
+    if (have && (tile == 6 || S > 1)) {
+      GemmArgsX a;
+      a.klist = a.kcnt = nullptr;
+      a.A = static_cast<const __bf16*>(A); a.B = static_cast<const __bf16*>(B);
+      a.C32 = C32; a.C16 = static_cast<__bf16*>(C16); a.bias = bias; a.aux16 = static_cast<__bf16*>(aux16); a.colpart = colpart;
+      a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc32 = ldc32; a.ldc16 = ldc16; a.ldaux = ldaux;
+      a.epi = epi; a.accumulate = accumulate; a.k_chunk = K; a.slab_stride = 0; a.tiles_n = N / 256;
+      sk.nprob = 0; sk.KT = KT; sk.total = tiles * KT;
+      const int key[8] = {300 + 1 + 4 * layout_a + 8 * layout_b + 16 + 64 + 128, layout_a, layout_b, 2, M, N, K, tile == 6 ? 0 : S};
+      const int rec = prof_begin(key, stream);
+      const int rc = launch_p256_streamk(a, sk, layout_a, layout_b, blocks, tile == 6 ? 0 : KT / S, stream);
+      prof_end(rec, stream);
+      return rc;
+    }
+  }
   const bool split_ok = allow_split && epi == EPI_NONE && C32 && !C16 && !colpart;
   if (splits <= 0) {
     splits = 1;
@@ -526,6 +605,68 @@ int mtvaf_gemm_bf16x_ktiles(int layout_a, int layout_b, const void* A, int lda, 
                             int splits, int stages, const int* klist, const int* kcnt, hipStream_t stream) {
   return gemm_bf16x_core(layout_a, layout_b, A, lda, B, ldb, C32, ldc32, C16, ldc16, M, N, K, bias, epi, aux16, ldaux, accumulate,
                          colpart, allow_split, workspace, workspace_bytes, tile, splits, stages, klist, kcnt, stream);
+}
+
+// Attach a caller-owned scratch to `stream` for the stream-K launches of the 256x256 kernel (gemm_bf16p.hip): at least
+// mtvaf_streamk_scratch_bytes(blocks) bytes, 16-byte aligned, ZERO-INITIALISED by the caller (the kernel leaves the flag words
+// zero behind every launch), alive until detached (ptr = NULL) or replaced.  Without a scratch the library uses the
+// tile-per-block / split-K forms.
+int mtvaf_streamk_attach(void* scratch, size_t bytes, hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  int slot = -1;
+  for (int i = 0; i < g_sk_n; ++i)
+    if (g_sk[i].stream == stream) slot = i;
+  if (!scratch) {
+    if (slot >= 0) g_sk[slot] = g_sk[--g_sk_n];
+    return MTVAF_OK;
+  }
+  if (((uintptr_t)scratch & 15) || bytes < SK_HEADER + 8 * SK_SLAB) return MTVAF_ERR_WORKSPACE;
+  if (slot < 0) {
+    if (g_sk_n == 8) return MTVAF_ERR_WORKSPACE;
+    slot = g_sk_n++;
+  }
+  g_sk[slot] = StreamKScratch{stream, static_cast<unsigned char*>(scratch), bytes};
+  return MTVAF_OK;
+}
+int mtvaf_streamk_attached(hipStream_t stream) {
+  P256SK sk = {};
+  int blocks = 0;
+  return streamk_lookup(stream, &sk, &blocks) ? blocks : 0;
+}
+size_t mtvaf_streamk_scratch_bytes(int blocks) { return SK_HEADER + (size_t)std::max(blocks, 8) * SK_SLAB; }
+
+// Up to four weight-gradient products dW_i[M_i, N_i] = A_i^T . B_i (layouts KM x KM: A_i [K, M_i], B_i [K, N_i] bf16 row-major,
+// fp32 results) that share the reduction length K -- the four products of one encoder layer -- in ONE stream-K launch of the
+// 256x256 kernel: 36 + 36 + 27 + 9 output tiles cannot fill 256 CUs one product at a time.  Requires a scratch attached to
+// `stream` (MTVAF_ERR_WORKSPACE otherwise), M_i % 256 == 0, N_i % 256 == 0, K % 64 == 0, leading dimensions % 8 == 0.
+int mtvaf_gemm_bf16x_dw_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C32,
+                              const int* ldc32, const int* M, const int* N, int K, hipStream_t stream) {
+  if (n < 1 || n > 4 || K <= 0 || K % 64) return MTVAF_ERR_SHAPE;
+  P256SK sk = {};
+  int blocks = 0;
+  if (!streamk_lookup(stream, &sk, &blocks)) return MTVAF_ERR_WORKSPACE;
+  long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (M[i] <= 0 || N[i] <= 0 || M[i] % 256 || N[i] % 256) return MTVAF_ERR_SHAPE;
+    if (lda[i] % 8 || ldb[i] % 8 || ldc32[i] % 4 || (((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C32[i]) & 15)) return MTVAF_ERR_ALIGN;
+    sk.pr[i] = P256Prob{static_cast<const __bf16*>(A[i]), static_cast<const __bf16*>(B[i]), C32[i], lda[i], ldb[i], ldc32[i], N[i] / 256};
+    sk.tile_begin[i] = (int)tiles;
+    tiles += (long)(M[i] / 256) * (N[i] / 256);
+  }
+  sk.nprob = n; sk.KT = K / 64; sk.total = tiles * sk.KT;
+  GemmArgsX a = {};
+  a.A = sk.pr[0].A; a.B = sk.pr[0].B; a.C32 = sk.pr[0].C32;
+  a.M = M[0]; a.N = N[0]; a.K = K; a.lda = lda[0]; a.ldb = ldb[0]; a.ldc32 = ldc32[0]; a.k_chunk = K; a.tiles_n = N[0] / 256;
+  a.epi = EPI_NONE;
+  long flop_m = 0;
+  for (int i = 0; i < n; ++i) flop_m += (long)M[i] * N[i];
+  const int key[8] = {300 + 1 + 4 + 8 + 16 + 64 + 128 + 256, 1, 1, 2, (int)(flop_m / 768), 768, K, n};  // (M x 768 x K: the group's flops)
+  const int rec = prof_begin(key, stream);
+  int S = 1;
+  p256_plan(tiles, sk.KT, blocks, &S);
+  const int rc = launch_p256_streamk(a, sk, 1, 1, blocks, sk.KT / S, stream);
+  prof_end(rec, stream);
+  return rc;
 }
 
 // out[c] (+)= sum over rows of part[rows][cols] (fixed order): finishes the epilogue column sums of mtvaf_gemm_bf16x

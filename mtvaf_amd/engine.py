@@ -331,6 +331,15 @@ def _bwd_layout(M, H, I, B, NH, S, Pn, use_h):
     return lay
 
 
+def _streamk_on(stream, device) -> bool:
+    """Attach the stream-K scratch of the 256x256 bf16 kernel to `stream` (None: the current one) if it is not yet, and say
+    whether that stream has one (hip.STREAMK / MTVAF_STREAMK=0 switch it off)."""
+    if stream is None:
+        return hip.streamk_ensure(device)
+    with torch.cuda.stream(stream):
+        return hip.streamk_ensure(device)
+
+
 def _exec_workspace_bytes(M, H, I, use_h):
     """Scratch one stream of the executor may need: split-K slabs of the largest product, LayerNorm / column-sum partials."""
     big = max(M * 3 * H, M * I, I * H, 3 * H * H)
@@ -472,6 +481,8 @@ def _native_backward(ctx, douts):
     ws_main = hip.workspace(_exec_workspace_bytes(M, H, I, use_h), dev)
     if ws_side is None:
         ws_side = ws_main
+    if use_h and need_param_grads:
+        _streamk_on(side, dev)  # the executor groups the layer's weight-gradient products when its dW stream has a scratch
     (flay, _), (blay, btotal) = _fwd_layout(M, H, I, B, NH, S, use_h), _bwd_layout(M, H, I, B, NH, S, Pn, use_h)
     o_h2, o_h2h = dict(flay)["h2"], dict(flay)["h2_h"]
     fn = hip.lib().mtvaf_encoder_layer_bwd
@@ -768,13 +779,18 @@ class EncoderFunction(torch.autograd.Function):
                 df_h = _bf16(M, H, like=dev_like)
                 hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, None, dh1, False, G[14], G[15], False, p_hidden, seed,
                                        off + 2, dbias_x=G[13], dx16=df_h)
-                on_side((df_h,), lambda: hip.gemm_bf16x(df_h, KM, act, KM, H, I, M, out32=G[12], allow_split=True, ktiles=ktiles))
+                # (the four weight gradients of the layer as ONE launch when a stream-K scratch is attached to the second stream:
+                # the same decision, on the same inputs, as csrc/executor.hip)
+                grp = ktiles is None and M % 256 == 0 and H % 256 == 0 and I % 256 == 0 and _streamk_on(side, dev_like.device)
+                if not grp:
+                    on_side((df_h,), lambda: hip.gemm_bf16x(df_h, KM, act, KM, H, I, M, out32=G[12], allow_split=True, ktiles=ktiles))
                 dpre_h, part = _bf16(M, I, like=dev_like), _empty(M // 128, I, like=dev_like)
                 hip.gemm_bf16x(df_h, KC, w2_h, KM, M, I, H, out16=dpre_h, epi=hip.EPI_DGELU, aux16=pre, colpart=part)
 
                 def ffn1_grads():
                     hip.colsum_small(part, G[11])
-                    hip.gemm_bf16x(dpre_h, KM, h1_h, KM, I, H, M, out32=G[10], allow_split=True, ktiles=ktiles)
+                    if not grp:
+                        hip.gemm_bf16x(dpre_h, KM, h1_h, KM, I, H, M, out32=G[10], allow_split=True, ktiles=ktiles)
                 on_side((dpre_h, part), ffn1_grads)
                 hip.gemm_bf16x(dpre_h, KC, w1_h, KM, M, H, I, out32=dh1, accumulate=True)
             else:
@@ -796,7 +812,8 @@ class EncoderFunction(torch.autograd.Function):
                 da_h, dctx = _bf16(M, H, like=dev_like), _bf16(M, H, like=dev_like)
                 hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, None, dh0, False, G[8], G[9], False, p_hidden, seed,
                                        off + 1, dbias_x=G[7], dx16=da_h)
-                on_side((da_h,), lambda: hip.gemm_bf16x(da_h, KM, cx, KM, H, H, M, out32=G[6], allow_split=True, ktiles=ktiles))
+                if not grp:
+                    on_side((da_h,), lambda: hip.gemm_bf16x(da_h, KM, cx, KM, H, H, M, out32=G[6], allow_split=True, ktiles=ktiles))
                 hip.gemm_bf16x(da_h, KC, wo_h, KM, M, H, H, out16=dctx)
                 dqkv = _bf16(M, 3 * H, like=dev_like)
                 nqt, nkt = (S + 63) // 64, (Pn + S + 63) // 64
@@ -808,8 +825,11 @@ class EncoderFunction(torch.autograd.Function):
                 def qkv_grads():
                     (hip.colsum_small if partq.shape[0] <= 256 else hip.colsum)(partq, dbqkv[:H])
                     (hip.colsum_small if partkv.shape[0] <= 256 else hip.colsum)(partkv, dbqkv[H:])
-                    hip.gemm_bf16x(dqkv, KM, x_h, KM, 3 * H, H, M, out32=dwqkv, allow_split=True, ktiles=ktiles)
-                on_side((dqkv, partq, partkv), qkv_grads)
+                    if grp:
+                        hip.gemm_bf16x_dw_group([(df_h, act, G[12]), (dpre_h, h1_h, G[10]), (da_h, cx, G[6]), (dqkv, x_h, dwqkv)], M)
+                    else:
+                        hip.gemm_bf16x(dqkv, KM, x_h, KM, 3 * H, H, M, out32=dwqkv, allow_split=True, ktiles=ktiles)
+                on_side((dqkv, partq, partkv, df_h, dpre_h, da_h), qkv_grads)
                 hip.gemm_bf16x(dqkv, KC, wqkv_h, KM, M, H, 3 * H, out32=dh0, accumulate=True)
             else:
                 dctx = dh1  # reuse (LayerNorm backward has consumed it by the time the dX product writes)

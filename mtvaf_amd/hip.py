@@ -82,6 +82,10 @@ _SIGS = {
     "mtvaf_gemm_bf16x": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P]),
     "mtvaf_gemm_bf16x_ktiles": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P, P, P]),
     "mtvaf_colsum_small": (c_int, [P, I, I, P, I, P]),
+    "mtvaf_streamk_attach": (c_int, [P, SZ, P]),
+    "mtvaf_streamk_scratch_bytes": (SZ, [I]),
+    "mtvaf_streamk_attached": (c_int, [P]),
+    "mtvaf_gemm_bf16x_dw_group": (c_int, [I, P, P, P, P, P, P, P, P, I, P]),
     "mtvaf_cast_bf16": (c_int, [P, I, P, I, P, I, I, I, P]),
     "mtvaf_adamw": (c_int, [P, P, P, P, L, F, c_double, c_double, F, F, F, F, F, P, I, P]),
     "mtvaf_adamw_multi": (c_int, [I, P, P, P, P, P, F, c_double, c_double, F, F, F, F, F, P]),
@@ -539,6 +543,54 @@ def gemm_bf16x(a, layout_a, b, layout_b, M, N, K, out32=None, out16=None, bias=N
                                out16.stride(0) if out16 is not None else 0, M, N, K, _p(bias), epi, _p(aux16),
                                aux16.stride(0) if aux16 is not None else 0, int(accumulate), _p(colpart), int(allow_split),
                                _p(ws), wsb, tile, splits, stages, _st()), "mtvaf_gemm_bf16x")
+
+
+_sk_scratch = {}
+STREAMK = os.environ.get("MTVAF_STREAMK", "1") != "0"
+
+
+def streamk_ensure(device) -> bool:
+    """Attach (once per device and stream) the scratch of the stream-K launches of the 256x256 bf16 kernel to the CURRENT
+    stream: 4 KiB of flag words + one 256-KiB slab per CU, zero-initialised, owned here.  MTVAF_STREAMK=0 / STREAMK = False:
+    no scratch is attached and the library keeps to its tile-per-block / split-K launches."""
+    if not STREAMK:
+        return False
+    key = (torch.device(device).index or 0, _st())
+    if key not in _sk_scratch:
+        nbytes = int(lib().mtvaf_streamk_scratch_bytes(256))
+        # zero-filled ON the stream it is attached to: every launch that uses it is ordered behind the fill (no host sync --
+        # this may run inside a HIP-graph capture, where the fill simply becomes the graph's first node)
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+        if lib().mtvaf_streamk_attach(_p(buf), nbytes, key[1]) != 0:  # (the library serves 8 streams)
+            _sk_scratch[key] = None
+        else:
+            _sk_scratch[key] = buf
+    return _sk_scratch[key] is not None
+
+
+def streamk_detach_all():
+    for (_, st), buf in list(_sk_scratch.items()):
+        if buf is not None:
+            _ck(lib().mtvaf_streamk_attach(None, 0, st), "mtvaf_streamk_attach")
+    _sk_scratch.clear()
+
+
+def streamk_error(device) -> int:
+    """The error word of the current stream's scratch (non-zero: a bounded wait inside a stream-K launch ran out)."""
+    buf = _sk_scratch.get((torch.device(device).index or 0, _st()))
+    return 0 if buf is None else int(buf[4092:4096].view(torch.int32).item())
+
+
+def gemm_bf16x_dw_group(items, K):
+    """items: up to four (a [K,M] bf16, b [K,N] bf16, out [M,N] fp32): out = a^T . b for each, ONE stream-K launch."""
+    n = len(items)
+    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ia = lambda xs: (ctypes.c_int * n)(*xs)
+    As, Bs, Cs = [i[0] for i in items], [i[1] for i in items], [i[2] for i in items]
+    streamk_ensure(As[0].device)
+    _ck(lib().mtvaf_gemm_bf16x_dw_group(n, vp(As), ia([t.stride(0) for t in As]), vp(Bs), ia([t.stride(0) for t in Bs]), vp(Cs),
+                                        ia([t.stride(0) for t in Cs]), ia([t.shape[1] for t in As]), ia([t.shape[1] for t in Bs]),
+                                        K, _st()), "mtvaf_gemm_bf16x_dw_group")
 
 
 def colsum_small(part, out, accumulate=False):

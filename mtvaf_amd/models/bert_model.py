@@ -40,6 +40,7 @@ def _on_second_stream(fn, inputs, join=False):
         return fn()
     main, side = torch.cuda.current_stream(), engine._side_stream(ts[0].device)
     side.wait_stream(main)
+    _accumulate_on_producer_stream()
     with torch.cuda.stream(side):
         out = fn()
         ev = torch.cuda.Event()
@@ -52,6 +53,23 @@ def _on_second_stream(fn, inputs, join=False):
     else:
         pkv.ready_event = ev
     return out
+
+
+_warned_off = False
+
+
+def _accumulate_on_producer_stream():
+    """The generator's parameter gradients are PRODUCED on the second stream (autograd runs a node's backward on the stream
+    its forward ran on), while their AccumulateGrad nodes were created on the default stream when the parameters were: torch
+    (>= 2.9) warns about that mismatch on every backward pass.  It is intended here, and it costs no host synchronisation --
+    the engine orders the accumulation behind the producer with a stream-to-stream event wait, and the encoder backward
+    joins the two streams anyway -- so the warning is switched off once."""
+    global _warned_off
+    if not _warned_off:
+        _warned_off = True
+        fn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if fn is not None:
+            fn(False)
 
 
 class ImageModel(nn.Module):

@@ -165,3 +165,33 @@ def span_head_params(cfg, seed):
     return {"dense.weight": n((H, H), 0.05), "dense.bias": n((H,), 0.02), "unary_affine.weight": n((1, H), 0.1),
             "unary_affine.bias": n((1,), 0.02), "binary_affine.weight": n((2, H), 0.1), "binary_affine.bias": n((2,), 0.02),
             "classifier.weight": n((4, H), 0.1), "classifier.bias": n((4,), 0.02)}
+
+
+def resnet_params(model: "torch.nn.Module", seed: int) -> Dict[str, torch.Tensor]:
+    """Seeded (numpy PCG64) state_dict for a torchvision-layout ResNet trunk (mtvaf_amd/models/resnet.py): He-scaled
+    convolutions, BatchNorm scale in [0.5, 1.5], small BatchNorm shifts, non-trivial running statistics -- so that
+    train-mode and eval-mode BatchNorm give visibly different pyramids."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = {}
+    for k, v in model.state_dict().items():
+        shape = tuple(v.shape)
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.zeros(shape, dtype=v.dtype)
+        elif k.endswith("running_var"):
+            out[k] = _uniform(rng, shape, 0.5, 2.0)
+        elif k.endswith("running_mean"):
+            out[k] = _normal(rng, shape, 0.2)
+        elif v.dim() == 4:  # convolution: fan_out scaling (what torchvision's own initialisation uses)
+            out[k] = _normal(rng, shape, float(np.sqrt(2.0 / (shape[0] * shape[2] * shape[3]))))
+        elif v.dim() == 1 and k.endswith("weight"):
+            out[k] = _uniform(rng, shape, 0.5, 1.5)
+        elif v.dim() == 1:
+            out[k] = _normal(rng, shape, 0.1)
+        else:
+            out[k] = _normal(rng, shape, 0.02)
+    return out
+
+
+def image_batch(seed: int, B: int, n_aux: int, hw: int = 64):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return _normal(rng, (B, 3, hw, hw), 1.0), _normal(rng, (B, n_aux, 3, hw, hw), 1.0)

@@ -949,3 +949,87 @@ def test_gemm_bf16_eight_phase_tile(hip, M, N, K):
         close(out, ref, rtol=2e-5, name="strided A")
     with pytest.raises(RuntimeError):
         hip.gemm_bf16x(xh, hip.KC, wh[:N - 128], hip.KC, M, N - 128, K, out32=out[:, :N - 128], tile=5)  # N % 256 != 0
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 16384), (512, 768, 1216), (768, 512, 3072), (2048, 2304, 768),
+                                   (1024, 768, 4096)])
+def test_gemm_bf16_stream_k(hip, M, N, K):
+    """Stream-K form of the 256x256 kernel (tile 6): one block per CU walks an equal run of k-tile steps; tiles shared by
+    several blocks are combined in the launch (contribution slabs behind an agent-scope release / acquire).  Shapes: fewer
+    steps than CUs, ONE tile cut over all 256 blocks (255 contributions to one finisher), runs that start and end inside
+    tiles, 3+ blocks per tile.  Against the exact model, all three layouts, every epilogue; repeated launches bit-identical
+    (the combine order is the block order, not the arrival order); the flag words are zero after every launch."""
+    assert hip.streamk_ensure(DEV)
+    x, w, b = rnd(M, K, seed=21), rnd(N, K, seed=22), rnd(N, seed=23)
+    xh, wh = x.to(torch.bfloat16).to(DEV), w.to(torch.bfloat16).to(DEV)
+    xt, wt = xh.t().contiguous(), wh.t().contiguous()
+    ref = xh.double().cpu() @ wh.double().cpu().t()
+    out = torch.empty(M, N, device=DEV)
+    bd = b.to(DEV)
+    scratch = hip._sk_scratch[(0, hip._st())]
+    for name, a_, la, b_, lb in [("KCxKC", xh, hip.KC, wh, hip.KC), ("KCxKM", xh, hip.KC, wt, hip.KM), ("KMxKM", xt, hip.KM, wt, hip.KM)]:
+        out.fill_(float("nan"))
+        hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=out, bias=bd, tile=6)
+        close(out, ref + b.double(), rtol=2e-5, name=f"{name} bias")
+        for _ in range(3):
+            o2 = torch.full_like(out, float("nan"))
+            hip.gemm_bf16x(a_, la, b_, lb, M, N, K, out32=o2, bias=bd, tile=6)
+            assert torch.equal(o2, out), f"{name}: repeated launch differs"
+        torch.cuda.synchronize()
+        assert not scratch[:4096].any(), "flag / error words must be zero between launches"
+    o16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    pre16 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_bf16x(xh, hip.KC, wh, hip.KC, M, N, K, out32=out, out16=o16, bias=bd, epi=hip.EPI_GELU, aux16=pre16, tile=6)
+    pre_ref = (ref + b.double()).float().to(torch.bfloat16)
+    assert (pre16.cpu() != pre_ref).float().mean() < 2e-3
+    close(out, F.gelu(pre16.double().cpu()), rtol=2e-5, atol=2e-6 * float(ref.abs().max()), name="gelu")
+    assert torch.equal(o16, out.to(torch.bfloat16))
+    pre = rnd(M, N, seed=25).to(torch.bfloat16)
+    pd = pre.double().requires_grad_(True)
+    F.gelu(pd).sum().backward()
+    part = torch.full((M // 128, N), float("nan"), device=DEV)
+    hip.gemm_bf16x(xh, hip.KC, wt, hip.KM, M, N, K, out32=out, out16=o16, epi=hip.EPI_DGELU, aux16=pre.to(DEV), colpart=part, tile=6)
+    close(out, ref * pd.grad, rtol=3e-5, atol=3e-6 * float(ref.abs().max()), name="dgelu")
+    cs = torch.empty(N, device=DEV)
+    hip.colsum_small(part, cs)
+    close(cs, out.double().sum(0), rtol=1e-5, atol=1e-5 * float(out.abs().sum(0).max()), name="colsum")
+    acc0 = rnd(M, N, seed=26)
+    out.copy_(acc0)
+    hip.gemm_bf16x(xt, hip.KM, wt, hip.KM, M, N, K, out32=out, accumulate=True, tile=6)
+    close(out, ref + acc0.double(), rtol=2e-5, name="accumulate")
+    torch.cuda.synchronize()
+    assert not scratch[:4096].any()
+
+
+def test_gemm_bf16_dw_group_stream_k(hip):
+    """The four weight-gradient products of an encoder layer in ONE stream-K launch (mtvaf_gemm_bf16x_dw_group): shapes of
+    BERT-base at 1024 and 4096 token rows, against the exact model; under load from another stream (uneven arrival of the
+    blocks) and with the slabs' lines pre-read by the consumer's CU set (an L1-warm consumer), bit-identical every time."""
+    assert hip.streamk_ensure(DEV)
+    H, I = 768, 3072
+    for T in (1024, 4096):
+        dy, dy3, dyq = (rnd(T, n, seed=31 + n).to(torch.bfloat16).to(DEV) for n in (H, I, 3 * H))
+        xs, x3 = rnd(T, H, seed=41).to(torch.bfloat16).to(DEV), rnd(T, I, seed=42).to(torch.bfloat16).to(DEV)
+        items = [(dy, x3, torch.empty(H, I, device=DEV)), (dy3, xs, torch.empty(I, H, device=DEV)),
+                 (dy, xs, torch.empty(H, H, device=DEV)), (dyq, xs, torch.empty(3 * H, H, device=DEV))]
+        hip.gemm_bf16x_dw_group(items, T)
+        first = []
+        for a_, b_, o in items:
+            close(o, a_.double().cpu().t() @ b_.double().cpu(), rtol=3e-5, name=f"dW {tuple(o.shape)} over {T} rows")
+            first.append(o.clone())
+        side = torch.cuda.Stream()
+        big = torch.randn(4096, 4096, device=DEV)
+        for rep in range(4):
+            for _, _, o in items:
+                o.fill_(float("nan"))
+            with torch.cuda.stream(side):  # a competing kernel: the group's blocks arrive unevenly
+                for _ in range(3):
+                    big @ big
+            _ = hip._sk_scratch[(0, hip._st())][4096:4096 + (64 << 20)].view(torch.float32).sum()  # pre-read the slabs
+            hip.gemm_bf16x_dw_group(items, T)
+            torch.cuda.synchronize()
+            for (_, _, o), f in zip(items, first):
+                assert torch.equal(o, f), f"repeat {rep}: stream-K result changed"
+        assert hip.streamk_error(DEV) == 0
+    with pytest.raises(RuntimeError):
+        hip.gemm_bf16x_dw_group([(dy[:, :128], xs, torch.empty(128, H, device=DEV))], T)  # M % 256 != 0

@@ -34,7 +34,7 @@ def main():
             ("wo dX", dy, 0, w_o, 1, (M, H, H), "b16"), ("qkv dX", dyq, 0, w_qkv, 1, (M, H, 3 * H), "acc"),
             ("ffn2 dW", dy, 1, x3, 1, (H, I, M), "split"), ("ffn1 dW", dy3, 1, x, 1, (I, H, M), "split"),
             ("wo dW", dy, 1, x, 1, (H, H, M), "split"), ("qkv dW", dyq, 1, x, 1, (3 * H, H, M), "split")]
-        tot_old, tot_new, tot_best, tot_fl = 0.0, 0.0, 0.0, 0.0
+        tot_old, tot_new, tot_best, tot_fl, tot_sk = 0.0, 0.0, 0.0, 0.0, 0.0
         for name, a, la, b, lb, (m, n, k), kind in cases:
             out32 = torch.empty(m, n, device=dev)
             out16 = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
@@ -64,10 +64,18 @@ def main():
                 if k // 64 < sp or sp > 8:
                     continue
                 res.append((t(lambda: run(5, sp)), sp))
+            hip.streamk_ensure(dev)
+            us_sk = t(lambda: run(6))
             us_new, sp_new = min(res)
             print(f"M={M:6d} {name:14s} [{m:5d}x{n:5d}x{k:5d}] auto(old) {us_old:7.1f} us {fl / us_old / 1e6:7.1f} TF | 256x256: "
-                  + "  ".join(f"s{sp} {us:6.1f}" for us, sp in res) + f" | best s{sp_new} {fl / us_new / 1e6:7.1f} TF", flush=True)
-            tot_old += us_old; tot_new += us_new; tot_best += min(us_old, us_new); tot_fl += fl
+                  + "  ".join(f"s{sp} {us:6.1f}" for us, sp in res) + f" | best s{sp_new} {fl / us_new / 1e6:7.1f} TF | stream-K {us_sk:6.1f} us {fl / us_sk / 1e6:7.1f} TF", flush=True)
+            tot_old += us_old; tot_new += us_new; tot_best += min(us_old, us_new, us_sk); tot_fl += fl; tot_sk += us_sk
+        # the four weight gradients as one grouped stream-K launch
+        items = [(dy, x3, torch.empty(H, I, device=dev)), (dy3, x, torch.empty(I, H, device=dev)),
+                 (dy, x, torch.empty(H, H, device=dev)), (dyq, x, torch.empty(3 * H, H, device=dev))]
+        us_g = t(lambda: hip.gemm_bf16x_dw_group(items, M))
+        fl_g = 2.0 * M * (H * I * 2 + H * H + 3 * H * H)
+        print(f"M={M:6d} four dW as ONE stream-K group: {us_g:7.1f} us {fl_g / us_g / 1e6:7.1f} TF; stream-K everywhere {tot_sk:.0f} us", flush=True)
         print(f"M={M}: one layer's 12 products: old auto {tot_old:.0f} us ({tot_fl / tot_old / 1e6:.0f} TF), 256x256 everywhere "
               f"{tot_new:.0f} us ({tot_fl / tot_new / 1e6:.0f} TF), best of both {tot_best:.0f} us ({tot_fl / tot_best / 1e6:.0f} TF)\n", flush=True)
 
