@@ -142,6 +142,10 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
                        int accumulate, int B, int S, int H, int vocab, int max_pos, int type_vocab, int word_pad,
                        int pos_pad, float p_drop, uint64_t seed, uint64_t offset, float* dz_ws, void* workspace,
                        size_t workspace_bytes, mtvaf_stream_t stream);
+/* How mtvaf_embed_ln_bwd adds token-row gradients into the word (and RoBERTa position) table: 0 (default) one owner wave per
+ * table row sums its tokens in row order -- bit-reproducible; 1 float atomics (MTVAF_EMBED_ATOMIC=1).  mode 0 / 1 sets, any
+ * other value queries; returns the mode in force.  (nn.Embedding's backward, modeling_bert.py:170-172.) */
+int mtvaf_embed_scatter_mode(int mode);
 
 /* ---- dropout + residual + LayerNorm --------------------------------------------------------------------
  * replaces BertSelfOutput / BertOutput `LayerNorm(dropout(dense_out) + input)` (modeling_bert.py:354-355,

@@ -7,6 +7,8 @@
 // Dropout masks are regenerated from (seed, offset, element index) in the backward kernels.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace mtvaf {
 
 constexpr int MAXC = 4;  // float4 chunks per lane -> H <= 1024
@@ -312,6 +314,51 @@ __global__ void embed_scatter_kernel(const float* __restrict__ dz, const int64_t
   }
 }
 
+// Deterministic form of the scatter-add (the default; MTVAF_EMBED_ATOMIC=1 keeps the float-atomic kernel above): one wave per
+// token row.  The FIRST row that carries an id (no earlier row has it: a ballot scan over the ids before it) owns that table
+// row: it sums the gradient rows of every token with the same id IN ROW ORDER into registers and adds them to the table
+// with plain stores -- one writer per table row, a fixed summation order, no atomics.  KEY selects the table: 0 word ids
+// (int64), 1 position ids (int32, RoBERTa).  O(M^2 / 64) id comparisons in total: 0.3 M wave-iterations at 4096 tokens.
+constexpr int DET_NC = 16;  // columns per lane of the deterministic scatter: H <= 1024
+template <int KEY>
+__global__ __launch_bounds__(256) void embed_scatter_det_kernel(const float* __restrict__ dz, const int64_t* __restrict__ ids,
+                                                               const int32_t* __restrict__ pos_ids, float* __restrict__ table,
+                                                               int M, int H, long pad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto key_of = [&](int r) -> long { return KEY == 0 ? (long)ids[r] : (long)pos_ids[r]; };
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const long id = key_of(row);
+    if (id == pad) continue;  // (wave-uniform)
+    bool earlier = false;
+    for (int r0 = 0; r0 < row && !earlier; r0 += 64) {
+      const int r = r0 + lane;
+      earlier = __ballot(r < row && key_of(r) == id) != 0ull;
+    }
+    if (earlier) continue;  // another row owns this id
+    float acc[DET_NC];
+#pragma unroll
+    for (int i = 0; i < DET_NC; ++i) acc[i] = 0.f;
+    for (int r0 = row & ~63; r0 < M; r0 += 64) {
+      const int r = r0 + lane;
+      unsigned long long m = __ballot(r >= row && r < M && key_of(r) == id);
+      while (m) {  // matching rows of this chunk, in increasing row order
+        const int rr = r0 + __builtin_ctzll(m);
+        m &= m - 1;
+#pragma unroll
+        for (int i = 0; i < DET_NC; ++i) {
+          const int c = lane + 64 * i;
+          if (c < H) acc[i] += dz[(long)rr * H + c];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DET_NC; ++i) {
+      const int c = lane + 64 * i;
+      if (c < H) table[id * H + c] += acc[i];  // (zero-filled just before unless the caller accumulates)
+    }
+  }
+}
+
 // BERT positions are arange(S): dpos[s] (+)= sum_b dz[b*S+s]   (deterministic)
 __global__ void pos_reduce_kernel(const float* __restrict__ dz, float* __restrict__ dpos, int B, int S, int H,
                                   int accumulate) {
@@ -436,6 +483,20 @@ int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res
   return MTVAF_OK;
 }
 
+// 0 (default): deterministic scatter-add of the word / position table gradients; 1: float atomics (MTVAF_EMBED_ATOMIC=1)
+static int g_embed_atomic = -1;
+static bool embed_scatter_atomic() {
+  if (g_embed_atomic < 0) {
+    const char* e = getenv("MTVAF_EMBED_ATOMIC");
+    g_embed_atomic = (e && e[0] == '1') ? 1 : 0;
+  }
+  return g_embed_atomic == 1;
+}
+int mtvaf_embed_scatter_mode(int mode) {  // mode 0 / 1 sets, anything else queries; -> the mode in force
+  if (mode == 0 || mode == 1) g_embed_atomic = mode;
+  return embed_scatter_atomic() ? 1 : 0;
+}
+
 // Backward of K1.  dz_ws: [M,H] scratch for the gradient of the summed embeddings.  Word-table rows
 // equal to word_pad (and position rows equal to pos_pad when pos_ids != NULL) receive no gradient
 // (nn.Embedding padding_idx, models/modeling_bert.py:170, models/modeling_roberta.py:97-100).
@@ -462,8 +523,15 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
     zero_f32(dword, (long)vocab * H, st);
     if (pos_ids) zero_f32(dpos, (long)max_pos * H, st);
   }
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(g), dim3(256), 0, st, dz_ws, ids, pos_ids, dword, dpos, M, H, word_pad,
-                     pos_pad);
+  if (embed_scatter_atomic() || H > DET_NC * 64) {
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(g), dim3(256), 0, st, dz_ws, ids, pos_ids, dword, dpos, M, H, word_pad,
+                       pos_pad);
+  } else {  // bit-reproducible: one owner per table row, gradient rows added in token order
+    const int gd = (M + 3) / 4;
+    hipLaunchKernelGGL((embed_scatter_det_kernel<0>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, dword, M, H, (long)word_pad);
+    if (pos_ids)
+      hipLaunchKernelGGL((embed_scatter_det_kernel<1>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, dpos, M, H, (long)pos_pad);
+  }
   if (!pos_ids) {
     if (!accumulate && max_pos > S) zero_f32(dpos + (long)S * H, (long)(max_pos - S) * H, st);
     hipLaunchKernelGGL(pos_reduce_kernel, dim3(S), dim3(256), 0, st, dz_ws, dpos, B, S, H, accumulate);

@@ -82,6 +82,7 @@ _SIGS = {
     "mtvaf_gemm_bf16x": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P]),
     "mtvaf_gemm_bf16x_ktiles": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P, P, P]),
     "mtvaf_colsum_small": (c_int, [P, I, I, P, I, P]),
+    "mtvaf_embed_scatter_mode": (c_int, [I]),
     "mtvaf_streamk_attach": (c_int, [P, SZ, P]),
     "mtvaf_streamk_scratch_bytes": (SZ, [I]),
     "mtvaf_streamk_attached": (c_int, [P]),

@@ -449,35 +449,42 @@ def test_config5_full_size_properties(dtype):
         hip.set_compute_dtype("fp32")
 
 
-def test_word_table_gradient_reproducibility_contract():
-    """What is and is not bit-reproducible in a training step.  Every gradient except the word table's is bit-identical from
-    run to run (deterministic split-K, ordered reductions: asserted by the determinism tests above).  The word-table
-    gradient is a scatter-add of 4096 token rows into 30522 table rows with float atomics: rows that a single token touches
-    (the common case) ARE bit-identical; rows shared by several tokens ([CLS], [SEP], repeated words) see their addends in
-    arbitrary order and may differ in the last bits -- never by more than a few ulp of the row's largest addend.  Under
-    data parallelism every rank holds the bit-identical REDUCED gradient either way (GradSync's ordered fp32 sum)."""
+def test_word_table_gradient_is_bit_reproducible():
+    """Every gradient of a training step is bit-identical from run to run, the word table's included: its scatter-add (4096
+    token rows into 30522 table rows; [CLS], [SEP] and repeated words share rows) is done by ONE owner wave per table row that
+    sums its tokens in row order (mtvaf_embed_scatter_mode 0, the default).  The float-atomic form (mode 1, MTVAF_EMBED_ATOMIC=1)
+    is kept for comparison: equal to rounding, rows touched by a single token equal bit for bit."""
+    from mtvaf_amd import hip
     cfg = P.BASE_BERT
     B, S, n_aux = 32, 128, 8
     m = _props_model(cfg, "bert-base-uncased").eval()
     ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 83, B, S, lo_id=1000))
     feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(84, B, n_aux))
     w = m.bert.embeddings.word_embeddings.weight
-    runs = []
-    for _ in range(3):
+
+    def grad():
         m.zero_grad(set_to_none=True)
         m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux).loss.backward()
         torch.cuda.synchronize()
-        runs.append(w.grad.detach().clone())
+        return w.grad.detach().clone()
+    assert hip.lib().mtvaf_embed_scatter_mode(-1) == 0
+    runs = [grad() for _ in range(3)]
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0]), "word-table gradient differs between two runs of the same step"
     valid_ids = ids[mask.bool()]
     uniq, counts = torch.unique(valid_ids, return_counts=True)
-    single = uniq[counts == 1]
-    shared = uniq[counts > 1]
+    single, shared = uniq[counts == 1], uniq[counts > 1]
     assert len(single) > 1000 and len(shared) >= 2
     untouched = torch.ones(w.shape[0], dtype=torch.bool, device=DEV)
     untouched[uniq] = False
-    for r in runs[1:]:
-        assert torch.equal(r[single], runs[0][single]), "rows touched by one token must be bit-reproducible"
-        assert not r[untouched].any() and not runs[0][untouched].any(), "rows no token touches have exact-zero gradient"
-        scale = runs[0][shared].abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
-        assert float(((r[shared] - runs[0][shared]).abs() / scale).max()) < 1e-5
+    assert not runs[0][untouched].any(), "rows no token touches have exact-zero gradient"
     assert not runs[0][0].any(), "padding_idx row gets no gradient (nn.Embedding(padding_idx=0), modeling_bert.py:171)"
+    # reference for the shared rows: the token rows' gradients summed in fp64 (dz is not exposed: compare with the atomic form)
+    hip.lib().mtvaf_embed_scatter_mode(1)
+    try:
+        atomic = grad()
+    finally:
+        hip.lib().mtvaf_embed_scatter_mode(0)
+    assert torch.equal(atomic[single], runs[0][single])
+    scale = runs[0][shared].abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    assert float(((atomic[shared] - runs[0][shared]).abs() / scale).max()) < 1e-5

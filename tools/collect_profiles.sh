@@ -1,8 +1,9 @@
 #!/bin/bash
-# Everything profiles/ holds for one round, in one GPU call:  tools/collect_profiles.sh r02   (writes gpurun_out/<tag>/)
+# Everything profiles/ holds for one round, in one GPU call:  tools/collect_profiles.sh r03   (writes gpurun_out/<tag>/)
 # Bench lines, rocprofv3 kernel stats (default = two streams, and serialised = one kernel at a time), PMC passes.
 export TMPDIR=/tmp
-T=${1:-r02}
+T=${1:-r03}
+PHASE=${2:-all}   # lines | stats | pmc | all  (one GPU call holds 20 minutes: the round-3 set is collected in three)
 R=$PWD
 O=$R/gpurun_out/$T
 mkdir -p $O
@@ -15,13 +16,17 @@ stats() {  # <name> <env> <bench args...>
   python tools/prof_summary.py $O/${T}_${name}_kernel_stats.csv 7 60 > $O/${T}_${name}_kernel_stats_per_step.txt
   rm -rf $O/prof_$name
 }
+if [ $PHASE = all ] || [ $PHASE = lines ]; then
 echo "== bench lines"; date
 python bench.py --steps 20 --warmup 5 > $O/${T}_bench_line.json 2> $O/bench_fp32.err
 python bench.py --steps 20 --warmup 5 --dtype bf16 --model roberta --no-cpu-baseline > $O/${T}_bench_line_bf16_c3.json 2> $O/bench_c3.err
 python bench.py --steps 20 --warmup 5 --dtype bf16 --batch 64 --no-cpu-baseline > $O/${T}_bench_line_bf16_c4.json 2> $O/bench_c4.err
 python bench.py --steps 20 --warmup 5 --dtype bf16 --no-cpu-baseline > $O/${T}_bench_line_bf16_c2shape.json 2> $O/bench_c2b.err
+python bench.py --steps 5 --warmup 4 --dtype bf16 --batch 128 --seq 512 --no-cpu-baseline > $O/${T}_bench_line_bf16_c5.json 2> $O/bench_c5.err
 python bench.py --steps 20 --warmup 5 --unpad --no-cpu-baseline > $O/${T}_bench_line_unpad.json 2> $O/bench_unpad.err
 python bench.py --steps 20 --warmup 5 --unpad --dtype bf16 --batch 64 --no-cpu-baseline --no-roofline > $O/${T}_bench_line_unpad_bf16_c4.json 2> $O/bench_unpad_c4.err
+fi
+if [ $PHASE = all ] || [ $PHASE = stats ]; then
 echo "== kernel stats"; date
 stats fp32 MTVAF_DW_STREAM=1
 stats fp32_serial MTVAF_DW_STREAM=0
@@ -29,12 +34,19 @@ stats fp32_unpad_serial MTVAF_DW_STREAM=0 --unpad
 stats bf16_c3_serial MTVAF_DW_STREAM=0 --dtype bf16 --model roberta
 stats bf16_c4_serial MTVAF_DW_STREAM=0 --dtype bf16 --batch 64
 stats bf16_c4 MTVAF_DW_STREAM=1 --dtype bf16 --batch 64
+S="--steps 3 --warmup 4 --no-cpu-baseline --no-roofline --no-optimizer --no-secondary"
+stats bf16_c5_serial MTVAF_DW_STREAM=0 --dtype bf16 --batch 128 --seq 512
+fi
+if [ $PHASE = all ] || [ $PHASE = pmc ]; then
 echo "== pmc"; date
 bash tools/pmc_passes.sh $T/pmc_fp32 > /dev/null
 bash tools/pmc_passes.sh $T/pmc_bf16_c4 --dtype bf16 --batch 64 > /dev/null
 bash tools/pmc_passes.sh $T/pmc_bf16_c3 --dtype bf16 --model roberta > /dev/null
+bash tools/pmc_passes.sh $T/pmc_bf16_c5 --dtype bf16 --batch 128 --seq 512 > /dev/null
 python tools/pmc_to_json.py $O/pmc_fp32 $O $T pmc_gemm.json > /dev/null
 python tools/pmc_to_json.py $O/pmc_bf16_c4 $O $T pmc_gemm_bf16_b64.json > /dev/null
 python tools/pmc_to_json.py $O/pmc_bf16_c3 $O $T pmc_gemm_bf16_b32.json > /dev/null
-rm -rf $O/pmc_fp32 $O/pmc_bf16_c4 $O/pmc_bf16_c3
+python tools/pmc_to_json.py $O/pmc_bf16_c5 $O $T pmc_gemm_bf16_b128.json > /dev/null
+rm -rf $O/pmc_fp32 $O/pmc_bf16_c4 $O/pmc_bf16_c3 $O/pmc_bf16_c5
+fi
 date; ls -la $O
