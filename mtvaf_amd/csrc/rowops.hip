@@ -319,20 +319,36 @@ __global__ void embed_scatter_kernel(const float* __restrict__ dz, const int64_t
 // row: it sums the gradient rows of every token with the same id IN ROW ORDER into registers and adds them to the table
 // with plain stores -- one writer per table row, a fixed summation order, no atomics.  KEY selects the table: 0 word ids
 // (int64), 1 position ids (int32, RoBERTa).  O(M^2 / 64) id comparisons in total: 0.3 M wave-iterations at 4096 tokens.
+// Rows whose gradient is EXACTLY zero (flags from row_nonzero_kernel) neither own nor contribute -- adding them would change
+// nothing -- which is what keeps the chains short: the reference's dataset pads RoBERTa ids with 0 = <s>, not with the
+// padding id (modules/dataset.py:414-415), so ~40 % of a batch's rows share ONE id, all with exact-zero gradients (masked
+// rows: DESIGN.md section 4.5b); as one serial chain they cost 8 ms.  Four matching rows are fetched at a time.
 constexpr int DET_NC = 16;  // columns per lane of the deterministic scatter: H <= 1024
+__global__ __launch_bounds__(256) void row_nonzero_kernel(const float* __restrict__ dz, int* __restrict__ flags, int M, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    bool nz = false;
+    for (int c = lane * 4; c < H; c += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(dz + (long)row * H + c);
+      nz = nz || v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f;
+    }
+    const bool any = __ballot(nz) != 0ull;
+    if (lane == 0) flags[row] = any ? 1 : 0;
+  }
+}
 template <int KEY>
 __global__ __launch_bounds__(256) void embed_scatter_det_kernel(const float* __restrict__ dz, const int64_t* __restrict__ ids,
-                                                               const int32_t* __restrict__ pos_ids, float* __restrict__ table,
-                                                               int M, int H, long pad) {
+                                                               const int32_t* __restrict__ pos_ids, const int* __restrict__ flags,
+                                                               float* __restrict__ table, int M, int H, long pad) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   auto key_of = [&](int r) -> long { return KEY == 0 ? (long)ids[r] : (long)pos_ids[r]; };
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
     const long id = key_of(row);
-    if (id == pad) continue;  // (wave-uniform)
+    if (id == pad || flags[row] == 0) continue;  // (wave-uniform)
     bool earlier = false;
     for (int r0 = 0; r0 < row && !earlier; r0 += 64) {
       const int r = r0 + lane;
-      earlier = __ballot(r < row && key_of(r) == id) != 0ull;
+      earlier = __ballot(r < row && key_of(r) == id && flags[r] != 0) != 0ull;
     }
     if (earlier) continue;  // another row owns this id
     float acc[DET_NC];
@@ -340,15 +356,28 @@ __global__ __launch_bounds__(256) void embed_scatter_det_kernel(const float* __r
     for (int i = 0; i < DET_NC; ++i) acc[i] = 0.f;
     for (int r0 = row & ~63; r0 < M; r0 += 64) {
       const int r = r0 + lane;
-      unsigned long long m = __ballot(r >= row && r < M && key_of(r) == id);
-      while (m) {  // matching rows of this chunk, in increasing row order
-        const int rr = r0 + __builtin_ctzll(m);
-        m &= m - 1;
+      unsigned long long m = __ballot(r >= row && r < M && key_of(r) == id && flags[r] != 0);
+      while (m) {  // matching rows of this chunk, in increasing row order, four fetched at a time
+        int rr[4];
+        bool ok[4];
 #pragma unroll
-        for (int i = 0; i < DET_NC; ++i) {
-          const int c = lane + 64 * i;
-          if (c < H) acc[i] += dz[(long)rr * H + c];
+        for (int u = 0; u < 4; ++u) {
+          ok[u] = m != 0ull;
+          rr[u] = ok[u] ? r0 + __builtin_ctzll(m) : row;
+          m &= m - 1;  // (0 & anything = 0)
         }
+        float v[4][DET_NC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < DET_NC; ++i) {
+            const int c = lane + 64 * i;
+            v[u][i] = (c < H) ? dz[(long)rr[u] * H + c] : 0.f;
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < DET_NC; ++i) acc[i] += ok[u] ? v[u][i] : 0.f;
       }
     }
 #pragma unroll
@@ -426,7 +455,9 @@ using namespace mtvaf;
 
 extern "C" {
 
-size_t mtvaf_ln_bwd_workspace_bytes(int M, int H) { return (size_t)row_grid_bwd(M) * 4 * H * sizeof(float); }
+size_t mtvaf_ln_bwd_workspace_bytes(int M, int H) {  // column partials of the LayerNorm backward + one flag word per token row (embedding backward)
+  return (size_t)row_grid_bwd(M) * 4 * H * sizeof(float) + (size_t)M * sizeof(int) + 16;
+}
 
 int mtvaf_roberta_position_ids(const int64_t* ids, int32_t* pos_ids, int B, int S, int pad_idx, hipStream_t st) {
   if (B <= 0 || S <= 0) return MTVAF_ERR_SHAPE;
@@ -510,7 +541,7 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
   if (H % 4 || H > MAXC * 256 || B <= 0 || S <= 0 || type_vocab > 2) return MTVAF_ERR_SHAPE;
   const int M = B * S;
   const int g = row_grid_bwd(M);
-  if (workspace_bytes < (size_t)g * 4 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
+  if (workspace_bytes < (size_t)g * 4 * H * sizeof(float) + (size_t)M * sizeof(int)) return MTVAF_ERR_WORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(g), dim3(256), 0, st, dout, nullptr, nullptr, ids, type_ids, pos_ids,
                      word, pos, type, gamma, mean, rstd, dz_ws, nullptr, 0, part, M, S, H, p_drop, seed, offset,
@@ -528,9 +559,11 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
                        pos_pad);
   } else {  // bit-reproducible: one owner per table row, gradient rows added in token order
     const int gd = (M + 3) / 4;
-    hipLaunchKernelGGL((embed_scatter_det_kernel<0>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, dword, M, H, (long)word_pad);
+    int* flags = reinterpret_cast<int*>(part + (size_t)g * 4 * H);  // (behind the column partials, already consumed by the launch above ... but kept apart)
+    hipLaunchKernelGGL(row_nonzero_kernel, dim3(std::min(gd, 2048)), dim3(256), 0, st, dz_ws, flags, M, H);
+    hipLaunchKernelGGL((embed_scatter_det_kernel<0>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, flags, dword, M, H, (long)word_pad);
     if (pos_ids)
-      hipLaunchKernelGGL((embed_scatter_det_kernel<1>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, dpos, M, H, (long)pos_pad);
+      hipLaunchKernelGGL((embed_scatter_det_kernel<1>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, flags, dpos, M, H, (long)pos_pad);
   }
   if (!pos_ids) {
     if (!accumulate && max_pos > S) zero_f32(dpos + (long)S * H, (long)(max_pos - S) * H, st);
