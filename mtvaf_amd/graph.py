@@ -138,6 +138,9 @@ class GraphedTrainStep:
         if getattr(self, "epoch", None) is not None:
             hip._ck(hip.lib().mtvaf_rng_set_epoch_ptr(None), "mtvaf_rng_set_epoch_ptr")
             self.epoch = None
+            # stream-K scratches attached during the capture live in the graph's memory pool: the library must not keep
+            # their addresses either (eager streams re-attach theirs on the next mixed-precision backward)
+            hip.streamk_detach_all()
 
     def __del__(self):
         try:

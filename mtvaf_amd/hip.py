@@ -220,8 +220,8 @@ def kernel_symbol(cfg, la, lb, fast):
     klist, fast = bool(fast & 8), fast & 7  # (+8: the launch walked a k-tile list)
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>
         c = cfg - 300
-        if c & 64:
-            return f"gemm_bf16_p256_kernel<{b(c & 4)}, {b(c & 8)}>"
+        if c & 64:  # gemm_bf16_p256_kernel<A_KM, B_KM, SK> (+128: the in-launch-combine form, +256: a grouped launch)
+            return f"gemm_bf16_p256_kernel<{b(c & 4)}, {b(c & 8)}, {b(c & 128)}>"
         t = "256, 192, 4, 2" if c & 32 else ("256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"))
         return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}, {b(klist)}>"
     if cfg >= 100:
