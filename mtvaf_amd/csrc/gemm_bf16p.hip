@@ -37,21 +37,24 @@
 // STREAM-K mode (template flag SK; launch_p256_streamk).  The products of the path are small against the chip -- a
 // [8192 x 3072] output is 384 tiles for 256 CUs (1.5 rounds), the four weight gradients of a layer are 36 + 36 + 27 + 9 tiles
 // with reductions of 64 .. 1024 k-tiles -- so a tile-per-block launch leaves most CUs idle for part of it.  In this mode the
-// grid is ONE block per CU and the unit of work is the k-tile STEP: all steps of all output tiles (of up to four products
-// that share a launch: the weight gradients of one layer) are laid out tile after tile and cut into `grid` equal runs; a
-// block walks its run, which may begin in the middle of a tile's reduction and end in the middle of another's.
-//   * a run's first piece that starts at k > 0 is a CONTRIBUTION: its accumulators go to this block's slab (256 KiB, in the
-//     register order of the kernel itself: lane-contiguous 16-byte stores, and the finisher's lanes read back exactly what
-//     the same lanes of the contributor wrote), then the slab is published: every wave drains its stores, the block's
-//     barrier, one lane's agent-scope release fence, a second drain, a relaxed agent-scope flag store;
-//   * the piece that holds a tile's k = 0 is its FINISHER (always the LAST piece of its block's run, so the contributions --
-//     first pieces of the following blocks -- are long there): one lane polls the following blocks' flags (relaxed, bounded),
-//     one agent-scope acquire fence + drain + the block's barrier, then every wave adds the slabs to its accumulators in
-//     block order (= k order: the result does not depend on arrival order, only on the grid size) and runs the ordinary
-//     epilogue; the finisher resets the flags it consumed, so a zero-initialised flag array stays zero between launches.
-// No block ever waits before it has published its own contribution, and waits only for HIGHER block ids: no cycle, whatever
-// the dispatch order or residency.  Slabs and flags live in a caller-owned scratch attached to the stream
-// (mtvaf_streamk_attach), never shared with the split-K workspaces.
+// unit of work is the k-tile STEP: all steps of all output tiles (of up to four products that share a launch: the weight
+// gradients of one layer) are laid out tile after tile and cut into RUNS of W steps; a run may begin in the middle of a
+// tile's reduction and end in the middle of another's, and every part of a run inside one tile is a PIECE -- one block.
+//   * a piece that starts at k > 0 (always the FIRST piece of its run) is a CONTRIBUTION: its accumulators go to the run's
+//     slab (256 KiB, in the register order of the kernel itself: lane-contiguous 16-byte stores, and the finisher's lanes
+//     read back exactly what the same lanes of the contributor wrote), then the slab is published: every wave drains its
+//     stores, the block's barrier, one lane's agent-scope release fence, a second drain, a relaxed agent-scope flag store;
+//   * the piece that holds a tile's k = 0 is its FINISHER (always the LAST piece of its run): one lane polls the flags of
+//     the following runs (relaxed, bounded), one agent-scope acquire fence + drain + the block's barrier, then every wave
+//     adds the slabs to its accumulators in run order (= k order: the result depends on the cut, never on arrival order)
+//     and runs the ordinary epilogue; it resets the flags it consumed, so a zero-initialised flag array stays zero
+//     between launches (also under HIP-graph replay).
+// No piece waits before it has published, and a finisher waits only for first pieces of LATER runs, which wait for nothing:
+// no cycle, whatever the dispatch order or residency (runs are dispatched in reverse so that contributions usually run
+// first).  The planner cuts every tile into S equal pieces that fill ONE round of the CUs (W = KT / S); W = ceil(total / 256)
+// wherever it falls is the general cut (tile 6: tested, not planned -- a run's unequal pieces are separate blocks, and a
+// persistent loop over them compiled to spills around the k-loop: DESIGN.md section 4.1d).  Slabs and flags live in a
+// caller-owned scratch attached to the stream (mtvaf_streamk_attach), never shared with the split-K workspaces.
 #include "gemm_bf16x.h"
 
 #include <algorithm>
