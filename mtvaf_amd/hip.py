@@ -582,6 +582,13 @@ def streamk_error(device) -> int:
     return 0 if buf is None else int(buf[4092:4096].view(torch.int32).item())
 
 
+def streamk_errors() -> int:
+    """Sum of the error words of every attached scratch (all streams); synchronises.  Non-zero: some finisher's bounded wait
+    ran out and its tile is wrong -- never observed; bench.py and the tests assert it."""
+    torch.cuda.synchronize()
+    return sum(int(buf[4092:4096].view(torch.int32).item()) for buf in _sk_scratch.values() if buf is not None)
+
+
 def gemm_bf16x_dw_group(items, K):
     """items: up to four (a [K,M] bf16, b [K,N] bf16, out [M,N] fp32): out = a^T . b for each, ONE stream-K launch."""
     n = len(items)

@@ -180,7 +180,9 @@ def _bf16(fn):
     from mtvaf_amd import hip
     hip.set_compute_dtype("bf16")
     try:
-        return fn()
+        r = fn()
+        assert hip.streamk_errors() == 0, "a stream-K launch (grouped weight gradients) reported a timed-out wait"
+        return r
     finally:
         hip.set_compute_dtype("fp32")
 
