@@ -136,6 +136,7 @@ int mtvaf_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_
                        float* mean, float* rstd, int B, int S, int H, float eps, float p_drop, uint64_t seed,
                        uint64_t offset, void* out_bf16 /* nullable: bf16 copy of out (mixed-precision GEMM operand) */,
                        mtvaf_stream_t stream);
+size_t mtvaf_embed_ln_bwd_workspace_bytes(int M, int H, int vocab, int max_pos);
 int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* type_ids, const int32_t* pos_ids,
                        const float* word, const float* pos, const float* type, const float* gamma, const float* mean,
                        const float* rstd, float* dword, float* dpos, float* dtype, float* dgamma, float* dbeta,

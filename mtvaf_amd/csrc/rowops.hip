@@ -314,15 +314,18 @@ __global__ void embed_scatter_kernel(const float* __restrict__ dz, const int64_t
   }
 }
 
-// Deterministic form of the scatter-add (the default; MTVAF_EMBED_ATOMIC=1 keeps the float-atomic kernel above): one wave per
-// token row.  The FIRST row that carries an id (no earlier row has it: a ballot scan over the ids before it) owns that table
-// row: it sums the gradient rows of every token with the same id IN ROW ORDER into registers and adds them to the table
-// with plain stores -- one writer per table row, a fixed summation order, no atomics.  KEY selects the table: 0 word ids
-// (int64), 1 position ids (int32, RoBERTa).  O(M^2 / 64) id comparisons in total: 0.3 M wave-iterations at 4096 tokens.
-// Rows whose gradient is EXACTLY zero (flags from row_nonzero_kernel) neither own nor contribute -- adding them would change
-// nothing -- which is what keeps the chains short: the reference's dataset pads RoBERTa ids with 0 = <s>, not with the
-// padding id (modules/dataset.py:414-415), so ~40 % of a batch's rows share ONE id, all with exact-zero gradients (masked
-// rows: DESIGN.md section 4.5b); as one serial chain they cost 8 ms.  Four matching rows are fetched at a time.
+// Deterministic form of the scatter-add (the default; MTVAF_EMBED_ATOMIC=1 keeps the float-atomic kernel above), O(M + V):
+//   1. row_nonzero_kernel: flag[r] = the gradient row r is not EXACTLY zero.  Zero rows neither own nor contribute -- adding
+//      them changes nothing -- which is what keeps the segments short: the reference's dataset pads RoBERTa ids with 0 = <s>,
+//      not with the padding id (modules/dataset.py:414-415), so ~40 % of a batch's rows share ONE id, all with exact-zero
+//      gradients (masked rows: DESIGN.md section 4.5b);
+//   2. count[id] (integer atomics: the final counts do not depend on order), an exclusive scan over the table's V ids ->
+//      offset[id], and a fill pass seg[offset[id] + cursor[id]++] = r: every id's rows sit in one segment, in ARBITRARY order;
+//   3. one wave per flagged row: the row that is the MINIMUM of its segment owns the table row; it ranks the segment (each
+//      lane counts the entries below its own), walks it in increasing row order four rows at a time and adds the sum to the
+//      table with plain stores.  One writer per table row, a fixed summation order, no float atomics.
+// KEY selects the table: 0 word ids (int64), 1 position ids (int32, RoBERTa).  (A first version let the first row of an id
+// find its partners by scanning the other rows' ids: O(M^2 / 64) dependent L2 round trips, 2 ms at 65 536 rows.)
 constexpr int DET_NC = 16;  // columns per lane of the deterministic scatter: H <= 1024
 __global__ __launch_bounds__(256) void row_nonzero_kernel(const float* __restrict__ dz, int* __restrict__ flags, int M, int H) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -337,47 +340,137 @@ __global__ __launch_bounds__(256) void row_nonzero_kernel(const float* __restric
   }
 }
 template <int KEY>
+__device__ __forceinline__ long det_key(const int64_t* __restrict__ ids, const int32_t* __restrict__ pos_ids, int r) {
+  return KEY == 0 ? (long)ids[r] : (long)pos_ids[r];
+}
+template <int KEY>
+__global__ __launch_bounds__(256) void det_count_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
+                                                       const int* __restrict__ flags, int* __restrict__ count, int M, long pad) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= M) return;
+  const long id = det_key<KEY>(ids, pos_ids, r);
+  if (id != pad && flags[r]) atomicAdd(count + id, 1);
+}
+// offset[i] = sum of count[0 .. i) for the V table rows: one block of 1024 threads; a thread owns a contiguous share of
+// PER = 4 * ceil(V / 4096) entries, fetched as int4 vectors (all loads in flight before the first add: as a plain loop the
+// scan took 47 us of dependent L2 round trips), the shares are scanned with wave shuffles.  count / offset are allocated with
+// room for 1024 * PER entries; entries beyond V are zero (the fill that precedes the count pass covers them).
+__global__ __launch_bounds__(1024) void det_scan_kernel(const int* __restrict__ count, int* __restrict__ offset, int V) {
+  __shared__ int wsum[16];
+  constexpr int MAXQ = 16;  // int4 vectors per thread: V <= 65536
+  const int nq = (V + 4095) / 4096;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int4* src = reinterpret_cast<const int4*>(count) + (long)threadIdx.x * nq;
+  int4 v[MAXQ];
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) v[i] = i < nq ? src[i] : int4{0, 0, 0, 0};
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) s += v[i].x + v[i].y + v[i].z + v[i].w;
+  // inclusive scan of the thread sums inside the wave, then over the 16 waves
+  int inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  int run = base + inc - s;  // exclusive prefix of this thread's share
+  int4* dst = reinterpret_cast<int4*>(offset) + (long)threadIdx.x * nq;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    if (i < nq) {
+      int4 o;
+      o.x = run; run += v[i].x;
+      o.y = run; run += v[i].y;
+      o.z = run; run += v[i].z;
+      o.w = run; run += v[i].w;
+      dst[i] = o;
+    }
+  }
+}
+template <int KEY>
+__global__ __launch_bounds__(256) void det_fill_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ pos_ids,
+                                                      const int* __restrict__ flags, const int* __restrict__ offset,
+                                                      int* __restrict__ cursor, int* __restrict__ seg, int M, long pad) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= M) return;
+  const long id = det_key<KEY>(ids, pos_ids, r);
+  if (id != pad && flags[r]) seg[offset[id] + atomicAdd(cursor + id, 1)] = r;
+}
+template <int KEY>
 __global__ __launch_bounds__(256) void embed_scatter_det_kernel(const float* __restrict__ dz, const int64_t* __restrict__ ids,
                                                                const int32_t* __restrict__ pos_ids, const int* __restrict__ flags,
-                                                               float* __restrict__ table, int M, int H, long pad) {
+                                                               const int* __restrict__ count, const int* __restrict__ offset,
+                                                               const int* __restrict__ seg, float* __restrict__ table, int M,
+                                                               int H, long pad) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  auto key_of = [&](int r) -> long { return KEY == 0 ? (long)ids[r] : (long)pos_ids[r]; };
   for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const long id = key_of(row);
+    const long id = det_key<KEY>(ids, pos_ids, row);
     if (id == pad || flags[row] == 0) continue;  // (wave-uniform)
-    bool earlier = false;
-    for (int r0 = 0; r0 < row && !earlier; r0 += 64) {
-      const int r = r0 + lane;
-      earlier = __ballot(r < row && key_of(r) == id && flags[r] != 0) != 0ull;
-    }
-    if (earlier) continue;  // another row owns this id
+    const int n = count[id];
+    const int* sg = seg + offset[id];
+    // the owner is the smallest row of the segment (wave-uniform decision)
+    int mn = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) mn = min(mn, sg[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o, 64));
+    if (mn != row) continue;
     float acc[DET_NC];
 #pragma unroll
     for (int i = 0; i < DET_NC; ++i) acc[i] = 0.f;
-    for (int r0 = row & ~63; r0 < M; r0 += 64) {
-      const int r = r0 + lane;
-      unsigned long long m = __ballot(r >= row && r < M && key_of(r) == id && flags[r] != 0);
-      while (m) {  // matching rows of this chunk, in increasing row order, four fetched at a time
+    auto add_rows = [&](const int (&rr)[4], const bool (&ok)[4]) {
+      float v[4][DET_NC];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < DET_NC; ++i) {
+          const int c = lane + 64 * i;
+          v[u][i] = (c < H) ? dz[(long)rr[u] * H + c] : 0.f;
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < DET_NC; ++i) acc[i] += ok[u] ? v[u][i] : 0.f;
+    };
+    if (n <= 64) {
+      // rank the segment in registers: lane i holds entry i, rank = how many entries are smaller (rows are distinct)
+      const int mine = lane < n ? sg[lane] : 0x7fffffff;
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (__shfl(mine, j, 64) < mine) ? 1 : 0;
+      for (int k = 0; k < n; k += 4) {
         int rr[4];
         bool ok[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          ok[u] = m != 0ull;
-          rr[u] = ok[u] ? r0 + __builtin_ctzll(m) : row;
-          m &= m - 1;  // (0 & anything = 0)
+          ok[u] = k + u < n;
+          const unsigned long long who = __ballot(lane < n && rank == k + u);
+          rr[u] = ok[u] ? __shfl(mine, (int)__builtin_ctzll(who | (1ull << 63)), 64) : row;
         }
-        float v[4][DET_NC];
+        add_rows(rr, ok);
+      }
+    } else {
+      // long segments (hundreds of tokens with one id and non-zero gradients: rare): repeated minimum above the last row
+      int last = -1;
+      for (int k = 0; k < n; k += 4) {
+        int rr[4];
+        bool ok[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
+          ok[u] = k + u < n;
+          int nx = 0x7fffffff;
+          if (ok[u]) {
+            for (int i = lane; i < n; i += 64) { const int v = sg[i]; nx = (v > last && v < nx) ? v : nx; }
 #pragma unroll
-          for (int i = 0; i < DET_NC; ++i) {
-            const int c = lane + 64 * i;
-            v[u][i] = (c < H) ? dz[(long)rr[u] * H + c] : 0.f;
+            for (int o = 32; o > 0; o >>= 1) nx = min(nx, __shfl_xor(nx, o, 64));
+            last = nx;
           }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int i = 0; i < DET_NC; ++i) acc[i] += ok[u] ? v[u][i] : 0.f;
+          rr[u] = ok[u] ? nx : row;
+        }
+        add_rows(rr, ok);
       }
     }
 #pragma unroll
@@ -455,8 +548,11 @@ using namespace mtvaf;
 
 extern "C" {
 
-size_t mtvaf_ln_bwd_workspace_bytes(int M, int H) {  // column partials of the LayerNorm backward + one flag word per token row (embedding backward)
-  return (size_t)row_grid_bwd(M) * 4 * H * sizeof(float) + (size_t)M * sizeof(int) + 16;
+size_t mtvaf_ln_bwd_workspace_bytes(int M, int H) { return (size_t)row_grid_bwd(M) * 4 * H * sizeof(float); }
+// scratch of mtvaf_embed_ln_bwd: the LayerNorm column partials + the deterministic scatter's flags / segments ([M] each) and
+// per-id count / cursor / offset tables ([max(vocab, max_pos)] each)
+size_t mtvaf_embed_ln_bwd_workspace_bytes(int M, int H, int vocab, int max_pos) {
+  return (size_t)row_grid_bwd(M) * 4 * H * sizeof(float) + ((size_t)2 * M + (size_t)3 * ((std::max(vocab, max_pos) + 4095) / 4096 * 4096)) * sizeof(int) + 64;
 }
 
 int mtvaf_roberta_position_ids(const int64_t* ids, int32_t* pos_ids, int B, int S, int pad_idx, hipStream_t st) {
@@ -541,7 +637,7 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
   if (H % 4 || H > MAXC * 256 || B <= 0 || S <= 0 || type_vocab > 2) return MTVAF_ERR_SHAPE;
   const int M = B * S;
   const int g = row_grid_bwd(M);
-  if (workspace_bytes < (size_t)g * 4 * H * sizeof(float) + (size_t)M * sizeof(int)) return MTVAF_ERR_WORKSPACE;
+  if (workspace_bytes < mtvaf_embed_ln_bwd_workspace_bytes(M, H, vocab, max_pos)) return MTVAF_ERR_WORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(g), dim3(256), 0, st, dout, nullptr, nullptr, ids, type_ids, pos_ids,
                      word, pos, type, gamma, mean, rstd, dz_ws, nullptr, 0, part, M, S, H, p_drop, seed, offset,
@@ -558,12 +654,32 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(g), dim3(256), 0, st, dz_ws, ids, pos_ids, dword, dpos, M, H, word_pad,
                        pos_pad);
   } else {  // bit-reproducible: one owner per table row, gradient rows added in token order
-    const int gd = (M + 3) / 4;
-    int* flags = reinterpret_cast<int*>(part + (size_t)g * 4 * H);  // (behind the column partials, already consumed by the launch above ... but kept apart)
+    const int gd = (M + 3) / 4, gm = (M + 255) / 256;
+    int* flags = reinterpret_cast<int*>(part + (size_t)g * 4 * H);
+    int* seg = flags + M;
+    int* count = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(seg + M) + 15) & ~(uintptr_t)15);  // [Vmax] count, [Vmax] cursor, [Vmax] offset (16-byte aligned: int4 scan)
+    const int Vmax = (std::max(vocab, max_pos) + 4095) / 4096 * 4096;  // (the scan's int4 shares: 1024 threads x 4 * ceil(V / 4096))
+    if (Vmax > 65536) return MTVAF_ERR_SHAPE;
     hipLaunchKernelGGL(row_nonzero_kernel, dim3(std::min(gd, 2048)), dim3(256), 0, st, dz_ws, flags, M, H);
-    hipLaunchKernelGGL((embed_scatter_det_kernel<0>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, flags, dword, M, H, (long)word_pad);
-    if (pos_ids)
-      hipLaunchKernelGGL((embed_scatter_det_kernel<1>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, flags, dpos, M, H, (long)pos_pad);
+    for (int key = 0; key < (pos_ids ? 2 : 1); ++key) {
+      const int V = key == 0 ? vocab : max_pos;
+      int* cursor = count + Vmax;
+      int* offset = cursor + Vmax;
+      zero_f32(reinterpret_cast<float*>(count), (long)2 * Vmax, st);  // count and cursor (a kernel, not a memset node: DESIGN.md section 5, HIP graphs)
+      if (key == 0) {
+        hipLaunchKernelGGL((det_count_kernel<0>), dim3(gm), dim3(256), 0, st, ids, pos_ids, flags, count, M, (long)word_pad);
+        hipLaunchKernelGGL(det_scan_kernel, dim3(1), dim3(1024), 0, st, count, offset, V);
+        hipLaunchKernelGGL((det_fill_kernel<0>), dim3(gm), dim3(256), 0, st, ids, pos_ids, flags, offset, cursor, seg, M, (long)word_pad);
+        hipLaunchKernelGGL((embed_scatter_det_kernel<0>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, flags, count, offset, seg,
+                           dword, M, H, (long)word_pad);
+      } else {
+        hipLaunchKernelGGL((det_count_kernel<1>), dim3(gm), dim3(256), 0, st, ids, pos_ids, flags, count, M, (long)pos_pad);
+        hipLaunchKernelGGL(det_scan_kernel, dim3(1), dim3(1024), 0, st, count, offset, V);
+        hipLaunchKernelGGL((det_fill_kernel<1>), dim3(gm), dim3(256), 0, st, ids, pos_ids, flags, offset, cursor, seg, M, (long)pos_pad);
+        hipLaunchKernelGGL((embed_scatter_det_kernel<1>), dim3(gd), dim3(256), 0, st, dz_ws, ids, pos_ids, flags, count, offset, seg,
+                           dpos, M, H, (long)pos_pad);
+      }
+    }
   }
   if (!pos_ids) {
     if (!accumulate && max_pos > S) zero_f32(dpos + (long)S * H, (long)(max_pos - S) * H, st);

@@ -83,6 +83,7 @@ _SIGS = {
     "mtvaf_gemm_bf16x_ktiles": (c_int, [I, I, P, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P, I, P, SZ, I, I, I, P, P, P]),
     "mtvaf_colsum_small": (c_int, [P, I, I, P, I, P]),
     "mtvaf_embed_scatter_mode": (c_int, [I]),
+    "mtvaf_embed_ln_bwd_workspace_bytes": (SZ, [I, I, I, I]),
     "mtvaf_streamk_attach": (c_int, [P, SZ, P]),
     "mtvaf_streamk_scratch_bytes": (SZ, [I]),
     "mtvaf_streamk_attached": (c_int, [P]),
@@ -356,7 +357,7 @@ def embed_ln_bwd(dout, ids, tts, pos_ids, word, pos, typ, gamma, mean, rstd, dwo
                  accumulate, word_pad, pos_pad, p, seed, offset, dz_ws):
     B, S = ids.shape
     H = word.shape[1]
-    wsb = lib().mtvaf_ln_bwd_workspace_bytes(B * S, H)
+    wsb = lib().mtvaf_embed_ln_bwd_workspace_bytes(B * S, H, word.shape[0], pos.shape[0])
     ws = workspace(wsb, dout.device)
     _ck(lib().mtvaf_embed_ln_bwd(_p(dout), _p(ids), _p(tts), _p(pos_ids), _p(word), _p(pos), _p(typ), _p(gamma), _p(mean),
                                  _p(rstd), _p(dword), _p(dpos), _p(dtype), _p(dgamma), _p(dbeta), int(accumulate), B, S, H,
