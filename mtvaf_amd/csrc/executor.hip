@@ -10,6 +10,8 @@
 // produced, so they are enqueued on `side` behind an event of `main`; `side == main` serialises.
 #include "common.h"
 
+#include <cstdlib>
+
 #include <cstddef>
 
 extern "C" {
@@ -21,6 +23,9 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
                      void* C16, int ldc16, int M, int N, int K, const float* bias, int epi, void* aux16, int ldaux,
                      int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
                      int splits, int stages, hipStream_t stream);
+int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                            const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
+                            void* workspace, size_t workspace_bytes, int splits, hipStream_t stream);
 int mtvaf_streamk_attached(hipStream_t stream);
 int mtvaf_gemm_bf16x_dw_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C32,
                               const int* ldc32, const int* M, const int* N, int K, hipStream_t stream);
@@ -200,6 +205,20 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
   return MTVAF_OK;
 }
 
+// fp32 mode: the four weight-gradient products of a layer go out as ONE grouped launch (mtvaf_gemm_f32_dw_group) when the layer
+// has at most this many token rows (0: never).  Few-token steps (BASELINE configs[0]: 256 rows) are bound by their launch
+// count; at 4096 rows the four tuned launches + their split-K reductions are as fast (measured), so the default stops at 1024.
+// MTVAF_DW_GROUP_ROWS overrides; mtvaf_dw_group_rows(rows >= 0) sets, (-1) queries.  The Python orchestration reads the same.
+static int g_dw_group_rows = -1;
+int mtvaf_dw_group_rows(int rows) {
+  if (rows >= 0) g_dw_group_rows = rows;
+  if (g_dw_group_rows < 0) {
+    const char* e = getenv("MTVAF_DW_GROUP_ROWS");
+    g_dw_group_rows = e ? atoi(e) : 1024;
+  }
+  return g_dw_group_rows;
+}
+
 // Backward of one layer.  g->dh holds d loss / d h2 on entry and d loss / d x on return.  `settle` != 0: the second stream
 // additionally waits for the layer's LAST main-stream kernel (an optimizer update hanging off the caller's hook must be
 // behind every product that still reads the weights).
@@ -264,23 +283,24 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     const float* cx = static_cast<const float*>(L->cx);
     float* pre = static_cast<float*>(L->pre);
     const float* act = static_cast<const float*>(L->act);
+    const bool grp = M <= mtvaf_dw_group_rows(-1) && M % 32 == 0 && H % 128 == 0 && I % 128 == 0 && H % 96 == 0 && I % 96 == 0;
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0, M, H,
                                        L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, nullptr, mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, df, H, act, I, g->dw2, I, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+    if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, df, H, act, I, g->dw2, I, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, df, H, L->w2, I, dpre, I, M, I, H, nullptr, X_EPI_DGELU, pre, I, 0, 1, g->ws_main, g->ws_main_bytes, -1, -1,
                              mainS));
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
-    MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dpre, I, L->h1, H, g->dw1, H, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+    if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dpre, I, L->h1, H, g->dw1, H, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dpre, I, L->w1, H, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, 1, g->ws_main,
                              g->ws_main_bytes, -1, -1, mainS));
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, 0, g->dg1, g->db1, g->dbo, 0, M, H,
                                        L->p_hidden, L->seed, L->offset + 1, g->ws_main, g->ws_main_bytes, nullptr, mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, da, H, cx, H, g->dwo, H, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
+    if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, da, H, cx, H, g->dwo, H, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, da, H, L->wo, H, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_main,
                              g->ws_main_bytes, -1, -1, mainS));
@@ -294,8 +314,16 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     }
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
-    MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dqkv, 3 * H, L->x, H, g->dwqkv, H, 3 * H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1,
+    if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dqkv, 3 * H, L->x, H, g->dwqkv, H, 3 * H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1,
                              g->ws_side, g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
+    if (grp) {
+      const float* const As[4] = {df, dpre, da, dqkv};
+      const float* const Bs[4] = {act, static_cast<const float*>(L->h1), cx, static_cast<const float*>(L->x)};
+      float* const Cs[4] = {g->dw2, g->dw1, g->dwo, g->dwqkv};
+      const int lda[4] = {H, I, H, 3 * H}, ldb[4] = {I, H, H, H}, ldc[4] = {I, H, H, H};
+      const int Ms[4] = {H, I, H, 3 * H}, Ns[4] = {I, H, H, H};
+      MTVAF_TRY(mtvaf_gemm_f32_dw_group(4, As, lda, Bs, ldb, Cs, ldc, Ms, Ns, M, g->klist, g->kcnt, g->ws_side, g->ws_side_bytes, -1, side));
+    }
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dqkv, 3 * H, L->wqkv, H, g->dh, H, M, H, 3 * H, nullptr, X_EPI_NONE, nullptr, 0, 1, 1,
                              g->ws_main, g->ws_main_bytes, -1, -1, mainS));
   }

@@ -14,6 +14,8 @@
 // KC operand is fetched with one ds_read_b128 per four MFMAs.  A and B use the same permutation,
 // so the sum over k is unchanged.
 #include "gemm_common.h"
+
+#include <climits>
 #include <cstdlib>
 #include <type_traits>
 
@@ -259,8 +261,8 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE = 3, bool KLIST = false>
-__global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma_kernel(GemmArgs p) {
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE, bool KLIST, bool GROUP>
+__device__ __forceinline__ void gemm_f32_dma_body(GemmArgs p) {
   static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
   constexpr int BK = 32;
   constexpr int NW = WM * WN;
@@ -277,7 +279,14 @@ __global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, h = lane >> 5;
 
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  if constexpr (GROUP) {  // which product of the group this tile belongs to (p is this block's private copy of the arguments)
+    const int q = (bid >= p.grp_tile_begin[1]) + (bid >= p.grp_tile_begin[2]) + (bid >= p.grp_tile_begin[3]);
+    const GemmProb& g = p.grp[q];
+    bid -= p.grp_tile_begin[q];
+    p.A = g.A; p.B = g.B; p.C = g.C; p.lda = g.lda; p.ldb = g.ldb; p.ldc = g.ldc; p.tiles_n = g.tiles_n;
+    p.slab_stride = g.slab_stride;
+  }
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
   int kbeg = blockIdx.z * p.k_chunk;
@@ -541,6 +550,17 @@ __global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma
       }
     }
   }
+}
+
+// the kernels proper: the body above, instantiated as the ordinary launch (one product) and as the GROUPED launch (the tiles of
+// up to four weight-gradient products back to back: mtvaf_gemm_f32_dw_group)
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE = 3, bool KLIST = false>
+__global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma_kernel(GemmArgs p) {
+  gemm_f32_dma_body<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST, false>(p);
+}
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool KLIST>
+__global__ __launch_bounds__(WM* WN * 64, NSTAGE == 3 ? 1 : 2) void gemm_f32_dma_group_kernel(GemmArgs p) {
+  gemm_f32_dma_body<BM, BN, WM, WN, true, true, NSTAGE, KLIST, true>(p);
 }
 
 // dst[r][c] (ld ldd) = (accumulate ? dst : 0) + epi(sum_z slabs[z][r][c] + bias[c]);  every element-wise epilogue of the
@@ -872,7 +892,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     if (splits < 1) splits = 1;
   }
   GemmArgs a;
-  a.klist = nullptr; a.kcnt = nullptr;
+  a.klist = nullptr; a.kcnt = nullptr; a.ngrp = 0;
   a.A = A; a.B = B; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldaux = ldaux;
   a.epi = epi; a.accumulate = accumulate;
@@ -967,6 +987,90 @@ int mtvaf_gemm_f32_ktiles(int layout_a, int layout_b, const float* A, int lda, c
                           const int* kcnt, hipStream_t stream) {
   return gemm_dispatch(0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
                        allow_split, workspace, workspace_bytes, cfg, splits, stream, klist, kcnt);
+}
+
+// Up to four weight-gradient products dW_i[M_i, N_i] = A_i^T . B_i (layouts KM x KM: A_i [K, M_i], B_i [K, N_i] fp32 row-major)
+// that share the reduction axis K -- the four products of one encoder layer -- in ONE launch of the 128x96 two-blocks-per-CU
+// LDS-DMA kernel (its GROUP instantiation: blockIdx.x walks the tiles of the products back to back), with an optional k-tile
+// list as mtvaf_gemm_f32_ktiles.  One launch instead of four (+ their split-K reductions when the tiles alone fill the chip):
+// at 256 token rows (BASELINE configs[0]) the four products are 576 tiles of 8 k-tiles -- a single 16-us launch where four
+// launches + four slab reductions took 80.  Deterministic split-K with per-product slabs in `workspace` when the reduction is
+// long.  Requires M_i % 128 == 0, N_i % 96 == 0, K % 32 == 0, leading dimensions % 4 == 0, 16-byte aligned pointers;
+// MTVAF_ERR_SHAPE / _ALIGN otherwise (no fallback inside the library: the caller launches the products one by one).
+int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                            const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
+                            void* workspace, size_t workspace_bytes, int splits, hipStream_t stream) {
+  if (n < 1 || n > 4 || K <= 0 || K % 32) return MTVAF_ERR_SHAPE;
+  GemmArgs a = {};
+  long tiles = 0, outs = 0;
+  for (int i = 0; i < n; ++i) {
+    if (M[i] <= 0 || N[i] <= 0 || M[i] % 128 || N[i] % 96) return MTVAF_ERR_SHAPE;
+    if (lda[i] % 4 || ldb[i] % 4 || ldc[i] % 4 || (((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C[i]) & 15)) return MTVAF_ERR_ALIGN;
+    a.grp_tile_begin[i] = (int)tiles;
+    tiles += (long)(M[i] / 128) * (N[i] / 96);
+    outs += (long)M[i] * N[i];
+  }
+  for (int i = n; i < 4; ++i) a.grp_tile_begin[i] = INT_MAX;
+  // splits: fill the 512 block slots of the two-blocks-per-CU ring several times over when the reduction is long enough
+  const int ktiles = K / 32;
+  if (splits <= 0) {
+    splits = 1;
+    while (tiles * splits < 2048 && ktiles / (splits + 1) >= 16 && splits < 8) ++splits;
+  }
+  while (splits > 1 && ((size_t)splits * outs * sizeof(float) > workspace_bytes || ktiles / splits < 4)) --splits;
+  int kc = (int)cdiv(cdiv(K, splits), 32) * 32;
+  splits = (int)cdiv(K, kc);
+  float* slab = static_cast<float*>(workspace);
+  for (int i = 0; i < n; ++i) {
+    GemmProb& g = a.grp[i];
+    g.A = A[i]; g.B = B[i]; g.lda = lda[i]; g.ldb = ldb[i]; g.tiles_n = N[i] / 96;
+    if (splits > 1) {
+      g.C = slab; g.ldc = N[i]; g.slab_stride = (long)M[i] * N[i];
+      slab += (long)splits * M[i] * N[i];
+    } else {
+      g.C = C[i]; g.ldc = ldc[i]; g.slab_stride = 0;
+    }
+  }
+  a.ngrp = n;
+  a.A = a.grp[0].A; a.B = a.grp[0].B; a.C = a.grp[0].C;
+  a.M = M[0]; a.N = N[0]; a.K = K; a.lda = lda[0]; a.ldb = ldb[0]; a.ldc = a.grp[0].ldc;
+  a.k_chunk = kc; a.epi = EPI_NONE; a.a_vec = a.b_vec = 1; a.tiles_n = a.grp[0].tiles_n;
+  a.klist = (klist && kcnt) ? klist : nullptr;
+  a.kcnt = a.klist ? kcnt : nullptr;
+  a.wide = 1;  // every product: whole tiles, ldc % 4 == 0, 16-byte aligned result / slabs
+  const size_t smem = std::max((size_t)2 * (128 + 96) * 32 * sizeof(float), (size_t)128 * (96 + 4) * sizeof(float));
+  const dim3 grid((unsigned)tiles, 1, (unsigned)splits), block(256);
+  // (profiler key: the group's flops as one M x 768 x K product, fast bit 8 = the launch walks a k-tile list)
+  const int key[8] = {12, 1, 1, a.klist ? 10 : 2, (int)(outs / 768), 768, K, splits};
+  const int rec = prof_begin(key, stream);
+  if (a.klist) {
+    auto kern = gemm_f32_dma_group_kernel<128, 96, 4, 1, 2, true>;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
+  } else {
+    auto kern = gemm_f32_dma_group_kernel<128, 96, 4, 1, 2, false>;
+    static bool attr = false;
+    if (!attr) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, a);
+  }
+  prof_end(rec, stream);
+  MTVAF_LAUNCH_CHECK();
+  if (splits > 1) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = launch_splitk_reduce(a.grp[i].C, splits, C[i], M[i], N[i], ldc[i], nullptr, 0, EPI_NONE, nullptr, 0, stream);
+      if (rc != MTVAF_OK) return rc;
+    }
+  }
+  return MTVAF_OK;
 }
 
 // Same contract as mtvaf_gemm_f32 (fp32 operands and results in memory), but the products run on the bf16

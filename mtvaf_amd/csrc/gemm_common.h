@@ -7,6 +7,15 @@ namespace mtvaf {
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_TANH = 2, EPI_DGELU = 3, EPI_DTANH = 4 };
 
+// one product of a grouped launch (the weight gradients of one encoder layer: same layouts, same reduction axis)
+struct GemmProb {
+  const float* A;
+  const float* B;
+  float* C;  // result, or this product's split-K slabs
+  int lda, ldb, ldc, tiles_n;
+  long slab_stride;
+};
+
 struct GemmArgs {
   const float* A;
   const float* B;
@@ -25,6 +34,12 @@ struct GemmArgs {
   // padded positions).  NULL: the whole reduction range.  Both live on the device: no host sync.
   const int* klist;
   const int* kcnt;
+  // grouped launch (template flag GROUP of gemm_f32_dma_kernel): blockIdx.x walks the tiles of ngrp products back to back;
+  // product q owns tiles grp_tile_begin[q] .. grp_tile_begin[q+1]-1.  The table stays in the kernel-argument segment and is
+  // indexed at run time (scalar loads on demand).
+  int ngrp;
+  int grp_tile_begin[4];
+  GemmProb grp[4];
 };
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so

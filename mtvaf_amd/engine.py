@@ -798,12 +798,16 @@ class EncoderFunction(torch.autograd.Function):
                 hip.dropout_res_ln_bwd(dh, f, h1, w.g2, mean2, rstd2, df, dh1, False, G[14], G[15], False, p_hidden, seed,
                                        off + 2, dbias_x=G[13])
                 dpre = _empty(M, I, like=dev_like)
-                on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12], ktiles=ktiles))
+                # (few token rows: the layer's four weight gradients as ONE launch -- the same rule as csrc/executor.hip)
+                grp = M <= hip.dw_group_rows() and M % 32 == 0 and H % 128 == 0 and I % 128 == 0 and H % 96 == 0 and I % 96 == 0
+                if not grp:
+                    on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12], ktiles=ktiles))
                 hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
 
                 def ffn1_grads():
                     hip.colsum(dpre, G[11])
-                    hip.linear_bwd_weight(dpre, h1, G[10], ktiles=ktiles)
+                    if not grp:
+                        hip.linear_bwd_weight(dpre, h1, G[10], ktiles=ktiles)
                 on_side((dpre,), ffn1_grads)
                 hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
             # ---- attention block ----
@@ -833,10 +837,12 @@ class EncoderFunction(torch.autograd.Function):
                 hip.gemm_bf16x(dqkv, KC, wqkv_h, KM, M, H, 3 * H, out32=dh0, accumulate=True)
             else:
                 dctx = dh1  # reuse (LayerNorm backward has consumed it by the time the dX product writes)
-                da = df if side is None else _empty(M, H, like=dev_like)  # df is still being read on the side stream
+                # (df is still to be read: on the side stream, or by the grouped launch at the end of the layer)
+                da = df if (side is None and not grp) else _empty(M, H, like=dev_like)
                 hip.dropout_res_ln_bwd(dh1, a, x, w.g1, mean1, rstd1, da, dh0, False, G[8], G[9], False, p_hidden, seed,
                                        off + 1, dbias_x=G[7])
-                on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6], ktiles=ktiles))
+                if not grp:
+                    on_side((da,), lambda: hip.linear_bwd_weight(da, cx, G[6], ktiles=ktiles))
                 hip.linear_bwd_input(da, w.wo, dctx)
                 dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
                 hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
@@ -845,8 +851,11 @@ class EncoderFunction(torch.autograd.Function):
 
                 def qkv_grads():
                     hip.colsum(dqkv, dbqkv)
-                    hip.linear_bwd_weight(dqkv, x, dwqkv, ktiles=ktiles)
-                on_side((dqkv,), qkv_grads)
+                    if grp:
+                        hip.gemm_f32_dw_group([(df, act, G[12]), (dpre, h1, G[10]), (da, cx, G[6]), (dqkv, x, dwqkv)], M, ktiles=ktiles)
+                    else:
+                        hip.linear_bwd_weight(dqkv, x, dwqkv, ktiles=ktiles)
+                on_side((dqkv, df, dpre, da) if grp else (dqkv,), qkv_grads)
                 hip.linear_bwd_input(dqkv, w.wqkv, dh0, accumulate=True)
             dh = dh0
             if gviews is None:

@@ -84,6 +84,8 @@ _SIGS = {
     "mtvaf_colsum_small": (c_int, [P, I, I, P, I, P]),
     "mtvaf_embed_scatter_mode": (c_int, [I]),
     "mtvaf_embed_ln_bwd_workspace_bytes": (SZ, [I, I, I, I]),
+    "mtvaf_gemm_f32_dw_group": (c_int, [I, P, P, P, P, P, P, P, P, I, P, P, P, SZ, I, P]),
+    "mtvaf_dw_group_rows": (c_int, [I]),
     "mtvaf_streamk_attach": (c_int, [P, SZ, P]),
     "mtvaf_streamk_scratch_bytes": (SZ, [I]),
     "mtvaf_streamk_attached": (c_int, [P]),
@@ -588,6 +590,27 @@ def streamk_errors() -> int:
     ran out and its tile is wrong -- never observed; bench.py and the tests assert it."""
     torch.cuda.synchronize()
     return sum(int(buf[4092:4096].view(torch.int32).item()) for buf in _sk_scratch.values() if buf is not None)
+
+
+def dw_group_rows(rows: int = -1) -> int:
+    """fp32 mode: layers of at most this many token rows send their four weight-gradient products as one grouped launch
+    (csrc/executor.hip: mtvaf_dw_group_rows; default 1024, MTVAF_DW_GROUP_ROWS).  rows >= 0 sets it."""
+    return lib().mtvaf_dw_group_rows(rows)
+
+
+def gemm_f32_dw_group(items, K, ktiles=None, splits=-1):
+    """items: up to four (a [K,M] fp32, b [K,N] fp32, out [M,N] fp32): out = a^T . b for each, ONE launch of the 128x96 LDS-DMA
+    kernel (+ one ordered slab reduction per product when the reduction is split)."""
+    n = len(items)
+    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ia = lambda xs: (ctypes.c_int * n)(*xs)
+    As, Bs, Cs = [i[0] for i in items], [i[1] for i in items], [i[2] for i in items]
+    wsb = 8 * sum(c.numel() for c in Cs) * 4
+    ws = workspace(wsb, As[0].device)
+    kl, kc = (ktiles if ktiles is not None else (None, None))
+    _ck(lib().mtvaf_gemm_f32_dw_group(n, vp(As), ia([t.stride(0) for t in As]), vp(Bs), ia([t.stride(0) for t in Bs]), vp(Cs),
+                                      ia([t.stride(0) for t in Cs]), ia([t.shape[1] for t in As]), ia([t.shape[1] for t in Bs]),
+                                      K, _p(kl), _p(kc), _p(ws), ws.numel(), splits, _st()), "mtvaf_gemm_f32_dw_group")
 
 
 def gemm_bf16x_dw_group(items, K):

@@ -1033,3 +1033,45 @@ def test_gemm_bf16_dw_group_stream_k(hip):
         assert hip.streamk_error(DEV) == 0
     with pytest.raises(RuntimeError):
         hip.gemm_bf16x_dw_group([(dy[:, :128], xs, torch.empty(128, H, device=DEV))], T)  # M % 256 != 0
+
+
+@pytest.mark.parametrize("T", [256, 1024, 4096])
+def test_gemm_f32_dw_group(hip, T):
+    """The four fp32 weight-gradient products of an encoder layer in ONE launch (mtvaf_gemm_f32_dw_group): BERT-base shapes at
+    256 (BASELINE configs[0]), 1024 and 4096 token rows against the fp64 products, planned and forced split counts, with a
+    k-tile list (rows outside the list exactly zero), fewer than four products, and the documented shape errors."""
+    H, I = 768, 3072
+    valid = torch.ones(T, dtype=torch.bool)
+    valid[T // 2 + 5: T // 2 + 5 + T // 4] = False  # (a masked run that empties whole 32-row k-tiles)
+    dy, dy3, dyq = (rnd(T, n, seed=31 + n) for n in (H, I, 3 * H))
+    xs, x3 = rnd(T, H, seed=41), rnd(T, I, seed=42)
+    for use_list in (False, True):
+        if use_list:
+            dy, dy3, dyq = (t * valid[:, None] for t in (dy, dy3, dyq))
+            tiles = sorted(set(int(r) // 32 for r in torch.nonzero(valid).flatten()))
+            assert len(tiles) < T // 32
+            kt = (torch.tensor(tiles, dtype=torch.int32, device=DEV), torch.tensor([len(tiles)], dtype=torch.int32, device=DEV))
+        else:
+            kt = None
+        d = [t.to(DEV) for t in (dy, dy3, dyq, xs, x3)]
+        items = [(d[0], d[4], torch.empty(H, I, device=DEV)), (d[1], d[3], torch.empty(I, H, device=DEV)),
+                 (d[0], d[3], torch.empty(H, H, device=DEV)), (d[2], d[3], torch.empty(3 * H, H, device=DEV))]
+        refs = [a_.double().cpu().t() @ b_.double().cpu() for a_, b_, _ in items]
+        for sp in (-1, 1, 2, 3):
+            for _, _, o in items:
+                o.fill_(float("nan"))
+            hip.gemm_f32_dw_group(items, T, ktiles=kt, splits=sp)
+            for (_, _, o), r in zip(items, refs):
+                close(o, r, rtol=2e-5, name=f"dW {tuple(o.shape)} over {T} rows, splits {sp}, list {use_list}")
+        first = [o.clone() for _, _, o in items]
+        hip.gemm_f32_dw_group(items, T, ktiles=kt, splits=3)
+        for (_, _, o), f in zip(items, first):
+            assert torch.equal(o, f)  # ordered slab reduction: the same bits every time
+        two = [(items[2][0], items[2][1], torch.empty(H, H, device=DEV)), (items[1][0], items[1][1], torch.empty(I, H, device=DEV))]
+        hip.gemm_f32_dw_group(two, T, ktiles=kt)
+        close(two[0][2], refs[2], rtol=2e-5, name="two products: first")
+        close(two[1][2], refs[1], rtol=2e-5, name="two products: second")
+    with pytest.raises(RuntimeError):
+        hip.gemm_f32_dw_group([(d[0][:, :64], d[3], torch.empty(64, H, device=DEV))], T)  # M % 128 != 0
+    with pytest.raises(RuntimeError):
+        hip.gemm_f32_dw_group([(d[0], d[3][:, :100], torch.empty(H, 100, device=DEV))], T)  # N % 96 != 0
