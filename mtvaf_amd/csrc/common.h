@@ -124,4 +124,31 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return 0.5f * (1.0f + copysignf(e, x)) + x * 0.39894228040143268f * ez2;
 }
 
+// The mixed-precision kernels' GELU (256 x 256 tile: 128 evaluations per lane in the epilogue -- 10 us of VALU time per tile
+// with the form above against a 17-us k-loop at K = 768): Phi(x) = 0.5 erfc(-x / sqrt 2) from ONE exponential and no
+// reciprocal.  log2 of the lower tail Q(z) = Phi(-z), z = min(|x|, 6), is -1 + z P(z) with P of degree 6 fitted for the
+// absolute error of x Phi(x) (tools/fit_gelu.py: 1.9e-7 for GELU, 1.6e-7 for GELU' in fp32 arithmetic -- the level of the
+// form above); Phi = Q or 1 - Q by the sign (no cancellation: Q <= 1/2).  Two elements per call: the polynomial compiles to
+// v_pk_fma_f32.  Results of this mode are rounded to bf16 right after.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 phi_fast2(f32x2 x) {
+  const f32x2 z = {fminf(fabsf(x.x), 6.0f), fminf(fabsf(x.y), 6.0f)};
+  f32x2 p = {6.466566447e-06f, 6.466566447e-06f};
+  p = p * z + f32x2{-3.617612674e-05f, -3.617612674e-05f};
+  p = p * z + f32x2{-4.794954148e-04f, -4.794954148e-04f};
+  p = p * z + f32x2{7.477600127e-03f, 7.477600127e-03f};
+  p = p * z + f32x2{-5.275298283e-02f, -5.275298283e-02f};
+  p = p * z + f32x2{-4.591362476e-01f, -4.591362476e-01f};
+  p = p * z + f32x2{-1.151111722e+00f, -1.151111722e+00f};
+  const f32x2 s = p * z - f32x2{1.0f, 1.0f};
+  const f32x2 q = {__builtin_amdgcn_exp2f(s.x), __builtin_amdgcn_exp2f(s.y)};
+  return f32x2{x.x < 0.f ? q.x : 1.0f - q.x, x.y < 0.f ? q.y : 1.0f - q.y};
+}
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) { return x * phi_fast2(x); }
+__device__ __forceinline__ f32x2 gelu_fast_grad2(f32x2 x) {
+  const f32x2 e = x * x * f32x2{-0.72134752f, -0.72134752f};  // -x^2 / 2 in log2 units
+  const f32x2 pdf = f32x2{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)} * f32x2{0.39894228f, 0.39894228f};
+  return phi_fast2(x) + x * pdf;
+}
+
 }  // namespace mtvaf

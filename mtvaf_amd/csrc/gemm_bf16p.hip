@@ -304,103 +304,149 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK
   if (wr == 0) P256_BAR();
   };
 
-  // ---- epilogue: straight from the registers (lane: row 16*I + l15, columns 16*J + 4*g .. +3 of the wave's block) ----
-  // One straight-line body per epilogue KIND, chosen once: a runtime `if (epi == ..)` around each of the 32 loads of the
-  // DGELU / accumulate forms makes hipcc branch around every load and drain vmcnt per element (32 dependent round trips:
-  // measured 26 us per tile); inside a body the loads of half the tile are issued together, then consumed.
+  // ---- epilogue.  Two forms, chosen once per block (one straight-line body per KIND: a runtime `if (epi == ..)` around each
+  // load made hipcc drain vmcnt per element).
+  //  * fp32-only results (split-K / stream-K slabs, plain fp32, accumulate): straight from the registers -- the transposed
+  //    MFMA leaves a lane with four consecutive columns of row 16*I + l15: 16-byte stores, 64 bytes per row per instruction.
+  //  * anything with a bf16 array (bf16 result, GELU's saved pre-activation, GELU' reading it): through the LDS (free once the
+  //    k-loop is over: eight wave-private 16-KiB regions) into a ROW layout -- lane (rl = lane >> 4, cl = lane & 15) holds the
+  //    four consecutive columns 4*cl .. +3 of row 4*s + rl, s = 0..15 per pass of 64 rows -- so that one instruction of the wave
+  //    covers FOUR WHOLE ROWS of its 64 columns (bf16: one full 128-byte line per row).  Straight from the MFMA layout a bf16
+  //    store instruction touched 16 lines with 32 bytes each and the tile's stores took 8 us against a 17-us k-loop at
+  //    K = 768 (measured: the same launches without their stores; skewing the blocks' start times changed nothing -- the cost
+  //    sits in each CU's own store path, not in the HBM burst); in the row layout 4.6 us.  fp32 stores gained nothing from
+  //    it (64 bytes per row already), hence the first form.  fp32 image of a pass: 64 rows x 256 B, 16-byte chunk c of row r at
+  //    c ^ (r & 15) (conflict-free both ways).  Everything element-wise happens in the row layout; GELU / GELU' by the
+  //    one-exponential form of common.h (the A&S erf cost 10 us of VALU time per tile: 128 evaluations per lane).
   typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
   // what the path combines (checked by the launcher): bias with the plain / GELU forms only, column sums with DGELU only
   enum { K_RAW = 0, K_PLAIN = 1, K_GELU = 2, K_DGELU = 3, K_ACC = 4 };
   auto epilogue = [&](bool raw, __bf16* C16) __attribute__((always_inline)) {
-    // addresses = wave-uniform base (advanced per 16-row block on the scalar unit) + ONE 32-bit per-lane offset per array:
-    // per-element 64-bit address arithmetic in vector registers (8 row blocks x 3 arrays) pushed the epilogue into spills
     unsigned char* const Cb = reinterpret_cast<unsigned char*>(Cout);
     unsigned char* const C16b = reinterpret_cast<unsigned char*>(C16);
     unsigned char* const auxb = reinterpret_cast<unsigned char*>(p.aux16);
-    const int colw = n0 + wc * 64 + 4 * g;
-    const int rowl = m0 + wr * 128 + l15;
-    const unsigned vo32 = (unsigned)rowl * (unsigned)ldc32 * 4u + (unsigned)colw * 4u;
-    const unsigned vo16 = (unsigned)rowl * (unsigned)p.ldc16 * 2u + (unsigned)colw * 2u;
-    const unsigned voax = (unsigned)rowl * (unsigned)p.ldaux * 2u + (unsigned)colw * 2u;
-    const long rs32 = (long)ldc32 * 64, rs16 = (long)p.ldc16 * 32, rsax = (long)p.ldaux * 32;  // bytes per 16 rows
-    auto body = [&](auto kind_c) __attribute__((always_inline)) {
+    // addresses = wave-uniform base (advanced on the scalar unit) + ONE 32-bit per-lane offset per array: per-element 64-bit
+    // address arithmetic in vector registers pushed the epilogue into spills
+    auto direct = [&](auto kind_c) __attribute__((always_inline)) {
       constexpr int KIND = decltype(kind_c)::value;
-      constexpr bool BIAS = KIND == K_PLAIN || KIND == K_GELU, SUMS = KIND == K_DGELU;
-      f32x4v cs[4], bias4[4];
+      const int colw = n0 + wc * 64 + 4 * g;
+      const int rowl = m0 + wr * 128 + l15;
+      const unsigned vo32 = (unsigned)rowl * (unsigned)ldc32 * 4u + (unsigned)colw * 4u;
+      const long rs32 = (long)ldc32 * 64;  // bytes per 16 rows
+      f32x4v bias4[4];
 #pragma unroll
-      for (int J = 0; J < 4; ++J) {
-        cs[J] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        bias4[J] = (BIAS && p.bias) ? *reinterpret_cast<const f32x4v*>(p.bias + colw + 16 * J) : f32x4v{0.f, 0.f, 0.f, 0.f};
-      }
-      constexpr int NB = KIND == K_ACC ? 2 : 4;  // 16-row blocks per batch of loads: 32 registers in flight either way
+      for (int J = 0; J < 4; ++J)
+        bias4[J] = (KIND == K_PLAIN && p.bias) ? *reinterpret_cast<const f32x4v*>(p.bias + colw + 16 * J) : f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int hI = 0; hI < 8 / NB; ++hI) {
-        bf16x4v pre[NB][4];
-        f32x4v old[NB][4];
-        if (KIND == K_DGELU) {
-#pragma unroll
-          for (int i = 0; i < NB; ++i)
-#pragma unroll
-            for (int J = 0; J < 4; ++J)
-              pre[i][J] = *reinterpret_cast<const bf16x4v*>(auxb + (NB * hI + i) * rsax + 32 * J + voax);
-        }
+      for (int hI = 0; hI < 4; ++hI) {
+        f32x4v old[2][4];
         if (KIND == K_ACC) {
 #pragma unroll
-          for (int i = 0; i < NB; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int J = 0; J < 4; ++J)
-              old[i][J] = *reinterpret_cast<const f32x4v*>(Cb + (NB * hI + i) * rs32 + 64 * J + vo32);
+            for (int J = 0; J < 4; ++J) old[i][J] = *reinterpret_cast<const f32x4v*>(Cb + (2 * hI + i) * rs32 + 64 * J + vo32);
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-          const int I = NB * hI + i;
+        for (int i = 0; i < 2; ++i) {
+          const int I = 2 * hI + i;
 #pragma unroll
           for (int J = 0; J < 4; ++J) {
             f32x4v v = acc[I][J];
-            if (BIAS) v += bias4[J];
-            if (KIND == K_GELU) {
-              bf16x4v pr;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) pr[e] = (__bf16)v[e];
-              *reinterpret_cast<bf16x4v*>(auxb + I * rsax + 32 * J + voax) = pr;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = gelu_erf((float)pr[e]);  // of the SAVED (rounded) pre-activation: fwd/bwd consistent
-            } else if (KIND == K_DGELU) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] *= gelu_erf_grad((float)pre[i][J][e]);
-            } else if (KIND == K_ACC) {
-              v += old[i][J];
-            }
-            if (Cb) *reinterpret_cast<f32x4v*>(Cb + I * rs32 + 64 * J + vo32) = v;
-            if (C16b) {
-              bf16x4v o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-              *reinterpret_cast<bf16x4v*>(C16b + I * rs16 + 32 * J + vo16) = o;
-            }
-            if (SUMS) cs[J] += v;
+            if (KIND == K_PLAIN) v += bias4[J];
+            if (KIND == K_ACC) v += old[i][J];
+            *reinterpret_cast<f32x4v*>(Cb + I * rs32 + 64 * J + vo32) = v;
           }
-        }
-      }
-      if (SUMS && p.colpart) {  // column sums of this wave's 128 rows: over the 8 row blocks (above), then over the 16 row lanes
-#pragma unroll
-        for (int J = 0; J < 4; ++J) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float sum = cs[J][e];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-            cs[J][e] = sum;
-          }
-          if (l15 == 0) *reinterpret_cast<f32x4v*>(p.colpart + (long)(m0 / 128 + wr) * p.N + colw + 16 * J) = cs[J];
         }
       }
     };
-    if (raw) body(std::integral_constant<int, K_RAW>{});
-    else if (p.epi == EPI_GELU) body(std::integral_constant<int, K_GELU>{});
-    else if (p.epi == EPI_DGELU) body(std::integral_constant<int, K_DGELU>{});
-    else if (p.accumulate) body(std::integral_constant<int, K_ACC>{});
-    else body(std::integral_constant<int, K_PLAIN>{});
+    auto staged = [&](auto kind_c) __attribute__((always_inline)) {
+      constexpr int KIND = decltype(kind_c)::value;
+      constexpr bool BIAS = KIND == K_PLAIN || KIND == K_GELU, SUMS = KIND == K_DGELU;
+      P256_BAR();  // every wave has read its last operand fragments: the tile buffers become staging space
+      unsigned char* const stg = smem_b + wave * 16384;
+      const int rl = lane >> 4, cl = lane & 15;
+      const unsigned wr32 = (unsigned)(l15 * 256 + (((l15 & 12) | (g ^ (l15 & 3))) << 4));  // MFMA layout: block (i, J) at i*4096 + (wr32 ^ (J << 6))
+      const unsigned rd32 = (unsigned)(rl * 256 + ((cl ^ rl) << 4));                        // row layout: step s at s*1024 + (rd32 ^ ((s & 3) << 6))
+      const int colw = n0 + wc * 64 + 4 * cl;
+      const int rowl = m0 + wr * 128 + rl;
+      const unsigned vo32 = (unsigned)rowl * (unsigned)ldc32 * 4u + (unsigned)colw * 4u;
+      const unsigned vo16 = (unsigned)rowl * (unsigned)p.ldc16 * 2u + (unsigned)colw * 2u;
+      const unsigned voax = (unsigned)rowl * (unsigned)p.ldaux * 2u + (unsigned)colw * 2u;
+      const long rs32 = (long)ldc32 * 16, rs16 = (long)p.ldc16 * 8, rsax = (long)p.ldaux * 8;  // bytes per 4 rows
+      f32x4v cs = f32x4v{0.f, 0.f, 0.f, 0.f};
+      const f32x4v bias4 = (BIAS && p.bias) ? *reinterpret_cast<const f32x4v*>(p.bias + colw) : f32x4v{0.f, 0.f, 0.f, 0.f};
+      // GELU': the saved pre-activations of a batch of 8 steps are requested one batch AHEAD (behind the LDS round trip and
+      // the arithmetic of the batch before), never waited for right after their issue
+      bf16x4v pre[2][8];
+      if (KIND == K_DGELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pre[0][e] = *reinterpret_cast<const bf16x4v*>(auxb + e * rsax + voax);
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int J = 0; J < 4; ++J) *reinterpret_cast<f32x4v*>(stg + i * 4096 + (wr32 ^ (unsigned)(J << 6))) = acc[4 * h + i][J];
+        P256_LGKM0();
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          const int bt = h * 2 + sb;  // batch 0..3
+          f32x4v v[8];
+          if (KIND == K_DGELU && bt < 3) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pre[(bt + 1) & 1][e] = *reinterpret_cast<const bf16x4v*>(auxb + ((bt + 1) * 8 + e) * rsax + voax);
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = *reinterpret_cast<const f32x4v*>(stg + (sb * 8 + e) * 1024 + (rd32 ^ (unsigned)((e & 3) << 6)));
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int s = bt * 8 + e;
+            f32x4v x = v[e];
+            if (BIAS) x += bias4;
+            if (KIND == K_GELU) {
+              bf16x4v pr;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) pr[q] = (__bf16)x[q];
+              *reinterpret_cast<bf16x4v*>(auxb + s * rsax + voax) = pr;
+              // of the SAVED (rounded) pre-activation: fwd/bwd consistent
+              const f32x2 lo = gelu_fast2(f32x2{(float)pr[0], (float)pr[1]}), hi = gelu_fast2(f32x2{(float)pr[2], (float)pr[3]});
+              x = f32x4v{lo.x, lo.y, hi.x, hi.y};
+            } else if (KIND == K_DGELU) {
+              const bf16x4v pq = pre[bt & 1][e];
+              const f32x2 lo = gelu_fast_grad2(f32x2{(float)pq[0], (float)pq[1]});
+              const f32x2 hi = gelu_fast_grad2(f32x2{(float)pq[2], (float)pq[3]});
+              x *= f32x4v{lo.x, lo.y, hi.x, hi.y};
+            }
+            if (Cb) *reinterpret_cast<f32x4v*>(Cb + s * rs32 + vo32) = x;
+            if (C16b) {
+              bf16x4v o;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = (__bf16)x[q];
+              *reinterpret_cast<bf16x4v*>(C16b + s * rs16 + vo16) = o;
+            }
+            if (SUMS) cs += x;
+          }
+        }
+        P256_LGKM0();  // (the next pass overwrites the image)
+      }
+      if (SUMS && p.colpart) {  // column sums of this wave's 128 rows: over the 32 steps (above), then over the four row lanes
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float sum = cs[q];
+          sum += __shfl_xor(sum, 16, 64);
+          sum += __shfl_xor(sum, 32, 64);
+          cs[q] = sum;
+        }
+        if (rl == 0) *reinterpret_cast<f32x4v*>(p.colpart + (long)(m0 / 128 + wr) * p.N + colw) = cs;
+      }
+    };
+    if (raw) direct(std::integral_constant<int, K_RAW>{});
+    else if (p.epi == EPI_GELU) staged(std::integral_constant<int, K_GELU>{});
+    else if (p.epi == EPI_DGELU) staged(std::integral_constant<int, K_DGELU>{});
+    else if (p.accumulate) direct(std::integral_constant<int, K_ACC>{});
+    else if (C16b) staged(std::integral_constant<int, K_PLAIN>{});
+    else direct(std::integral_constant<int, K_PLAIN>{});
   };
 
   if (!SK) {  // one tile (and one split of its reduction) per block
@@ -523,7 +569,7 @@ static int p256_check(const GemmArgsX& a) {
   // the epilogue bodies of the kernel cover the combinations the path uses
   if (a.bias && (a.epi == EPI_DGELU || a.accumulate)) return MTVAF_ERR_ARG;
   if (a.colpart && a.epi != EPI_DGELU) return MTVAF_ERR_ARG;
-  if (a.accumulate && a.epi != EPI_NONE) return MTVAF_ERR_ARG;
+  if (a.accumulate && (a.epi != EPI_NONE || a.C16 || !a.C32)) return MTVAF_ERR_ARG;
   return MTVAF_OK;
 }
 

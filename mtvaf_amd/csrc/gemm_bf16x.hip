@@ -258,11 +258,19 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
           for (int t = 0; t < 8; ++t) pre[t] = (__bf16)v[t];
           *reinterpret_cast<bf16x8*>(p.aux16 + row * p.ldaux + col) = pre;
 #pragma unroll
-          for (int t = 0; t < 8; ++t) v[t] = gelu_erf((float)pre[t]);  // of the SAVED (rounded) pre-activation: fwd/bwd consistent
+          for (int t = 0; t < 8; t += 2) {  // of the SAVED (rounded) pre-activation: fwd/bwd consistent
+            const f32x2 y = gelu_fast2(f32x2{(float)pre[t], (float)pre[t + 1]});
+            v[t] = y.x;
+            v[t + 1] = y.y;
+          }
         } else if (p.epi == EPI_DGELU) {
           const bf16x8 pre = *reinterpret_cast<const bf16x8*>(p.aux16 + row * p.ldaux + col);
 #pragma unroll
-          for (int t = 0; t < 8; ++t) v[t] *= gelu_erf_grad((float)pre[t]);
+          for (int t = 0; t < 8; t += 2) {
+            const f32x2 y = gelu_fast_grad2(f32x2{(float)pre[t], (float)pre[t + 1]});
+            v[t] *= y.x;
+            v[t + 1] *= y.y;
+          }
         }
         if (p.accumulate) {
           const f32x4 c0 = *reinterpret_cast<const f32x4*>(C + row * p.ldc32 + col), c1 = *reinterpret_cast<const f32x4*>(C + row * p.ldc32 + col + 4);
@@ -502,7 +510,7 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
     // 256 tiles (measured, tools/p256_bench.py): it wins once a forward / dX product has two rounds of tiles (M = 65536:
     // 0.78-1.19 PFLOP/s against 0.55-0.86), and on the weight-gradient products (long reductions over the tokens, few
     // output tiles) once tiles x splits fill the chip with at least 12 k-tiles per split
-    const bool p256_epi = !(bias && (epi == EPI_DGELU || accumulate)) && !(colpart && epi != EPI_DGELU) && !(accumulate && epi != EPI_NONE) &&
+    const bool p256_epi = !(bias && (epi == EPI_DGELU || accumulate)) && !(colpart && epi != EPI_DGELU) && !(accumulate && (epi != EPI_NONE || C16)) &&
                           !(klist && kcnt);
     if (canp256 && p256_epi) {
       const long t256 = (long)(M / 256) * (N / 256);
@@ -539,7 +547,7 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
     if (tile == 6 && !have) return MTVAF_ERR_WORKSPACE;
     if (have) p256_plan(tiles, KT, blocks, &S);
     if (have && (tile == 6 || S > 1)) {
-      GemmArgsX a;
+      GemmArgsX a = {};
       a.klist = a.kcnt = nullptr;
       a.A = static_cast<const __bf16*>(A); a.B = static_cast<const __bf16*>(B);
       a.C32 = C32; a.C16 = static_cast<__bf16*>(C16); a.bias = bias; a.aux16 = static_cast<__bf16*>(aux16); a.colpart = colpart;
@@ -560,7 +568,7 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
   }
   if (!split_ok) splits = 1;
   while (splits > 1 && ((size_t)splits * M * N * sizeof(float) > workspace_bytes || (K / 64) / splits < (bn == 256 ? 1 : 4))) --splits;
-  GemmArgsX a;
+  GemmArgsX a = {};
   a.klist = (klist && kcnt && layout_a == 1 && layout_b == 1) ? klist : nullptr;
   a.kcnt = a.klist ? kcnt : nullptr;
   a.A = static_cast<const __bf16*>(A);
