@@ -271,6 +271,18 @@ int mtvaf_gemm_bf16x_ktiles(int layout_a, int layout_b, const void* A, int lda, 
                             int accumulate, float* colpart, int allow_split, void* workspace, size_t workspace_bytes, int tile,
                             int splits, int stages, const int* klist, const int* kcnt, mtvaf_stream_t stream);
 int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int accumulate, mtvaf_stream_t stream);
+/* mtvaf_gemm_f32 computed on the bf16 matrix pipe: each fp32 operand value is split into three bf16 planes while its tile
+ * is staged into the LDS and a product is the six significant bf16 MFMA products, accumulated in fp32 (the dropped terms are
+ * below 2^-26 |a||b|: accuracy of the fp32 pipe; operands and results stay fp32 in memory).  Same arguments as
+ * mtvaf_gemm_f32 (modeling_bert.py:266, 283-284, 353, 420-421, 433 and their autograd backward); shapes it does not cover
+ * (not whole 64x64 tiles, K % 32 != 0, unaligned operands) run the fp32 pipe.  mtvaf_f32_split(1 / 0): mtvaf_gemm_f32 and
+ * mtvaf_gemm_f32_ktiles use it everywhere they can / never (default: MTVAF_F32_SPLIT, else 0); -1 queries. */
+int mtvaf_gemm_f32x3(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                     int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                     int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                     mtvaf_stream_t stream);
+int mtvaf_f32_split(int on);
+
 /* The (up to four) weight-gradient products of one encoder layer in fp32, dW_i[M_i,N_i] = A_i^T . B_i with A_i [K,M_i], B_i [K,N_i]
  * row-major, as ONE launch of the 128x96 LDS-DMA kernel (autograd backward of modeling_bert.py:266, 283-284, 353, 420-421, 433);
  * klist / kcnt as mtvaf_gemm_f32_ktiles (NULL: the whole reduction); deterministic split-K through per-product slabs in

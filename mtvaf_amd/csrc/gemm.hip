@@ -704,6 +704,7 @@ static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, int mode, hi
 }
 
 int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, bool aligned, hipStream_t st);  // gemm_bf16.hip
+int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st);                // gemm_f32x3.hip
 
 // ordered split-K slab reduction (+ bias / tanh / dtanh epilogue), shared with gemm_bf16kc.hip
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
@@ -773,7 +774,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
   for (int c = 0; c < kNumCfgs; ++c) {
     if (eff[c] <= 0.0) continue;
     if (compute == 1 && !(c == 6 || c == 5 || c == 3)) continue;  // bf16 kernels exist for 128x96, 128x128, 64x64
-    const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute == 1 ? 32 : kCfgs[c].bk;
+    if (compute == 2 && !((c == 5 && M % 128 == 0 && N % 128 == 0) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
+    const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute != 0 ? 32 : kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
     const int max_s = allow_split ? 16 : 1;
     for (int s = 1; s <= max_s; ++s) {
@@ -878,6 +880,13 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     if (!ok) compute = 0;
     if (compute == 1 && !(cfg == 6 || cfg == 5 || cfg == 3)) cfg = -1;
   }
+  if (compute == 2) {
+    // the split kernels take whole 64x64 tiles of k-aligned, vector-loadable operands; anything else runs the fp32 pipe
+    const bool ok = (K % 32 == 0) && (M % 64 == 0) && (N % 64 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
+                    (((uintptr_t)B & 15) == 0) && !(layout_a == 1 && layout_b == 0);
+    if (!ok) compute = 0;
+    if (compute == 2 && !((cfg == 5 && M % 128 == 0 && N % 128 == 0) || cfg == 3)) cfg = -1;
+  }
   if (!A || !B || !C) return MTVAF_ERR_ARG;
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
   if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1) return MTVAF_ERR_ARG;
@@ -898,7 +907,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   a.epi = epi; a.accumulate = accumulate;
   a.a_vec = (lda % 4 == 0) && (((uintptr_t)A & 15) == 0);
   a.b_vec = (ldb % 4 == 0) && (((uintptr_t)B & 15) == 0);
-  const int bk = compute == 1 ? 32 : kCfgs[cfg].bk;
+  const int bk = compute != 0 ? 32 : kCfgs[cfg].bk;
   int kc = (int)cdiv(cdiv(K, splits), bk) * bk;
   splits = (int)cdiv(K, kc);
   a.k_chunk = kc;
@@ -918,14 +927,14 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   a.wide = aligned && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) &&
            (!aux || ((ldaux % 4 == 0) && (((uintptr_t)aux & 15) == 0))) && (!bias || (((uintptr_t)bias & 15) == 0)) &&
            (a.slab_stride % 4 == 0);
-  if (cfg >= kFirstDma && !(aligned && !(layout_a == 1 && layout_b == 0))) {
+  if (compute == 0 && cfg >= kFirstDma && !(aligned && !(layout_a == 1 && layout_b == 0))) {
     if (cfg_forced) return MTVAF_ERR_SHAPE;
     static const int staged_twin[9] = {6, 5, 8, 6, 5, 4, 4, 3, 3};  // same tile, register-staged kernel (handles any alignment)
     cfg = staged_twin[cfg - kFirstDma];
   }
   // the k-tile list only reaches the LDS-DMA kernels (32-row k-tiles of k-major operands); any other plan reduces over
   // the whole range, which gives the same result (the skipped k-tiles are exact zeros by the caller's contract)
-  if (klist && kcnt && compute == 0 && cfg >= kFirstDma && layout_a == 1 && layout_b == 1 && K % 32 == 0) {
+  if (klist && kcnt && ((compute == 0 && cfg >= kFirstDma) || compute == 2) && layout_a == 1 && layout_b == 1 && K % 32 == 0) {
     a.klist = klist;
     a.kcnt = kcnt;
   }
@@ -933,13 +942,19 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if (g_prof && g_prof_n < g_prof_cap) {
     pr = &g_prof[g_prof_n++];
     // (key[3]: alignment mode 0..2, +8 when the launch walks a k-tile list: its flops are 2 M N 32 (*kcnt), not 2 M N K)
-    const int key[8] = {compute == 1 ? 100 + cfg : cfg, layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
+    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
     hipEventRecord(pr->e0, stream);
   }
   int rc;
   if (compute == 1) {
     rc = launch_gemm_bf16(cfg == 6 ? 0 : (cfg == 5 ? 1 : 2), a, layout_a, layout_b, grid, aligned, stream);
+  } else if (compute == 2) {
+    // 128x128: two LDS buffers + one block per CU when the launch gives a CU one block anyway (<= 256 tiles of a short
+    // reduction) and for the weight gradients; otherwise one buffer and two co-resident blocks (measured: tools/f32x3_bench.py)
+    const long nblk = (long)grid.x * grid.z;
+    const bool two_buf = (layout_a == 1) || (nblk <= 256 && kc <= 1024);
+    rc = launch_gemm_f32x3(cfg == 5 ? (two_buf ? 0 : 1) : 2, a, layout_a, layout_b, grid, stream);
   } else
   switch (cfg) {
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;
@@ -968,11 +983,33 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   return MTVAF_OK;
 }
 
+// fp32 products on the bf16 matrix pipe by three-way operand splitting (gemm_f32x3.hip: six bf16 MFMA products per fp32
+// product, fp32 accumulation, fp32 operands and results in memory; accuracy of the fp32 pipe).  mtvaf_f32_split(1 / 0) makes
+// mtvaf_gemm_f32 / mtvaf_gemm_f32_ktiles use it for every shape it covers (whole 64x64 tiles, K % 32 == 0, aligned
+// operands) / never; (-1) queries.  Default: MTVAF_F32_SPLIT, else off.
+static int g_f32_split = -1;
+int mtvaf_f32_split(int on) {
+  if (on >= 0) g_f32_split = on ? 1 : 0;
+  if (g_f32_split < 0) {
+    const char* e = getenv("MTVAF_F32_SPLIT");
+    g_f32_split = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return g_f32_split;
+}
+
+int mtvaf_gemm_f32x3(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                     int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                     int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                     hipStream_t stream) {
+  return gemm_dispatch(2, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
+                       allow_split, workspace, workspace_bytes, cfg, splits, stream);
+}
+
 int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                    int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
                    int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
                    hipStream_t stream) {
-  return gemm_dispatch(0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
+  return gemm_dispatch(mtvaf_f32_split(-1) ? 2 : 0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
                        allow_split, workspace, workspace_bytes, cfg, splits, stream);
 }
 
@@ -985,7 +1022,7 @@ int mtvaf_gemm_f32_ktiles(int layout_a, int layout_b, const float* A, int lda, c
                           int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
                           int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits, const int* klist,
                           const int* kcnt, hipStream_t stream) {
-  return gemm_dispatch(0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
+  return gemm_dispatch(mtvaf_f32_split(-1) ? 2 : 0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
                        allow_split, workspace, workspace_bytes, cfg, splits, stream, klist, kcnt);
 }
 

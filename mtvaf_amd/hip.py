@@ -32,6 +32,8 @@ _SIGS = {
     "mtvaf_prof_stop": (c_int, [P, P, P, I]),
     "mtvaf_gemm_f32_plan": (c_int, [I, I, I, I, I, I, I, P, P]),
     "mtvaf_gemm_f32": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
+    "mtvaf_gemm_f32x3": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
+    "mtvaf_f32_split": (c_int, [I]),
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -279,7 +281,8 @@ def gemm(a: torch.Tensor, layout_a: int, b: torch.Tensor, layout_b: int, out: to
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    fn = lib().mtvaf_gemm_bf16 if (compute or COMPUTE) == "bf16" else lib().mtvaf_gemm_f32
+    mode = compute or COMPUTE
+    fn = lib().mtvaf_gemm_bf16 if mode == "bf16" else (lib().mtvaf_gemm_f32x3 if mode == "fp32x3" else lib().mtvaf_gemm_f32)
     _ck(fn(layout_a, layout_b, _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, _p(bias), epi, _p(aux),
            aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws), wsb, cfg, splits, _st()),
         "mtvaf_gemm")
