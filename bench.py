@@ -30,7 +30,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0,  # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+               "fp32x3": 2500.0 / 6}  # fp32 products as six bf16 MFMA products (csrc/gemm_f32x3.hip): fp32-equivalent peak
 LABELS = ["O", "B-NEU", "I-NEU", "B-POS", "I-POS", "B-NEG", "I-NEG", "X", "[CLS]", "[SEP]"]
 
 
@@ -143,7 +144,7 @@ def pmc_traffic(symbol, dtype="fp32", batch=32, seq=128):
 
 
 
-def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3):
+def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3, peak_key=None):
     """Roofline object of the dominant GEMM kernel of `eager_step`, measured live: HIP events that the library records on the
     launch stream directly around each main GEMM kernel (mtvaf_prof_start/stop) in `nprof` further steps, with the
     weight-gradient side stream serialised so that every kernel is timed alone."""
@@ -182,16 +183,17 @@ def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3):
     avg_us = 1e3 * ms / cnt
     ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
     # (no PMC passes were collected for the padding-free workload: its row counts differ from the committed files')
-    traffic, traffic_src = (None, None) if unpad else pmc_traffic(sym, dtype, B, S)
+    traffic, traffic_src = (None, None) if (unpad or peak_key) else pmc_traffic(sym, dtype, B, S)
+    peak = PEAK_TFLOPS[peak_key or dtype]
     return {
-        "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-        "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": sym,
+        "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": sym,
         "avg_launch_us": round(avg_us, 1), "launches_per_step": cnt // nprof,
         "measured": f"HIP events around each main GEMM kernel, {nprof} steps with the weight-gradient side stream serialised "
                     "(MTVAF_DW_STREAM=0) so that every kernel is timed alone",
         "flops_per_launch_avg": fl / cnt,
         "all_gemm_kernels": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                             "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_TFLOPS[dtype], 4),
+                             "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
                              "executed_tflop_per_step": round(tot_fl / 1e12, 4)},
         "per_kernel": [{"kernel": s_, "launches_per_step": c_ // nprof, "avg_us": round(1e3 * m_ / c_, 1),
                         "tflops": round(f_ / (m_ * 1e-3) / 1e12, 1)}
@@ -202,13 +204,15 @@ def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3):
                       for k_, (m_, c_) in sorted(by_shape.items(), key=lambda kv: -kv[1][0])[:12]]}
 
 
-def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3):
+def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3, split=False):
     """One of the other BASELINE configurations measured in the same process, AFTER the headline's timed region (the
     headline's value / config / dtype are untouched): the same step (forward incl. Viterbi + backward + AdamW overlapped
     with the backward pass), `steps` timed steps bracketed by synchronisation, its own roofline object."""
     from mtvaf_amd import hip
     from mtvaf_amd.optim import AdamW
     hip.set_compute_dtype(dtype)
+    split_was = hip.f32_split()
+    hip.f32_split(split)
     try:
         model, cfg = build_model(device, arch, S)
         model.train()
@@ -244,10 +248,18 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3)
                                 "(tests/test_configs_gpu.py; north_star's 1e-3 / bit-exact tags hold in fp32 mode only)")
         if hip.streamk_errors():
             raise RuntimeError("a stream-K launch reported a timed-out wait")
-        res["roofline"] = roofline_pass(step, mask, B, S, dtype)
+        if split:
+            res["dtype"] = ("fp32 operands / results / accumulation; every fp32 product formed on the bf16 matrix pipe as the six "
+                            "significant partial products of three-way bf16-split operands (each exact in fp32)")
+            res["accuracy"] = ("error of the split GEMM against the fp64 product is at or below the fp32 MFMA pipe's on the same "
+                               "inputs (tests/test_ops_gpu.py::test_gemm_f32_split_accuracy); every fp32 parity test (1e-3 vs the "
+                               "oracle, bit-exact tags, reference goldens) passes in this mode (MTVAF_F32_SPLIT=1)")
+            res["mfma_fraction_of_step"] = round(v * 3 * f_fwd(S, P) / (PEAK_TFLOPS["fp32x3"] * 1e12), 4)
+        res["roofline"] = roofline_pass(step, mask, B, S, dtype, peak_key="fp32x3" if split else None)
         return res
     finally:
         hip.set_compute_dtype("fp32")
+        hip.f32_split(split_was)
 
 
 def log(msg):
@@ -588,10 +600,10 @@ def main():
         step = eager_step = None  # noqa: F841
         torch.cuda.empty_cache()
         res["secondary"] = {}
-        for key, (dt_, arch_, b_, s_, aux_) in {"c1_fp32": ("fp32", "bert", 4, 64, 3), "c3_bf16": ("bf16", "roberta", 32, 128, 8),
-                                                "c4_bf16": ("bf16", "bert", 64, 128, 8)}.items():
+        for key, (dt_, arch_, b_, s_, aux_) in {"c2_fp32_split": ("fp32", "bert", 32, 128, 8), "c1_fp32": ("fp32", "bert", 4, 64, 3),
+                                                "c3_bf16": ("bf16", "roberta", 32, 128, 8), "c4_bf16": ("bf16", "bert", 64, 128, 8)}.items():
             try:
-                res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_)
+                res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_, split=key.endswith("_split"))
             except Exception as e:  # a secondary figure must never cost the headline line
                 res["secondary"][key] = {"error": repr(e)}
             torch.cuda.empty_cache()

@@ -229,6 +229,9 @@ def kernel_symbol(cfg, la, lb, fast):
             return f"gemm_bf16_p256_kernel<{b(c & 4)}, {b(c & 8)}, {b(c & 128)}>"
         t = "256, 192, 4, 2" if c & 32 else ("256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"))
         return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}, {b(klist)}>"
+    if cfg >= 200:  # gemm_f32x3_kernel<BM, BN, WM, WN, A_KM, B_KM, KLIST, TWO>  (+50: the two-buffer form)
+        d = (64, 64, 2, 2) if cfg % 50 == 3 else (128, 128, 2, 2)
+        return f"gemm_f32x3_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(klist)}, {b(cfg >= 250)}>"
     if cfg >= 100:
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
         return f"gemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(fast == 2)}>"
@@ -255,6 +258,14 @@ EPI_NONE, EPI_GELU, EPI_TANH, EPI_DGELU, EPI_DTANH = 0, 1, 2, 3, 4
 # GEMM arithmetic: "fp32" (v_mfma_f32_32x32x2_f32) or "bf16" (operands rounded to bf16 while staged, fp32
 # accumulation; buffers stay fp32).  Set per call or process-wide through set_compute_dtype().
 COMPUTE = "fp32"
+
+
+def f32_split(on=None) -> bool:
+    """fp32-mode GEMMs on the bf16 matrix pipe by three-way operand splitting (csrc/gemm_f32x3.hip: six exact bf16 partial
+    products per fp32 product, fp32 accumulate; operands and results stay fp32).  on = True / False switches every
+    mtvaf_gemm_f32 / _ktiles call of the process (Python orchestration and native executor alike); None queries.
+    Default: MTVAF_F32_SPLIT, else off."""
+    return bool(lib().mtvaf_f32_split(-1 if on is None else int(bool(on))))
 
 
 def set_compute_dtype(dtype: str):

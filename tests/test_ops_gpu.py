@@ -1075,3 +1075,96 @@ def test_gemm_f32_dw_group(hip, T):
         hip.gemm_f32_dw_group([(d[0][:, :64], d[3], torch.empty(64, H, device=DEV))], T)  # M % 128 != 0
     with pytest.raises(RuntimeError):
         hip.gemm_f32_dw_group([(d[0], d[3][:, :100], torch.empty(H, 100, device=DEV))], T)  # N % 96 != 0
+
+
+def _x3_operands(M, N, K, la, lb, seed, spread=0):
+    """fp32 operands in the layouts (la, lb); spread > 0 scales rows of A / columns of B by 2^[-spread, spread] (every bf16 plane
+    of the split is exercised across the exponent range); -> (a, b, fp64 product, fp64 |A|.|B|)"""
+    g = torch.Generator().manual_seed(seed)
+    A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    if spread:
+        A = A * torch.exp2(torch.randint(-spread, spread + 1, (M, 1), generator=g).float())
+        B = B * torch.exp2(torch.randint(-spread, spread + 1, (1, N), generator=g).float())
+    a = (A if la == 0 else A.t().contiguous()).to(DEV)
+    b = (B.t().contiguous() if lb == 0 else B).to(DEV)
+    return a, b, A.double() @ B.double(), A.double().abs() @ B.double().abs()
+
+
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K,spread", [(512, 768, 768, 0), (256, 384, 3072, 12), (128, 128, 32, 30), (192, 320, 96, 6)])
+def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread):
+    """fp32 GEMM by three-way bf16 operand splitting (mtvaf_gemm_f32x3, csrc/gemm_f32x3.hip) is an fp32 GEMM: against the fp64
+    product its error is bounded element-wise by a few fp32 roundings of |A|.|B| (the six partial products are exact, the
+    dropped terms are below 2^-26 |a||b|) and is not larger than the fp32 MFMA pipe's on the same operands -- all three
+    operand layouts, both tile sizes (128x128, 64x64), operands spread over 2^+-30."""
+    a, b, ref, mag = _x3_operands(M, N, K, la, lb, seed=M + N + K + 7 * la + lb, spread=spread)
+    o_nat, o_spl = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(a, la, b, lb, o_nat, M, N, K, compute="fp32")
+    hip.gemm(a, la, b, lb, o_spl, M, N, K, compute="fp32x3")
+    e_nat = (o_nat.double().cpu() - ref).abs() / mag
+    e_spl = (o_spl.double().cpu() - ref).abs() / mag
+    # element-wise bound: accumulation of K terms in fp32 (worst case K 2^-24, in practice ~sqrt(K)) + the 2^-26 split remainder
+    assert float(e_spl.max()) <= 2.0 ** -24 * (4 + K ** 0.5), (float(e_spl.max()), float(e_nat.max()))
+    assert float(e_spl.max()) <= 1.25 * float(e_nat.max()) + 2.0 ** -25, (float(e_spl.max()), float(e_nat.max()))
+    assert float(e_spl.pow(2).mean().sqrt()) <= 1.1 * float(e_nat.pow(2).mean().sqrt()) + 2.0 ** -27
+
+
+def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
+    """The split kernel behind the fp32 entry points: every epilogue of the path (bias, bias + GELU with the saved
+    pre-activation, GELU', tanh, accumulate), forced split-K, a k-tile list (weight gradient: dY exactly zero outside the listed
+    32-row tiles), shapes it does not cover (run the fp32 pipe: same result), and the process-wide switch."""
+    M, N, K = 256, 384, 512
+    x, w, bias = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2).to(DEV), rnd(N, seed=3).to(DEV)
+    ref = x.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, compute="fp32x3")
+    close(out, ref, rtol=2e-6, name="bias")
+    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, epi=hip.EPI_GELU, aux=aux, compute="fp32x3")
+    close(aux, ref, rtol=2e-6, name="saved pre-activation")
+    close(out, torch.nn.functional.gelu(ref), rtol=2e-6, name="GELU")
+    dy = rnd(M, N, seed=4).to(DEV)
+    wt = w.t().contiguous()  # [K, N] -> dX = dY . W with W as a KM operand: here dy [M, N] . w [N, K]
+    dx = torch.empty(M, K, device=DEV)
+    pre = rnd(M, K, seed=5).to(DEV)
+    hip.gemm(dy, 0, w, 1, dx, M, K, N, epi=hip.EPI_DGELU, aux=pre, compute="fp32x3")
+    p64 = pre.double().cpu()
+    gp = 0.5 * (1 + torch.erf(p64 / 2 ** 0.5)) + p64 * torch.exp(-p64 * p64 / 2) / (2 * torch.pi) ** 0.5
+    close(dx, (dy.double().cpu() @ w.double().cpu()) * gp, rtol=3e-6, name="GELU'")
+    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, epi=hip.EPI_TANH, compute="fp32x3")
+    close(out, torch.tanh(ref), rtol=5e-5, name="tanh")  # (|pre-activation| up to ~90: its fp32 rounding alone is 1e-5 of tanh's range)
+    acc0 = rnd(M, N, seed=6)
+    out.copy_(acc0)
+    hip.gemm(x, 0, w, 0, out, M, N, K, accumulate=True, compute="fp32x3")
+    close(out, ref - bias.double().cpu() + acc0.double(), rtol=2e-6, name="accumulate")
+    for sp in (2, 4):
+        out.fill_(float("nan"))
+        hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, allow_split=True, splits=sp, compute="fp32x3")
+        close(out, ref, rtol=2e-6, name=f"split-K {sp}")
+    del wt
+    # weight gradient over a k-tile list
+    T, NO, KI = 1024, 256, 384
+    valid = torch.ones(T, dtype=torch.bool)
+    valid[300:700] = False
+    dyw = (rnd(T, NO, seed=7) * valid[:, None]).to(DEV)
+    xw = rnd(T, KI, seed=8).to(DEV)
+    tiles = sorted(set(int(r) // 32 for r in torch.nonzero(valid).flatten()))
+    kl, kc = torch.tensor(tiles, dtype=torch.int32, device=DEV), torch.tensor([len(tiles)], dtype=torch.int32, device=DEV)
+    dw = torch.empty(NO, KI, device=DEV)
+    refw = dyw.double().cpu().t() @ xw.double().cpu()
+    was = hip.f32_split()
+    try:
+        assert hip.f32_split(True) is True
+        for sp in (-1, 1, 3):
+            dw.fill_(float("nan"))
+            hip.gemm_ktiles(dyw, xw, dw, NO, KI, T, kl, kc, splits=sp)
+            close(dw, refw, rtol=2e-6, name=f"k-tile list through the switch, splits {sp}")
+        # shapes outside the split kernels' cover run the fp32 pipe under the switch
+        xs, ws_ = rnd(100, 72, seed=9).to(DEV), rnd(50, 72, seed=10).to(DEV)
+        os_ = torch.empty(100, 50, device=DEV)
+        hip.gemm(xs, 0, ws_, 0, os_, 100, 50, 72)
+        close(os_, xs.double().cpu() @ ws_.double().cpu().t(), rtol=2e-6, name="uncovered shape")
+        hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias)
+        close(out, ref, rtol=2e-6, name="fp32 entry under the switch")
+    finally:
+        hip.f32_split(was)
+    assert hip.f32_split() == was
