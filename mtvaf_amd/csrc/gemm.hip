@@ -884,7 +884,10 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     // the split kernels take whole 64x64 tiles of k-aligned, vector-loadable operands; anything else runs the fp32 pipe
     const bool ok = (K % 32 == 0) && (M % 64 == 0) && (N % 64 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
                     (((uintptr_t)B & 15) == 0) && !(layout_a == 1 && layout_b == 0);
-    if (!ok) compute = 0;
+    // (few output tiles -- the 256-token products of BASELINE configs[0] -- leave most CUs without a block of the 128x128
+    // kernel: the fp32 pipe's 64x64 tiles are faster there, measured 4.37 vs 4.53 ms per C1 step)
+    const bool forced = cfg == 5 || cfg == 3;
+    if (!ok || (!forced && (long)(M / 128) * (N / 128) < 96)) compute = 0;
     if (compute == 2 && !((cfg == 5 && M % 128 == 0 && N % 128 == 0) || cfg == 3)) cfg = -1;
   }
   if (!A || !B || !C) return MTVAF_ERR_ARG;
@@ -945,7 +948,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if (g_prof && g_prof_n < g_prof_cap) {
     pr = &g_prof[g_prof_n++];
     // (key[3]: alignment mode 0..2, +8 when the launch walks a k-tile list: its flops are 2 M N 32 (*kcnt), not 2 M N K)
-    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + (x3_two_buf ? 50 : 0) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
+    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + ((cfg == 5 && a.wide) ? 20 : (x3_two_buf ? 50 : 0)) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
     hipEventRecord(pr->e0, stream);
   }
@@ -953,7 +956,11 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if (compute == 1) {
     rc = launch_gemm_bf16(cfg == 6 ? 0 : (cfg == 5 ? 1 : 2), a, layout_a, layout_b, grid, aligned, stream);
   } else if (compute == 2) {
-    rc = launch_gemm_f32x3(cfg == 5 ? (x3_two_buf ? 0 : 1) : 2, a, layout_a, layout_b, grid, stream);
+    // 128x128: the wave-specialised kernel (tile 4).  MTVAF_X3_TILE forces one of the earlier forms (tools/f32x3_bench.py):
+    // 0 two buffers / one block per CU, 1 one buffer / two blocks, 3 BK = 16 / three blocks
+    static const char* e = getenv("MTVAF_X3_TILE");
+    const int force = e ? atoi(e) : -1;
+    rc = launch_gemm_f32x3(cfg == 5 ? (force >= 0 ? force : (a.wide ? 4 : (x3_two_buf ? 0 : 1))) : 2, a, layout_a, layout_b, grid, stream);
   } else
   switch (cfg) {
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;

@@ -24,7 +24,6 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace x3 {
 
-constexpr int BK = 32, LDH = BK + 8;
 
 // x -> three bf16 planes (round to nearest even at every level), two values at a time: v_cvt_pk_bf16_f32, the packed pair
 // widened back by a shift / a mask, v_pk_add_f32 for the residual
@@ -33,11 +32,18 @@ __device__ __forceinline__ unsigned cvt_pk(const f32x2 v) { return __builtin_bit
 __device__ __forceinline__ f32x2 widen(const unsigned pk) {
   return f32x2{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
 }
+// (plain v_sub_f32 for the residuals: beside MFMAs a v_pk_add_f32 costs several plain instructions' issue time)
+__device__ __forceinline__ f32x2 sub2(const f32x2 a, const f32x2 b) {
+  f32x2 r;
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.x));
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+  return r;
+}
 __device__ __forceinline__ void split3_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
   h = cvt_pk(x);
-  const f32x2 r = x - widen(h);
+  const f32x2 r = sub2(x, widen(h));
   m = cvt_pk(r);
-  l = cvt_pk(r - widen(m));
+  l = cvt_pk(sub2(r, widen(m)));
 }
 __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16x4& l) {
   unsigned h0, m0, l0, h1, m1, l1;
@@ -48,31 +54,39 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16
   l = __builtin_bit_cast(bf16x4, uint2{l0, l1});
 }
 
-template <int ROWS, int NT, bool KM>
+template <int ROWS, int NT, bool KM, int BK>
 struct Stage {
-  static constexpr int NKC = (ROWS * 8) / NT;  // float4 per thread, KC
-  static constexpr int NU = (ROWS * 4) / NT;   // units per thread, KM (two float4 each)
+  static constexpr int NKC = (ROWS * (BK / 4)) / NT;  // float4 per thread, KC
+  static constexpr int NU = (ROWS * (BK / 8)) / NT;   // units per thread, KM (two float4 each)
   static constexpr int NREG = KM ? 2 * NU : NKC;
-  static_assert((ROWS * 8) % NT == 0 && (ROWS * 4) % NT == 0, "whole float4s / units per thread");
+  static_assert((ROWS * (BK / 4)) % NT == 0 && (ROWS * (BK / 8)) % NT == 0, "whole float4s / units per thread");
 };
+// KM unit u -> (k pair, first of 4 rows): 8 row groups fastest (one 128-byte line of a k-row), then the BK/2 k pairs, then
+// the next 32 rows
+template <int BK>
+__device__ __forceinline__ void km_unit(int u, int& kp, int& c4) {
+  kp = (u >> 3) & (BK / 2 - 1);
+  c4 = ((u & 7) + (u / (4 * BK)) * 8) * 4;
+}
 
-// global -> registers (whole tiles only: the launcher checks alignment).  KC: float4 idx -> (row = idx >> 3, k = (idx & 7) * 4).
-// KM: unit u -> (k pair kp = (u >> 3) & 15, 4 rows c4 = ((u & 7) + 8 (u >> 7)) * 4): two float4 (same rows at k and k + 1);
-// eight consecutive lanes fetch one whole 128-byte line of a k-row, and the transposed 4-byte LDS writes of a wave fall on
-// 32 distinct banks (2-way conflicts; with the rows fastest over all lanes they were 8-way).
-template <int ROWS, int NT, bool KM>
+// global -> registers (whole tiles only: the launcher checks alignment).  KC: float4 idx -> (row = idx / (BK/4), k = (idx %
+// (BK/4)) * 4).  KM: unit u -> (k pair kp, 4 rows c4; km_unit): two float4 (same rows at k and k + 1); eight consecutive
+// lanes fetch one whole 128-byte line of a k-row, and the transposed 4-byte LDS writes of a wave fall on 32 distinct banks
+// (2-way conflicts; with the rows fastest over all lanes they were 8-way).
+template <int ROWS, int NT, bool KM, int BK>
 __device__ __forceinline__ void g_load(f32x4* reg, const float* base, int ld, int r0, int k0, int tid) {
   if constexpr (!KM) {
 #pragma unroll
-    for (int i = 0; i < Stage<ROWS, NT, KM>::NKC; ++i) {
+    for (int i = 0; i < Stage<ROWS, NT, KM, BK>::NKC; ++i) {
       const int idx = tid + i * NT;
-      reg[i] = *reinterpret_cast<const f32x4*>(base + (long)(r0 + (idx >> 3)) * ld + k0 + (idx & 7) * 4);
+      reg[i] = *reinterpret_cast<const f32x4*>(base + (long)(r0 + idx / (BK / 4)) * ld + k0 + (idx % (BK / 4)) * 4);
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < Stage<ROWS, NT, KM>::NU; ++i) {
+    for (int i = 0; i < Stage<ROWS, NT, KM, BK>::NU; ++i) {
       const int u = tid + i * NT;
-      const int kp = (u >> 3) & 15, c4 = ((u & 7) + (u >> 7) * 8) * 4;
+      int kp, c4;
+      km_unit<BK>(u, kp, c4);
       const float* q = base + (long)(k0 + 2 * kp) * ld + r0 + c4;
       reg[2 * i] = *reinterpret_cast<const f32x4*>(q);
       reg[2 * i + 1] = *reinterpret_cast<const f32x4*>(q + ld);
@@ -101,17 +115,19 @@ __device__ __forceinline__ void convert_unit(const f32x4* reg, int unit, unsigne
     }
   }
 }
-template <int NT, bool KM, int PS>
+template <int NT, bool KM, int PS, int BK>
 __device__ __forceinline__ void put_unit(const unsigned (&w)[KM ? 12 : 6], int unit, __bf16* s, int tid) {
+  constexpr int LDH = BK + 8;
   if constexpr (!KM) {
     const int idx = tid + unit * NT;
-    __bf16* d = s + (idx >> 3) * LDH + (idx & 7) * 4;
+    __bf16* d = s + (idx / (BK / 4)) * LDH + (idx % (BK / 4)) * 4;
     *reinterpret_cast<uint2*>(d) = uint2{w[0], w[1]};
     *reinterpret_cast<uint2*>(d + PS) = uint2{w[2], w[3]};
     *reinterpret_cast<uint2*>(d + 2 * PS) = uint2{w[4], w[5]};
   } else {
     const int u = tid + unit * NT;
-    const int kp = (u >> 3) & 15, c4 = ((u & 7) + (u >> 7) * 8) * 4;
+    int kp, c4;
+    km_unit<BK>(u, kp, c4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       __bf16* d = s + (c4 + q) * LDH + 2 * kp;
@@ -126,10 +142,12 @@ __device__ __forceinline__ void put_unit(const unsigned (&w)[KM ? 12 : 6], int u
 
 // Requirements (checked by the launcher): M % BM == 0, N % BN == 0, K and every k-chunk multiples of 32, 16-byte aligned
 // operands with leading dimensions % 4 == 0.
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, bool KLIST, bool TWO>
-__global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : 2) void gemm_f32x3_kernel(GemmArgs p) {
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, bool KLIST, bool TWO, int BK>
+__global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : (BK == 16 ? 3 : 2)) void gemm_f32x3_kernel(GemmArgs p) {
   using namespace x3;
   static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
+  static_assert(BK == 16 || BK == 32, "one or two MFMA k-slices per k-tile");
+  constexpr int LDH = BK + 8;
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;  // bf16 elements per plane
@@ -150,11 +168,12 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : 2) void gemm_f32x3_kernel(Ge
   const int kend = min(p.K, kbeg + p.k_chunk);
   int nk = (kend - kbeg) / BK;
   int lbeg = 0;
+  constexpr int SUB = 32 / BK;  // k-tiles of this kernel per listed 32-row tile
   if constexpr (KLIST) {  // this split's share of the listed k-tiles (the count lives on the device)
     const int cnt = *p.kcnt;
     const int per = (cnt + (int)gridDim.z - 1) / (int)gridDim.z;
     lbeg = blockIdx.z * per;
-    nk = max(0, min(cnt - lbeg, per));
+    nk = max(0, min(cnt - lbeg, per)) * SUB;
     kbeg = 0;
   }
 
@@ -168,27 +187,28 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : 2) void gemm_f32x3_kernel(Ge
 
   // two register sets: the tile staged during step t was requested during step t-1 (a whole k-tile of matrix work between a
   // global load and its first use: requested in the step that consumes them, the loads stalled every step for their latency)
-  f32x4 ra0[Stage<BM, NT, A_KM>::NREG], rb0[Stage<BN, NT, B_KM>::NREG], ra1[Stage<BM, NT, A_KM>::NREG], rb1[Stage<BN, NT, B_KM>::NREG];
-  constexpr int UA = A_KM ? Stage<BM, NT, true>::NU : Stage<BM, NT, false>::NKC;  // staging units per thread
-  constexpr int UB = B_KM ? Stage<BN, NT, true>::NU : Stage<BN, NT, false>::NKC;
+  f32x4 ra0[Stage<BM, NT, A_KM, BK>::NREG], rb0[Stage<BN, NT, B_KM, BK>::NREG], ra1[TWO ? Stage<BM, NT, A_KM, BK>::NREG : 1],
+      rb1[TWO ? Stage<BN, NT, B_KM, BK>::NREG : 1];
+  constexpr int UA = A_KM ? Stage<BM, NT, true, BK>::NU : Stage<BM, NT, false, BK>::NKC;  // staging units per thread
+  constexpr int UB = B_KM ? Stage<BN, NT, true, BK>::NU : Stage<BN, NT, false, BK>::NKC;
 
   auto gload = [&](int kt, f32x4* ra, f32x4* rb) __attribute__((always_inline)) {
     int k0;
-    if constexpr (KLIST) k0 = p.klist[lbeg + kt] * BK;
+    if constexpr (KLIST) k0 = p.klist[lbeg + kt / SUB] * 32 + (kt % SUB) * BK;
     else k0 = kbeg + kt * BK;
-    g_load<BM, NT, A_KM>(ra, p.A, p.lda, m0, k0, tid);
-    g_load<BN, NT, B_KM>(rb, p.B, p.ldb, n0, k0, tid);
+    g_load<BM, NT, A_KM, BK>(ra, p.A, p.lda, m0, k0, tid);
+    g_load<BN, NT, B_KM, BK>(rb, p.B, p.ldb, n0, k0, tid);
   };
   // unit u of the UA + UB staging units of a k-tile: registers -> three planes -> LDS buffer `buf`
   auto stage = [&](int u, int buf, const f32x4* ra, const f32x4* rb) __attribute__((always_inline)) {
     if (u < UA) {
       unsigned w[A_KM ? 12 : 6];
       convert_unit<A_KM>(ra, u, w);
-      put_unit<NT, A_KM, A_SZ>(w, u, sA + buf * BUF, tid);
+      put_unit<NT, A_KM, A_SZ, BK>(w, u, sA + buf * BUF, tid);
     } else if (u < UA + UB) {
       unsigned w[B_KM ? 12 : 6];
       convert_unit<B_KM>(rb, u - UA, w);
-      put_unit<NT, B_KM, B_SZ>(w, u - UA, sB + buf * BUF, tid);
+      put_unit<NT, B_KM, B_SZ, BK>(w, u - UA, sB + buf * BUF, tid);
     }
   };
   // the 2 x 6 MFMA groups of a k-tile (TM x TN independent accumulators each); `side(g)` is issued behind group g: the
@@ -221,11 +241,12 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : 2) void gemm_f32x3_kernel(Ge
       }
     }
   };
-  constexpr int NU_ALL = UA + UB, PER = (NU_ALL + 11) / 12;  // units staged behind each of the 12 groups
+  constexpr int NGRP = 6 * (BK / 16);
+  constexpr int NU_ALL = UA + UB, PER = (NU_ALL + NGRP - 1) / NGRP;  // units staged behind each of the MFMA groups
   // step kt (not the last): compute tile kt from buffer kt & 1, stage tile kt+1 (registers `cur`) into the other buffer,
   // request tile kt+2 into the registers that held tile kt
   auto step = [&](int kt, f32x4* cura, f32x4* curb, f32x4* nxta, f32x4* nxtb) __attribute__((always_inline)) {
-    if (kt + 2 < nk) gload(kt + 2, nxta, nxtb);
+    gload(min(kt + 2, nk - 1), nxta, nxtb);  // (unconditional: see the wave-specialised kernel below)
     compute(kt & 1, [&](int g) __attribute__((always_inline)) {
 #pragma unroll
       for (int e = 0; e < PER; ++e) stage(g * PER + e, (kt & 1) ^ 1, cura, curb);
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : 2) void gemm_f32x3_kernel(Ge
   if (TWO) {
     if (nk > 0) {
       gload(0, ra0, rb0);
-      if (nk > 1) gload(1, ra1, rb1);
+      gload(min(1, nk - 1), ra1, rb1);
 #pragma unroll
       for (int u = 0; u < NU_ALL; ++u) stage(u, 0, ra0, rb0);
       __syncthreads();
@@ -274,7 +295,51 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : 2) void gemm_f32x3_kernel(Ge
   }
 
   if (p.wide) {
-    epilogue_wide<BM, BN, WM, WN, TM, TN, NT>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, wm, wn, li, h, tid);
+    // wide epilogue, one ROW OF WAVES per pass: the (BM / WM) x BN accumulator rows of the waves wm == pass are transposed
+    // through the LDS so that every lane applies the epilogue to 4 consecutive columns and stores one dwordx4 (as
+    // gemm_common.h: epilogue_wide, whose whole-tile image -- 66 KiB at 128 x 128 -- would cost the third block per CU)
+    constexpr int LDE = BN + 4, RP = BM / WM, C4 = BN / 4;
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    float* C = p.C + (long)blockIdx.z * p.slab_stride;
+    const bool split = gridDim.z > 1;
+#pragma unroll
+    for (int pass = 0; pass < WM; ++pass) {
+      __syncthreads();  // the operand tiles (pass 0) / the previous pass's image have been read
+      if (wm == pass) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              smem[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int idx = tid; idx < RP * C4; idx += NT) {
+        const int r = idx / C4, c = (idx % C4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
+        const long row = m0 + pass * RP + r;
+        const int col = n0 + c;
+        if (!split) {
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+          if (p.epi == EPI_GELU) {
+            *reinterpret_cast<f32x4*>(p.aux + row * p.ldaux + col) = v;
+            v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+          } else if (p.epi == EPI_TANH) {
+            v = f32x4{tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w)};
+          } else if (p.epi == EPI_DGELU) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+            v = f32x4{v.x * gelu_erf_grad(a.x), v.y * gelu_erf_grad(a.y), v.z * gelu_erf_grad(a.z), v.w * gelu_erf_grad(a.w)};
+          } else if (p.epi == EPI_DTANH) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+            v = v * (1.f - t * t);
+          }
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * p.ldc + col);
+        }
+        *reinterpret_cast<f32x4*>(C + row * p.ldc + col) = v;
+      }
+    }
     return;
   }
   float* C = p.C + (long)blockIdx.z * p.slab_stride;
@@ -309,15 +374,228 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : 2) void gemm_f32x3_kernel(Ge
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool TWO>
+// WAVE-SPECIALISED form (128 x 128 x 32, 512 threads, one block per CU, two LDS buffers): waves 0-3 are CONSUMERS (2 x 2
+// grid of 64 x 64 wave tiles: fragment reads + the 48 MFMAs of a k-tile, nothing else), waves 4-7 are PRODUCERS (global loads
+// two k-tiles ahead into two register sets, split, plane stores into the other buffer).  A SIMD holds one wave of each kind
+// (a workgroup's waves go to the SIMDs in cyclic order), so the producers' vector work runs on the SIMD's vector ALU while
+// its matrix core is busy with the consumer's MFMAs -- measured on the forms above (rocprofv3 --pmc, FFN-1 forward):
+// SQ_VALU_MFMA_COEXEC_CYCLES 3 % of the MFMA cycles, MFMA busy 0.41: with every wave running the same phases, the vector
+// work (4.7 VALU instructions per MFMA) and the matrix work took turns instead of overlapping, whatever the occupancy.
+// One barrier per k-tile; both kinds execute the same number of barriers.
+template <bool A_KM, bool B_KM, bool KLIST>
+__global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
+  using namespace x3;
+  static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
+  constexpr int BM = 128, BN = 128, BK = 32, LDH = BK + 8, NP = 256, NT = 512, WN = 2, TM = 2, TN = 2;
+  constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH, BUF = 3 * (A_SZ + B_SZ);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* sA = reinterpret_cast<__bf16*>(smem_raw);  // [2][ [3][A_SZ] | [3][B_SZ] ]
+  __bf16* sB = sA + 3 * A_SZ;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool consumer = wave < 4;
+  const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
+  const int li = lane & 31, h = lane >> 5;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / p.tiles_n) * BM;
+  const int n0 = (bid % p.tiles_n) * BN;
+  int kbeg = blockIdx.z * p.k_chunk;
+  const int kend = min(p.K, kbeg + p.k_chunk);
+  int nk = (kend - kbeg) / BK;
+  int lbeg = 0;
+  if constexpr (KLIST) {
+    const int cnt = *p.kcnt;
+    const int per = (cnt + (int)gridDim.z - 1) / (int)gridDim.z;
+    lbeg = blockIdx.z * per;
+    nk = max(0, min(cnt - lbeg, per));
+    kbeg = 0;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (consumer) {
+    // Fragment reads run ONE k-slice ahead of the MFMAs that consume them, across the barrier too: an in-order wave that
+    // reads the 12 fragments of a slice and then issues its 24 MFMAs pays the LDS latency per slice (measured: reads +
+    // barriers alone 48 us, MFMAs + reads 113 us on FFN-1 forward -- the matrix time ADDED to the read time).  Slice 1 of
+    // tile t is read before the barrier that ends step t and multiplied after it, while the reads of tile t+1 / slice 0
+    // are in flight (the producers refill the buffer of tile t only behind that barrier: its fragments are in registers).
+    bf16x8 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+    auto rd = [&](int buf, int ks, bf16x8 (&fa)[3][TM], bf16x8 (&fb)[3][TN]) __attribute__((always_inline)) {
+      const __bf16* a = sA + buf * BUF;
+      const __bf16* b = sB + buf * BUF;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[q][i] = *reinterpret_cast<const bf16x8*>(a + q * A_SZ + ((wm * TM + i) * 32 + li) * LDH + 16 * ks + 8 * h);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[q][j] = *reinterpret_cast<const bf16x8*>(b + q * B_SZ + ((wn * TN + j) * 32 + li) * LDH + 16 * ks + 8 * h);
+      }
+    };
+    auto mm = [&](const bf16x8 (&fa)[3][TM], const bf16x8 (&fb)[3][TN]) __attribute__((always_inline)) {
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_setprio(2);  // (the matrix stream first: measured -2..5 % against equal priorities, +3 % the other way round)
+    __syncthreads();  // k-tile 0 is in buffer 0
+    if (nk > 0) {
+      rd(0, 0, fa0, fb0);
+      for (int kt = 0; kt < nk; ++kt) {
+        rd(kt & 1, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();  // the other buffer is complete, and this one may be refilled (its last fragments are in fa1 / fb1)
+        if (kt + 1 < nk) rd((kt + 1) & 1, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+    const int ptid = tid - NP;
+    f32x4 ra0[Stage<BM, NP, A_KM, BK>::NREG], rb0[Stage<BN, NP, B_KM, BK>::NREG], ra1[Stage<BM, NP, A_KM, BK>::NREG],
+        rb1[Stage<BN, NP, B_KM, BK>::NREG];
+    constexpr int UA = A_KM ? Stage<BM, NP, true, BK>::NU : Stage<BM, NP, false, BK>::NKC;
+    constexpr int UB = B_KM ? Stage<BN, NP, true, BK>::NU : Stage<BN, NP, false, BK>::NKC;
+    auto gload = [&](int kt, f32x4* ra, f32x4* rb) __attribute__((always_inline)) {
+      int k0;
+      if constexpr (KLIST) k0 = p.klist[lbeg + kt] * BK;
+      else k0 = kbeg + kt * BK;
+      g_load<BM, NP, A_KM, BK>(ra, p.A, p.lda, m0, k0, ptid);
+      g_load<BN, NP, B_KM, BK>(rb, p.B, p.ldb, n0, k0, ptid);
+    };
+    auto stage_all = [&](int buf, const f32x4* ra, const f32x4* rb) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        unsigned w[A_KM ? 12 : 6];
+        convert_unit<A_KM>(ra, u, w);
+        put_unit<NP, A_KM, A_SZ, BK>(w, u, sA + buf * BUF, ptid);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        unsigned w[B_KM ? 12 : 6];
+        convert_unit<B_KM>(rb, u, w);
+        put_unit<NP, B_KM, B_SZ, BK>(w, u, sB + buf * BUF, ptid);
+      }
+    };
+    // during step kt (the consumers work on tile kt): stage tile kt+1 from its register set, then request tile kt+3 into it
+    // (the requests are UNCONDITIONAL -- past the end they fetch the last tile again: behind a conditional request hipcc
+    // cannot count on the newer batch being in flight and waits for vmcnt(0), i.e. for the loads issued one step ago: every
+    // step then lasted one global-load latency, ~1.6 us, whatever else overlapped)
+    auto pstep = [&](int kt, f32x4* ra, f32x4* rb) __attribute__((always_inline)) {
+      stage_all((kt + 1) & 1, ra, rb);  // (past the end: a harmless copy of the last tile into the idle buffer)
+      gload(min(kt + 3, nk - 1), ra, rb);
+      __syncthreads();
+    };
+    if (nk > 0) {
+      gload(0, ra0, rb0);
+      gload(min(1, nk - 1), ra1, rb1);
+      stage_all(0, ra0, rb0);
+      gload(min(2, nk - 1), ra0, rb0);
+    }
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {  // tile kt+1 sits in set 1, tile kt+2 in set 0
+      pstep(kt, ra1, rb1);
+      pstep(kt + 1, ra0, rb0);
+    }
+    if (kt < nk) pstep(kt, ra1, rb1);
+  }
+
+  // wide epilogue, one row of consumer waves per pass (as the kernel above), stores by all 512 threads
+  {
+    constexpr int LDE = BN + 4, RP = 64, C4 = BN / 4;
+    float* smem = reinterpret_cast<float*>(smem_raw);
+    float* C = p.C + (long)blockIdx.z * p.slab_stride;
+    const bool split = gridDim.z > 1;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass) __syncthreads();  // the previous pass's image has been read (pass 0: the k-loop ended with a barrier)
+      if (consumer && wm == pass) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              smem[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int idx = tid; idx < RP * C4; idx += NT) {
+        const int r = idx / C4, c = (idx % C4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
+        const long row = m0 + pass * RP + r;
+        const int col = n0 + c;
+        if (!split) {
+          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+          if (p.epi == EPI_GELU) {
+            *reinterpret_cast<f32x4*>(p.aux + row * p.ldaux + col) = v;
+            v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+          } else if (p.epi == EPI_TANH) {
+            v = f32x4{tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w)};
+          } else if (p.epi == EPI_DGELU) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+            v = f32x4{v.x * gelu_erf_grad(a.x), v.y * gelu_erf_grad(a.y), v.z * gelu_erf_grad(a.z), v.w * gelu_erf_grad(a.w)};
+          } else if (p.epi == EPI_DTANH) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+            v = v * (1.f - t * t);
+          }
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * p.ldc + col);
+        }
+        *reinterpret_cast<f32x4*>(C + row * p.ldc + col) = v;
+      }
+    }
+  }
+}
+
+static int launch_x3_ws(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
+  if (!a.wide) return MTVAF_ERR_ALIGN;
+  const size_t smem = (size_t)2 * 3 * 256 * 40 * sizeof(__bf16);  // 122880 (the epilogue image of 64 x 132 floats fits inside)
+#define MTVAF_X3_WS(AK, BKM, KL)                                                                                      \
+  do {                                                                                                               \
+    auto kern = gemm_f32x3_ws_kernel<AK, BKM, KL>;                                                                   \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
+      if (e != hipSuccess) return (int)e;                                                                            \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);                                                          \
+  } while (0)
+  if (la == 0 && lb == 0) MTVAF_X3_WS(false, false, false);
+  else if (la == 0 && lb == 1) MTVAF_X3_WS(false, true, false);
+  else if (la == 1 && lb == 1) { if (a.klist) MTVAF_X3_WS(true, true, true); else MTVAF_X3_WS(true, true, false); }
+  else return MTVAF_ERR_ARG;
+#undef MTVAF_X3_WS
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+template <int BM, int BN, int WM, int WN, bool TWO, int BK>
 static int launch_x3_tile(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
-  size_t smem = (size_t)(TWO ? 2 : 1) * 3 * (BM + BN) * x3::LDH * sizeof(__bf16);
-  const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
+  size_t smem = (size_t)(TWO ? 2 : 1) * 3 * (BM + BN) * (BK + 8) * sizeof(__bf16);
+  const size_t epi = (size_t)(BM / WM) * (BN + 4) * sizeof(float);
   if (epi > smem) smem = epi;
   dim3 block(WM * WN * 64);
 #define MTVAF_X3_LAUNCH(AK, BKM, KL)                                                                                  \
   do {                                                                                                               \
-    auto kern = gemm_f32x3_kernel<BM, BN, WM, WN, AK, BKM, KL, TWO>;                                                     \
+    auto kern = gemm_f32x3_kernel<BM, BN, WM, WN, AK, BKM, KL, TWO, BK>;                                             \
     static bool attr_set = false;                                                                                    \
     if (smem > 64 * 1024 && !attr_set) {                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
@@ -335,12 +613,15 @@ static int launch_x3_tile(const GemmArgs& a, int la, int lb, dim3 grid, hipStrea
   return MTVAF_OK;
 }
 
-// Called by the common launcher in gemm.hip (whole tiles only).  tile: 0 = 128x128 (2x2 waves), 1 = 64x128 (1x2), 2 = 64x64 (2x2 of 32x32).
+// Called by the common launcher in gemm.hip (whole tiles only).  tile: 0 = 128x128x32, two LDS buffers, one block per CU;
+// 1 = 128x128x32, one buffer, two blocks per CU; 3 = 128x128x16, one buffer, three blocks per CU; 2 = 64x64x32 (2x2 waves of 32x32).
 int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   switch (tile) {
-    case 0: return launch_x3_tile<128, 128, 2, 2, true>(a, la, lb, grid, st);
-    case 1: return launch_x3_tile<128, 128, 2, 2, false>(a, la, lb, grid, st);
-    default: return launch_x3_tile<64, 64, 2, 2, false>(a, la, lb, grid, st);
+    case 0: return launch_x3_tile<128, 128, 2, 2, true, 32>(a, la, lb, grid, st);
+    case 1: return launch_x3_tile<128, 128, 2, 2, false, 32>(a, la, lb, grid, st);
+    case 3: return launch_x3_tile<128, 128, 2, 2, false, 16>(a, la, lb, grid, st);
+    case 4: return launch_x3_ws(a, la, lb, grid, st);
+    default: return launch_x3_tile<64, 64, 2, 2, false, 32>(a, la, lb, grid, st);
   }
 }
 
