@@ -607,6 +607,10 @@ def main():
             except Exception as e:  # a secondary figure must never cost the headline line
                 res["secondary"][key] = {"error": repr(e)}
             torch.cuda.empty_cache()
+        sp = res["secondary"].get("c2_fp32_split", {})
+        if "value" in sp:  # the same workload as `value`, fp32 products formed on the bf16 matrix pipe (details: secondary.c2_fp32_split)
+            res["value_fp32_split"] = sp["value"]
+            res["ms_per_step_fp32_split"] = sp["ms_per_step"]
         log("secondary configurations done")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(B, S, a.aux)

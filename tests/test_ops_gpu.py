@@ -1091,7 +1091,8 @@ def _x3_operands(M, N, K, la, lb, seed, spread=0):
 
 
 @pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K,spread", [(512, 768, 768, 0), (256, 384, 3072, 12), (128, 128, 32, 30), (192, 320, 96, 6)])
+@pytest.mark.parametrize("M,N,K,spread", [(512, 768, 768, 0), (256, 384, 3072, 12), (128, 128, 32, 30), (192, 320, 96, 6),
+                                          (1024, 1536, 256, 3)])
 def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread):
     """fp32 GEMM by three-way bf16 operand splitting (mtvaf_gemm_f32x3, csrc/gemm_f32x3.hip) is an fp32 GEMM: against the fp64
     product its error is bounded element-wise by a few fp32 roundings of |A|.|B| (the six partial products are exact, the
@@ -1100,7 +1101,8 @@ def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread):
     a, b, ref, mag = _x3_operands(M, N, K, la, lb, seed=M + N + K + 7 * la + lb, spread=spread)
     o_nat, o_spl = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
     hip.gemm(a, la, b, lb, o_nat, M, N, K, compute="fp32")
-    hip.gemm(a, la, b, lb, o_spl, M, N, K, compute="fp32x3")
+    # (the tile is forced: left to itself the library keeps products of fewer than 96 tiles of 128 x 128 on the fp32 pipe)
+    hip.gemm(a, la, b, lb, o_spl, M, N, K, compute="fp32x3", cfg=5 if (M % 128 == 0 and N % 128 == 0) else 3)
     e_nat = (o_nat.double().cpu() - ref).abs() / mag
     e_spl = (o_spl.double().cpu() - ref).abs() / mag
     # element-wise bound: accumulation of K terms in fp32 (worst case K 2^-24, in practice ~sqrt(K)) + the 2^-26 split remainder
@@ -1117,28 +1119,28 @@ def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
     x, w, bias = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2).to(DEV), rnd(N, seed=3).to(DEV)
     ref = x.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
     out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, compute="fp32x3")
+    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, compute="fp32x3", cfg=5)
     close(out, ref, rtol=2e-6, name="bias")
-    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, epi=hip.EPI_GELU, aux=aux, compute="fp32x3")
+    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, epi=hip.EPI_GELU, aux=aux, compute="fp32x3", cfg=5)
     close(aux, ref, rtol=2e-6, name="saved pre-activation")
     close(out, torch.nn.functional.gelu(ref), rtol=2e-6, name="GELU")
     dy = rnd(M, N, seed=4).to(DEV)
     wt = w.t().contiguous()  # [K, N] -> dX = dY . W with W as a KM operand: here dy [M, N] . w [N, K]
     dx = torch.empty(M, K, device=DEV)
     pre = rnd(M, K, seed=5).to(DEV)
-    hip.gemm(dy, 0, w, 1, dx, M, K, N, epi=hip.EPI_DGELU, aux=pre, compute="fp32x3")
+    hip.gemm(dy, 0, w, 1, dx, M, K, N, epi=hip.EPI_DGELU, aux=pre, compute="fp32x3", cfg=5)
     p64 = pre.double().cpu()
     gp = 0.5 * (1 + torch.erf(p64 / 2 ** 0.5)) + p64 * torch.exp(-p64 * p64 / 2) / (2 * torch.pi) ** 0.5
     close(dx, (dy.double().cpu() @ w.double().cpu()) * gp, rtol=3e-6, name="GELU'")
-    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, epi=hip.EPI_TANH, compute="fp32x3")
+    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, epi=hip.EPI_TANH, compute="fp32x3", cfg=5)
     close(out, torch.tanh(ref), rtol=5e-5, name="tanh")  # (|pre-activation| up to ~90: its fp32 rounding alone is 1e-5 of tanh's range)
     acc0 = rnd(M, N, seed=6)
     out.copy_(acc0)
-    hip.gemm(x, 0, w, 0, out, M, N, K, accumulate=True, compute="fp32x3")
+    hip.gemm(x, 0, w, 0, out, M, N, K, accumulate=True, compute="fp32x3", cfg=5)
     close(out, ref - bias.double().cpu() + acc0.double(), rtol=2e-6, name="accumulate")
     for sp in (2, 4):
         out.fill_(float("nan"))
-        hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, allow_split=True, splits=sp, compute="fp32x3")
+        hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, allow_split=True, splits=sp, compute="fp32x3", cfg=5)
         close(out, ref, rtol=2e-6, name=f"split-K {sp}")
     del wt
     # weight gradient over a k-tile list
@@ -1156,15 +1158,22 @@ def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
         assert hip.f32_split(True) is True
         for sp in (-1, 1, 3):
             dw.fill_(float("nan"))
-            hip.gemm_ktiles(dyw, xw, dw, NO, KI, T, kl, kc, splits=sp)
+            hip.gemm_ktiles(dyw, xw, dw, NO, KI, T, kl, kc, splits=sp, cfg=5)
             close(dw, refw, rtol=2e-6, name=f"k-tile list through the switch, splits {sp}")
         # shapes outside the split kernels' cover run the fp32 pipe under the switch
         xs, ws_ = rnd(100, 72, seed=9).to(DEV), rnd(50, 72, seed=10).to(DEV)
         os_ = torch.empty(100, 50, device=DEV)
         hip.gemm(xs, 0, ws_, 0, os_, 100, 50, 72)
         close(os_, xs.double().cpu() @ ws_.double().cpu().t(), rtol=2e-6, name="uncovered shape")
-        hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias)
-        close(out, ref, rtol=2e-6, name="fp32 entry under the switch")
+        hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias)  # (24 tiles: stays on the fp32 pipe)
+        close(out, ref, rtol=2e-6, name="fp32 entry under the switch, small product")
+        xb, wb = rnd(1024, 256, seed=11).to(DEV), rnd(1536, 256, seed=12).to(DEV)
+        ob = torch.empty(1024, 1536, device=DEV)
+        hip.prof_start(4)
+        hip.gemm(xb, 0, wb, 0, ob, 1024, 1536, 256)  # (96 tiles: the split kernel, chosen by the library)
+        recs = hip.prof_stop(4)
+        assert recs and recs[0][0]["cfg"] >= 200, recs
+        close(ob, xb.double().cpu() @ wb.double().cpu().t(), rtol=2e-6, name="fp32 entry under the switch, 96 tiles")
     finally:
         hip.f32_split(was)
     assert hip.f32_split() == was
