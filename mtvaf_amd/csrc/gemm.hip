@@ -941,14 +941,11 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     a.klist = klist;
     a.kcnt = kcnt;
   }
-  // split kernels, 128x128: two LDS buffers + one block per CU when the launch gives a CU one block anyway (<= 256 tiles of a
-  // short reduction) and for the weight gradients; otherwise one buffer and two co-resident blocks (tools/f32x3_bench.py)
-  const bool x3_two_buf = compute == 2 && cfg == 5 && ((layout_a == 1) || ((long)grid.x * grid.z <= 256 && kc <= 1024));
   ProfRec* pr = nullptr;
   if (g_prof && g_prof_n < g_prof_cap) {
     pr = &g_prof[g_prof_n++];
     // (key[3]: alignment mode 0..2, +8 when the launch walks a k-tile list: its flops are 2 M N 32 (*kcnt), not 2 M N K)
-    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + ((cfg == 5 && a.wide) ? 20 : (x3_two_buf ? 50 : 0)) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
+    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + ((cfg == 5 && a.wide) ? 20 : 0) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
     hipEventRecord(pr->e0, stream);
   }
@@ -956,11 +953,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if (compute == 1) {
     rc = launch_gemm_bf16(cfg == 6 ? 0 : (cfg == 5 ? 1 : 2), a, layout_a, layout_b, grid, aligned, stream);
   } else if (compute == 2) {
-    // 128x128: the wave-specialised kernel (tile 4).  MTVAF_X3_TILE forces one of the earlier forms (tools/f32x3_bench.py):
-    // 0 two buffers / one block per CU, 1 one buffer / two blocks, 3 BK = 16 / three blocks
-    static const char* e = getenv("MTVAF_X3_TILE");
-    const int force = e ? atoi(e) : -1;
-    rc = launch_gemm_f32x3(cfg == 5 ? (force >= 0 ? force : (a.wide ? 4 : (x3_two_buf ? 0 : 1))) : 2, a, layout_a, layout_b, grid, stream);
+    // 128x128: the wave-specialised kernel; without the wide epilogue's alignment the every-wave-does-everything form
+    rc = launch_gemm_f32x3(cfg == 5 ? (a.wide ? 4 : 1) : 2, a, layout_a, layout_b, grid, stream);
   } else
   switch (cfg) {
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;

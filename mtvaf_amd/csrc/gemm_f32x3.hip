@@ -9,11 +9,11 @@
 // are worth 417 TFLOP/s of fp32-equivalent work, 2.6x the fp32 pipe, at the accuracy of the fp32 pipe (measured against
 // fp64: tests/test_ops_gpu.py::test_gemm_f32_split_accuracy).
 //
-// Tile: BM x BN x 32 per block, WM x WN waves with 64 x 64 (or 32 x 32) wave tiles; TWO LDS buffers of 3 planes x (BM + BN)
-// rows x 80 B (conflict-free ds_read_b128 fragments, as gemm_bf16.hip).  While the 48 MFMAs of k-tile t run, the same wave
-// fetches tile t+1 into registers, splits it and writes its planes into the other buffer: the staging work is spread
-// behind the twelve MFMA groups of the tile (hipcc keeps the interleaving), one barrier per k-tile.
-// LDS traffic is the budget of this scheme (three planes per operand): 64 x 64 wave tiles read 24 fragments per 48 MFMAs.
+// Two kernels.  gemm_f32x3_ws_kernel (128 x 128 x 32, the planner's choice): wave-specialised, see its header below.
+// gemm_f32x3_kernel (BM x BN x 32, 64 x 64 or 32 x 32 wave tiles): every wave loads, splits, stores and multiplies; ONE LDS
+// buffer of 3 planes x (BM + BN) rows x 80 B (conflict-free ds_read_b128 fragments, as gemm_bf16.hip), the next k-tile
+// prefetched into registers during the MFMA phase, two blocks per CU -- the first form built (headline 18.55 -> 16.15 ms),
+// kept for the 64 x 64 tile and for results without the wide epilogue's alignment.
 #include "gemm_common.h"
 
 namespace mtvaf {
@@ -142,8 +142,8 @@ __device__ __forceinline__ void put_unit(const unsigned (&w)[KM ? 12 : 6], int u
 
 // Requirements (checked by the launcher): M % BM == 0, N % BN == 0, K and every k-chunk multiples of 32, 16-byte aligned
 // operands with leading dimensions % 4 == 0.
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, bool KLIST, bool TWO, int BK>
-__global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : (BK == 16 ? 3 : 2)) void gemm_f32x3_kernel(GemmArgs p) {
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, bool KLIST, int BK>
+__global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32x3_kernel(GemmArgs p) {
   using namespace x3;
   static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
   static_assert(BK == 16 || BK == 32, "one or two MFMA k-slices per k-tile");
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : (BK == 16 ? 3 : 2)) void gem
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH;  // bf16 elements per plane
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  constexpr int BUF = 3 * (A_SZ + B_SZ);             // elements per k-tile buffer (two of them)
-  __bf16* sA = reinterpret_cast<__bf16*>(smem_raw);  // [2][ [3][A_SZ] | [3][B_SZ] ]
+  constexpr int BUF = 3 * (A_SZ + B_SZ);
+  __bf16* sA = reinterpret_cast<__bf16*>(smem_raw);  // [3][A_SZ] | [3][B_SZ]
   __bf16* sB = sA + 3 * A_SZ;
 
   const int tid = threadIdx.x;
@@ -185,10 +185,7 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : (BK == 16 ? 3 : 2)) void gem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // two register sets: the tile staged during step t was requested during step t-1 (a whole k-tile of matrix work between a
-  // global load and its first use: requested in the step that consumes them, the loads stalled every step for their latency)
-  f32x4 ra0[Stage<BM, NT, A_KM, BK>::NREG], rb0[Stage<BN, NT, B_KM, BK>::NREG], ra1[TWO ? Stage<BM, NT, A_KM, BK>::NREG : 1],
-      rb1[TWO ? Stage<BN, NT, B_KM, BK>::NREG : 1];
+  f32x4 ra0[Stage<BM, NT, A_KM, BK>::NREG], rb0[Stage<BN, NT, B_KM, BK>::NREG];
   constexpr int UA = A_KM ? Stage<BM, NT, true, BK>::NU : Stage<BM, NT, false, BK>::NKC;  // staging units per thread
   constexpr int UB = B_KM ? Stage<BN, NT, true, BK>::NU : Stage<BN, NT, false, BK>::NKC;
 
@@ -211,9 +208,8 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : (BK == 16 ? 3 : 2)) void gem
       put_unit<NT, B_KM, B_SZ, BK>(w, u - UA, sB + buf * BUF, tid);
     }
   };
-  // the 2 x 6 MFMA groups of a k-tile (TM x TN independent accumulators each); `side(g)` is issued behind group g: the
-  // split + store of the NEXT k-tile (into the other buffer) runs in the shadow of this tile's matrix work
-  auto compute = [&](int buf, auto side) __attribute__((always_inline)) {
+  // the 2 x 6 MFMA groups of a k-tile (TM x TN independent accumulators each)
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const __bf16* a = sA + buf * BUF;
     const __bf16* b = sB + buf * BUF;
 #pragma unroll
@@ -237,61 +233,29 @@ __global__ __launch_bounds__(WM* WN * 64, TWO ? 1 : (BK == 16 ? 3 : 2)) void gem
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
-        side(ks * 6 + t);
       }
     }
   };
-  constexpr int NGRP = 6 * (BK / 16);
-  constexpr int NU_ALL = UA + UB, PER = (NU_ALL + NGRP - 1) / NGRP;  // units staged behind each of the MFMA groups
-  // step kt (not the last): compute tile kt from buffer kt & 1, stage tile kt+1 (registers `cur`) into the other buffer,
-  // request tile kt+2 into the registers that held tile kt
-  auto step = [&](int kt, f32x4* cura, f32x4* curb, f32x4* nxta, f32x4* nxtb) __attribute__((always_inline)) {
-    gload(min(kt + 2, nk - 1), nxta, nxtb);  // (unconditional: see the wave-specialised kernel below)
-    compute(kt & 1, [&](int g) __attribute__((always_inline)) {
-#pragma unroll
-      for (int e = 0; e < PER; ++e) stage(g * PER + e, (kt & 1) ^ 1, cura, curb);
-    });
-    __syncthreads();  // the other buffer is complete, and every wave is done with this one
-  };
+  constexpr int NU_ALL = UA + UB;
 
-  if (TWO) {
-    if (nk > 0) {
-      gload(0, ra0, rb0);
-      gload(min(1, nk - 1), ra1, rb1);
+  // ONE buffer, two blocks per CU: the next tile is requested before this tile's matrix work and split + stored behind it
+  // (between two barriers) -- that phase of one block runs under the matrix phase of the other block of the CU
+  if (nk > 0) {
+    gload(0, ra0, rb0);
 #pragma unroll
-      for (int u = 0; u < NU_ALL; ++u) stage(u, 0, ra0, rb0);
-      __syncthreads();
-      int kt = 0;
-      for (; kt + 2 < nk; kt += 2) {  // tile kt+1 sits in set 1, tile kt+2 goes to set 0
-        step(kt, ra1, rb1, ra0, rb0);
-        step(kt + 1, ra0, rb0, ra1, rb1);
-      }
-      if (kt + 1 < nk) {  // two tiles left: kt (computed, staging kt+1 from set 1) and kt+1
-        step(kt, ra1, rb1, ra0, rb0);
-        ++kt;
-      }
-      compute(kt & 1, [&](int) __attribute__((always_inline)) {});
-    }
-  } else {
-    // ONE buffer, two blocks per CU: the next tile is requested before this tile's matrix work and split + stored behind it
-    // (between two barriers) -- that phase of one block runs under the matrix phase of the other block of the CU
-    if (nk > 0) {
-      gload(0, ra0, rb0);
+    for (int u = 0; u < NU_ALL; ++u) stage(u, 0, ra0, rb0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = kt + 1 < nk;
+    if (more) gload(kt + 1, ra0, rb0);
+    compute(0);
+    __syncthreads();  // every wave has read this k-tile
+    if (more) {
 #pragma unroll
       for (int u = 0; u < NU_ALL; ++u) stage(u, 0, ra0, rb0);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-      const bool more = kt + 1 < nk;
-      if (more) gload(kt + 1, ra0, rb0);
-      compute(0, [&](int) __attribute__((always_inline)) {});
-      __syncthreads();  // every wave has read this k-tile
-      if (more) {
-#pragma unroll
-        for (int u = 0; u < NU_ALL; ++u) stage(u, 0, ra0, rb0);
-      }
-      __syncthreads();
-    }
   }
 
   if (p.wide) {
@@ -467,7 +431,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
       }
     }
   } else {
-    const int ptid = tid - NP;
+    const int ptid = tid - 256;
     f32x4 ra0[Stage<BM, NP, A_KM, BK>::NREG], rb0[Stage<BN, NP, B_KM, BK>::NREG], ra1[Stage<BM, NP, A_KM, BK>::NREG],
         rb1[Stage<BN, NP, B_KM, BK>::NREG];
     constexpr int UA = A_KM ? Stage<BM, NP, true, BK>::NU : Stage<BM, NP, false, BK>::NKC;
@@ -587,15 +551,15 @@ static int launch_x3_ws(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_
   return MTVAF_OK;
 }
 
-template <int BM, int BN, int WM, int WN, bool TWO, int BK>
+template <int BM, int BN, int WM, int WN, int BK>
 static int launch_x3_tile(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
-  size_t smem = (size_t)(TWO ? 2 : 1) * 3 * (BM + BN) * (BK + 8) * sizeof(__bf16);
+  size_t smem = (size_t)3 * (BM + BN) * (BK + 8) * sizeof(__bf16);
   const size_t epi = (size_t)(BM / WM) * (BN + 4) * sizeof(float);
   if (epi > smem) smem = epi;
   dim3 block(WM * WN * 64);
 #define MTVAF_X3_LAUNCH(AK, BKM, KL)                                                                                  \
   do {                                                                                                               \
-    auto kern = gemm_f32x3_kernel<BM, BN, WM, WN, AK, BKM, KL, TWO, BK>;                                             \
+    auto kern = gemm_f32x3_kernel<BM, BN, WM, WN, AK, BKM, KL, BK>;                                                  \
     static bool attr_set = false;                                                                                    \
     if (smem > 64 * 1024 && !attr_set) {                                                                             \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
@@ -613,15 +577,14 @@ static int launch_x3_tile(const GemmArgs& a, int la, int lb, dim3 grid, hipStrea
   return MTVAF_OK;
 }
 
-// Called by the common launcher in gemm.hip (whole tiles only).  tile: 0 = 128x128x32, two LDS buffers, one block per CU;
-// 1 = 128x128x32, one buffer, two blocks per CU; 3 = 128x128x16, one buffer, three blocks per CU; 2 = 64x64x32 (2x2 waves of 32x32).
+// Called by the common launcher in gemm.hip (whole tiles only).  tile: 4 = 128x128x32 wave-specialised (the one the planner
+// uses; needs the wide epilogue's alignment); 1 = 128x128x32, every wave doing everything, one buffer, two blocks per CU;
+// 2 = 64x64x32 (2x2 waves of 32x32; small results).
 int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   switch (tile) {
-    case 0: return launch_x3_tile<128, 128, 2, 2, true, 32>(a, la, lb, grid, st);
-    case 1: return launch_x3_tile<128, 128, 2, 2, false, 32>(a, la, lb, grid, st);
-    case 3: return launch_x3_tile<128, 128, 2, 2, false, 16>(a, la, lb, grid, st);
     case 4: return launch_x3_ws(a, la, lb, grid, st);
-    default: return launch_x3_tile<64, 64, 2, 2, false, 32>(a, la, lb, grid, st);
+    case 1: return launch_x3_tile<128, 128, 2, 2, 32>(a, la, lb, grid, st);
+    default: return launch_x3_tile<64, 64, 2, 2, 32>(a, la, lb, grid, st);
   }
 }
 

@@ -229,11 +229,11 @@ def kernel_symbol(cfg, la, lb, fast):
             return f"gemm_bf16_p256_kernel<{b(c & 4)}, {b(c & 8)}, {b(c & 128)}>"
         t = "256, 192, 4, 2" if c & 32 else ("256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"))
         return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}, {b(klist)}>"
-    if cfg >= 200:  # split-fp32 kernels (csrc/gemm_f32x3.hip): +20 the wave-specialised kernel, +50 the two-buffer form
+    if cfg >= 200:  # split-fp32 kernels (csrc/gemm_f32x3.hip): +20 the wave-specialised kernel
         if cfg == 225:
             return f"gemm_f32x3_ws_kernel<{b(la)}, {b(lb)}, {b(klist)}>"
-        d = (64, 64, 2, 2) if cfg % 50 == 3 else (128, 128, 2, 2)
-        return f"gemm_f32x3_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(klist)}, {b(cfg >= 250)}, 32>"
+        d = (64, 64, 2, 2) if cfg == 203 else (128, 128, 2, 2)
+        return f"gemm_f32x3_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(klist)}, false, 32>"
     if cfg >= 100:
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
         return f"gemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(fast == 2)}>"

@@ -59,7 +59,9 @@ def test_unpadded_run_equals_padded_run(holes):
         if "word_embeddings" in n:  # float-atomic scatter-add
             close(g1[n], g0[n], rtol=1e-4, atol=2e-6 * float(g0[n].abs().max()), name=n)
         else:
-            close(g1[n], g0[n], rtol=2e-5, atol=1e-6 * float(g0[n].abs().max()) + 1e-9, name=n)
+            # (4e-6 of the largest entry: with MTVAF_F32_SPLIT=1 a product can run the split kernel at 4096 rows and the fp32
+            # pipe at the packed row count -- two correct fp32 roundings of the same sums, 1.6e-6 apart at most as measured)
+            close(g1[n], g0[n], rtol=2e-5, atol=4e-6 * float(g0[n].abs().max()) + 1e-9, name=n)
 
 
 def test_unpadded_training_step_with_dropout_is_finite_and_deterministic():
