@@ -585,12 +585,20 @@ def main():
             sync.enabled = False
         if a.graph:
             gstep.close()  # the profiled steps run eagerly (the launch profiler brackets individual launches)
-        res["roofline"] = roofline_pass(eager_step, mask, B, S, a.dtype, a.unpad)
+        from mtvaf_amd import hip as _hip
+        env_split = a.dtype == "fp32" and _hip.f32_split()  # (MTVAF_F32_SPLIT=1 in the environment: the whole run is the split mode)
+        res["roofline"] = roofline_pass(eager_step, mask, B, S, a.dtype, a.unpad, peak_key="fp32x3" if env_split else None)
+        if env_split:
+            res["dtype"] = ("fp32 operands / results / accumulation; fp32 products formed on the bf16 matrix pipe from three-way "
+                            "bf16-split operands (MTVAF_F32_SPLIT=1; DESIGN.md 4.1e)")
         ex = res["roofline"]["all_gemm_kernels"]["executed_tflop_per_step"]
         # the whole step by the flops its GEMM launches EXECUTE (the weight-gradient products skip the k-tiles of masked
         # token rows) plus the attention products' algorithmic share, next to the algorithmic figure above
         attn_tflop = B * 3 * 12 * 4 * S * (S + P) * 768 / 1e12
         res["mfma_fraction_of_step_executed"] = round((ex + attn_tflop) / (1e-3 * res["ms_per_step"]) / PEAK_TFLOPS[a.dtype], 4)
+        if env_split:  # fractions of the fp32-equivalent peak of the bf16 pipe (the attention products still run the fp32 pipe)
+            for k_ in ("mfma_fraction_of_step", "mfma_fraction_of_step_executed"):
+                res[k_] = round(res[k_] * PEAK_TFLOPS["fp32"] / PEAK_TFLOPS["fp32x3"], 4)
     if rank == 0:
         log("roofline pass done")
     if rank == 0 and world == 1 and not a.no_secondary and not a.graph and (B, S, a.aux, a.dtype, a.model, a.unpad) == (32, 128, 8, "fp32", "bert", False):
