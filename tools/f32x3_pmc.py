@@ -1,5 +1,4 @@
-"""Two product shapes on the split-fp32 GEMM (csrc/gemm_f32x3.hip) for a rocprofv3 --pmc pass (MTVAF_X3_TILE forces the
-128x128 variant: 0 two buffers, 1 one buffer / two blocks, 3 BK = 16 / three blocks):
+"""Two product shapes on the split-fp32 GEMM (csrc/gemm_f32x3.hip: the wave-specialised 128x128 kernel) for a rocprofv3 --pmc pass:
     rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -- python3 tools/f32x3_pmc.py
 FFN-1 forward [4096 x 3072 x 768] (KC x KC) and its weight gradient [3072 x 768 x 4096] (KM x KM)."""
 import os, sys, torch
