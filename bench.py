@@ -204,15 +204,17 @@ def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3, peak_key=
                       for k_, (m_, c_) in sorted(by_shape.items(), key=lambda kv: -kv[1][0])[:12]]}
 
 
-def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3, split=False):
+def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3, split=False, unpad=False):
     """One of the other BASELINE configurations measured in the same process, AFTER the headline's timed region (the
     headline's value / config / dtype are untouched): the same step (forward incl. Viterbi + backward + AdamW overlapped
     with the backward pass), `steps` timed steps bracketed by synchronisation, its own roofline object."""
     from mtvaf_amd import hip
     from mtvaf_amd.optim import AdamW
     hip.set_compute_dtype(dtype)
-    split_was = hip.f32_split()
+    from mtvaf_amd import engine as _engine
+    split_was, unpad_was = hip.f32_split(), _engine.UNPAD
     hip.f32_split(split)
+    _engine.UNPAD = bool(unpad)
     try:
         model, cfg = build_model(device, arch, S)
         model.train()
@@ -255,11 +257,15 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3,
                                "inputs (tests/test_ops_gpu.py::test_gemm_f32_split_accuracy); every fp32 parity test (1e-3 vs the "
                                "oracle, bit-exact tags, reference goldens) passes in this mode (MTVAF_F32_SPLIT=1)")
             res["mfma_fraction_of_step"] = round(v * 3 * f_fwd(S, P) / (PEAK_TFLOPS["fp32x3"] * 1e12), 4)
-        res["roofline"] = roofline_pass(step, mask, B, S, dtype, peak_key="fp32x3" if split else None)
+        if unpad:
+            res["workload"] += ", padding-free execution (masked token rows not computed: DESIGN.md 4.6)"
+            res["mfma_fraction_of_step"] = None  # (the algorithmic flop count includes the masked rows this mode does not compute)
+        res["roofline"] = roofline_pass(step, mask, B, S, dtype, unpad=unpad, peak_key="fp32x3" if split else None)
         return res
     finally:
         hip.set_compute_dtype("fp32")
         hip.f32_split(split_was)
+        _engine.UNPAD = unpad_was
 
 
 def log(msg):
@@ -608,10 +614,12 @@ def main():
         step = eager_step = None  # noqa: F841
         torch.cuda.empty_cache()
         res["secondary"] = {}
-        for key, (dt_, arch_, b_, s_, aux_) in {"c2_fp32_split": ("fp32", "bert", 32, 128, 8), "c1_fp32": ("fp32", "bert", 4, 64, 3),
+        for key, (dt_, arch_, b_, s_, aux_) in {"c2_fp32_split": ("fp32", "bert", 32, 128, 8), "c2_fp32_split_unpad": ("fp32", "bert", 32, 128, 8),
+                                                "c1_fp32": ("fp32", "bert", 4, 64, 3),
                                                 "c3_bf16": ("bf16", "roberta", 32, 128, 8), "c4_bf16": ("bf16", "bert", 64, 128, 8)}.items():
             try:
-                res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_, split=key.endswith("_split"))
+                res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_, split="_split" in key,
+                                                         unpad=key.endswith("_unpad"))
             except Exception as e:  # a secondary figure must never cost the headline line
                 res["secondary"][key] = {"error": repr(e)}
             torch.cuda.empty_cache()
