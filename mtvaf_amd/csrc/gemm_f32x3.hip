@@ -61,6 +61,10 @@ struct Stage {
   static constexpr int NREG = KM ? 2 * NU : NKC;
   static_assert((ROWS * (BK / 4)) % NT == 0 && (ROWS * (BK / 8)) % NT == 0, "whole float4s / units per thread");
 };
+// KC float4 idx -> row (BK = 32: 8 float4 per row): consecutive 8-lane groups take rows r, r+4, r+1, r+5, ... of each block of
+// 8 rows, so that the two rows a 16-lane group of ds_write_b64 stores to are 320 B apart = 16 banks (mod 32): adjacent rows
+// (80 B = 20 banks apart) overlap in 4 banks (SQ_LDS_BANK_CONFLICT: a third of the kernel's LDS cycles)
+__device__ __forceinline__ int kc_row(int g) { return (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3); }
 // KM unit u -> (k pair, first of 4 rows): 8 row groups fastest (one 128-byte line of a k-row), then the BK/2 k pairs, then
 // the next 32 rows
 template <int BK>
@@ -79,7 +83,8 @@ __device__ __forceinline__ void g_load(f32x4* reg, const float* base, int ld, in
 #pragma unroll
     for (int i = 0; i < Stage<ROWS, NT, KM, BK>::NKC; ++i) {
       const int idx = tid + i * NT;
-      reg[i] = *reinterpret_cast<const f32x4*>(base + (long)(r0 + idx / (BK / 4)) * ld + k0 + (idx % (BK / 4)) * 4);
+      const int row = BK == 32 ? kc_row(idx >> 3) : idx / (BK / 4);
+      reg[i] = *reinterpret_cast<const f32x4*>(base + (long)(r0 + row) * ld + k0 + (idx % (BK / 4)) * 4);
     }
   } else {
 #pragma unroll
@@ -120,7 +125,8 @@ __device__ __forceinline__ void put_unit(const unsigned (&w)[KM ? 12 : 6], int u
   constexpr int LDH = BK + 8;
   if constexpr (!KM) {
     const int idx = tid + unit * NT;
-    __bf16* d = s + (idx / (BK / 4)) * LDH + (idx % (BK / 4)) * 4;
+    const int row = BK == 32 ? kc_row(idx >> 3) : idx / (BK / 4);
+    __bf16* d = s + row * LDH + (idx % (BK / 4)) * 4;
     *reinterpret_cast<uint2*>(d) = uint2{w[0], w[1]};
     *reinterpret_cast<uint2*>(d + PS) = uint2{w[2], w[3]};
     *reinterpret_cast<uint2*>(d + 2 * PS) = uint2{w[4], w[5]};
