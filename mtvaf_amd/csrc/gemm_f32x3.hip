@@ -57,26 +57,28 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16
 template <int ROWS, int NT, bool KM, int BK>
 struct Stage {
   static constexpr int NKC = (ROWS * (BK / 4)) / NT;  // float4 per thread, KC
-  static constexpr int NU = (ROWS * (BK / 8)) / NT;   // units per thread, KM (two float4 each)
-  static constexpr int NREG = KM ? 2 * NU : NKC;
-  static_assert((ROWS * (BK / 4)) % NT == 0 && (ROWS * (BK / 8)) % NT == 0, "whole float4s / units per thread");
+  static constexpr int UNITS = ROWS * (BK / 16);      // KM units of a tile: 4 k x 4 rows (four float4 each)
+  static constexpr int NU = (UNITS + NT - 1) / NT;    // units per thread, KM (threads beyond UNITS idle: the 64-row tile)
+  static constexpr int NREG = KM ? 4 * NU : NKC;
+  static_assert((ROWS * (BK / 4)) % NT == 0, "whole float4s per thread");
 };
 // KC float4 idx -> row (BK = 32: 8 float4 per row): consecutive 8-lane groups take rows r, r+4, r+1, r+5, ... of each block of
 // 8 rows, so that the two rows a 16-lane group of ds_write_b64 stores to are 320 B apart = 16 banks (mod 32): adjacent rows
 // (80 B = 20 banks apart) overlap in 4 banks (SQ_LDS_BANK_CONFLICT: a third of the kernel's LDS cycles)
 __device__ __forceinline__ int kc_row(int g) { return (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3); }
-// KM unit u -> (k pair, first of 4 rows): 8 row groups fastest (one 128-byte line of a k-row), then the BK/2 k pairs, then
-// the next 32 rows
+// KM unit u -> (k quad kq = u & (BK/4 - 1), first of 4 rows c4 = 4 (u / (BK/4))): a unit is 4 consecutive k of 4 consecutive rows
+// (four float4 along the rows).  Lanes: kq fastest over 8 lanes, then the row groups -- a 16-lane group of the plane stores
+// (ds_write_b64: 4 k of one row) covers all 8 k quads of two adjacent row groups = 32 distinct banks (conflict-free; the
+// first form -- k PAIRS, 4-byte stores -- ran the weight-gradient kernel with 60 % of its LDS cycles in bank conflicts),
+// and the 64 lanes of a load instruction cover 8 k-rows x 128 contiguous bytes.
 template <int BK>
-__device__ __forceinline__ void km_unit(int u, int& kp, int& c4) {
-  kp = (u >> 3) & (BK / 2 - 1);
-  c4 = ((u & 7) + (u / (4 * BK)) * 8) * 4;
+__device__ __forceinline__ void km_unit(int u, int& kq, int& c4) {
+  kq = u & (BK / 4 - 1);
+  c4 = (u / (BK / 4)) * 4;
 }
 
 // global -> registers (whole tiles only: the launcher checks alignment).  KC: float4 idx -> (row = idx / (BK/4), k = (idx %
-// (BK/4)) * 4).  KM: unit u -> (k pair kp, 4 rows c4; km_unit): two float4 (same rows at k and k + 1); eight consecutive
-// lanes fetch one whole 128-byte line of a k-row, and the transposed 4-byte LDS writes of a wave fall on 32 distinct banks
-// (2-way conflicts; with the rows fastest over all lanes they were 8-way).
+// (BK/4)) * 4).  KM: unit u -> (k quad kq, 4 rows c4; km_unit): four float4 (the same 4 rows at k .. k + 3).
 template <int ROWS, int NT, bool KM, int BK>
 __device__ __forceinline__ void g_load(f32x4* reg, const float* base, int ld, int r0, int k0, int tid) {
   if constexpr (!KM) {
@@ -90,38 +92,36 @@ __device__ __forceinline__ void g_load(f32x4* reg, const float* base, int ld, in
 #pragma unroll
     for (int i = 0; i < Stage<ROWS, NT, KM, BK>::NU; ++i) {
       const int u = tid + i * NT;
-      int kp, c4;
-      km_unit<BK>(u, kp, c4);
-      const float* q = base + (long)(k0 + 2 * kp) * ld + r0 + c4;
-      reg[2 * i] = *reinterpret_cast<const f32x4*>(q);
-      reg[2 * i + 1] = *reinterpret_cast<const f32x4*>(q + ld);
+      if (Stage<ROWS, NT, KM, BK>::UNITS % NT != 0 && u >= Stage<ROWS, NT, KM, BK>::UNITS) continue;
+      int kq, c4;
+      km_unit<BK>(u, kq, c4);
+      const float* q = base + (long)(k0 + 4 * kq) * ld + r0 + c4;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) reg[4 * i + kk] = *reinterpret_cast<const f32x4*>(q + (long)kk * ld);
     }
   }
 }
 
-// One unit of staging work: a KC float4 (4 consecutive k of one row), or a KM pair of float4 (4 rows at k and k + 1).
-// convert: registers -> six packed dwords (three planes); put: the dwords -> LDS ([plane][row][LDH]; plane stride PS elements).
+// One unit of staging work: a KC float4 (4 consecutive k of one row), or a KM quad of float4 (4 rows at k .. k + 3).
+// convert: registers -> six packed dwords per row (three planes x 4 k); put: the dwords -> LDS ([plane][row][LDH]; plane
+// stride PS elements), 8 bytes per store either way.
 template <bool KM>
-__device__ __forceinline__ void convert_unit(const f32x4* reg, int unit, unsigned (&w)[KM ? 12 : 6]) {
+__device__ __forceinline__ void convert_unit(const f32x4* reg, int unit, unsigned (&w)[KM ? 24 : 6]) {
   if constexpr (!KM) {
     bf16x4 h, m, l;
     split3(reg[unit], h, m, l);
     const uint2 hh = __builtin_bit_cast(uint2, h), mm = __builtin_bit_cast(uint2, m), ll = __builtin_bit_cast(uint2, l);
     w[0] = hh.x; w[1] = hh.y; w[2] = mm.x; w[3] = mm.y; w[4] = ll.x; w[5] = ll.y;
   } else {
-    bf16x4 h0, m0, l0, h1, m1, l1;
-    split3(reg[2 * unit], h0, m0, l0);
-    split3(reg[2 * unit + 1], h1, m1, l1);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      w[q] = __builtin_bit_cast(unsigned, bf16x2{h0[q], h1[q]});
-      w[4 + q] = __builtin_bit_cast(unsigned, bf16x2{m0[q], m1[q]});
-      w[8 + q] = __builtin_bit_cast(unsigned, bf16x2{l0[q], l1[q]});
+    for (int q = 0; q < 4; ++q) {  // row c4 + q: its four k are element q of the four float4
+      split3_pair(f32x2{reg[4 * unit][q], reg[4 * unit + 1][q]}, w[6 * q], w[6 * q + 2], w[6 * q + 4]);
+      split3_pair(f32x2{reg[4 * unit + 2][q], reg[4 * unit + 3][q]}, w[6 * q + 1], w[6 * q + 3], w[6 * q + 5]);
     }
   }
 }
-template <int NT, bool KM, int PS, int BK>
-__device__ __forceinline__ void put_unit(const unsigned (&w)[KM ? 12 : 6], int unit, __bf16* s, int tid) {
+template <int NT, bool KM, int PS, int BK, int ROWS>
+__device__ __forceinline__ void put_unit(const unsigned (&w)[KM ? 24 : 6], int unit, __bf16* s, int tid) {
   constexpr int LDH = BK + 8;
   if constexpr (!KM) {
     const int idx = tid + unit * NT;
@@ -132,14 +132,15 @@ __device__ __forceinline__ void put_unit(const unsigned (&w)[KM ? 12 : 6], int u
     *reinterpret_cast<uint2*>(d + 2 * PS) = uint2{w[4], w[5]};
   } else {
     const int u = tid + unit * NT;
-    int kp, c4;
-    km_unit<BK>(u, kp, c4);
+    if (u >= ROWS * (BK / 16)) return;
+    int kq, c4;
+    km_unit<BK>(u, kq, c4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      __bf16* d = s + (c4 + q) * LDH + 2 * kp;
-      *reinterpret_cast<unsigned*>(d) = w[q];
-      *reinterpret_cast<unsigned*>(d + PS) = w[4 + q];
-      *reinterpret_cast<unsigned*>(d + 2 * PS) = w[8 + q];
+      __bf16* d = s + (c4 + q) * LDH + 4 * kq;
+      *reinterpret_cast<uint2*>(d) = uint2{w[6 * q], w[6 * q + 1]};
+      *reinterpret_cast<uint2*>(d + PS) = uint2{w[6 * q + 2], w[6 * q + 3]};
+      *reinterpret_cast<uint2*>(d + 2 * PS) = uint2{w[6 * q + 4], w[6 * q + 5]};
     }
   }
 }
@@ -205,13 +206,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32x3_kernel(GemmArgs p) 
   // unit u of the UA + UB staging units of a k-tile: registers -> three planes -> LDS buffer `buf`
   auto stage = [&](int u, int buf, const f32x4* ra, const f32x4* rb) __attribute__((always_inline)) {
     if (u < UA) {
-      unsigned w[A_KM ? 12 : 6];
+      unsigned w[A_KM ? 24 : 6];
       convert_unit<A_KM>(ra, u, w);
-      put_unit<NT, A_KM, A_SZ, BK>(w, u, sA + buf * BUF, tid);
+      put_unit<NT, A_KM, A_SZ, BK, BM>(w, u, sA + buf * BUF, tid);
     } else if (u < UA + UB) {
-      unsigned w[B_KM ? 12 : 6];
+      unsigned w[B_KM ? 24 : 6];
       convert_unit<B_KM>(rb, u - UA, w);
-      put_unit<NT, B_KM, B_SZ, BK>(w, u - UA, sB + buf * BUF, tid);
+      put_unit<NT, B_KM, B_SZ, BK, BN>(w, u - UA, sB + buf * BUF, tid);
     }
   };
   // the 2 x 6 MFMA groups of a k-tile (TM x TN independent accumulators each)
@@ -455,15 +456,15 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     auto stage_all = [&](int buf, const f32x4* ra, const f32x4* rb) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
-        unsigned w[A_KM ? 12 : 6];
+        unsigned w[A_KM ? 24 : 6];
         convert_unit<A_KM>(ra, u, w);
-        put_unit<NP, A_KM, A_SZ, BK>(w, u, sA + buf * BUF, ptid);
+        put_unit<NP, A_KM, A_SZ, BK, BM>(w, u, sA + buf * BUF, ptid);
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
-        unsigned w[B_KM ? 12 : 6];
+        unsigned w[B_KM ? 24 : 6];
         convert_unit<B_KM>(rb, u, w);
-        put_unit<NP, B_KM, B_SZ, BK>(w, u, sB + buf * BUF, ptid);
+        put_unit<NP, B_KM, B_SZ, BK, BN>(w, u, sB + buf * BUF, ptid);
       }
     };
     // during step kt (the consumers work on tile kt): stage tile kt+1 from its register set, then request tile kt+3 into it
