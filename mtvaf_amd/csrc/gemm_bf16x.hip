@@ -165,6 +165,25 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
     }
   }
 
+  bf16x8 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+  auto rdf = [&](const unsigned char* a, const unsigned char* b, int ks, bf16x8 (&fa)[TM], bf16x8 (&fb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (!A_KM) fa[i] = *reinterpret_cast<const bf16x8*>(a + offA[i][0] + (((2 * ks + h) ^ offA[i][1]) << 4));
+      else fa[i] = tr_read8(a + offA[i][0] + 4096 * ks, a + offA[i][1] + 4096 * ks);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      if (!B_KM) fb[j] = *reinterpret_cast<const bf16x8*>(b + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
+      else fb[j] = tr_read8(b + offB[j][0] + (BN == 128 ? 4096 : 3072) * ks, b + offB[j][1] + (BN == 128 ? 4096 : 3072) * ks);
+    }
+  };
+  auto mm = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fb)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  };
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s);
@@ -185,28 +204,33 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
     }
     const unsigned char* a = smem_b + st * STAGE_B;
     const unsigned char* b = a + A_B;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 fa[TM], fb[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (!A_KM) fa[i] = *reinterpret_cast<const bf16x8*>(a + offA[i][0] + (((2 * ks + h) ^ offA[i][1]) << 4));
-        else fa[i] = tr_read8(a + offA[i][0] + 4096 * ks, a + offA[i][1] + 4096 * ks);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (!B_KM) fb[j] = *reinterpret_cast<const bf16x8*>(b + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
-        else fb[j] = tr_read8(b + offB[j][0] + (BN == 128 ? 4096 : 3072) * ks, b + offB[j][1] + (BN == 128 ? 4096 : 3072) * ks);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    // Fragment reads run ONE k-slice ahead of the MFMAs that consume them, across the tile barrier too (slice 3 of tile kt-1
+    // is multiplied behind the barrier of tile kt, while slice 0 of tile kt is in flight): a slice is only TM x TN MFMAs
+    // (128-512 cycles), and an in-order wave that reads and then multiplies pays the LDS latency per slice.
+    if (kt > 0) {
+      rdf(a, b, 0, fa0, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      mm(fa1, fb1);
+    } else {
+      rdf(a, b, 0, fa0, fb0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    rdf(a, b, 1, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    rdf(a, b, 2, fa0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    rdf(a, b, 3, fa1, fb1);
+    __builtin_amdgcn_sched_barrier(0);
+    mm(fa0, fb0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads of tile kt done before its stage can be refilled
     __builtin_amdgcn_sched_barrier(0);
     st = st + 1 == NSTAGE ? 0 : st + 1;
   }
+  if (nk > 0) mm(fa1, fb1);  // slice 3 of the last tile
 
   // ---- epilogue: accumulator tile -> LDS (transposed to row-major) -> 8 columns per lane ----
   // in passes of 128 rows (one pass for the 128-row tiles): a [256][BN + 4] fp32 image does not fit the LDS at BN = 192,
