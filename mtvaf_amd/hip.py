@@ -233,7 +233,7 @@ def kernel_symbol(cfg, la, lb, fast):
         if cfg == 225:
             return f"gemm_f32x3_ws_kernel<{b(la)}, {b(lb)}, {b(klist)}>"
         d = (64, 64, 2, 2) if cfg == 203 else (128, 128, 2, 2)
-        return f"gemm_f32x3_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(klist)}, false, 32>"
+        return f"gemm_f32x3_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(klist)}, 32>"
     if cfg >= 100:
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
         return f"gemm_bf16_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(fast == 2)}>"
