@@ -145,7 +145,14 @@ def exported_symbols():
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+    """Device pointer of a tensor handed to a kernel.  A host tensor here would be dereferenced by the GPU (a memory fault that
+    takes the process -- and on a shared host possibly more -- down): there is no CPU fallback, so it is an error, loudly."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"mtvaf_amd: a {t.device} tensor reached a HIP kernel -- the path has no CPU fallback; move the "
+                           "model and its inputs to the GPU")
+    return t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -618,7 +625,7 @@ def gemm_f32_dw_group(items, K, ktiles=None, splits=-1):
     """items: up to four (a [K,M] fp32, b [K,N] fp32, out [M,N] fp32): out = a^T . b for each, ONE launch of the 128x96 LDS-DMA
     kernel (+ one ordered slab reduction per product when the reduction is split)."""
     n = len(items)
-    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    vp = lambda ts: (ctypes.c_void_p * n)(*[_p(t) for t in ts])
     ia = lambda xs: (ctypes.c_int * n)(*xs)
     As, Bs, Cs = [i[0] for i in items], [i[1] for i in items], [i[2] for i in items]
     wsb = 8 * sum(c.numel() for c in Cs) * 4
@@ -632,7 +639,7 @@ def gemm_f32_dw_group(items, K, ktiles=None, splits=-1):
 def gemm_bf16x_dw_group(items, K):
     """items: up to four (a [K,M] bf16, b [K,N] bf16, out [M,N] fp32): out = a^T . b for each, ONE stream-K launch."""
     n = len(items)
-    vp = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    vp = lambda ts: (ctypes.c_void_p * n)(*[_p(t) for t in ts])
     ia = lambda xs: (ctypes.c_int * n)(*xs)
     As, Bs, Cs = [i[0] for i in items], [i[1] for i in items], [i[2] for i in items]
     streamk_ensure(As[0].device)
@@ -662,7 +669,7 @@ def adamw_multi(ps, gs, ms, vs, lr, beta1, beta2, eps, weight_decay, step, grad_
     k = len(ps)
     if k == 0:
         return
-    arr = lambda ts: (ctypes.c_void_p * k)(*[t.data_ptr() for t in ts])
+    arr = lambda ts: (ctypes.c_void_p * k)(*[_p(t) for t in ts])
     ns = (ctypes.c_long * k)(*[t.numel() for t in ps])
     bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
     _ck(lib().mtvaf_adamw_multi(k, arr(ps), arr(gs), arr(ms), arr(vs), ns, lr, beta1, beta2, eps, weight_decay, bc1,
