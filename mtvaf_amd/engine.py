@@ -65,8 +65,12 @@ class EmbeddingsFunction(torch.autograd.Function):
     def forward(ctx, word, pos, typ, gamma, beta, input_ids, token_type_ids, eps, p_drop, roberta, pad_idx):
         B, S = input_ids.shape
         H = word.shape[1]
-        ids = input_ids.contiguous()
-        tts = token_type_ids.contiguous()
+        # the kernels index the tables with 64-bit ids and S (+ the RoBERTa offset) positions: anything else must not reach them
+        ids = input_ids.to(torch.long).contiguous()
+        tts = token_type_ids.to(torch.long).contiguous()
+        if S + (pad_idx + 1 if roberta else 0) > pos.shape[0]:
+            raise ValueError(f"sequence length {S} exceeds the position table ({pos.shape[0]} rows"
+                             f"{', RoBERTa offset ' + str(pad_idx + 1) if roberta else ''})")
         pos_ids = None
         if roberta:
             pos_ids = _empty(B, S, like=word, dtype=torch.int32)

@@ -223,3 +223,26 @@ def test_from_pretrained_resolves_names_through_the_local_hf_cache(tmp_path, mon
         BertModel.from_pretrained("bert-large-uncased")
     monkeypatch.setenv("MTVAF_RANDOM_INIT", "1")
     assert BertModel.from_pretrained("bert-large-uncased", config=cfg).config.hidden_size == 128
+
+
+@pytest.mark.gpu
+def test_inputs_that_must_not_reach_a_kernel():
+    """On a GPU host: host tensors are refused before any launch (they used to be handed to the GPU as pointers), int32 ids are
+    widened (the kernels read 64-bit ids), and a sequence longer than the position table is an error on the host."""
+    m = tiny_model(use_prefix=False).to("cuda")
+    ids = torch.randint(3, 60, (2, 8))
+    mask, tt, labels = torch.ones(2, 8, dtype=torch.long), torch.zeros(2, 8, dtype=torch.long), torch.ones(2, 8, dtype=torch.long)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels)
+    torch.cuda.synchronize()  # nothing was launched with a host pointer: the device is healthy
+    dev = lambda *ts: [t.to("cuda") for t in ts]
+    m.eval()  # (no dropout: the two calls below must agree exactly)
+    i64 = m(**dict(zip(("input_ids", "attention_mask", "token_type_ids", "labels"), dev(ids, mask, tt, labels))))
+    i32 = m(**dict(zip(("input_ids", "attention_mask", "token_type_ids", "labels"), dev(ids.int(), mask, tt.int(), labels))))
+    assert float(i64.loss) == float(i32.loss) and list(i64.logits) == list(i32.logits)
+    long_ids = torch.randint(3, 60, (1, 72))
+    with pytest.raises(ValueError, match="position table"):
+        m(**dict(zip(("input_ids", "attention_mask", "token_type_ids", "labels"),
+                     dev(long_ids, torch.ones(1, 72, dtype=torch.long), torch.zeros(1, 72, dtype=torch.long),
+                         torch.ones(1, 72, dtype=torch.long)))))
+    torch.cuda.synchronize()
