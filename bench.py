@@ -204,7 +204,7 @@ def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3, peak_key=
                       for k_, (m_, c_) in sorted(by_shape.items(), key=lambda kv: -kv[1][0])[:12]]}
 
 
-def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3, split=False, unpad=False):
+def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3, split=False, unpad=False, graph=False):
     """One of the other BASELINE configurations measured in the same process, AFTER the headline's timed region (the
     headline's value / config / dtype are untouched): the same step (forward incl. Viterbi + backward + AdamW overlapped
     with the backward pass), `steps` timed steps bracketed by synchronisation, its own roofline object."""
@@ -218,13 +218,20 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3,
     try:
         model, cfg = build_model(device, arch, S)
         model.train()
-        opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model, overlap=True)
+        opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model, overlap=not graph)
         ids, mask, tt, labels, feats, aux = synthetic_batch(B, S, n_aux, cfg.vocab_size, 1234, device)
+        kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None, images=feats, aux_imgs=aux)
+        gstep = None
+        if graph:  # forward + backward as ONE HIP graph (mtvaf_amd.graph), the optimizer eagerly behind each replay
+            from mtvaf_amd.graph import GraphedTrainStep
+            gstep = GraphedTrainStep(model, kw)
 
         def step():
-            out = model(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None, images=feats,
-                        aux_imgs=aux)
-            out.loss.backward()
+            if gstep is not None:
+                out = gstep(**{k: v for k, v in kw.items() if v is not None})
+            else:
+                out = model(**kw)
+                out.loss.backward()
             opt.step()
             opt.zero_grad(set_to_none=True)
             assert len(out.logits) == B
@@ -250,6 +257,10 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3,
         if dtype != "fp32":
             res["tolerance"] = ("mixed precision: emissions <= 1.5e-2, loss <= 2e-3, >= 97 % of the decoded tags vs the fp32 oracle "
                                 "(tests/test_configs_gpu.py; north_star's 1e-3 / bit-exact tags hold in fp32 mode only)")
+        if graph:
+            res["workload"] += ", forward + backward replayed as one HIP graph (the host-bound configuration: eager runs read 780-1035)"
+            gstep.close()
+            gstep = None
         if hip.streamk_errors():
             raise RuntimeError("a stream-K launch reported a timed-out wait")
         if split:
@@ -618,15 +629,17 @@ def main():
         step = eager_step = None  # noqa: F841
         torch.cuda.empty_cache()
         res["secondary"] = {}
-        for key, (dt_, arch_, b_, s_, aux_) in {"c1_fp32": ("fp32", "bert", 4, 64, 3), "c2_fp32_split": ("fp32", "bert", 32, 128, 8),
+        for key, (dt_, arch_, b_, s_, aux_) in {"c1_fp32": ("fp32", "bert", 4, 64, 3), "c1_fp32_graph": ("fp32", "bert", 4, 64, 3),
+                                                "c2_fp32_split": ("fp32", "bert", 32, 128, 8),
                                                 "c2_fp32_split_unpad": ("fp32", "bert", 32, 128, 8),
                                                 "c3_bf16": ("bf16", "roberta", 32, 128, 8), "c4_bf16": ("bf16", "bert", 64, 128, 8)}.items():
             try:
                 # (C1 is the one host-bound configuration: 10 steps behind 3 warm-up steps read 750-930 sentences/s from call
                 # to call, 40 behind 10 read what `bench.py --batch 4 --seq 64 --aux 3` reads)
                 res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_, split="_split" in key,
-                                                         unpad=key.endswith("_unpad"), steps=40 if key == "c1_fp32" else 10,
-                                                         warmup=10 if key == "c1_fp32" else 5)
+                                                         unpad=key.endswith("_unpad"), graph=key.endswith("_graph"),
+                                                         steps=40 if key.startswith("c1_") else 10,
+                                                         warmup=10 if key.startswith("c1_") else 5)
             except Exception as e:  # a secondary figure must never cost the headline line
                 res["secondary"][key] = {"error": repr(e)}
             torch.cuda.empty_cache()
