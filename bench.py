@@ -177,14 +177,19 @@ def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3, peak_key=
         e = by_shape.setdefault(sk, [0.0, 0])
         e[0] += ms
         e[1] += 1
+    def peak_of(sym_):  # the matrix pipe a kernel symbol runs on (the split mode leaves few-tile products on the fp32 pipe)
+        if sym_.startswith("gemm_f32x3"):
+            return PEAK_TFLOPS["fp32x3"]
+        return PEAK_TFLOPS["bf16"] if sym_.startswith("gemm_bf16") else PEAK_TFLOPS["fp32"]
     tot_ms = sum(v[0] for v in by_sym.values()) / nprof
     tot_fl = sum(v[2] for v in by_sym.values()) / nprof
+    tot_ideal_ms = sum(v[2] / (peak_of(k_) * 1e12) * 1e3 for k_, v in by_sym.items()) / nprof  # every launch at ITS pipe's peak
     sym, (ms, cnt, fl) = max(by_sym.items(), key=lambda kv: kv[1][0])
     avg_us = 1e3 * ms / cnt
     ach = (fl / cnt) / (avg_us * 1e-6) / 1e12
     # (no PMC passes were collected for the padding-free workload: its row counts differ from the committed files')
-    traffic, traffic_src = (None, None) if (unpad or peak_key) else pmc_traffic(sym, dtype, B, S)
-    peak = PEAK_TFLOPS[peak_key or dtype]
+    traffic, traffic_src = (None, None) if unpad else pmc_traffic(sym, dtype, B, S)
+    peak = peak_of(sym)
     return {
         "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": sym,
@@ -193,7 +198,7 @@ def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3, peak_key=
                     "(MTVAF_DW_STREAM=0) so that every kernel is timed alone",
         "flops_per_launch_avg": fl / cnt,
         "all_gemm_kernels": {"ms_per_step": round(tot_ms, 3), "tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                             "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
+                             "frac": round(tot_ideal_ms / tot_ms, 4),
                              "executed_tflop_per_step": round(tot_fl / 1e12, 4)},
         "per_kernel": [{"kernel": s_, "launches_per_step": c_ // nprof, "avg_us": round(1e3 * m_ / c_, 1),
                         "tflops": round(f_ / (m_ * 1e-3) / 1e12, 1)}
@@ -249,7 +254,8 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3,
         P = 4 * (1 + n_aux)
         v = B * steps / dt
         res = {"config": name, "value": round(v, 2), "unit": "sentences/s", "ms_per_step": round(1e3 * dt / steps, 3), "steps": steps,
-               "dtype": dtype if dtype == "fp32" else "bf16 MFMA / fp32 accumulate+storage",
+               "dtype": "fp32 (fp32 MFMA pipe)" if dtype == "fp32" else "bf16 MFMA / fp32 accumulate+storage",
+               "dtype_short": ("fp32x3" if split else "fp32-pipe") if dtype == "fp32" else "bf16",
                "workload": f"TVNetSAModel2 {'RoBERTa' if arch == 'roberta' else 'BERT'}-base random-init, fwd+bwd+AdamW(HIP, overlapped), "
                            f"bs={B}, seq_len={S}, {P} visual prefix slots, train mode, ragged 16..S sequences",
                "mfma_fraction_of_step": round(v * 3 * f_fwd(S, P) / (PEAK_TFLOPS[dtype] * 1e12), 4),
@@ -263,22 +269,104 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3,
             gstep = None
         if hip.streamk_errors():
             raise RuntimeError("a stream-K launch reported a timed-out wait")
-        if split:
+        if split and dtype == "fp32":
             res["dtype"] = ("fp32 operands / results / accumulation; every fp32 product formed on the bf16 matrix pipe as the six "
                             "significant partial products of three-way bf16-split operands (each exact in fp32)")
             res["accuracy"] = ("error of the split GEMM against the fp64 product is at or below the fp32 MFMA pipe's on the same "
-                               "inputs (tests/test_ops_gpu.py::test_gemm_f32_split_accuracy); every fp32 parity test (1e-3 vs the "
-                               "oracle, bit-exact tags, reference goldens) passes in this mode (MTVAF_F32_SPLIT=1)")
+                               "inputs (tests/test_ops_gpu.py::test_gemm_f32_split_accuracy); the library default, so every fp32 "
+                               "parity test (1e-3 vs the oracle, bit-exact tags, reference goldens) runs in this mode")
             res["mfma_fraction_of_step"] = round(v * 3 * f_fwd(S, P) / (PEAK_TFLOPS["fp32x3"] * 1e12), 4)
         if unpad:
             res["workload"] += ", padding-free execution (masked token rows not computed: DESIGN.md 4.6)"
             res["mfma_fraction_of_step"] = None  # (the algorithmic flop count includes the masked rows this mode does not compute)
-        res["roofline"] = roofline_pass(step, mask, B, S, dtype, unpad=unpad, peak_key="fp32x3" if split else None)
+        res["roofline"] = roofline_pass(step, mask, B, S, dtype, unpad=unpad, peak_key="fp32x3" if (split and dtype == "fp32") else None)
         return res
     finally:
         hip.set_compute_dtype("fp32")
         hip.f32_split(split_was)
         _engine.UNPAD = unpad_was
+
+
+
+LINE_LIMIT = 4096  # the driver keeps ~8 KB of stdout tail: the final line stays far below it (tests/test_bench_line.py)
+_HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "median_ms_per_step", "loss", "mfma_fraction_of_step", "mfma_fraction_of_step_executed",
+              "value_fp32_pipe", "ms_per_step_fp32_pipe", "n_ranks_seen", "backend", "rank_ms_spread")
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches_per_step")
+
+
+def _short_roofline(rf):
+    if not isinstance(rf, dict):
+        return rf
+    out = {k: rf[k] for k in _ROOF_KEYS if k in rf}
+    if "all_gemm_kernels" in rf:
+        out["all_gemm_frac"] = rf["all_gemm_kernels"].get("frac")
+        out["all_gemm_ms_per_step"] = rf["all_gemm_kernels"].get("ms_per_step")
+    return out
+
+
+def compact_line(res):
+    """The ONE stdout line of the driver's contract, cut down from the full result (which goes to bench_detail.json and to
+    stderr): the contract's keys, `roofline` without its per-kernel / per-shape lists, `cpu_baseline`, and for every secondary
+    configuration {value, ms_per_step, dtype, roofline_frac, roofline_kernel}.  Never longer than LINE_LIMIT bytes: optional
+    parts are dropped, least important first, until it fits."""
+    line = {k: res[k] for k in _HEAD_KEYS if k in res}
+    if isinstance(line.get("config"), dict):
+        line["config"] = dict(line["config"])
+    if "roofline" in res:
+        line["roofline"] = _short_roofline(res["roofline"])
+    if "roofline_fp32_pipe" in res:
+        line["roofline_fp32_pipe"] = _short_roofline(res["roofline_fp32_pipe"])
+    if "cpu_baseline" in res:
+        line["cpu_baseline"] = {k: res["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample") if k in res["cpu_baseline"]}
+    if isinstance(res.get("grad_sync"), dict):
+        line["grad_sync"] = {k: v for k, v in res["grad_sync"].items() if k != "note"}
+    if isinstance(res.get("padding_free"), dict):
+        line["padding_free"] = {k: res["padding_free"][k] for k in ("value", "ms_per_step") if k in res["padding_free"]}
+    if isinstance(res.get("fwd_bwd_without_optimizer"), dict):
+        line["fwd_bwd_without_optimizer"] = res["fwd_bwd_without_optimizer"]
+    if isinstance(res.get("secondary"), dict):
+        sec = {}
+        for k, v in res["secondary"].items():
+            if "error" in v:
+                sec[k] = {"error": str(v["error"])[:80]}
+                continue
+            rf = v.get("roofline") or {}
+            sec[k] = {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"), "dtype": v.get("dtype_short", v.get("dtype")),
+                      "roofline_frac": rf.get("frac"), "roofline_kernel": rf.get("kernel")}
+        line["secondary"] = sec
+    line["detail"] = "bench_detail.json (also on stderr)"
+    # shrink until it fits: the contract's keys, roofline and cpu_baseline are never dropped
+    for drop in ("fwd_bwd_without_optimizer", "padding_free", "roofline_fp32_pipe", "grad_sync"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+    if len(json.dumps(line)) >= LINE_LIMIT and "secondary" in line:
+        line["secondary"] = {k: {"value": v.get("value")} for k, v in line["secondary"].items()}
+    if len(json.dumps(line)) >= LINE_LIMIT:
+        line.pop("secondary", None)
+    for k_, n_ in (("sample", 160), ("workload", 200)):
+        tgt = line.get("cpu_baseline", {}) if k_ == "sample" else line.get("config", {})
+        if len(json.dumps(line)) >= LINE_LIMIT and isinstance(tgt.get(k_), str):
+            tgt[k_] = tgt[k_][:n_]
+    assert len(json.dumps(line)) < LINE_LIMIT, "bench line over the limit even after dropping every optional part"
+    return line
+
+
+def emit(res, out=None, err=None, detail_path=None):
+    """Full result -> bench_detail.json next to bench.py (best effort) and stderr; THEN the compact line as the last thing on
+    stdout.  Nothing is printed to stdout after it."""
+    out, err = out or sys.stdout, err or sys.stderr
+    full = json.dumps(res)
+    try:
+        with open(detail_path or os.path.join(ROOT, "bench_detail.json"), "w") as f:
+            f.write(full + "\n")
+    except OSError as e:  # (a read-only checkout must not cost the line)
+        print(f"[bench] bench_detail.json not written: {e}", file=err, flush=True)
+    print("[bench detail] " + full, file=err, flush=True)
+    line = json.dumps(compact_line(res))
+    print(line, file=out, flush=True)
+    return line
 
 
 def log(msg):
@@ -352,6 +440,9 @@ def main():
     ap.add_argument("--model", default="bert", choices=["bert", "roberta"], help="encoder architecture (base size)")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16"],
                     help="GEMM arithmetic: fp32 (BASELINE config 2, default) or bf16 compute with fp32 accumulation (configs 3-4)")
+    ap.add_argument("--f32-pipe", action="store_true",
+                    help="fp32 mode: form the products on the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32) instead of the library default, "
+                         "six exact bf16 partial products of three-way split fp32 operands (csrc/gemm_f32x3.hip)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--optimizer", default="all", choices=["all", "reference", "torch"],
                     help="all: mtvaf_amd.optim.AdamW (HIP kernels, per-layer updates enqueued inside the backward pass) over "
@@ -409,6 +500,10 @@ def main():
     from mtvaf_amd import hip
     hip.lib()
     hip.set_compute_dtype(a.dtype)
+    if a.f32_pipe:
+        hip.f32_split(False)
+    split_mode = a.dtype == "fp32" and hip.f32_split()  # (the library default; MTVAF_F32_SPLIT=0 / --f32-pipe: the fp32 MFMA pipe)
+    peak_key = "fp32x3" if split_mode else a.dtype
 
     B, S, P = a.batch, a.seq, 4 * (1 + a.aux)
     from mtvaf_amd import engine
@@ -555,14 +650,16 @@ def main():
             dt2 = float(t)
         v2 = world * B * a.steps / dt2
         padding_free = {"value": round(v2, 2), "ms_per_step": round(1e3 * dt2 / a.steps, 3),
-                        "mfma_fraction_of_step_executed_flops": round(v2 / world * f_exec / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
+                        "mfma_fraction_of_step_executed_flops": round(v2 / world * f_exec / (PEAK_TFLOPS[peak_key] * 1e12), 4),
                         "note": "same workload and results (loss, tags, parameter gradients equal the padded run: "
                                 "tests/test_unpad_gpu.py); masked token rows are not computed; opt-in (`--unpad` / "
                                 "MTVAF_UNPAD=1), not the headline"}
 
     res = {"metric": "training sentences/sec (fwd+bwd)", "value": round(value, 2), "unit": "sentences/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype if a.dtype == "fp32" else "bf16 MFMA / fp32 accumulate+storage",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": ("fp32 (3xbf16 split products, fp32 accumulate)" if split_mode else "fp32 (fp32 MFMA pipe)") if a.dtype == "fp32"
+                    else "bf16 MFMA / fp32 accumulate+storage",
            "data": "synthetic",
            "config": {"workload": f"TVNetSAModel2 {'RoBERTa' if a.model == 'roberta' else 'BERT'}-base random-init, fwd+bwd{' as one HIP graph' if a.graph else ''}{'' if a.no_optimizer else {'torch': '+AdamW(torch fused)'}.get(a.optimizer, '+AdamW(HIP' + (', eager after the replay)' if a.graph else ', overlapped with backward)'))}, "
                                   f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
@@ -572,12 +669,14 @@ def main():
                       "parallelism": f"dp{world}" + (" (RCCL all-reduce overlapped with backward)" if world > 1 else "")},
            "median_ms_per_step": round(med_ms, 3), "value_median": round(world * B / (med_ms * 1e-3), 2),
            "loss": round(loss_val, 4),
-           "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS[a.dtype] * 1e12), 4),
+           "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS[peak_key] * 1e12), 4),
+           "peak_tflops": PEAK_TFLOPS[peak_key],
            "flop_per_sentence_train": ftrain, "fwd_bwd_without_optimizer": fwd_bwd_only,
            "real_token_rows": round(real_rows, 4), "flop_per_sentence_train_real_rows": round(f_exec),
-           "note_flops": "mfma_fraction_of_step credits the algorithmic 3 x F_fwd per sentence (SURVEY 8d); in the fp32 mode the "
-                         "weight-gradient products skip the k-tiles of masked token rows (exact zeros, DESIGN 4.5b): the roofline "
-                         "object below counts the flops those launches execute",
+           "note_flops": "mfma_fraction_of_step credits the algorithmic 3 x F_fwd per sentence (SURVEY 8d) against peak_tflops (split "
+                         "mode: 2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work on the bf16 pipe); in the fp32 mode the "
+                         "weight-gradient products skip the k-tiles of masked token rows (exact zeros): the roofline "
+                         "object counts the flops those launches execute",
            "padding": "skipped (--unpad): the fraction below counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
            "padding_free": padding_free}
     res["n_ranks_seen"] = dist.get_world_size() if world > 1 else 1
@@ -596,7 +695,7 @@ def main():
                                     "optimizer updates queued behind them), and how long the last exchange ran past the "
                                     "backward pass's own kernels"}
     if a.unpad:
-        res["mfma_fraction_of_step"] = round(per_gpu * f_exec / (PEAK_TFLOPS[a.dtype] * 1e12), 4)
+        res["mfma_fraction_of_step"] = round(per_gpu * f_exec / (PEAK_TFLOPS[peak_key] * 1e12), 4)
         res["config"]["workload"] += ", padding-free execution (masked token rows not computed)"
 
     # ---- roofline of the dominant kernel (fp32 MFMA GEMM), measured live with HIP events recorded by the
@@ -606,20 +705,13 @@ def main():
             sync.enabled = False
         if a.graph:
             gstep.close()  # the profiled steps run eagerly (the launch profiler brackets individual launches)
-        from mtvaf_amd import hip as _hip
-        env_split = a.dtype == "fp32" and _hip.f32_split()  # (MTVAF_F32_SPLIT=1 in the environment: the whole run is the split mode)
-        res["roofline"] = roofline_pass(eager_step, mask, B, S, a.dtype, a.unpad, peak_key="fp32x3" if env_split else None)
-        if env_split:
-            res["dtype"] = ("fp32 operands / results / accumulation; fp32 products formed on the bf16 matrix pipe from three-way "
-                            "bf16-split operands (MTVAF_F32_SPLIT=1; DESIGN.md 4.1e)")
+        res["roofline"] = roofline_pass(eager_step, mask, B, S, a.dtype, a.unpad, peak_key="fp32x3" if split_mode else None)
         ex = res["roofline"]["all_gemm_kernels"]["executed_tflop_per_step"]
         # the whole step by the flops its GEMM launches EXECUTE (the weight-gradient products skip the k-tiles of masked
-        # token rows) plus the attention products' algorithmic share, next to the algorithmic figure above
+        # token rows) plus the attention products' algorithmic share, next to the algorithmic figure above (split mode: both
+        # against the fp32-equivalent peak of the bf16 pipe; the attention products still run the fp32 pipe)
         attn_tflop = B * 3 * 12 * 4 * S * (S + P) * 768 / 1e12
-        res["mfma_fraction_of_step_executed"] = round((ex + attn_tflop) / (1e-3 * res["ms_per_step"]) / PEAK_TFLOPS[a.dtype], 4)
-        if env_split:  # fractions of the fp32-equivalent peak of the bf16 pipe (the attention products still run the fp32 pipe)
-            for k_ in ("mfma_fraction_of_step", "mfma_fraction_of_step_executed"):
-                res[k_] = round(res[k_] * PEAK_TFLOPS["fp32"] / PEAK_TFLOPS["fp32x3"], 4)
+        res["mfma_fraction_of_step_executed"] = round((ex + attn_tflop) / (1e-3 * res["ms_per_step"]) / PEAK_TFLOPS[peak_key], 4)
     if rank == 0:
         log("roofline pass done")
     if rank == 0 and world == 1 and not a.no_secondary and not a.graph and (B, S, a.aux, a.dtype, a.model, a.unpad) == (32, 128, 8, "fp32", "bert", False):
@@ -630,23 +722,28 @@ def main():
         torch.cuda.empty_cache()
         res["secondary"] = {}
         for key, (dt_, arch_, b_, s_, aux_) in {"c1_fp32": ("fp32", "bert", 4, 64, 3), "c1_fp32_graph": ("fp32", "bert", 4, 64, 3),
-                                                "c2_fp32_split": ("fp32", "bert", 32, 128, 8),
+                                                ("c2_fp32_pipe" if split_mode else "c2_fp32_split"): ("fp32", "bert", 32, 128, 8),
                                                 "c2_fp32_split_unpad": ("fp32", "bert", 32, 128, 8),
                                                 "c3_bf16": ("bf16", "roberta", 32, 128, 8), "c4_bf16": ("bf16", "bert", 64, 128, 8)}.items():
             try:
                 # (C1 is the one host-bound configuration: 10 steps behind 3 warm-up steps read 750-930 sentences/s from call
                 # to call, 40 behind 10 read what `bench.py --batch 4 --seq 64 --aux 3` reads)
-                res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_, split="_split" in key,
+                res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_,
+                                                         split=("_split" in key) or (bool(split_mode) and "_pipe" not in key),
                                                          unpad=key.endswith("_unpad"), graph=key.endswith("_graph"),
                                                          steps=40 if key.startswith("c1_") else 10,
                                                          warmup=10 if key.startswith("c1_") else 5)
             except Exception as e:  # a secondary figure must never cost the headline line
                 res["secondary"][key] = {"error": repr(e)}
             torch.cuda.empty_cache()
-        sp = res["secondary"].get("c2_fp32_split", {})
-        if "value" in sp:  # the same workload as `value`, fp32 products formed on the bf16 matrix pipe (details: secondary.c2_fp32_split)
-            res["value_fp32_split"] = sp["value"]
-            res["ms_per_step_fp32_split"] = sp["ms_per_step"]
+        # the same workload as `value` in the other fp32 arithmetic (kept in the line for continuity with rounds 1-3, whose
+        # headline was the fp32 MFMA pipe)
+        for key_, tag_ in (("c2_fp32_pipe", "fp32_pipe"), ("c2_fp32_split", "fp32_split")):
+            sp = res["secondary"].get(key_, {})
+            if "value" in sp:
+                res["value_" + tag_] = sp["value"]
+                res["ms_per_step_" + tag_] = sp["ms_per_step"]
+                res["roofline_" + tag_] = sp.get("roofline")
         log("secondary configurations done")
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(B, S, a.aux)
@@ -657,7 +754,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res)
 
 
 if __name__ == "__main__":

@@ -276,7 +276,7 @@ int mtvaf_colsum_small(const float* part, int rows, int cols, float* out, int ac
  * below 2^-26 |a||b|: accuracy of the fp32 pipe; operands and results stay fp32 in memory).  Same arguments as
  * mtvaf_gemm_f32 (modeling_bert.py:266, 283-284, 353, 420-421, 433 and their autograd backward); shapes it does not cover
  * (not whole 64x64 tiles, K % 32 != 0, unaligned operands) run the fp32 pipe.  mtvaf_f32_split(1 / 0): mtvaf_gemm_f32 and
- * mtvaf_gemm_f32_ktiles use it everywhere they can / never (default: MTVAF_F32_SPLIT, else 0); -1 queries. */
+ * mtvaf_gemm_f32_ktiles use it everywhere they can / never (default: 1; MTVAF_F32_SPLIT=0 in the environment: 0); -1 queries. */
 int mtvaf_gemm_f32x3(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                      int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
                      int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
@@ -291,6 +291,9 @@ int mtvaf_f32_split(int on);
 int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
                             const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
                             void* workspace, size_t workspace_bytes, int splits, mtvaf_stream_t stream);
+/* bytes of split-K slabs that call needs for these products (0: no split planned; too little workspace is MTVAF_ERR_WORKSPACE,
+ * never a silently different plan) */
+size_t mtvaf_gemm_f32_dw_group_workspace_bytes(int n, const int* M, const int* N, int K, int splits);
 int mtvaf_dw_group_rows(int rows);
 
 /* Stream-K form of the 256x256 eight-phase bf16 kernel (csrc/gemm_bf16p.hip; tile 5 = tile-per-block, tile 6 = stream-K forced,

@@ -650,7 +650,11 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
     zero_f32(dword, (long)vocab * H, st);
     if (pos_ids) zero_f32(dpos, (long)max_pos * H, st);
   }
-  if (embed_scatter_atomic() || H > DET_NC * 64) {
+  // the owner scheme's one-block scan covers tables of up to 65536 rows: larger vocabularies (bert-base-multilingual 119547,
+  // xlm-roberta 250002 -- the reference takes any `bert_name`) keep the atomic scatter (decided before anything is launched
+  // for the scatter; not bit-reproducible there, as torch's own nn.Embedding backward)
+  const int Vmax = (std::max(vocab, max_pos) + 4095) / 4096 * 4096;  // (the scan's int4 shares: 1024 threads x 4 * ceil(V / 4096))
+  if (embed_scatter_atomic() || H > DET_NC * 64 || Vmax > 65536) {
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(g), dim3(256), 0, st, dz_ws, ids, pos_ids, dword, dpos, M, H, word_pad,
                        pos_pad);
   } else {  // bit-reproducible: one owner per table row, gradient rows added in token order
@@ -658,8 +662,6 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
     int* flags = reinterpret_cast<int*>(part + (size_t)g * 4 * H);
     int* seg = flags + M;
     int* count = reinterpret_cast<int*>((reinterpret_cast<uintptr_t>(seg + M) + 15) & ~(uintptr_t)15);  // [Vmax] count, [Vmax] cursor, [Vmax] offset (16-byte aligned: int4 scan)
-    const int Vmax = (std::max(vocab, max_pos) + 4095) / 4096 * 4096;  // (the scan's int4 shares: 1024 threads x 4 * ceil(V / 4096))
-    if (Vmax > 65536) return MTVAF_ERR_SHAPE;
     hipLaunchKernelGGL(row_nonzero_kernel, dim3(std::min(gd, 2048)), dim3(256), 0, st, dz_ws, flags, M, H);
     for (int key = 0; key < (pos_ids ? 2 : 1); ++key) {
       const int V = key == 0 ? vocab : max_pos;

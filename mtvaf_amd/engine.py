@@ -469,8 +469,9 @@ def _native_backward(ctx, douts):
     gviews = grad_sink.acquire(params) if grad_sink is not None else None
     if grad_sink is not None:
         grad_sink.token_rows = M
-    # zero-copy gradients bypass AccumulateGrad: only when nobody listens there (tensor hooks, post-accumulate hooks -- which is
-    # also how torch DDP's reducer learns that a gradient is ready)
+    # zero-copy gradients bypass AccumulateGrad: only when nobody listens there (tensor hooks, post-accumulate hooks).  NOT
+    # detectable from Python: torch DDP's reducer, which hooks the AccumulateGrad nodes in C++ -- data parallelism here is
+    # mtvaf_amd.parallel.GradSync; a DDP-wrapped model must set MTVAF_DIRECT_GRADS=0 / engine.DIRECT_GRADS = False
     direct = gviews is not None and DIRECT_GRADS and not _has_grad_hooks(params)
     pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
     main = torch.cuda.current_stream()
@@ -600,6 +601,8 @@ def _native_backward(ctx, douts):
     dh0_out = dh.view(B, S, H) if dh is not None else None
     if not need_param_grads:
         pgrads = [None] * len(params)
+    if use_h and need_param_grads:
+        hip.streamk_poll()  # (a stream-K wait that ran out in the previous step raises here instead of training on)
     return (dh0_out, dpkv, None, None, None, None, *pgrads)
 
 

@@ -87,6 +87,7 @@ _SIGS = {
     "mtvaf_embed_scatter_mode": (c_int, [I]),
     "mtvaf_embed_ln_bwd_workspace_bytes": (SZ, [I, I, I, I]),
     "mtvaf_gemm_f32_dw_group": (c_int, [I, P, P, P, P, P, P, P, P, I, P, P, P, SZ, I, P]),
+    "mtvaf_gemm_f32_dw_group_workspace_bytes": (SZ, [I, P, P, I, I]),
     "mtvaf_dw_group_rows": (c_int, [I]),
     "mtvaf_streamk_attach": (c_int, [P, SZ, P]),
     "mtvaf_streamk_scratch_bytes": (SZ, [I]),
@@ -230,6 +231,8 @@ def kernel_symbol(cfg, la, lb, fast):
             16: (64, 64, 2, 2), 17: (64, 64, 2, 2)}.get(cfg)
     b = lambda x: "true" if x else "false"
     klist, fast = bool(fast & 8), fast & 7  # (+8: the launch walked a k-tile list)
+    if cfg >= 1000:  # the grouped weight-gradient launch of the fp32 LDS-DMA kernel (mtvaf_gemm_f32_dw_group)
+        return f"gemm_f32_dma_group_kernel<128, 96, 4, 1, 2, {b(klist)}>"
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>
         c = cfg - 300
         if c & 64:  # gemm_bf16_p256_kernel<A_KM, B_KM, SK> (+128: the in-launch-combine form, +256: a grouped launch)
@@ -273,7 +276,7 @@ def f32_split(on=None) -> bool:
     """fp32-mode GEMMs on the bf16 matrix pipe by three-way operand splitting (csrc/gemm_f32x3.hip: six exact bf16 partial
     products per fp32 product, fp32 accumulate; operands and results stay fp32).  on = True / False switches every
     mtvaf_gemm_f32 / _ktiles call of the process (Python orchestration and native executor alike); None queries.
-    Default: MTVAF_F32_SPLIT, else off."""
+    Default: ON (MTVAF_F32_SPLIT=0 in the environment keeps the fp32 MFMA pipe)."""
     return bool(lib().mtvaf_f32_split(-1 if on is None else int(bool(on))))
 
 
@@ -600,6 +603,7 @@ def streamk_detach_all():
         if buf is not None:
             _ck(lib().mtvaf_streamk_attach(None, 0, st), "mtvaf_streamk_attach")
     _sk_scratch.clear()
+    _sk_poll.clear()
 
 
 def streamk_error(device) -> int:
@@ -615,6 +619,37 @@ def streamk_errors() -> int:
     return sum(int(buf[4092:4096].view(torch.int32).item()) for buf in _sk_scratch.values() if buf is not None)
 
 
+_sk_poll = {}
+
+
+def streamk_poll():
+    """Asynchronous check of the stream-K error words, for once-per-step callers (the encoder backward in bf16 mode): raises if
+    the copy enqueued by the PREVIOUS call has landed non-zero, then enqueues a fresh 4-byte copy of every attached scratch's
+    error word to pinned memory on the current stream.  No host synchronisation: a timed-out wait (wrong weight gradients in
+    that launch) surfaces one step later instead of never; the header is re-zeroed so that later launches do not read the
+    stale flags the failed launch left behind."""
+    for key, buf in _sk_scratch.items():
+        if buf is None:
+            continue
+        ent = _sk_poll.get(key)
+        if ent is not None:
+            host, ev = ent
+            if ev.query() and int(host.item()) != 0:
+                buf[:4096].zero_()
+                host.zero_()
+                raise RuntimeError("a stream-K launch of the bf16 GEMM timed out waiting for a contribution: the weight gradients of "
+                                   "that step are wrong (mtvaf_amd.hip.streamk_poll); flags and error word were reset")
+        else:
+            host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            ev = torch.cuda.Event()
+            _sk_poll[key] = (host, ev)
+        if torch.cuda.is_current_stream_capturing():
+            continue
+        host, ev = _sk_poll[key]
+        host.copy_(buf[4092:4096].view(torch.int32), non_blocking=True)
+        ev.record()
+
+
 def dw_group_rows(rows: int = -1) -> int:
     """fp32 mode: layers of at most this many token rows send their four weight-gradient products as one grouped launch
     (csrc/executor.hip: mtvaf_dw_group_rows; default 1024, MTVAF_DW_GROUP_ROWS).  rows >= 0 sets it."""
@@ -628,11 +663,12 @@ def gemm_f32_dw_group(items, K, ktiles=None, splits=-1):
     vp = lambda ts: (ctypes.c_void_p * n)(*[_p(t) for t in ts])
     ia = lambda xs: (ctypes.c_int * n)(*xs)
     As, Bs, Cs = [i[0] for i in items], [i[1] for i in items], [i[2] for i in items]
-    wsb = 8 * sum(c.numel() for c in Cs) * 4
-    ws = workspace(wsb, As[0].device)
+    Ms, Ns = ia([t.shape[1] for t in As]), ia([t.shape[1] for t in Bs])
+    wsb = int(lib().mtvaf_gemm_f32_dw_group_workspace_bytes(n, Ms, Ns, K, splits))  # the library's own plan, as the executor's call
+    ws = workspace(max(wsb, 16), As[0].device)
     kl, kc = (ktiles if ktiles is not None else (None, None))
     _ck(lib().mtvaf_gemm_f32_dw_group(n, vp(As), ia([t.stride(0) for t in As]), vp(Bs), ia([t.stride(0) for t in Bs]), vp(Cs),
-                                      ia([t.stride(0) for t in Cs]), ia([t.shape[1] for t in As]), ia([t.shape[1] for t in Bs]),
+                                      ia([t.stride(0) for t in Cs]), Ms, Ns,
                                       K, _p(kl), _p(kc), _p(ws), ws.numel(), splits, _st()), "mtvaf_gemm_f32_dw_group")
 
 

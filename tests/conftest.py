@@ -21,3 +21,17 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(params=["split", "pipe"])
+def f32_arith(request):
+    """fp32 GEMM arithmetic of the library for one test: "split" = the default (six exact bf16 partial products of three-way
+    split fp32 operands, csrc/gemm_f32x3.hip), "pipe" = the fp32 MFMA pipe forced (MTVAF_F32_SPLIT=0).  The parity tests
+    that anchor the headline run in both; every other -m gpu test runs the default."""
+    from mtvaf_amd import hip
+    was = hip.f32_split()
+    hip.f32_split(request.param == "split")
+    try:
+        yield request.param
+    finally:
+        hip.f32_split(was)

@@ -40,3 +40,20 @@ def test_header_compiles_as_c():
         open(src, "w").write('#include "mtvaf_hip.h"\nint main(void){return MTVAF_OK;}\n')
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", src, "-o",
                         os.path.join(d, "t.o")], check=True)
+
+
+def test_split_fp32_is_the_library_default_and_the_environment_switches_it_off():
+    """mtvaf_f32_split: ON by default (the arithmetic bench.py times and every default-mode parity test runs), MTVAF_F32_SPLIT=0
+    keeps the fp32 MFMA pipe, the setter overrides both (host-side switch: no GPU call)."""
+    import subprocess
+    import sys
+    from mtvaf_amd.build import build_library
+    path = build_library(verbose=False)
+    code = (f"import ctypes; l = ctypes.CDLL({path!r}); print(l.mtvaf_f32_split(-1), l.mtvaf_f32_split(0), l.mtvaf_f32_split(-1), "
+            "l.mtvaf_f32_split(1), l.mtvaf_f32_split(-1))")
+    env = {k: v for k, v in os.environ.items() if k != "MTVAF_F32_SPLIT"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["1", "0", "0", "1", "1"], out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(env, MTVAF_F32_SPLIT="0"), capture_output=True, text=True,
+                         check=True).stdout.split()
+    assert out[0] == "0", out

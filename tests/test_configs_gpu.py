@@ -86,9 +86,10 @@ GRADS = ["encoder_conv.2.weight", "projectors.0.weight", "bert.encoder.layer.5.i
 
 
 @pytest.mark.parametrize("B", [8, 32])
-def test_assembled_forward_on_the_timed_path_vs_oracle(B):
+def test_assembled_forward_on_the_timed_path_vs_oracle(B, f32_arith):
     """BASELINE configs[1] (the bench workload): BERT-base 12 layers, S = 128, 8 aux crops -> P = 36, use_prefix=True.
-    B = 8 (1024 tokens) and B = 32 (the bench batch): prompt generator and Viterbi on the second stream, DeferredTags."""
+    B = 8 (1024 tokens) and B = 32 (the bench batch): prompt generator and Viterbi on the second stream, DeferredTags.
+    In both fp32 arithmetics (`f32_arith`): the library default that bench.py times, and the fp32 MFMA pipe."""
     from mtvaf_amd import engine
     from mtvaf_amd.modules.crf import DeferredTags
     if not engine.DW_SIDE_STREAM:
@@ -417,7 +418,7 @@ def test_native_executor_equals_python_orchestration(dtype):
 
 
 # ---- BASELINE configs[4] (C5): S = 512, 36 visual regions ------------------------------------------------------------------
-def test_config5_assembled_seq512_vs_oracle():
+def test_config5_assembled_seq512_vs_oracle(f32_arith):
     """C5 shape on the ASSEMBLED model: TVNetSAModel2, BERT-base 12 layers, S = 512, 8 aux crops (P = 36), B = 4, fp32, against
     the oracle: prompt generator on the second stream, CRF / Viterbi at S = 512, weight-gradient k-tile lists (half the rows
     of a ragged S = 512 batch are padding), second stream in backward."""

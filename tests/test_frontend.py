@@ -64,32 +64,42 @@ def _frontend_case(name, device):
     return im.to(device), sd, x.to(device), aux.to(device), fx
 
 
-def _check_frontend(name, device, rtol, atol, norm_tol=None):
+LEVEL_TOL = 2e-3  # per pyramid level, relative error in norm (GPU; and hosts whose oneDNN sums in another order)
+
+
+def _levels(t, name):
+    """[..., C, 2, 2] pyramid -> its four levels (the channel blocks of layer1..layer4 that get_resnet_prompt concatenates,
+    bert_model.py:101-111)."""
+    widths = (64, 128, 256, 512) if name == "resnet18" else (256, 512, 1024, 2048)
+    return torch.split(t, widths, dim=-3)
+
+
+def _close_per_level(got, ref, name, msg, device, strict):
+    """strict = (rtol, atol): element-wise first (it holds on the CPU that wrote the fixture); wherever it does not -- another
+    host's oneDNN kernel selection, MIOpen's algorithm choice on the GPU -- EVERY level of the pyramid must still agree to
+    LEVEL_TOL in norm (a wrong pooling window or tap on one level moves that level by O(1), which a whole-tensor norm over
+    3840 channels would dilute), and no single element may be far off."""
+    if strict is not None:
+        try:
+            torch.testing.assert_close(got, ref, rtol=strict[0], atol=strict[1])
+            return "element-wise"
+        except AssertionError:
+            pass
+    worst = 0.0
+    for li, (g, r) in enumerate(zip(_levels(got, name), _levels(ref, name))):
+        rel = float((g.double() - r.double()).norm() / r.double().norm())
+        worst = max(worst, rel)
+        assert rel < LEVEL_TOL, (msg, f"level {li + 1}", rel)
+    print(f"[frontend {name} {device}] {msg}: per-level relative error in norm <= {worst:.2e}", flush=True)
+    if device == "cpu":
+        torch.testing.assert_close(got, ref, rtol=5e-2, atol=5e-3, msg=msg)
+    return "per-level norm"
+
+
+def _check_frontend(name, device, strict):
     from mtvaf_amd.features import RegionFeatureCache
     im, sd, x, aux, fx = _frontend_case(name, device)
-    if norm_tol is not None:
-        # MIOpen picks its own convolution algorithms, and train-mode BatchNorm over the 2 x 2 x 2 values a channel has left
-        # at layer4 (64-pixel images) divides by a tiny batch variance: single elements can move far more than the tensor does.
-        # On the GPU the pyramids are compared in norm; the element-wise comparison runs on the host (CPU test below).
-        class _T:
-            @staticmethod
-            def assert_close(a, b, rtol=None, atol=None, msg=""):
-                rel = float((a.double() - b.double()).norm() / b.double().norm())
-                print(f"[frontend {name} {device}] {msg}: relative error in norm {rel:.2e}", flush=True)
-                assert rel < norm_tol, (msg, rel)
-        tt = _T
-    else:
-        tt = torch.testing
-
-    class _HostNorm:  # host run: another CPU (another oneDNN kernel selection) sums the convolutions / the 2 x 2 x 2 batch
-        tol = 1e-3     # statistics in another order -- the fixture's authoring CPU matches element-wise, others in norm
-        @classmethod
-        def assert_close(cls, a, b, rtol=None, atol=None, msg=""):
-            rel = float((a.double() - b.double()).norm() / b.double().norm())
-            assert rel < cls.tol, (msg, rel)
-            torch.testing.assert_close(a, b, rtol=5e-2, atol=5e-3, msg=msg)  # and no single element far off
-    if norm_tol is None:
-        tt = _HostNorm
+    how = set()
     for mode in ("train", "eval"):
         im.train(mode == "train")
         im.resnet.load_state_dict(sd)  # (train mode moves the running statistics)
@@ -97,21 +107,21 @@ def _check_frontend(name, device, rtol, atol, norm_tol=None):
             pyr, aux_pyr = im(x, aux)
         got = torch.cat(pyr, 1).cpu()
         got_aux = torch.stack([torch.cat(a, 1) for a in aux_pyr], 1).cpu()
-        tm = tt
-        tm.assert_close(got, torch.from_numpy(fx[f"{mode}_main"]), rtol=rtol, atol=atol, msg=f"{name} {mode} main")
-        tm.assert_close(got_aux, torch.from_numpy(fx[f"{mode}_aux"]), rtol=rtol, atol=atol, msg=f"{name} {mode} aux")
+        how.add(_close_per_level(got, torch.from_numpy(fx[f"{mode}_main"]), name, f"{mode} main", device, strict))
+        how.add(_close_per_level(got_aux, torch.from_numpy(fx[f"{mode}_aux"]), name, f"{mode} aux", device, strict))
         if mode == "train":  # BatchNorm ran in train mode, as the reference's merely requires_grad=False "frozen" trunk does
-            tt.assert_close(im.resnet.bn1.running_mean.cpu(), torch.from_numpy(fx["train_bn1_running_mean_after"]),
-                            rtol=rtol, atol=atol, msg="bn1 running mean")
+            rm, ref_rm = im.resnet.bn1.running_mean.cpu(), torch.from_numpy(fx["train_bn1_running_mean_after"])
+            assert float((rm.double() - ref_rm.double()).norm() / ref_rm.double().norm()) < (1e-5 if device == "cpu" else LEVEL_TOL)
     # train-mode and eval-mode pyramids really differ (the documented deviation of the feature cache is not vacuous)
     assert float(np_rel(fx["train_main"], fx["eval_main"])) > 1e-2
     # the cache = the reference's EVAL-mode pyramid, whatever mode the model is in
     im.resnet.load_state_dict(sd)
     im.train()
     feats, fa = RegionFeatureCache(im).extract(x, aux)
-    tt.assert_close(feats.cpu(), torch.from_numpy(fx["eval_main"]), rtol=rtol, atol=atol, msg="cache main")
-    tt.assert_close(fa.cpu(), torch.from_numpy(fx["eval_aux"]), rtol=rtol, atol=atol, msg="cache aux")
+    how.add(_close_per_level(feats.cpu(), torch.from_numpy(fx["eval_main"]), name, "cache main", device, strict))
+    how.add(_close_per_level(fa.cpu(), torch.from_numpy(fx["eval_aux"]), name, "cache aux", device, strict))
     assert im.training
+    return how
 
 
 def np_rel(a, b):
@@ -125,14 +135,16 @@ def test_frontend_matches_reference_golden_cpu(name):
     gen_frontend_fixture.py: reference class imported in the authoring container, seeded trunk and images): pyramid taps,
     AvgPool2d(ft // 2) pooling, aux-image order, train-mode and eval-mode BatchNorm; and RegionFeatureCache against the
     reference's eval-mode pyramid.  Plain torch on the host: no GPU needed."""
-    _check_frontend(name, "cpu", rtol=1e-4, atol=1e-5)
+    how = _check_frontend(name, "cpu", strict=(1e-4, 1e-5))
+    print(f"[frontend {name} cpu] compared: {sorted(how)}")
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["resnet18", "resnet50"])
 def test_frontend_matches_reference_golden_gpu(name):
-    """The same on the MI355X, in norm (see _check_frontend)."""
-    _check_frontend(name, "cuda", rtol=None, atol=None, norm_tol=1e-2)
+    """The same on the MI355X (MIOpen picks its own convolution algorithms): every pyramid level to 2e-3 in norm, train-mode and
+    eval-mode BatchNorm, main and aux images, and the feature cache (see _close_per_level)."""
+    _check_frontend(name, "cuda", strict=None)
 
 
 @pytest.mark.gpu

@@ -167,7 +167,11 @@ def test_dropout_res_ln_with_dropout(hip):
     assert not torch.equal(keep2.cpu(), keep)
 
 
-@pytest.mark.parametrize("cfg", [P.TINY_BERT, P.TINY_ROBERTA, P.EncCfg(vocab_size=1000, hidden=768, max_pos=512)])
+@pytest.mark.parametrize("cfg", [P.TINY_BERT, P.TINY_ROBERTA, P.EncCfg(vocab_size=1000, hidden=768, max_pos=512),
+                                 # vocabularies beyond the owner scheme's 65536-row scan (bert-base-multilingual, xlm-roberta: the
+                                 # reference takes any `bert_name`) keep the atomic scatter
+                                 P.EncCfg(vocab_size=119547, hidden=128, max_pos=64),
+                                 P.EncCfg(vocab_size=250002, hidden=128, type_vocab=1, eps=1e-5, roberta=True, pad_idx=1, max_pos=66)])
 def test_embed_ln(hip, cfg):
     B, S = 5, 24
     sd = {k: v for k, v in P.encoder_params(cfg, 5).items() if k.startswith("embeddings.")}

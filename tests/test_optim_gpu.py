@@ -218,7 +218,8 @@ def test_state_dict_round_trip_keeps_the_flat_moments_and_step():
 
 def test_tensor_hooks_on_encoder_parameters_still_fire():
     """The zero-copy gradient path assigns .grad itself and bypasses AccumulateGrad; with a hook registered on an encoder
-    parameter the backward must go through autograd so that the hook runs (torch DDP's reducer relies on that)."""
+    parameter the backward must go through autograd so that the hook runs (Python-visible hooks only: torch DDP's C++ reducer
+    hooks are not detectable -- INTEGRATION.md, `MTVAF_DIRECT_GRADS=0`)."""
     m, cfg = _model(layers=2)
     m.eval()
     batch = _batch(cfg)

@@ -20,3 +20,5 @@ def test_kernel_symbols_of_every_gemm_family():
     # bf16-operand kernels: the 256 x 256 eight-phase kernel and the rings
     assert hip.kernel_symbol(300 + 64 + 4 + 8 + 128, 1, 1, 2) == "gemm_bf16_p256_kernel<true, true, true>"
     assert hip.kernel_symbol(300 + 1 + 8, 0, 1, 2) == "gemm_bf16x_kernel<128, 128, 2, 2, false, true, 2, false>"
+    # the grouped weight-gradient launch of the fp32 LDS-DMA kernel has a key of its own (1000 + tile)
+    assert hip.kernel_symbol(1012, 1, 1, 2 + 8) == "gemm_f32_dma_group_kernel<128, 96, 4, 1, 2, true>"
