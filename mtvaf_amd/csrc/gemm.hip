@@ -774,7 +774,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
   for (int c = 0; c < kNumCfgs; ++c) {
     if (eff[c] <= 0.0) continue;
     if (compute == 1 && !(c == 6 || c == 5 || c == 3)) continue;  // bf16 kernels exist for 128x96, 128x128, 64x64
-    if (compute == 2 && !((c == 5 && M % 128 == 0 && N % 128 == 0) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
+    if (compute == 2 && !((c == 5 && M % 128 == 0 && N % 128 == 0) || (c == 6 && M % 128 == 0 && N % 96 == 0) ||
+                          (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute != 0 ? 32 : kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
     const int max_s = allow_split ? 16 : 1;
@@ -790,7 +791,9 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       const double occ2 = two_blocks ? (tiles * s >= 384 ? 1.08 : 0.95) : 1.0;  // (>= 1.5 blocks per CU: M = 2432 rows measured)
       // the 64x64 tile re-reads operands twice as often as 128x64 (its 0.60), which only costs once the CUs are full:
       // with at most one block per CU -- few-token products -- a wave's own MFMA chain is the limit and the small tile wins
-      const double e = (c >= 16 && tiles * s <= 256) ? 1.0 : eff[c];
+      // split kernels (one block per CU, whole rounds decide): 128x128 a little ahead of 128x96 at equal rounds x area
+      // (fewer operand bytes per flop), the 64x64 every-wave kernel well behind both
+      const double e = compute == 2 ? (c == 5 ? 0.70 : (c == 6 ? 0.68 : 0.45)) : ((c >= 16 && tiles * s <= 256) ? 1.0 : eff[c]);
       double cost = (double)rounds * bm * bn * kc / 128.0 / (e * occ2);
       cost += 3000.0;  // fill/drain + launch
       if (s > 1) {
@@ -886,9 +889,10 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
                     (((uintptr_t)B & 15) == 0) && !(layout_a == 1 && layout_b == 0);
     // (few output tiles -- the 256-token products of BASELINE configs[0] -- leave most CUs without a block of the 128x128
     // kernel: the fp32 pipe's 64x64 tiles are faster there, measured 4.37 vs 4.53 ms per C1 step)
-    const bool forced = cfg == 5 || cfg == 3;
-    if (!ok || (!forced && (long)(M / 128) * (N / 128) < 96)) compute = 0;
-    if (compute == 2 && !((cfg == 5 && M % 128 == 0 && N % 128 == 0) || cfg == 3)) cfg = -1;
+    const bool forced = cfg == 5 || cfg == 6 || cfg == 3;
+    const long tiles96 = (M % 128 == 0 && N % 96 == 0) ? (long)(M / 128) * (N / 96) : 0;
+    if (!ok || (!forced && std::max((long)(M / 128) * (N / 128), tiles96) < 96)) compute = 0;
+    if (compute == 2 && !((cfg == 5 && M % 128 == 0 && N % 128 == 0) || (cfg == 6 && M % 128 == 0 && N % 96 == 0) || cfg == 3)) cfg = -1;
   }
   if (!A || !B || !C) return MTVAF_ERR_ARG;
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
@@ -945,7 +949,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if (g_prof && g_prof_n < g_prof_cap) {
     pr = &g_prof[g_prof_n++];
     // (key[3]: alignment mode 0..2, +8 when the launch walks a k-tile list: its flops are 2 M N 32 (*kcnt), not 2 M N K)
-    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + ((cfg == 5 && a.wide) ? 20 : 0) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
+    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + (((cfg == 5 || cfg == 6) && a.wide) ? 20 : 0) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
     hipEventRecord(pr->e0, stream);
   }
@@ -953,8 +957,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if (compute == 1) {
     rc = launch_gemm_bf16(cfg == 6 ? 0 : (cfg == 5 ? 1 : 2), a, layout_a, layout_b, grid, aligned, stream);
   } else if (compute == 2) {
-    // 128x128: the wave-specialised kernel; without the wide epilogue's alignment the every-wave-does-everything form
-    rc = launch_gemm_f32x3(cfg == 5 ? (a.wide ? 4 : 1) : 2, a, layout_a, layout_b, grid, stream);
+    // 128x128 / 128x96: the wave-specialised kernel; without the wide epilogue's alignment the every-wave-does-everything form
+    rc = launch_gemm_f32x3(cfg == 5 ? (a.wide ? 4 : 1) : (cfg == 6 ? (a.wide ? 5 : 3) : 2), a, layout_a, layout_b, grid, stream);
   } else
   switch (cfg) {
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;

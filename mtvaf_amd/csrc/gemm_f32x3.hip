@@ -9,7 +9,7 @@
 // are worth 417 TFLOP/s of fp32-equivalent work, 2.6x the fp32 pipe, at the accuracy of the fp32 pipe (measured against
 // fp64: tests/test_ops_gpu.py::test_gemm_f32_split_accuracy).
 //
-// Two kernels.  gemm_f32x3_ws_kernel (128 x 128 x 32, the planner's choice): wave-specialised, see its header below.
+// Two kernels.  gemm_f32x3_ws_kernel (128 x 128 x 32 or 128 x 96 x 32, the planner's choice): wave-specialised, see its header below.
 // gemm_f32x3_kernel (BM x BN x 32, 64 x 64 or 32 x 32 wave tiles): every wave loads, splits, stores and multiplies; ONE LDS
 // buffer of 3 planes x (BM + BN) rows x 80 B (conflict-free ds_read_b128 fragments, as gemm_bf16.hip), the next k-tile
 // prefetched into registers during the MFMA phase, two blocks per CU -- the first form built (headline 18.55 -> 16.15 ms),
@@ -356,11 +356,16 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32x3_kernel(GemmArgs p) 
 // 48 MFMAs per k-tile -- producers, fragment reads and barriers switched off -- takes 88-91 us on the K = 768 / 3072 products
 // of 4096 token rows (18.4 ns per MFMA: 32 cycles at the ~1.75-1.9 GHz the chip holds under that stream), the whole kernel
 // 108-114: ~80 % of its own matrix stream.
-template <bool A_KM, bool B_KM, bool KLIST>
+// BN = 128: consumers as 2 x 2 wave tiles of 64 x 64.  BN = 96 (round 4): consumers as 4 x 1 wave tiles of 32 x 96 -- the tile of
+// the N = 768 / 2304 results of 4096 token rows (256 / 768 tiles = whole rounds of the 256 CUs, where 128 x 128 tiles are 192 /
+// 576: three quarters of the chip idle in the last round).
+template <bool A_KM, bool B_KM, bool KLIST, int BN>
 __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   using namespace x3;
   static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
-  constexpr int BM = 128, BN = 128, BK = 32, LDH = BK + 8, NP = 256, NT = 512, WN = 2, TM = 2, TN = 2;
+  static_assert(BN == 128 || BN == 96, "consumer layouts exist for 128 x 128 and 128 x 96");
+  constexpr int BM = 128, BK = 32, LDH = BK + 8, NP = 256, NT = 512;
+  constexpr int WN = BN == 128 ? 2 : 1, TM = BN == 128 ? 2 : 1, TN = BN == 128 ? 2 : 3;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH, BUF = 3 * (A_SZ + B_SZ);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sA = reinterpret_cast<__bf16*>(smem_raw);  // [2][ [3][A_SZ] | [3][B_SZ] ]
@@ -491,23 +496,26 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     if (kt < nk) pstep(kt, ra1, rb1);
   }
 
-  // wide epilogue, one row of consumer waves per pass (as the kernel above), stores by all 512 threads
+  // wide epilogue, 64 result rows per pass (the consumer waves that own them write their accumulators through the LDS), stores
+  // by all 512 threads
   {
     constexpr int LDE = BN + 4, RP = 64, C4 = BN / 4;
     float* smem = reinterpret_cast<float*>(smem_raw);
     float* C = p.C + (long)blockIdx.z * p.slab_stride;
     const bool split = gridDim.z > 1;
+    const int wrow = wm * TM * 32;  // first result row of this consumer wave inside the tile
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       if (pass) __syncthreads();  // the previous pass's image has been read (pass 0: the k-loop ended with a barrier)
-      if (consumer && wm == pass) {
+      if (consumer && wrow / RP == pass) {
+        const int rofs = wrow % RP;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              smem[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
+              smem[(rofs + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
       }
       __syncthreads();
 #pragma unroll 2
@@ -538,12 +546,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   }
 }
 
+template <int BN>
 static int launch_x3_ws(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   if (!a.wide) return MTVAF_ERR_ALIGN;
-  const size_t smem = (size_t)2 * 3 * 256 * 40 * sizeof(__bf16);  // 122880 (the epilogue image of 64 x 132 floats fits inside)
+  const size_t smem = (size_t)2 * 3 * (128 + BN) * 40 * sizeof(__bf16);  // 122880 / 107520 (the epilogue image of 64 x (BN + 4) floats fits inside)
 #define MTVAF_X3_WS(AK, BKM, KL)                                                                                      \
   do {                                                                                                               \
-    auto kern = gemm_f32x3_ws_kernel<AK, BKM, KL>;                                                                   \
+    auto kern = gemm_f32x3_ws_kernel<AK, BKM, KL, BN>;                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
@@ -587,13 +596,15 @@ static int launch_x3_tile(const GemmArgs& a, int la, int lb, dim3 grid, hipStrea
   return MTVAF_OK;
 }
 
-// Called by the common launcher in gemm.hip (whole tiles only).  tile: 4 = 128x128x32 wave-specialised (the one the planner
-// uses; needs the wide epilogue's alignment); 1 = 128x128x32, every wave doing everything, one buffer, two blocks per CU;
-// 2 = 64x64x32 (2x2 waves of 32x32; small results).
+// Called by the common launcher in gemm.hip (whole tiles only).  tile: 4 / 5 = 128x128x32 / 128x96x32 wave-specialised (the
+// ones the planner uses; they need the wide epilogue's alignment); 1 / 3 = the same tiles, every wave doing everything, one
+// buffer, two blocks per CU; 2 = 64x64x32 (2x2 waves of 32x32; small results).
 int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   switch (tile) {
-    case 4: return launch_x3_ws(a, la, lb, grid, st);
+    case 4: return launch_x3_ws<128>(a, la, lb, grid, st);
+    case 5: return launch_x3_ws<96>(a, la, lb, grid, st);
     case 1: return launch_x3_tile<128, 128, 2, 2, 32>(a, la, lb, grid, st);
+    case 3: return launch_x3_tile<128, 96, 4, 1, 32>(a, la, lb, grid, st);
     default: return launch_x3_tile<64, 64, 2, 2, 32>(a, la, lb, grid, st);
   }
 }

@@ -240,9 +240,9 @@ def kernel_symbol(cfg, la, lb, fast):
         t = "256, 192, 4, 2" if c & 32 else ("256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"))
         return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}, {b(klist)}>"
     if cfg >= 200:  # split-fp32 kernels (csrc/gemm_f32x3.hip): +20 the wave-specialised kernel
-        if cfg == 225:
-            return f"gemm_f32x3_ws_kernel<{b(la)}, {b(lb)}, {b(klist)}>"
-        d = (64, 64, 2, 2) if cfg == 203 else (128, 128, 2, 2)
+        if cfg in (225, 226):
+            return f"gemm_f32x3_ws_kernel<{b(la)}, {b(lb)}, {b(klist)}, {128 if cfg == 225 else 96}>"
+        d = (64, 64, 2, 2) if cfg == 203 else ((128, 96, 4, 1) if cfg == 206 else (128, 128, 2, 2))
         return f"gemm_f32x3_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(klist)}, 32>"
     if cfg >= 100:
         d = {106: (128, 96, 4, 1), 105: (128, 128, 2, 2), 103: (64, 64, 2, 2)}[cfg]
@@ -627,7 +627,10 @@ def streamk_poll():
     the copy enqueued by the PREVIOUS call has landed non-zero, then enqueues a fresh 4-byte copy of every attached scratch's
     error word to pinned memory on the current stream.  No host synchronisation: a timed-out wait (wrong weight gradients in
     that launch) surfaces one step later instead of never; the header is re-zeroed so that later launches do not read the
-    stale flags the failed launch left behind."""
+    stale flags the failed launch left behind.  Inside a HIP-graph capture it does nothing (pinned allocations and host
+    reads would invalidate the capture; bench.py and the graph tests call streamk_errors() instead)."""
+    if torch.cuda.is_current_stream_capturing():
+        return
     for key, buf in _sk_scratch.items():
         if buf is None:
             continue
@@ -643,8 +646,6 @@ def streamk_poll():
             host = torch.zeros(1, dtype=torch.int32).pin_memory()
             ev = torch.cuda.Event()
             _sk_poll[key] = (host, ev)
-        if torch.cuda.is_current_stream_capturing():
-            continue
         host, ev = _sk_poll[key]
         host.copy_(buf[4092:4096].view(torch.int32), non_blocking=True)
         ev.record()

@@ -8,6 +8,7 @@ import torch
 import torch.nn.functional as F
 
 import params as P
+from x3_cases import CASES as X3_CASES, operands as x3_operands
 from oracle import mtvaf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -1095,24 +1096,69 @@ def _x3_operands(M, N, K, la, lb, seed, spread=0):
 
 
 @pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K,spread", [(512, 768, 768, 0), (256, 384, 3072, 12), (128, 128, 32, 30), (192, 320, 96, 6),
-                                          (1024, 1536, 256, 3)])
-def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread):
+@pytest.mark.parametrize("M,N,K,spread,tile", [(512, 768, 768, 0, 5), (256, 384, 3072, 12, 5), (128, 128, 32, 30, 5), (192, 320, 96, 6, 3),
+                                               (1024, 1536, 256, 3, 5), (512, 768, 768, 0, 6), (256, 384, 3072, 12, 6),
+                                               (128, 96, 32, 30, 6), (1024, 1536, 256, 3, 6)])
+def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread, tile):
     """fp32 GEMM by three-way bf16 operand splitting (mtvaf_gemm_f32x3, csrc/gemm_f32x3.hip) is an fp32 GEMM: against the fp64
     product its error is bounded element-wise by a few fp32 roundings of |A|.|B| (the six partial products are exact, the
     dropped terms are below 2^-26 |a||b|) and is not larger than the fp32 MFMA pipe's on the same operands -- all three
-    operand layouts, both tile sizes (128x128, 64x64), operands spread over 2^+-30."""
+    operand layouts, every tile (cfg 5 = 128x128 and 6 = 128x96 wave-specialised, 3 = 64x64), operands spread over 2^+-30."""
     a, b, ref, mag = _x3_operands(M, N, K, la, lb, seed=M + N + K + 7 * la + lb, spread=spread)
     o_nat, o_spl = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
     hip.gemm(a, la, b, lb, o_nat, M, N, K, compute="fp32")
     # (the tile is forced: left to itself the library keeps products of fewer than 96 tiles of 128 x 128 on the fp32 pipe)
-    hip.gemm(a, la, b, lb, o_spl, M, N, K, compute="fp32x3", cfg=5 if (M % 128 == 0 and N % 128 == 0) else 3)
+    hip.prof_start(4)
+    hip.gemm(a, la, b, lb, o_spl, M, N, K, compute="fp32x3", cfg=tile)
+    recs = hip.prof_stop(4)
+    assert recs[0][0]["cfg"] == {5: 225, 6: 226, 3: 203}[tile], recs  # (the kernel that was asked for really ran)
     e_nat = (o_nat.double().cpu() - ref).abs() / mag
     e_spl = (o_spl.double().cpu() - ref).abs() / mag
     # element-wise bound: accumulation of K terms in fp32 (worst case K 2^-24, in practice ~sqrt(K)) + the 2^-26 split remainder
     assert float(e_spl.max()) <= 2.0 ** -24 * (4 + K ** 0.5), (float(e_spl.max()), float(e_nat.max()))
     assert float(e_spl.max()) <= 1.25 * float(e_nat.max()) + 2.0 ** -25, (float(e_spl.max()), float(e_nat.max()))
     assert float(e_spl.pow(2).mean().sqrt()) <= 1.1 * float(e_nat.pow(2).mean().sqrt()) + 2.0 ** -27
+
+
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("case", X3_CASES)
+def test_gemm_f32_split_adversarial(hip, la, lb, case):
+    """The split GEMM on operands chosen against it (tests/x3_cases.py; measured table: tools/f32x3_adversarial.py): exponents
+    that vary per ELEMENT inside a row (not a per-row scale), rows whose sum cancels to 2^-12 of its terms, operands near
+    2^+-120 / 2^+-58 with in-range products, |a| up to 2^127 (1 - 2^-9), values with all 24 significant bits set.  Bound as
+    test_gemm_f32_split_accuracy: element-wise against the fp64 product, normalised by |A|.|B|, within a few fp32 roundings
+    and not worse than the fp32 MFMA pipe on the same operands.  ONE documented limit: operands below 2^-109 put their second
+    / third planes into bf16's subnormal range (8 exponent bits, as fp32, with 16 fewer mantissa bits per plane to spend
+    below 2^-126), so the result keeps an ABSOLUTE error of at most K 2^-133 max|other operand| -- for `tiny_times_one` /
+    `huge_times_tiny` that floor is what is asserted (values of 1e-36 against O(1) weights: far below anything the step reads;
+    the fp32 pipe keeps full relative accuracy there)."""
+    M, N, K = 256, 384, 512
+    A, B = x3_operands(case, M, N, K, seed=5 + la + 2 * lb)
+    ref, mag = A.double() @ B.double(), A.double().abs() @ B.double().abs()
+    a = (A if la == 0 else A.t().contiguous()).to(DEV)
+    b = (B.t().contiguous() if lb == 0 else B).to(DEV)
+    o_nat, o_spl = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    was = hip.f32_split()
+    try:
+        hip.f32_split(False)
+        hip.gemm(a, la, b, lb, o_nat, M, N, K)
+    finally:
+        hip.f32_split(was)
+    hip.gemm(a, la, b, lb, o_spl, M, N, K, compute="fp32x3", cfg=5)
+    assert bool(torch.isfinite(o_spl).all()), "the first plane must not round to infinity / NaN"
+    e_nat = (o_nat.double().cpu() - ref).abs() / mag
+    e_spl = (o_spl.double().cpu() - ref).abs()
+    bound = 2.0 ** -24 * (4 + K ** 0.5) * mag
+    if case in ("tiny_times_one", "huge_times_tiny"):
+        tiny, other = (A, B) if case == "tiny_times_one" else (B, A)
+        assert float(tiny.abs().max()) < 2.0 ** -109
+        bound = bound + K * 2.0 ** -133 * float(other.abs().max())
+        assert bool((e_spl <= bound).all()), float((e_spl / mag).max())
+        return
+    assert bool((e_spl <= bound).all()), (float((e_spl / mag).max()), float(e_nat.max()))
+    e_spl = e_spl / mag
+    assert float(e_spl.max()) <= 1.5 * float(e_nat.max()) + 2.0 ** -25, (float(e_spl.max()), float(e_nat.max()))
+    assert float(e_spl.pow(2).mean().sqrt()) <= 1.25 * float(e_nat.pow(2).mean().sqrt()) + 2.0 ** -26
 
 
 def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):

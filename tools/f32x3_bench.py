@@ -2,7 +2,7 @@
 (mtvaf_gemm_f32) on the product shapes of the headline configuration: time, fp32-equivalent TFLOP/s and the error of both
 against the fp64 product (max |err| / max |ref| and the rms ratio).
 
-    python tools/f32x3_bench.py [M]          # default 4096
+    python tools/f32x3_bench.py [M] [--tiles]    # default 4096; --tiles: also each split tile forced (128x128, 128x96) per product
 """
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,9 @@ def t(fn, n=20):
 
 
 def main():
-    M = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    tiles = "--tiles" in sys.argv
+    M = int(args[0]) if args else 4096
     g = torch.Generator(device=dev).manual_seed(1)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g) * torch.exp2(torch.randint(-6, 6, (s[0], 1), device=dev, generator=g).float())
     x, x3 = rn(M, H), rn(M, I)
@@ -43,6 +45,7 @@ def main():
         fl = 2.0 * m * n * k
         flops += fl
         for mode in ("fp32", "fp32x3"):
+            hip.f32_split(mode == "fp32x3")  # ("fp32" = the fp32 MFMA pipe: the library default is the split)
             run = lambda: hip.gemm(a, la, b, lb, out, m, n, k, allow_split=True, compute=mode)
             run()
             err = (out.double() - ref)
@@ -51,6 +54,16 @@ def main():
             us = t(run)
             tot[mode] += us
             line += f" | {mode:7s} {us:6.1f} us {fl / us / 1e6:5.1f} TF err {emax:.1e}/{erms:.1e}"
+        hip.f32_split(True)
+        if tiles:
+            for cfg in (5, 6):
+                if n % (128 if cfg == 5 else 96):
+                    continue
+                for sp in ((-1,) if la == KC else (-1, 2, 3, 4, 6, 8)):
+                    run = lambda: hip.gemm(a, la, b, lb, out, m, n, k, allow_split=True, compute="fp32x3", cfg=cfg, splits=sp)
+                    run()
+                    us = t(run)
+                    line += f" | {'128x128' if cfg == 5 else '128x96'}{'' if sp < 0 else '/s' + str(sp)} {us:6.1f}"
         print(line, flush=True)
     print(f"M={M}: one layer's 12 products: fp32 pipe {tot['fp32']:.0f} us ({flops / tot['fp32'] / 1e6:.0f} TF), split {tot['fp32x3']:.0f} us "
           f"({flops / tot['fp32x3'] / 1e6:.0f} TF fp32-equivalent)")
