@@ -460,6 +460,9 @@ def main():
                     help="N > 1: wire format of the gradient exchange (mtvaf_amd.parallel.GradSync): fp32 = RCCL all_reduce(AVG) in "
                          "place; bf16 = pack -> all_to_all -> fp32 sum -> all_gather (mesh-shaped, half the bytes); auto = fp32 in "
                          "fp32 compute mode, bf16 in bf16 compute mode")
+    ap.add_argument("--grad-buckets", type=int, default=4,
+                    help="N > 1, bf16 wire: encoder layers are exchanged in this many all_to_all + all_gather pairs per step (4 = "
+                         "three BERT-base layers, 85 MB, per exchange); 0 = one exchange per layer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -513,7 +516,8 @@ def main():
     sync = None
     if world > 1:
         from mtvaf_amd.parallel import GradSync
-        sync = GradSync(model, compress={"auto": "auto", "fp32": None, "bf16": "bf16"}[a.grad_wire])
+        sync = GradSync(model, compress={"auto": "auto", "fp32": None, "bf16": "bf16"}[a.grad_wire],
+                        layer_buckets=a.grad_buckets if a.grad_buckets > 0 else None)
     sched = None
     if a.no_optimizer:
         opt = None
@@ -582,14 +586,22 @@ def main():
     for i in range(a.steps):
         out = step()
         marks[i + 1].record()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0  # this rank's own K steps (before it waits for the others)
     barrier()
     dt = time.perf_counter() - t0
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     med_ms = statistics.median(step_ms)
+    rank_ms_spread = None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
+        # per-rank step times (each rank's batch is ragged in its own way): (max - min) / mean over the ranks
+        tl = torch.zeros(world, device=device, dtype=torch.float64)
+        tl[rank] = dt_local
+        dist.all_reduce(tl)
+        rank_ms_spread = round(float((tl.max() - tl.min()) / tl.mean()), 4)
     loss_val = float(out.loss.detach())
     if hip.streamk_errors():
         raise SystemExit("a stream-K launch of the bf16 GEMM reported a timed-out wait (mtvaf_amd.hip.streamk_errors)")
@@ -679,6 +691,9 @@ def main():
                          "object counts the flops those launches execute",
            "padding": "skipped (--unpad): the fraction below counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
            "padding_free": padding_free}
+    res["rank_ms_spread"] = rank_ms_spread
+    if rank_ms_spread is not None and rank_ms_spread >= 0.03:
+        log(f"per-rank step times differ by {100 * rank_ms_spread:.1f} % (>= 3 %): the slowest rank sets `value`")
     res["n_ranks_seen"] = dist.get_world_size() if world > 1 else 1
     res["backend"] = dist.get_backend() if world > 1 else None
     if sync is not None:
@@ -688,7 +703,7 @@ def main():
             step()
         tm = sync.take_timing()
         sync.timing = False
-        res["grad_sync"] = {"wire": sync.compress or "fp32",
+        res["grad_sync"] = {"wire": sync.compress or "fp32", "layer_exchanges_per_step": sync.layer_buckets or len(sync.encoder.layer),
                             "comm_stream_ms_per_step": round(tm["comm_stream_ms"] / max(1, tm["passes"]), 3),
                             "exposed_tail_ms_per_step": round(tm["exposed_tail_ms"] / max(1, tm["passes"]), 3),
                             "note": "rank 0, 3 extra steps: time the communication stream spent in exchanges (and the per-layer "

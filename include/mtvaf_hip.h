@@ -282,6 +282,18 @@ int mtvaf_gemm_f32x3(int layout_a, int layout_b, const float* A, int lda, const 
                      int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
                      mtvaf_stream_t stream);
 int mtvaf_f32_split(int on);
+/* Weights split ONCE: mtvaf_f32_split_planes writes the three bf16 planes of an fp32 tensor (dst[i + q * stride] = plane q of
+ * src[i], the split the GEMM applies to fp32 tiles; n % 4 == 0, stride % 8 == 0, stride >= n); mtvaf_gemm_f32_wp is
+ * mtvaf_gemm_f32 with the B operand's plane image beside it: in the split mode the 128x128 products of a row-major A take
+ * their B tiles from the planes by LDS-DMA instead of splitting them again in every block -- bit-identical results (the
+ * forward and dX products of modeling_bert.py:266, 283-284, 353, 420-421, 433, whose B is a weight).  mtvaf_f32_wplanes(0 / 1)
+ * ignores / uses the images (default 1; MTVAF_F32_WPLANES=0); -1 queries. */
+int mtvaf_f32_split_planes(const float* src, void* dst, long n, long stride, mtvaf_stream_t stream);
+int mtvaf_gemm_f32_wp(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, const void* Bplanes,
+                      long plane_stride, float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
+                      int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                      mtvaf_stream_t stream);
+int mtvaf_f32_wplanes(int on);
 
 /* The (up to four) weight-gradient products of one encoder layer in fp32, dW_i[M_i,N_i] = A_i^T . B_i with A_i [K,M_i], B_i [K,N_i]
  * row-major, as ONE launch of the 128x96 LDS-DMA kernel (autograd backward of modeling_bert.py:266, 283-284, 353, 420-421, 433);

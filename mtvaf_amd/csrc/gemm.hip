@@ -705,6 +705,8 @@ static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, int mode, hi
 
 int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, bool aligned, hipStream_t st);  // gemm_bf16.hip
 int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st);                // gemm_f32x3.hip
+int launch_gemm_f32x3_wp(int tile, const GemmArgs& a, int lb, dim3 grid, hipStream_t st);                    // gemm_f32x3.hip
+int launch_split_planes(const float* src, void* dst, long n, long stride, hipStream_t st);                   // gemm_f32x3.hip
 
 // ordered split-K slab reduction (+ bias / tanh / dtanh epilogue), shared with gemm_bf16kc.hip
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
@@ -870,10 +872,14 @@ int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi
 // epi: 0 none, 1 bias+GELU (pre-activation stored to aux), 2 bias+tanh, 3 dGELU (multiply by
 // gelu'(aux)), 4 dtanh (multiply by 1-aux^2).  accumulate: C += result.  allow_split: permit a
 // deterministic split-K (slabs in workspace + ordered reduction); cfg/splits < 0 = heuristic.
+// weight-plane images (mtvaf_gemm_f32_wp) are used / ignored: MTVAF_F32_WPLANES=0 or mtvaf_f32_wplanes(0) switches them off
+static int g_f32_wplanes = [] { const char* e = getenv("MTVAF_F32_WPLANES"); return (e && atoi(e) == 0) ? 0 : 1; }();
+
 static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
                          int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
-                         hipStream_t stream, const int* klist = nullptr, const int* kcnt = nullptr) {
+                         hipStream_t stream, const int* klist = nullptr, const int* kcnt = nullptr, const void* Bplanes = nullptr,
+                         long plane_stride = 0) {
   if (M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_SHAPE;
   if (compute == 1) {
     // the bf16 kernels need k-aligned, vector-loadable operands; anything else runs the fp32 kernels
@@ -885,14 +891,15 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   }
   if (compute == 2) {
     // the split kernels take whole 64x64 tiles of k-aligned, vector-loadable operands; anything else runs the fp32 pipe
-    const bool ok = (K % 32 == 0) && (M % 64 == 0) && (N % 64 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
+    const bool ok = (K % 32 == 0) && (M % 64 == 0) && (N % 64 == 0 || (M % 128 == 0 && N % 96 == 0)) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
                     (((uintptr_t)B & 15) == 0) && !(layout_a == 1 && layout_b == 0);
     // (few output tiles -- the 256-token products of BASELINE configs[0] -- leave most CUs without a block of the 128x128
     // kernel: the fp32 pipe's 64x64 tiles are faster there, measured 4.37 vs 4.53 ms per C1 step)
     const bool forced = cfg == 5 || cfg == 6 || cfg == 3;
     const long tiles96 = (M % 128 == 0 && N % 96 == 0) ? (long)(M / 128) * (N / 96) : 0;
     if (!ok || (!forced && std::max((long)(M / 128) * (N / 128), tiles96) < 96)) compute = 0;
-    if (compute == 2 && !((cfg == 5 && M % 128 == 0 && N % 128 == 0) || (cfg == 6 && M % 128 == 0 && N % 96 == 0) || cfg == 3)) cfg = -1;
+    if (compute == 2 && !((cfg == 5 && M % 128 == 0 && N % 128 == 0) || (cfg == 6 && M % 128 == 0 && N % 96 == 0) ||
+                          (cfg == 3 && N % 64 == 0))) cfg = -1;
   }
   if (!A || !B || !C) return MTVAF_ERR_ARG;
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
@@ -909,6 +916,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   }
   GemmArgs a;
   a.klist = nullptr; a.kcnt = nullptr; a.ngrp = 0;
+  a.Bp = nullptr; a.bp_stride = 0;
   a.A = A; a.B = B; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldaux = ldaux;
   a.epi = epi; a.accumulate = accumulate;
@@ -957,6 +965,16 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if (compute == 1) {
     rc = launch_gemm_bf16(cfg == 6 ? 0 : (cfg == 5 ? 1 : 2), a, layout_a, layout_b, grid, aligned, stream);
   } else if (compute == 2) {
+    // B from a plane image split once (weights): 128x128 whole tiles, A row-major, DMA-able planes; anything else splits B
+    // in-kernel from fp32 -- the same planes, the same MFMA sequence: bit-identical results either way
+    const bool planes = Bplanes && cfg == 5 && a.wide && layout_a == 0 && (ldb % 8 == 0) && (plane_stride % 8 == 0) &&
+                        (((uintptr_t)Bplanes & 15) == 0) && g_f32_wplanes != 0;
+    if (planes) {
+      a.Bp = Bplanes;
+      a.bp_stride = plane_stride;
+      if (pr) pr->key[0] += 2000;  // (profiler key 2225: gemm_f32x3_wp_kernel)
+      rc = launch_gemm_f32x3_wp(4, a, layout_b, grid, stream);
+    } else
     // 128x128 / 128x96: the wave-specialised kernel; without the wide epilogue's alignment the every-wave-does-everything form
     rc = launch_gemm_f32x3(cfg == 5 ? (a.wide ? 4 : 1) : (cfg == 6 ? (a.wide ? 5 : 3) : 2), a, layout_a, layout_b, grid, stream);
   } else
@@ -993,6 +1011,11 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
 // operands) / never; (-1) queries.  Default since round 4: ON (the error against the fp64 product is at or below the fp32
 // MFMA pipe's on the same operands: tests/test_ops_gpu.py::test_gemm_f32_split_accuracy, ..._adversarial); MTVAF_F32_SPLIT=0
 // keeps every product on the fp32 pipe.
+int mtvaf_f32_wplanes(int on) {
+  if (on >= 0) g_f32_wplanes = on ? 1 : 0;
+  return g_f32_wplanes;
+}
+
 static int g_f32_split = -1;
 int mtvaf_f32_split(int on) {
   if (on >= 0) g_f32_split = on ? 1 : 0;
@@ -1017,6 +1040,27 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
                    hipStream_t stream) {
   return gemm_dispatch(mtvaf_f32_split(-1) ? 2 : 0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
                        allow_split, workspace, workspace_bytes, cfg, splits, stream);
+}
+
+// mtvaf_gemm_f32 whose B operand (a WEIGHT: unchanged between optimizer steps) also exists as the three bf16 planes of its
+// split, written once by mtvaf_f32_split_planes: Bplanes[i + q * plane_stride] = plane q of B[i] (same offsets / ldb as B).  In
+// the split mode the 128x128 products take their B tiles from the planes by LDS-DMA instead of splitting them again in every
+// block (csrc/gemm_f32x3.hip: gemm_f32x3_wp_kernel); results are bit-identical to mtvaf_gemm_f32 on B.  Bplanes == NULL, the
+// fp32 pipe (mtvaf_f32_split(0)), other tiles / layouts: exactly mtvaf_gemm_f32.
+int mtvaf_gemm_f32_wp(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, const void* Bplanes,
+                      long plane_stride, float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
+                      int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
+                      hipStream_t stream) {
+  return gemm_dispatch(mtvaf_f32_split(-1) ? 2 : 0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
+                       allow_split, workspace, workspace_bytes, cfg, splits, stream, nullptr, nullptr, Bplanes, plane_stride);
+}
+
+// dst[i + q * stride] = bf16 plane q (q = 0, 1, 2) of src[i]: x = x1 + x2 + x3 with RNE at every level, exactly the split the
+// GEMM producers apply to fp32 tiles.  n % 4 == 0, stride % 8 == 0, 16-byte aligned pointers.  HBM-bound: 10 bytes per element.
+int mtvaf_f32_split_planes(const float* src, void* dst, long n, long stride, hipStream_t stream) {
+  if (!src || !dst || n <= 0 || (n & 3) || (stride & 7) || stride < n) return MTVAF_ERR_ARG;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return MTVAF_ERR_ALIGN;
+  return launch_split_planes(src, dst, n, stride, stream);
 }
 
 // mtvaf_gemm_f32 for a weight-gradient product (layouts KM x KM: C[M,N] = A[K,M]^T . B[K,N], the reduction index is the

@@ -40,6 +40,10 @@ struct GemmArgs {
   int ngrp;
   int grp_tile_begin[4];
   GemmProb grp[4];
+  // split-fp32 kernels: the B operand's three bf16 planes, split once (mtvaf_f32_split_planes: plane q of element i at
+  // Bp[i + q * bp_stride]; same offsets / leading dimension as B), or NULL (B is split in-kernel from fp32)
+  const void* Bp;
+  long bp_stride;
 };
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so

@@ -23,6 +23,10 @@ Two wire formats:
   unpacked into the fp32 gradient buffer.  Half the bytes of the fp32 ring on every link, one rounding per phase
   instead of one per ring hop, and every rank ends with bit-identical gradients.  Pack / reduce / unpack are HIP
   kernels (``mtvaf_grad_pack_bf16`` / ``_reduce_bf16`` / ``_unpack_bf16`` in ``csrc/optim.hip``) on the communication stream.
+  ``layer_buckets=k`` sends the encoder layers in k exchanges instead of one per layer (3 layers = 85 MB per exchange at
+  k = 4 for BERT-base): a layer's packed gradients land in its slice of ONE send buffer and the all_to_all / sum /
+  all_gather run once per bucket, when the bucket's last layer is done -- 2 k collectives per step where the per-layer form
+  issues 24, so that an 8-GPU step is not bound by collective launch latency.
 
 Dropout under data parallelism: ``engine.RNG`` derives its seed from ``torch.initial_seed()``; launchers that seed
 every rank alike would make all ranks draw the same masks for the same (site, row).  GradSync therefore folds the
@@ -38,7 +42,7 @@ import torch.distributed as dist
 
 class GradSync:
     def __init__(self, model: torch.nn.Module, process_group=None, force: bool = False, big_numel: int = 1 << 20,
-                 compress: Optional[str] = "auto", seed_per_rank: bool = True):
+                 compress: Optional[str] = "auto", seed_per_rank: bool = True, layer_buckets: Optional[int] = None):
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised process group (backend 'nccl' = RCCL on ROCm)")
         self.model = model
@@ -54,6 +58,18 @@ class GradSync:
             raise ValueError(f"compress must be None, 'bf16' or 'auto', got {compress!r}")
         self.compress = compress
         self.encoder = model.bert.encoder if hasattr(model, "bert") else model.encoder
+        # bf16 wire: encoder layers per exchange.  Layers finish from the last to the first; bucket b = a run of consecutive
+        # layers, exchanged when all of them have reported (any order).  None / fp32 wire: one collective per layer.
+        L = len(self.encoder.layer)
+        self.layer_buckets = None
+        self._bucket_of, self._bucket_size, self._bucket_acc = {}, {}, {}
+        if layer_buckets is not None and compress == "bf16":
+            nb = max(1, min(int(layer_buckets), L))
+            self.layer_buckets = nb
+            for li in range(L):
+                b = (L - 1 - li) * nb // L  # bucket 0 = the layers that finish first
+                self._bucket_of[li] = b
+                self._bucket_size[b] = self._bucket_size.get(b, 0) + 1
         sink = self.encoder.grad_sink
         sink.on_layer_done = self._layer_done
         # this hook records events and switches to the communication stream with torch's stream context: it must be
@@ -165,6 +181,58 @@ class GradSync:
         else:
             flat.copy_(send[:n])
 
+    def _allreduce_mean_bf16_multi(self, tensors):
+        """One exchange for several flat fp32 tensors (the layers of a bucket): tensor i is packed into its slice of the send
+        buffer (slices start on 16-byte boundaries; the gaps and the tail are zeros), ONE all_to_all / fp32 sum / all_gather
+        over the concatenation, every tensor unpacked from its slice.  Same arithmetic per element as the single-tensor form
+        (the sum over ranks in rank order, one rounding), so bucketed and per-layer exchanges agree bit for bit."""
+        if len(tensors) == 1:
+            return self._allreduce_mean_bf16(tensors[0])
+        W = self.world
+        offs, off = [], 0
+        for t in tensors:
+            offs.append(off)
+            off += (t.numel() + 7) // 8 * 8
+        chunk = ((off + W - 1) // W + 7) // 8 * 8
+        dev = tensors[0].device
+        send = self._buf("send", W * chunk, torch.bfloat16, dev)[:W * chunk]
+        recv = self._buf("recv", W * chunk, torch.bfloat16, dev)[:W * chunk]
+        shard = self._buf("shard", chunk, torch.bfloat16, dev)[:chunk]
+        ends = offs[1:] + [W * chunk]
+        cuda = tensors[0].is_cuda
+        if cuda:
+            from . import hip
+        for t, o, e in zip(tensors, offs, ends):
+            n = t.numel()
+            if cuda:
+                hip.grad_pack_bf16(t.view(-1), send[o:], n, e - o)
+            else:
+                send[o:o + n].copy_(t.view(-1))
+                send[o + n:e].zero_()
+        dist.all_to_all_single(recv, send, group=self.group)
+        if cuda:
+            hip.grad_reduce_bf16(recv, shard, W, chunk, 1.0 / W)
+        else:
+            shard.copy_(recv.view(W, chunk).float().sum(0).mul_(1.0 / W))
+        dist.all_gather_into_tensor(send, shard, group=self.group)
+        for t, o in zip(tensors, offs):
+            if cuda:
+                hip.grad_unpack_bf16(send[o:], t.view(-1), t.numel())
+            else:
+                t.view(-1).copy_(send[o:o + t.numel()])
+
+    def _bucket_ready(self, li: int, flat_grad: Optional[torch.Tensor]):
+        """-> the (layer, flat gradient) list to exchange now, or None while the layer's bucket is still filling."""
+        if self.layer_buckets is None:
+            return [(li, flat_grad)]
+        b = self._bucket_of[li]
+        acc = self._bucket_acc.setdefault(b, [])
+        acc.append((li, flat_grad))
+        if len(acc) < self._bucket_size[b]:
+            return None
+        del self._bucket_acc[b]
+        return acc
+
     # -- called from inside EncoderFunction.backward, newest layer first ---------------------------------
     def _layer_done(self, li: int, flat_grad: Optional[torch.Tensor]):
         if self.before_layer is not None:
@@ -172,25 +240,38 @@ class GradSync:
         if not self.enabled or (self.world == 1 and not self.force):
             return
         self._arm()
+        ready = self._bucket_ready(li, flat_grad)
         if flat_grad is None:  # gradient-accumulation fallback: reduce the .grad tensors at the end
             self._slow_layers.append(li)
+        else:
+            self._fast_layers.append(li)
+        if ready is None:
             return
-        self._fast_layers.append(li)
+        fast = [(l, g) for l, g in ready if g is not None]
+        if not fast:
+            return
         if self._comm is None:  # CPU / gloo (tests)
             if self.compress is None:
-                self._pending.append((dist.all_reduce(flat_grad, group=self.group, async_op=True), flat_grad))
+                for l, g in fast:
+                    self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
             else:
-                self._allreduce_mean(flat_grad)
+                self._allreduce_mean_bf16_multi([g for _, g in fast])
             if self.after_layer_reduced is not None:
-                self._pending.append((None, li))
+                for l, _ in fast:
+                    self._pending.append((None, l))
             return
         ev = torch.cuda.Event()
         ev.record()
         with torch.cuda.stream(self._comm):
             self._comm.wait_event(ev)
-            self._timed(self._allreduce_mean, flat_grad)
+            if self.compress is None:
+                for _, g in fast:
+                    self._timed(self._allreduce_mean, g)
+            else:
+                self._timed(self._allreduce_mean_bf16_multi, [g for _, g in fast])
             if self.after_layer_reduced is not None:
-                self.after_layer_reduced(li)
+                for l, _ in fast:
+                    self.after_layer_reduced(l)
 
     def _arm(self):
         if not self._armed:
@@ -218,6 +299,24 @@ class GradSync:
     # -- runs once when the autograd pass is complete ---------------------------------------------------------
     def _finish(self):
         self._armed = False
+        if self._bucket_acc:  # a bucket that never filled (a layer did not report in this pass): exchange what it holds
+            pairs = [(l, g) for acc in self._bucket_acc.values() for l, g in acc if g is not None]
+            self._bucket_acc = {}
+            if pairs:
+                left = [g for _, g in pairs]
+                if self._comm is None:
+                    self._allreduce_mean_bf16_multi(left)
+                    if self.after_layer_reduced is not None:
+                        self._pending.extend((None, l) for l, _ in pairs)
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    with torch.cuda.stream(self._comm):
+                        self._comm.wait_event(ev)
+                        self._timed(self._allreduce_mean_bf16_multi, left)
+                        if self.after_layer_reduced is not None:
+                            for l, _ in pairs:
+                                self.after_layer_reduced(l)
         rest = [p for p in self.model.parameters()
                 if p.grad is not None and (id(p) not in self._enc_param_ids) and (id(p) not in self._early_done)]
         self._early_done = set()

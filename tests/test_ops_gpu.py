@@ -1161,6 +1161,78 @@ def test_gemm_f32_split_adversarial(hip, la, lb, case):
     assert float(e_spl.pow(2).mean().sqrt()) <= 1.25 * float(e_nat.pow(2).mean().sqrt()) + 2.0 ** -26
 
 
+def test_split_planes_are_the_rne_three_way_split(hip):
+    """mtvaf_f32_split_planes: plane 1 = RNE_bf16(x), plane 2 = RNE_bf16(x - p1), plane 3 = RNE_bf16(x - p1 - p2), bit for bit
+    (torch's own bf16 rounding as the model), over magnitudes 2^+-40, zeros and negative values."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8 * 1031, generator=g) * torch.exp2(torch.randint(-40, 41, (8 * 1031,), generator=g).float())
+    x[::97] = 0.0
+    d = torch.empty(3, x.numel(), dtype=torch.bfloat16, device=DEV)
+    hip.split_planes(x.to(DEV), d)
+    p1 = x.bfloat16()
+    r1 = x - p1.float()
+    p2 = r1.bfloat16()
+    p3 = (r1 - p2.float()).bfloat16()
+    for got, want in zip(d.cpu(), (p1, p2, p3)):
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    rec = d.cpu().double().sum(0)
+    assert float(((rec - x.double()).abs() / x.double().abs().clamp_min(1e-300)).max()) <= 2.0 ** -25
+
+
+@pytest.mark.parametrize("lb", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (256, 3072, 768), (384, 768, 3072), (128, 128, 32), (256, 256, 96)])
+def test_gemm_f32_weight_planes_equal_the_in_kernel_split_bit_for_bit(hip, lb, M, N, K):
+    """mtvaf_gemm_f32_wp (B = a weight whose three bf16 planes were split once, tiles fetched by LDS-DMA: gemm_f32x3_wp_kernel)
+    against the kernel that splits B in every block: the same planes, the same MFMA sequence and k order -> identical bits.
+    Forward (B row-major [N][K]) and dX (B [K][N]: the reduction index is the row) layouts, one to 96 k-tiles, every epilogue of
+    the path, split-K; the switch mtvaf_f32_wplanes(0) and a NULL image fall back to the in-kernel split."""
+    g = torch.Generator().manual_seed(M + N + K + lb)
+    A = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-8, 9, (M, 1), generator=g).float())).to(DEV)
+    W = (torch.randn(N, K, generator=g) if lb == 0 else torch.randn(K, N, generator=g)).to(DEV)
+    # the planes live in a larger flat image at an offset, as a layer's weights do (same offsets as the fp32 flat buffer)
+    off, total = 4096, 4096 + W.numel() + 512
+    flat = torch.zeros(total, device=DEV)
+    flat[off:off + W.numel()] = W.view(-1)
+    Wf = flat[off:off + W.numel()].view(W.shape)
+    img = torch.empty(3, total, dtype=torch.bfloat16, device=DEV)
+    hip.split_planes(flat, img)
+    planes = (img[0, off:off + W.numel()], total)
+    bias = torch.randn(N, generator=g).to(DEV)
+    aux_ref, aux_got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    pre = torch.randn(M, N, generator=g).to(DEV)
+    ref, got = torch.empty(M, N, device=DEV), torch.full((M, N), float("nan"), device=DEV)
+
+    def both(**kw):
+        hip.gemm(A, 0, Wf, lb, ref, M, N, K, cfg=5, **{k: (aux_ref if (k == "aux" and v is None) else v) for k, v in kw.items()})
+        got.fill_(float("nan"))
+        hip.prof_start(4)
+        hip.gemm(A, 0, Wf, lb, got, M, N, K, cfg=5, b_planes=planes, **{k: (aux_got if (k == "aux" and v is None) else v) for k, v in kw.items()})
+        rec = hip.prof_stop(4)
+        return rec[0][0]["cfg"]
+    assert hip.f32_split() and hip.f32_wplanes()
+    assert both() == 2225, "the plane kernel must have run"
+    assert torch.equal(got, ref)
+    close(got, A.double().cpu() @ (W.double().cpu().t() if lb == 0 else W.double().cpu()), rtol=3e-6, name="planes product")
+    assert both(bias=bias) == 2225 and torch.equal(got, ref)
+    if lb == 0:
+        assert both(bias=bias, epi=hip.EPI_GELU, aux=None) == 2225 and torch.equal(got, ref) and torch.equal(aux_got, aux_ref)
+    else:
+        assert both(epi=hip.EPI_DGELU, aux=pre) == 2225 and torch.equal(got, ref)
+    ref.normal_()
+    got.copy_(ref)
+    base = ref.clone()
+    hip.gemm(A, 0, Wf, lb, ref, M, N, K, cfg=5, accumulate=True)
+    hip.gemm(A, 0, Wf, lb, got, M, N, K, cfg=5, accumulate=True, b_planes=planes)
+    assert torch.equal(got, ref) and not torch.equal(got, base)
+    if K >= 768:
+        assert both(bias=bias, allow_split=True, splits=3) == 2225 and torch.equal(got, ref)
+    hip.f32_wplanes(False)
+    try:
+        assert both() == 225 and torch.equal(got, ref)
+    finally:
+        hip.f32_wplanes(True)
+
+
 def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
     """The split kernel behind the fp32 entry points: every epilogue of the path (bias, bias + GELU with the saved
     pre-activation, GELU', tanh, accumulate), forced split-K, a k-tile list (weight gradient: dY exactly zero outside the listed

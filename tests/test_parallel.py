@@ -481,3 +481,123 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["backend"] == "gloo" and d["value"] > 0
     assert d["config"]["global_batch"] == 16 and d["grad_sync"]["wire"] == "fp32"
     assert d["grad_sync"]["comm_stream_ms_per_step"] > 0
+
+
+class _OddModel(torch.nn.Module):
+    """Stand-in whose sizes divide by nothing: 5 layers of 7 x 7 + 7 + 7 = 63 gradient elements (not a multiple of 8 ranks x 8
+    elements: every bf16 exchange has a ragged last chunk and, bucketed, slices that start off the 16-byte grid before
+    padding), a 13 x 7 'table' above the early-reduction threshold, a 3-element head in the tail bucket."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = _FakeEncoder(L=5, n=7)
+        self.head = torch.nn.Linear(3, 1)
+        self.table = torch.nn.Parameter(torch.ones(13, 7))
+
+    def forward(self, x):
+        return self.encoder(x) + self.head(x[:3]).sum() + (self.table * x).sum()
+
+
+def _worker8(rank, world, port, q, wire, buckets):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtvaf_amd.parallel import GradSync
+    torch.manual_seed(0)
+    m = _OddModel()
+    sync = GradSync(m, big_numel=64, compress=wire, layer_buckets=buckets)
+    reduced = []
+    sync.after_layer_reduced = reduced.append
+    calls = {"a2a": 0}
+    real = dist.all_to_all_single
+
+    def counting(*a, **k):
+        calls["a2a"] += 1
+        return real(*a, **k)
+    dist.all_to_all_single = counting
+    x = torch.arange(7, dtype=torch.float32) * (rank + 1) * 0.125 - 0.3
+    opt = torch.optim.SGD(m.parameters(), lr=0.01)
+    for _ in range(2):  # two steps: the persistent send / receive buffers are reused
+        opt.zero_grad(set_to_none=True)
+        reduced.clear()
+        calls["a2a"] = 0
+        m(x).backward()
+        opt.step()
+    res = {"reduced": sorted(reduced), "a2a": calls["a2a"], "buckets": sync.layer_buckets,
+           "weights": {n: p.detach().tolist() for n, p in m.named_parameters()}}
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire,buckets", [(None, None), ("bf16", None), ("bf16", 2), ("bf16", 4)])
+def test_gradsync_eight_ranks_odd_sizes_gloo(wire, buckets):
+    """world_size 8 (the node the bench is scaled to), the REAL GradSync, both wire formats, chunk sizes that divide by nothing,
+    per-layer and bucketed exchanges: two optimizer steps equal the single-process steps on the mean gradient, every rank ends
+    bit-identical, the optimizer hook fires once per layer, and the bucketed form issues `buckets` + 2 exchanges (layers in k,
+    the table, the tail) where the per-layer form issues L + 2."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q, wire, buckets)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ref = _OddModel()
+    for _ in range(2):
+        grads = []
+        for r in range(world):
+            ref.zero_grad(set_to_none=True)
+            ref(torch.arange(7, dtype=torch.float32) * (r + 1) * 0.125 - 0.3).backward()
+            grads.append({n: p.grad.clone() for n, p in ref.named_parameters()})
+        with torch.no_grad():
+            for n, p in ref.named_parameters():
+                p -= 0.01 * sum(g[n] for g in grads) / world
+    tol = dict(rtol=3e-2, atol=2e-3) if wire == "bf16" else dict(rtol=1e-5, atol=1e-6)
+    for r in range(world):
+        assert out[r]["reduced"] == [0, 1, 2, 3, 4]
+        assert out[r]["buckets"] == (buckets if wire == "bf16" else None)
+        if wire == "bf16":
+            assert out[r]["a2a"] == (buckets if buckets else 5) + 2, out[r]["a2a"]
+        for n, p in ref.named_parameters():
+            torch.testing.assert_close(torch.tensor(out[r]["weights"][n]), p.detach(), msg=f"rank {r} {n}", **tol)
+            assert out[r]["weights"][n] == out[0]["weights"][n], n  # bit-identical across the ranks
+
+
+def _worker_bucket_eq(rank, world, port, q, buckets):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtvaf_amd.parallel import GradSync
+    torch.manual_seed(0)
+    m = _OddModel()
+    GradSync(m, big_numel=64, compress="bf16", layer_buckets=buckets)
+    m(torch.arange(7, dtype=torch.float32) * (rank + 1) * 0.125 - 0.3).backward()
+    q.put((rank, {n: p.grad.tolist() for n, p in m.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_bf16_exchange_equals_the_per_layer_exchange_bit_for_bit():
+    """Grouping layers into one all_to_all changes which chunk (= which rank) sums an element, not the sum: the fp32 sum over
+    the ranks in rank order, scaled, rounded once -- bucketed and per-layer gradients are identical."""
+    res = {}
+    for buckets in (None, 2):
+        world, port = 3, _free_port()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_worker_bucket_eq, args=(r, world, port, q, buckets)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = dict(q.get(timeout=180) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        res[buckets] = out[0]
+    assert res[None] == res[2]

@@ -55,6 +55,13 @@ def main():
             tot[mode] += us
             line += f" | {mode:7s} {us:6.1f} us {fl / us / 1e6:5.1f} TF err {emax:.1e}/{erms:.1e}"
         hip.f32_split(True)
+        if tiles and la == KC:  # B = a weight: its planes split once (mtvaf_gemm_f32_wp), 128x128 tile
+            img = torch.empty(3, b.numel(), dtype=torch.bfloat16, device=dev)
+            hip.split_planes(b.reshape(-1), img)
+            tsp = t(lambda: hip.split_planes(b.reshape(-1), img))
+            run = lambda: hip.gemm(a, la, b, lb, out, m, n, k, allow_split=True, cfg=5, b_planes=(img[0], b.numel()))
+            run()
+            line += f" | planes128 {t(run):6.1f} (split pass {tsp:.1f})"
         if tiles:
             for cfg in (5, 6):
                 if n % (128 if cfg == 5 else 96):
