@@ -707,6 +707,7 @@ int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, boo
 int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st);                // gemm_f32x3.hip
 int launch_gemm_f32x3_wp(int tile, const GemmArgs& a, int lb, dim3 grid, hipStream_t st);                    // gemm_f32x3.hip
 int launch_split_planes(const float* src, void* dst, long n, long stride, hipStream_t st);                   // gemm_f32x3.hip
+int launch_gemm_f32p(int bn, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st);                  // gemm_f32p.hip
 
 // ordered split-K slab reduction (+ bias / tanh / dtanh epilogue), shared with gemm_bf16kc.hip
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
@@ -872,6 +873,8 @@ int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi
 // epi: 0 none, 1 bias+GELU (pre-activation stored to aux), 2 bias+tanh, 3 dGELU (multiply by
 // gelu'(aux)), 4 dtanh (multiply by 1-aux^2).  accumulate: C += result.  allow_split: permit a
 // deterministic split-K (slabs in workspace + ordered reduction); cfg/splits < 0 = heuristic.
+static long long* g_x3_trace = nullptr;
+
 // weight-plane images (mtvaf_gemm_f32_wp) are used / ignored: MTVAF_F32_WPLANES=0 or mtvaf_f32_wplanes(0) switches them off
 static int g_f32_wplanes = [] { const char* e = getenv("MTVAF_F32_WPLANES"); return (e && atoi(e) == 0) ? 0 : 1; }();
 
@@ -917,6 +920,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   GemmArgs a;
   a.klist = nullptr; a.kcnt = nullptr; a.ngrp = 0;
   a.Bp = nullptr; a.bp_stride = 0;
+  a.Ap = nullptr; a.ap_stride = 0; a.Cp = nullptr; a.cp_stride = 0; a.ldcp = 0;
+  a.trace = g_x3_trace;
   a.A = A; a.B = B; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldaux = ldaux;
   a.epi = epi; a.accumulate = accumulate;
@@ -1011,6 +1016,13 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
 // operands) / never; (-1) queries.  Default since round 4: ON (the error against the fp64 product is at or below the fp32
 // MFMA pipe's on the same operands: tests/test_ops_gpu.py::test_gemm_f32_split_accuracy, ..._adversarial); MTVAF_F32_SPLIT=0
 // keeps every product on the fp32 pipe.
+// profiling hook (tools/x3_trace.py): every following launch of the wave-specialised split kernel records, in block 0, the
+// shader clock at which each wave arrives at / leaves each k-tile barrier into buf ([8][64][4] + 17 int64); NULL switches it off
+int mtvaf_f32x3_trace(void* buf) {
+  g_x3_trace = static_cast<long long*>(buf);
+  return MTVAF_OK;
+}
+
 int mtvaf_f32_wplanes(int on) {
   if (on >= 0) g_f32_wplanes = on ? 1 : 0;
   return g_f32_wplanes;
@@ -1061,6 +1073,69 @@ int mtvaf_f32_split_planes(const float* src, void* dst, long n, long stride, hip
   if (!src || !dst || n <= 0 || (n & 3) || (stride & 7) || stride < n) return MTVAF_ERR_ARG;
   if (((uintptr_t)src | (uintptr_t)dst) & 15) return MTVAF_ERR_ALIGN;
   return launch_split_planes(src, dst, n, stride, stream);
+}
+
+// Both operands as plane images (gemm_f32p.hip): C[M,N] (fp32, and / or its own plane image Cplanes) = opA . opB with
+// Aplanes[i + q * a_stride] / Bplanes[i + q * b_stride] = bf16 plane q of the fp32 operands (mtvaf_f32_split_planes, or a
+// producing kernel's plane output), in the operands' own row-major layouts (lda / ldb in elements).  Layouts KC x KC, KC x KM,
+// KM x KM (+ k-tile list).  M % 128 == 0, N % 128 == 0 or N % 96 == 0, K % 32 == 0, leading dimensions and strides % 8 == 0,
+// 16-byte aligned pointers: MTVAF_ERR_SHAPE / _ALIGN otherwise (no fallback inside: the caller keeps the fp32-operand entry
+// points for everything else).  Bit-identical to mtvaf_gemm_f32x3 on the fp32 operands the planes were split from (same tile
+// and split plan).  C may be NULL when Cplanes is given (the result exists as planes only; not with split-K).
+int mtvaf_gemm_f32p(int layout_a, int layout_b, const void* Aplanes, int lda, long a_stride, const void* Bplanes, int ldb,
+                    long b_stride, float* C, int ldc, void* Cplanes, int ldcp, long c_stride, int M, int N, int K, const float* bias,
+                    int epi, float* aux, int ldaux, int accumulate, int allow_split, void* workspace, size_t workspace_bytes,
+                    int tile_n, int splits, const int* klist, const int* kcnt, hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !Aplanes || !Bplanes || (!C && !Cplanes)) return MTVAF_ERR_ARG;
+  if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1 || (layout_a == 1 && layout_b == 0)) return MTVAF_ERR_ARG;
+  if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
+  if (M % 128 || K % 32 || (N % 128 && N % 96)) return MTVAF_ERR_SHAPE;
+  if ((lda % 8) || (ldb % 8) || (a_stride % 8) || (b_stride % 8) || (C && ldc % 4) || (Cplanes && ((ldcp % 4) || (c_stride % 4))) ||
+      (aux && ldaux % 4))
+    return MTVAF_ERR_ALIGN;
+  if ((((uintptr_t)Aplanes | (uintptr_t)Bplanes | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15) || ((uintptr_t)Cplanes & 7))
+    return MTVAF_ERR_ALIGN;
+  if (accumulate && !C) return MTVAF_ERR_ARG;
+  const bool can_split = allow_split && splittable(epi) && !Cplanes && C;
+  int cfg, s_auto;
+  choose(M, N, K, can_split, layout_a, layout_b, epi, &cfg, &s_auto, 2);
+  if (tile_n == 128 && N % 128 == 0) cfg = 5;
+  else if (tile_n == 96 && N % 96 == 0) cfg = 6;
+  if (cfg != 5 && cfg != 6) cfg = (N % 128 == 0) ? 5 : 6;  // (the planner's 64 x 64 tile does not exist here)
+  if (splits <= 0) splits = s_auto;
+  if (!can_split) splits = 1;
+  if (splits > 1 && (size_t)splits * M * N * sizeof(float) > workspace_bytes) {
+    splits = (int)(workspace_bytes / ((size_t)M * N * sizeof(float)));
+    if (splits < 1) splits = 1;
+  }
+  GemmArgs a = {};
+  a.Ap = Aplanes; a.ap_stride = a_stride; a.Bp = Bplanes; a.bp_stride = b_stride;
+  a.bias = bias; a.aux = aux; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldaux = ldaux;
+  a.epi = epi; a.accumulate = accumulate; a.a_vec = a.b_vec = 1;
+  int kc = (int)cdiv(cdiv(K, splits), 32) * 32;
+  splits = (int)cdiv(K, kc);
+  a.k_chunk = kc;
+  if (splits > 1) {
+    a.C = (float*)workspace; a.ldc = N; a.slab_stride = (long)M * N;
+    if ((uintptr_t)workspace & 15) return MTVAF_ERR_ALIGN;
+  } else {
+    a.C = C; a.ldc = ldc; a.slab_stride = 0;
+    a.Cp = Cplanes; a.cp_stride = c_stride; a.ldcp = ldcp;
+  }
+  const int bn = cfg == 5 ? 128 : 96;
+  a.tiles_n = N / bn;
+  a.wide = 1;
+  if (klist && kcnt && layout_a == 1 && layout_b == 1) { a.klist = klist; a.kcnt = kcnt; }
+  dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
+  // (profiler key 3000 + tile cfg: gemm_f32p_kernel; fast bit 8 = the launch walks a k-tile list)
+  const int key[8] = {3000 + cfg, layout_a, layout_b, 2 + (a.klist ? 8 : 0), M, N, K, splits};
+  const int rec = prof_begin(key, stream);
+  const int rc = launch_gemm_f32p(bn, a, layout_a, layout_b, grid, stream);
+  prof_end(rec, stream);
+  if (rc != MTVAF_OK) return rc;
+  if (splits > 1)
+    return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
+  return MTVAF_OK;
 }
 
 // mtvaf_gemm_f32 for a weight-gradient product (layouts KM x KM: C[M,N] = A[K,M]^T . B[K,N], the reduction index is the

@@ -399,6 +399,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  long long* const tr = (p.trace && blockIdx.x == 0 && blockIdx.z == 0) ? p.trace : nullptr;  // (block-uniform)
+  if (tr && tid == 0) tr[8 * 64 * 4] = __builtin_amdgcn_s_memtime();  // block start
 
   if (consumer) {
     // Fragment reads run ONE k-slice ahead of the MFMAs that consume them, across the barrier too: an in-order wave that
@@ -439,7 +441,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         mm(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
+        if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 2] = __builtin_amdgcn_s_memtime();
         __syncthreads();  // the other buffer is complete, and this one may be refilled (its last fragments are in fa1 / fb1)
+        if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 3] = __builtin_amdgcn_s_memtime();
         if (kt + 1 < nk) rd((kt + 1) & 1, 0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         mm(fa1, fb1);
@@ -478,9 +482,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     // cannot count on the newer batch being in flight and waits for vmcnt(0), i.e. for the loads issued one step ago: every
     // step then lasted one global-load latency, ~1.6 us, whatever else overlapped)
     auto pstep = [&](int kt, f32x4* ra, f32x4* rb) __attribute__((always_inline)) {
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 0] = __builtin_amdgcn_s_memtime();
       stage_all((kt + 1) & 1, ra, rb);  // (past the end: a harmless copy of the last tile into the idle buffer)
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 1] = __builtin_amdgcn_s_memtime();
       gload(min(kt + 3, nk - 1), ra, rb);
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 2] = __builtin_amdgcn_s_memtime();
       __syncthreads();
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 3] = __builtin_amdgcn_s_memtime();
     };
     if (nk > 0) {
       gload(0, ra0, rb0);
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     if (kt < nk) pstep(kt, ra1, rb1);
   }
 
+  if (tr && lane == 0) tr[8 * 64 * 4 + 1 + wave] = __builtin_amdgcn_s_memtime();  // this wave's k-loop is over
   // wide epilogue, 64 result rows per pass (the consumer waves that own them write their accumulators through the LDS), stores
   // by all 512 threads
   {
@@ -545,6 +554,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
       }
     }
   }
+  if (tr && lane == 0) tr[8 * 64 * 4 + 9 + wave] = __builtin_amdgcn_s_memtime();  // this wave's stores are issued
 }
 
 template <int BN>

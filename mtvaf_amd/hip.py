@@ -35,6 +35,9 @@ _SIGS = {
     "mtvaf_gemm_f32x3": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_f32_split": (c_int, [I]),
     "mtvaf_f32_wplanes": (c_int, [I]),
+    "mtvaf_f32x3_trace": (c_int, [P]),
+    "mtvaf_gemm_f32p": (c_int, [I, I, P, I, ctypes.c_long, P, I, ctypes.c_long, P, I, P, I, ctypes.c_long, I, I, I, P, I, P, I, I, I, P, SZ,
+                                I, I, P, P, P]),
     "mtvaf_f32_split_planes": (c_int, [P, P, ctypes.c_long, ctypes.c_long, P]),
     "mtvaf_gemm_f32_wp": (c_int, [I, I, P, I, P, I, P, ctypes.c_long, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
@@ -234,6 +237,8 @@ def kernel_symbol(cfg, la, lb, fast):
             16: (64, 64, 2, 2), 17: (64, 64, 2, 2)}.get(cfg)
     b = lambda x: "true" if x else "false"
     klist, fast = bool(fast & 8), fast & 7  # (+8: the launch walked a k-tile list)
+    if cfg >= 3000:  # both operands as plane images (csrc/gemm_f32p.hip)
+        return f"gemm_f32p_kernel<{b(la)}, {b(lb)}, {b(klist)}, {128 if cfg == 3005 else 96}>"
     if cfg >= 2000:  # split-fp32 kernel with the B operand from a plane image split once (mtvaf_gemm_f32_wp)
         return f"gemm_f32x3_wp_kernel<{b(lb)}, 128>"
     if cfg >= 1000:  # the grouped weight-gradient launch of the fp32 LDS-DMA kernel (mtvaf_gemm_f32_dw_group)
@@ -299,6 +304,39 @@ def split_planes(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
         raise ValueError("split_planes: src fp32 [n], dst bf16 [3, n], n % 8 == 0")
     _ck(lib().mtvaf_f32_split_planes(_p(src), _p(dst), n, n, _st()), "mtvaf_f32_split_planes")
     return dst
+
+
+class Planes:
+    """The three bf16 planes of an fp32 tensor: `img` [3, n] bf16 (n = numel of the flat fp32 tensor, or of a larger buffer the
+    tensor is a view of), `view(t)` = plane 0 of the sub-tensor t at t's offsets; `stride` = elements between planes."""
+    __slots__ = ("img", "stride", "base")
+
+    def __init__(self, src: torch.Tensor, img: Optional[torch.Tensor] = None):
+        flat = src.reshape(-1)
+        n = flat.numel()
+        self.img = img if img is not None else torch.empty(3, n, dtype=torch.bfloat16, device=src.device)
+        self.stride, self.base = n, flat.data_ptr()
+        split_planes(flat, self.img)
+
+    def view(self, t: torch.Tensor) -> torch.Tensor:
+        o = (t.data_ptr() - self.base) // 4
+        return self.img[0, o:o + t.numel()]
+
+
+def gemm_planes(a_pl, layout_a, lda, a_stride, b_pl, layout_b, ldb, b_stride, out, M, N, K, bias=None, epi=EPI_NONE, aux=None,
+                accumulate=False, allow_split=False, out_planes=None, ldcp=0, c_stride=0, tile_n=-1, splits=-1, ktiles=None):
+    """out[M,N] (fp32, may be None with out_planes) = opA . opB with both operands given as plane images (plane 0 tensors +
+    the element distance between planes): mtvaf_gemm_f32p."""
+    ws, wsb = None, 0
+    if allow_split:
+        wsb = lib().mtvaf_gemm_f32_workspace_bytes(M, N, K, 1)
+        ws = workspace(wsb, a_pl.device)
+    kl, kc = ktiles if ktiles is not None else (None, None)
+    _ck(lib().mtvaf_gemm_f32p(layout_a, layout_b, _p(a_pl), lda, a_stride, _p(b_pl), ldb, b_stride, _p(out),
+                              out.stride(0) if out is not None else 0, _p(out_planes), ldcp, c_stride, M, N, K, _p(bias), epi, _p(aux),
+                              aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws), wsb, tile_n, splits,
+                              _p(kl), _p(kc), _st()), "mtvaf_gemm_f32p")
+    return out
 
 
 def set_compute_dtype(dtype: str):

@@ -1233,6 +1233,82 @@ def test_gemm_f32_weight_planes_equal_the_in_kernel_split_bit_for_bit(hip, lb, M
         hip.f32_wplanes(True)
 
 
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K,bn", [(512, 768, 768, 128), (512, 768, 768, 96), (256, 3072, 768, 128), (384, 2304, 3072, 96), (128, 128, 32, 128),
+                                      (128, 96, 64, 96), (256, 384, 96, 128)])
+def test_gemm_f32_plane_operands_equal_the_in_kernel_split_bit_for_bit(hip, la, lb, M, N, K, bn):
+    """mtvaf_gemm_f32p (csrc/gemm_f32p.hip: BOTH operands as plane images, tiles by LDS-DMA, nothing split in the k-loop)
+    against mtvaf_gemm_f32x3 on the fp32 operands the planes were split from: same planes, same MFMA sequence, same k order ->
+    identical bits.  All three operand layouts of the path, both tiles, one to 96 k-tiles, every epilogue, split-K, a k-tile
+    list, and the result's own plane image (equal to the split of the fp32 result)."""
+    cfg = 5 if bn == 128 else 6
+    g = torch.Generator().manual_seed(M + N + K + 3 * la + lb)
+    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-8, 9, (M, 1), generator=g).float())
+    B = torch.randn(K, N, generator=g) * torch.exp2(torch.randint(-8, 9, (1, N), generator=g).float())
+    a = (A if la == 0 else A.t().contiguous()).to(DEV)
+    b = (B.t().contiguous() if lb == 0 else B).to(DEV)
+    pa, pb = hip.Planes(a), hip.Planes(b)
+    lda, ldb = a.stride(0), b.stride(0)
+    bias, pre = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    ref, got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    aux_r, aux_g = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+
+    def run(**kw):
+        kr = {k: (aux_r if (k == "aux" and v is None) else v) for k, v in kw.items()}
+        kg = {k: (aux_g if (k == "aux" and v is None) else v) for k, v in kw.items()}
+        hip.gemm(a, la, b, lb, ref, M, N, K, compute="fp32x3", cfg=cfg, **kr)
+        got.fill_(float("nan"))
+        hip.prof_start(4)
+        hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got, M, N, K, tile_n=bn, **kg)
+        rec = hip.prof_stop(4)
+        assert rec[0][0]["cfg"] == 3000 + cfg
+    run()
+    assert torch.equal(got, ref)
+    close(got, A.double() @ B.double(), rtol=3e-6, name="plane operands")
+    run(bias=bias)
+    assert torch.equal(got, ref)
+    run(bias=bias, epi=hip.EPI_GELU, aux=None)
+    assert torch.equal(got, ref) and torch.equal(aux_g, aux_r)
+    run(epi=hip.EPI_DGELU, aux=pre)
+    assert torch.equal(got, ref)
+    run(bias=bias, epi=hip.EPI_TANH)
+    assert torch.equal(got, ref)
+    ref.normal_()
+    base = ref.clone()
+    got2 = base.clone()
+    hip.gemm(a, la, b, lb, ref, M, N, K, compute="fp32x3", cfg=cfg, accumulate=True)
+    hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got2, M, N, K, tile_n=bn, accumulate=True)
+    assert torch.equal(got2, ref)
+    if K >= 768:
+        run(bias=bias if la == 0 else None, allow_split=True, splits=3)
+        assert torch.equal(got, ref)
+    # the result's own plane image, beside and instead of the fp32 result
+    img = torch.empty(3, M * N, dtype=torch.bfloat16, device=DEV)
+    hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got, M, N, K, tile_n=bn, bias=bias, epi=hip.EPI_GELU,
+                    aux=aux_g, out_planes=img, ldcp=N, c_stride=M * N)
+    want = hip.Planes(got)
+    assert torch.equal(img.view(torch.int16), want.img.view(torch.int16))
+    img2 = torch.zeros_like(img)
+    hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, None, M, N, K, tile_n=bn, bias=bias, epi=hip.EPI_GELU,
+                    aux=aux_g, out_planes=img2, ldcp=N, c_stride=M * N)
+    assert torch.equal(img2.view(torch.int16), img.view(torch.int16))
+    if la == 1 and K >= 96:  # weight gradient over a k-tile list: A exactly zero outside the listed 32-row tiles
+        valid = torch.ones(K, dtype=torch.bool)
+        valid[32:64] = False
+        az = (a * valid[:, None].to(DEV)).contiguous()
+        paz = hip.Planes(az)
+        tiles = sorted(set(int(r) // 32 for r in torch.nonzero(valid).flatten()))
+        kl, kc = torch.tensor(tiles, dtype=torch.int32, device=DEV), torch.tensor([len(tiles)], dtype=torch.int32, device=DEV)
+        for sp in (1, 2):
+            hip.gemm_ktiles(az, b, ref, M, N, K, kl, kc, splits=sp, cfg=cfg)
+            got.fill_(float("nan"))
+            hip.gemm_planes(paz.img[0], 1, lda, paz.stride, pb.img[0], 1, ldb, pb.stride, got, M, N, K, tile_n=bn, allow_split=True,
+                            splits=sp, ktiles=(kl, kc))
+            assert torch.equal(got, ref), f"k-tile list, splits {sp}"
+    with pytest.raises(RuntimeError):  # shapes outside its cover are refused (the caller keeps the fp32-operand entry points)
+        hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got, M, N - 32, K)
+
+
 def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
     """The split kernel behind the fp32 entry points: every epilogue of the path (bias, bias + GELU with the saved
     pre-activation, GELU', tanh, accumulate), forced split-K, a k-tile list (weight gradient: dY exactly zero outside the listed
