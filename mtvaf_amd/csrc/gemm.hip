@@ -874,6 +874,7 @@ int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi
 // gelu'(aux)), 4 dtanh (multiply by 1-aux^2).  accumulate: C += result.  allow_split: permit a
 // deterministic split-K (slabs in workspace + ordered reduction); cfg/splits < 0 = heuristic.
 static long long* g_x3_trace = nullptr;
+static int g_x3_tile_walk = [] { const char* e = getenv("MTVAF_X3_TILE_WALK"); return e ? atoi(e) : 0; }();
 
 // weight-plane images (mtvaf_gemm_f32_wp) are used / ignored: MTVAF_F32_WPLANES=0 or mtvaf_f32_wplanes(0) switches them off
 static int g_f32_wplanes = [] { const char* e = getenv("MTVAF_F32_WPLANES"); return (e && atoi(e) == 0) ? 0 : 1; }();
@@ -922,6 +923,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   a.Bp = nullptr; a.bp_stride = 0;
   a.Ap = nullptr; a.ap_stride = 0; a.Cp = nullptr; a.cp_stride = 0; a.ldcp = 0;
   a.trace = g_x3_trace;
+  a.tile_walk = g_x3_tile_walk;
   a.A = A; a.B = B; a.bias = bias; a.aux = aux;
   a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldaux = ldaux;
   a.epi = epi; a.accumulate = accumulate;
@@ -1110,6 +1112,7 @@ int mtvaf_gemm_f32p(int layout_a, int layout_b, const void* Aplanes, int lda, lo
   }
   GemmArgs a = {};
   a.Ap = Aplanes; a.ap_stride = a_stride; a.Bp = Bplanes; a.bp_stride = b_stride;
+  a.tile_walk = g_x3_tile_walk;
   a.bias = bias; a.aux = aux; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldaux = ldaux;
   a.epi = epi; a.accumulate = accumulate; a.a_vec = a.b_vec = 1;
   int kc = (int)cdiv(cdiv(K, splits), 32) * 32;

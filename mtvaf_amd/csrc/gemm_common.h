@@ -53,6 +53,7 @@ struct GemmArgs {
   // profiling hook of the wave-specialised split kernel (mtvaf_f32x3_trace): block 0 stores, per wave and k-tile, the shader
   // clock where it arrives at / leaves the tile barrier -- [8 waves][64 k-tiles][4] int64 -- or NULL (no cost but the test)
   long long* trace;
+  int tile_walk;  // split kernels: 0 = rows of the tile grid per XCD (xcd_remap), G > 0 = groups of G tile rows column by column
 };
 
 // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so
@@ -63,6 +64,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb) {
   const int xcd = bid & 7, idx = bid >> 3;
   const int q = nb >> 3, r = nb & 7;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// xcd_remap + a walk that keeps a B panel in the XCD's L2: inside an XCD's contiguous run of tiles, groups of G tile rows are
+// walked COLUMN by column (the 32 CUs of an XCD hold G x 32/G tiles at a time: 8 B panels and G A panels live, each B panel
+// fetched once per group instead of once per tile row).  Only when the XCD's run is whole groups of whole rows; otherwise the
+// plain remap.  Placement is a speed hint only.
+__device__ __forceinline__ int xcd_remap_cols(int bid, int nb, int tiles_n, int G) {
+  const int t = xcd_remap(bid, nb);
+  const int per = nb >> 3;
+  if ((nb & 7) || per % (G * tiles_n)) return t;
+  const int base = (bid & 7) * per, i = t - base;
+  const int grp = i / (G * tiles_n), rem = i % (G * tiles_n);
+  return base + (grp * G + rem % G) * tiles_n + rem / G;
 }
 
 __device__ __forceinline__ f32x4 ld4(const float* __restrict__ p, int nvalid, bool vec) {

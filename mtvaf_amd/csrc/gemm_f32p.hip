@@ -37,6 +37,7 @@ namespace mtvaf {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned frag_t __attribute__((ext_vector_type(4)));  // (fragments as four dwords: see gemm_f32x3.hip)
 
 namespace f32p {
 
@@ -48,11 +49,12 @@ __device__ __forceinline__ unsigned cvt_pk(const f32x2 v) {
 __device__ __forceinline__ f32x2 widen(const unsigned pk) {
   return f32x2{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
 }
+__device__ __forceinline__ f32x2 resid2(const f32x2 x, const unsigned hpk) { return x - widen(hpk); }
 __device__ __forceinline__ void split3_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
   h = cvt_pk(x);
-  const f32x2 r = x - widen(h);
+  const f32x2 r = resid2(x, h);
   m = cvt_pk(r);
-  l = cvt_pk(r - widen(m));
+  l = cvt_pk(resid2(r, m));
 }
 __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16x4& l) {
   unsigned h0, m0, l0, h1, m1, l1;
@@ -65,11 +67,14 @@ __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16
 
 }  // namespace f32p
 
-template <bool A_KM, bool B_KM, bool KLIST, int BN>
-__global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
+// DW: four more waves (one per SIMD) that do nothing but issue the LDS-DMA requests.  Why: a global_load_lds request costs the
+// issuing wave 80-95 cycles beside the matrix stream (tools/x3_trace.py), and a wave issues in order -- with the requests in the
+// MFMA waves a k-tile took 48 x ~42 + 12 x ~85 = ~3100 cycles; in waves of their own they overlap the MFMAs.
+template <bool A_KM, bool B_KM, bool KLIST, int BN, bool DW>
+__global__ __launch_bounds__(DW ? 512 : 256, 1) void gemm_f32p_kernel(GemmArgs p) {
   static_assert(BN == 128 || BN == 96, "tiles: 128 x 128 and 128 x 96");
   static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
-  constexpr int BM = 128, BK = 32, NT = 256, NS = 3, NW = 4;
+  constexpr int BM = 128, BK = 32, NT = DW ? 512 : 256, NS = 3, NW = 4;
   constexpr int WM = BN == 128 ? 2 : 4, WN = BN == 128 ? 2 : 1;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int AP_B = BM * 64;                       // bytes of one A plane tile (KC: 128 rows x 64 B; KM: 32 rows x 256 B)
@@ -86,9 +91,11 @@ __global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const bool dma_wave = DW && wave >= 4;      // (wave-uniform)
+  const int pw = DW ? (wave & 3) : wave;      // owner index of this wave's DMA pieces (DW: only the DMA waves issue them)
+  const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
   const int li = lane & 31, h = lane >> 5;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = p.tile_walk > 0 ? xcd_remap_cols(blockIdx.x, gridDim.x, p.tiles_n, p.tile_walk) : xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
   int kbeg = blockIdx.z * p.k_chunk;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
   const __bf16* Bp = reinterpret_cast<const __bf16*>(p.Bp);
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
-    const int I = wave * IA + i, plane = I / (AP_B / 1024), slot = (I % (AP_B / 1024)) * 64 + lane;
+    const int I = pw * IA + i, plane = I / (AP_B / 1024), slot = (I % (AP_B / 1024)) * 64 + lane;
     if constexpr (!A_KM) {
       const int row = slot >> 2, cp = slot & 3;
       pa[i] = reinterpret_cast<const unsigned char*>(Ap + plane * p.ap_stride + (long)(m0 + row) * p.lda + kbeg) + ((cp ^ ((row >> 2) & 3)) << 4);
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
   }
 #pragma unroll
   for (int i = 0; i < IB; ++i) {
-    int I = wave * IB + i;
+    int I = pw * IB + i;
     if (I >= BPIECES) I -= BPIECES;  // (BN = 96) dummy piece: piece I - 18 again, into the pad behind the planes
     const int plane = I / (BP_B / 1024), slot = (I % (BP_B / 1024)) * 64 + lane;
     if constexpr (!B_KM) {
@@ -152,13 +159,13 @@ __global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      const int I = wave * IA + i;
+      const int I = pw * IA + i;
       glds16x(pa[i] + oa, sa + I * 1024);
       if constexpr (!KLIST) pa[i] += stepA;
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      const int I = wave * IB + i;  // (dummy pieces land at 3 * BP_B + ..., behind the planes)
+      const int I = pw * IB + i;  // (dummy pieces land at 3 * BP_B + ..., behind the planes)
       glds16x(pb[i] + ob, sb + I * 1024);
       if constexpr (!KLIST) pb[i] += stepB;
     }
@@ -210,23 +217,23 @@ __global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
     }
   }
 
-  bf16x8 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
-  auto rdf = [&](const unsigned char* a, const unsigned char* b, int ks, bf16x8 (&fa)[3][TM], bf16x8 (&fb)[3][TN]) __attribute__((always_inline)) {
+  frag_t fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+  auto rdf = [&](const unsigned char* a, const unsigned char* b, int ks, frag_t (&fa)[3][TM], frag_t (&fb)[3][TN]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        if constexpr (!A_KM) fa[q][i] = *reinterpret_cast<const bf16x8*>(a + q * AP_B + offA[i][0] + (((2 * ks + h) ^ offA[i][1]) << 4));
-        else fa[q][i] = tr_read8(a + q * AP_B + offA[i][0] + KM_SLICE_A * ks, a + q * AP_B + offA[i][1] + KM_SLICE_A * ks);
+        if constexpr (!A_KM) fa[q][i] = *reinterpret_cast<const frag_t*>(a + q * AP_B + offA[i][0] + (((2 * ks + h) ^ offA[i][1]) << 4));
+        else fa[q][i] = __builtin_bit_cast(frag_t, tr_read8(a + q * AP_B + offA[i][0] + KM_SLICE_A * ks, a + q * AP_B + offA[i][1] + KM_SLICE_A * ks));
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        if constexpr (!B_KM) fb[q][j] = *reinterpret_cast<const bf16x8*>(b + q * BP_B + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
-        else fb[q][j] = tr_read8(b + q * BP_B + offB[j][0] + KM_SLICE_B * ks, b + q * BP_B + offB[j][1] + KM_SLICE_B * ks);
+        if constexpr (!B_KM) fb[q][j] = *reinterpret_cast<const frag_t*>(b + q * BP_B + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
+        else fb[q][j] = __builtin_bit_cast(frag_t, tr_read8(b + q * BP_B + offB[j][0] + KM_SLICE_B * ks, b + q * BP_B + offB[j][1] + KM_SLICE_B * ks));
       }
     }
   };
-  auto mm = [&](const bf16x8 (&fa)[3][TM], const bf16x8 (&fb)[3][TN]) __attribute__((always_inline)) {
+  auto mm = [&](const frag_t (&fa)[3][TM], const frag_t (&fb)[3][TN]) __attribute__((always_inline)) {
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first (as gemm_f32x3.hip)
 #pragma unroll
     for (int t = 0; t < 6; ++t)
@@ -234,27 +241,47 @@ __global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[PA[t]][i]), __builtin_bit_cast(bf16x8, fb[PB[t]][j]), acc[i][j], 0, 0, 0);
   };
 
+  if (!DW || dma_wave) {
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s)
-    if (s < nk) issue(s);
+    for (int s = 0; s < NS - 1; ++s)
+      if (s < nk) issue(s);
+  }
   // One step = the barrier that publishes a tile + the request for the tile two ahead (into the stage the previous tile left).
   // No MFMA sits inside a conditional: the accumulators never pass through a phi (a conditional product group made the
   // compiler copy all 64 accumulator registers twice per k-tile).
   auto publish = [&](int kt, int st) __attribute__((always_inline)) {
-    if (kt + 1 < nk) wait_vm<IA + IB>();  // this wave's pieces of tile kt have landed; tile kt + 1 stays in flight
-    else wait_vm<0>();
+    if constexpr (!DW) {
+      if (kt + 1 < nk) wait_vm<IA + IB>();  // this wave's pieces of tile kt have landed; tile kt + 1 stays in flight
+      else wait_vm<0>();
+    }
     __builtin_amdgcn_s_barrier();  // ... and everybody else's; every wave is done reading tile kt - 1
     asm volatile("" ::: "memory");
-    if (kt + NS - 1 < nk) {
-      int si = st + NS - 1;
-      if (si >= NS) si -= NS;
-      issue(si);
+    if constexpr (!DW) {
+      if (kt + NS - 1 < nk) {
+        int si = st + NS - 1;
+        if (si >= NS) si -= NS;
+        issue(si);
+      }
     }
   };
-  if (nk > 0) {
+  if (dma_wave) {
+    int st = 0;
+    for (int kt = 0; kt < nk; ++kt) {  // the same barrier count as the MFMA waves: one per k-tile
+      if (kt + 1 < nk) wait_vm<IA + IB>();
+      else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NS - 1 < nk) {
+        int si = st + NS - 1;
+        if (si >= NS) si -= NS;
+        issue(si);
+      }
+      st = st + 1 == NS ? 0 : st + 1;
+    }
+  } else if (nk > 0) {
     publish(0, 0);
     rdf(smem_b, smem_b + A_B, 0, fa0, fb0);
     int st = 0;
@@ -291,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       __syncthreads();  // (every DMA piece has landed: the last publish waited for vmcnt(0))
-      if (wrow / RP == pass) {
+      if (!dma_wave && wrow / RP == pass) {
         const int rofs = wrow % RP;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -338,19 +365,19 @@ __global__ __launch_bounds__(256, 1) void gemm_f32p_kernel(GemmArgs p) {
   }
 }
 
-template <int BN>
+template <int BN, bool DW>
 static int launch_f32p_t(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   constexpr size_t smem = (size_t)3 * (3 * 128 * 64 + (BN == 128 ? 24576 : 20480));
 #define MTVAF_F32P(AK, BKM, KL)                                                                                      \
   do {                                                                                                               \
-    auto kern = gemm_f32p_kernel<AK, BKM, KL, BN>;                                                                   \
+    auto kern = gemm_f32p_kernel<AK, BKM, KL, BN, DW>;                                                               \
     static bool attr_set = false;                                                                                    \
     if (!attr_set) {                                                                                                 \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
       if (e != hipSuccess) return (int)e;                                                                            \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, a);                                                          \
+    hipLaunchKernelGGL(kern, grid, dim3(DW ? 512 : 256), smem, st, a);                                               \
   } while (0)
   if (la == 0 && lb == 0) MTVAF_F32P(false, false, false);
   else if (la == 0 && lb == 1) MTVAF_F32P(false, true, false);
@@ -364,7 +391,9 @@ static int launch_f32p_t(const GemmArgs& a, int la, int lb, dim3 grid, hipStream
 // Both operands as plane images (a.Ap / a.Bp): bn = 128 or 96.  Called by gemm.hip's dispatcher (whole tiles, wide epilogue).
 int launch_gemm_f32p(int bn, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   if (!a.wide || !a.Ap || !a.Bp) return MTVAF_ERR_ALIGN;
-  return bn == 128 ? launch_f32p_t<128>(a, la, lb, grid, st) : launch_f32p_t<96>(a, la, lb, grid, st);
+  static const bool dw = [] { const char* e = getenv("MTVAF_F32P_DMA_WAVES"); return !(e && atoi(e) == 0); }();
+  if (dw) return bn == 128 ? launch_f32p_t<128, true>(a, la, lb, grid, st) : launch_f32p_t<96, true>(a, la, lb, grid, st);
+  return bn == 128 ? launch_f32p_t<128, false>(a, la, lb, grid, st) : launch_f32p_t<96, false>(a, la, lb, grid, st);
 }
 
 }  // namespace mtvaf

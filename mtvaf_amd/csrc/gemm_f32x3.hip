@@ -21,6 +21,10 @@
 namespace mtvaf {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// MFMA operand fragments travel as four dwords: a loop-carried / conditional value of type <8 x bf16> is legalised piece by
+// piece (48 v_perm_b32 + 48 v_lshrrev_b32 per k-tile in the consumer loop, found in round 4), a <4 x i32> is not
+typedef unsigned frag_t __attribute__((ext_vector_type(4)));
+#define MTVAF_FRAG(x) __builtin_bit_cast(bf16x8, x)
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 namespace x3 {
@@ -33,18 +37,23 @@ __device__ __forceinline__ unsigned cvt_pk(const f32x2 v) { return __builtin_bit
 __device__ __forceinline__ f32x2 widen(const unsigned pk) {
   return f32x2{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
 }
-// (plain v_sub_f32 for the residuals: beside MFMAs a v_pk_add_f32 costs several plain instructions' issue time)
-__device__ __forceinline__ f32x2 sub2(const f32x2 a, const f32x2 b) {
+// Residual x - bf16 pair by plain v_sub_f32 (beside MFMAs a v_pk_add_f32 costs several plain instructions' issue time).
+// Tried and dropped in round 4: v_dot2c_f32_bf16 with b = (-1, 0) / (0, -1) folds the widening into the subtraction (7
+// instead of 11 vector instructions per pair) but issues slower than the three instructions it replaces -- the producers'
+// staging went from 1840 to 2660 cycles per k-tile (tools/x3_trace.py) -- and hipcc 7.2 encodes the (-1, 0) operand as the
+// inline constant -1.0, which the instruction reads as (0, -1): wrong planes.
+__device__ __forceinline__ f32x2 resid2(const f32x2 x, const unsigned hpk) {
+  const f32x2 w = widen(hpk);
   f32x2 r;
-  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r.x) : "v"(a.x), "v"(b.x));
-  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r.y) : "v"(a.y), "v"(b.y));
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r.x) : "v"(x.x), "v"(w.x));
+  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r.y) : "v"(x.y), "v"(w.y));
   return r;
 }
 __device__ __forceinline__ void split3_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
   h = cvt_pk(x);
-  const f32x2 r = sub2(x, widen(h));
+  const f32x2 r = resid2(x, h);
   m = cvt_pk(r);
-  l = cvt_pk(sub2(r, widen(m)));
+  l = cvt_pk(resid2(r, m));
 }
 __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16x4& l) {
   unsigned h0, m0, l0, h1, m1, l1;
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32x3_kernel(GemmArgs p) 
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, h = lane >> 5;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = p.tile_walk > 0 ? xcd_remap_cols(blockIdx.x, gridDim.x, p.tiles_n, p.tile_walk) : xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
   int kbeg = blockIdx.z * p.k_chunk;
@@ -377,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   const bool consumer = wave < 4;
   const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
   const int li = lane & 31, h = lane >> 5;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = p.tile_walk > 0 ? xcd_remap_cols(blockIdx.x, gridDim.x, p.tiles_n, p.tile_walk) : xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
   int kbeg = blockIdx.z * p.k_chunk;
@@ -408,21 +417,21 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     // barriers alone 48 us, MFMAs + reads 113 us on FFN-1 forward -- the matrix time ADDED to the read time).  Slice 1 of
     // tile t is read before the barrier that ends step t and multiplied after it, while the reads of tile t+1 / slice 0
     // are in flight (the producers refill the buffer of tile t only behind that barrier: its fragments are in registers).
-    bf16x8 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
-    auto rd = [&](int buf, int ks, bf16x8 (&fa)[3][TM], bf16x8 (&fb)[3][TN]) __attribute__((always_inline)) {
+    frag_t fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+    auto rd = [&](int buf, int ks, frag_t (&fa)[3][TM], frag_t (&fb)[3][TN]) __attribute__((always_inline)) {
       const __bf16* a = sA + buf * BUF;
       const __bf16* b = sB + buf * BUF;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          fa[q][i] = *reinterpret_cast<const bf16x8*>(a + q * A_SZ + ((wm * TM + i) * 32 + li) * LDH + 16 * ks + 8 * h);
+          fa[q][i] = *reinterpret_cast<const frag_t*>(a + q * A_SZ + ((wm * TM + i) * 32 + li) * LDH + 16 * ks + 8 * h);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          fb[q][j] = *reinterpret_cast<const bf16x8*>(b + q * B_SZ + ((wn * TN + j) * 32 + li) * LDH + 16 * ks + 8 * h);
+          fb[q][j] = *reinterpret_cast<const frag_t*>(b + q * B_SZ + ((wn * TN + j) * 32 + li) * LDH + 16 * ks + 8 * h);
       }
     };
-    auto mm = [&](const bf16x8 (&fa)[3][TM], const bf16x8 (&fb)[3][TN]) __attribute__((always_inline)) {
+    auto mm = [&](const frag_t (&fa)[3][TM], const frag_t (&fb)[3][TN]) __attribute__((always_inline)) {
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
 #pragma unroll
       for (int t = 0; t < 6; ++t)
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MTVAF_FRAG(fa[PA[t]][i]), MTVAF_FRAG(fb[PB[t]][j]), acc[i][j], 0, 0, 0);
     };
     __builtin_amdgcn_s_setprio(2);  // (the matrix stream first: measured -2..5 % against equal priorities, +3 % the other way round)
     __syncthreads();  // k-tile 0 is in buffer 0
@@ -589,9 +598,9 @@ static int launch_x3_ws(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_
 // one of the 32 row tiles of a 4096-token product, in the forward and in the dX product, although a weight changes once per
 // optimizer step.  mtvaf_f32_split_planes writes the three bf16 planes of an fp32 tensor once ([3][n] bf16, the planes of
 // element i at i, i + stride, i + 2 stride: the same RNE split as split3 above, so the planes equal what the producers would
-// form); gemm_f32x3_wp_kernel takes its B operand from such an image: plane tiles travel L2 -> LDS by global_load_lds_dwordx4
-// (no registers, no vector work, no ds_write), through a 3-stage ring so that a tile has two k-steps to land; A (activations /
-// gradients: fp32, new in every call) is split in-kernel as before.  Bytes from L2 per k-tile: 16 KiB (A, fp32) + 24 KiB (B
+// form); gemm_f32x3_wp_kernel takes its B operand from such an image: the producers copy plane tiles global -> registers -> LDS
+// in 16-byte pieces (no vector work; as LDS-DMA the requests measured slower, see the kernel); A (activations / gradients:
+// fp32, new in every call) is split in-kernel as before.  Bytes from L2 per k-tile: 16 KiB (A, fp32) + 24 KiB (B
 // planes) = 40 KiB against 32 KiB.  Same MFMA sequence and k order as the kernel above: results are bit-identical to it.
 //
 // B images (lane-linear LDS-DMA, so both swizzles sit on the per-lane SOURCE address and again on the read):
@@ -612,27 +621,34 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 }
 
 template <bool B_KM, int BN>
-__global__ __launch_bounds__(512, 1) void gemm_f32x3_wp_kernel(GemmArgs p) {
+__global__ __launch_bounds__(768, 1) void gemm_f32x3_wp_kernel(GemmArgs p) {
   using namespace x3;
   static_assert(BN == 128, "plane images exist for 128-column tiles");
-  constexpr int BM = 128, BK = 32, LDH = BK + 8, NP = 256, NT = 512;
+  constexpr int BM = 128, BK = 32, LDH = BK + 8, NP = 256, NT = 768;
   constexpr int WN = 2, TM = 2, TN = 2;
   constexpr int A_SZ = BM * LDH;             // bf16 elements of one A plane
   constexpr int A_BUF = 3 * A_SZ;            // elements of one A buffer (three planes)
   constexpr int BP_B = BN * 64;              // bytes of one B plane tile (KC: BN rows x 64 B; KM: 32 rows x 2 BN B)
   constexpr int BST_B = 3 * BP_B;            // bytes of one B stage
-  constexpr int NBS = 3;                     // B stages
-  static_assert(BP_B % 1024 == 0, "whole 1-KiB DMA pieces per plane tile");
+  constexpr int NBS = 3;                     // B stages: a tile has two k-steps to land
+  constexpr int PPP = BP_B / 1024;           // 1-KiB DMA pieces per plane tile
+  constexpr int IB = 3 * PPP / 4;            // pieces per DMA wave and stage: 6
+  static_assert((3 * PPP) % 4 == 0, "whole DMA pieces per DMA wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sA = reinterpret_cast<__bf16*>(smem_raw);                  // [2][3][A_SZ]
   unsigned char* sB = smem_raw + 2 * A_BUF * sizeof(__bf16);         // [NBS][3][BP_B]
 
+  // twelve waves, three per SIMD: 0-3 consumers (fragment reads + MFMAs), 4-7 A producers (fp32 tile -> registers -> three
+  // planes -> LDS), 8-11 DMA waves (B plane tiles L2 -> LDS, nothing else).  Why separate DMA waves: a global_load_lds request
+  // costs the issuing wave 80-95 cycles beside the matrix stream and a wave issues in order (with the requests in the consumers
+  // a k-tile took +460 cycles); and a wave that also issues ds_write is made to wait vmcnt(0) in front of every store -- the
+  // compiler orders LDS stores behind pending LDS-DMA of the same wave, __restrict__ regions or not -- so not the producers.
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool consumer = wave < 4;
   const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
   const int li = lane & 31, h = lane >> 5;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = p.tile_walk > 0 ? xcd_remap_cols(blockIdx.x, gridDim.x, p.tiles_n, p.tile_walk) : xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (bid / p.tiles_n) * BM;
   const int n0 = (bid % p.tiles_n) * BN;
   const int kbeg = blockIdx.z * p.k_chunk;
@@ -647,9 +663,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_wp_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  long long* const tr = (p.trace && blockIdx.x == 0 && blockIdx.z == 0 && wave < 8) ? p.trace : nullptr;  // (wave-uniform)
+  if (tr && tid == 0) tr[8 * 64 * 4] = __builtin_amdgcn_s_memtime();
   if (nk > 0) {  // (block-uniform: an empty k-chunk writes a zero slab)
   if (consumer) {
-    // B fragment offsets inside a plane tile (bytes)
     int offB[TN][2];
     {
       const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
@@ -668,23 +685,23 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_wp_kernel(GemmArgs p) {
         }
       }
     }
-    bf16x8 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
-    auto rd = [&](int kt, int ks, bf16x8 (&fa)[3][TM], bf16x8 (&fb)[3][TN]) __attribute__((always_inline)) {
-      const __bf16* a = sA + (kt & 1) * A_BUF;
-      const unsigned char* b = sB + (kt % NBS) * BST_B;
+    frag_t fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+    auto rd = [&](int abuf, int bst, int ks, frag_t (&fa)[3][TM], frag_t (&fb)[3][TN]) __attribute__((always_inline)) {
+      const __bf16* a = sA + abuf * A_BUF;
+      const unsigned char* b = sB + bst * BST_B;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          fa[q][i] = *reinterpret_cast<const bf16x8*>(a + q * A_SZ + ((wm * TM + i) * 32 + li) * LDH + 16 * ks + 8 * h);
+          fa[q][i] = *reinterpret_cast<const frag_t*>(a + q * A_SZ + ((wm * TM + i) * 32 + li) * LDH + 16 * ks + 8 * h);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          if constexpr (!B_KM) fb[q][j] = *reinterpret_cast<const bf16x8*>(b + q * BP_B + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
-          else fb[q][j] = tr_read8(b + q * BP_B + offB[j][0] + 4096 * ks, b + q * BP_B + offB[j][1] + 4096 * ks);
+          if constexpr (!B_KM) fb[q][j] = *reinterpret_cast<const frag_t*>(b + q * BP_B + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
+          else fb[q][j] = __builtin_bit_cast(frag_t, tr_read8(b + q * BP_B + offB[j][0] + 4096 * ks, b + q * BP_B + offB[j][1] + 4096 * ks));
         }
       }
     };
-    auto mm = [&](const bf16x8 (&fa)[3][TM], const bf16x8 (&fb)[3][TN]) __attribute__((always_inline)) {
+    auto mm = [&](const frag_t (&fa)[3][TM], const frag_t (&fb)[3][TN]) __attribute__((always_inline)) {
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first (as the kernel above)
 #pragma unroll
       for (int t = 0; t < 6; ++t)
@@ -692,137 +709,113 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_wp_kernel(GemmArgs p) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[t]][i], fb[PB[t]][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MTVAF_FRAG(fa[PA[t]][i]), MTVAF_FRAG(fb[PB[t]][j]), acc[i][j], 0, 0, 0);
     };
     __builtin_amdgcn_s_setprio(2);
-    __builtin_amdgcn_s_barrier();  // k-tile 0: A planes in buffer 0, B planes in stage 0
+    __builtin_amdgcn_s_barrier();  // k-tile 0: A planes in buffer 0 (producers), B planes in stage 0 (DMA waves)
     asm volatile("" ::: "memory");
-    rd(0, 0, fa0, fb0);
+    rd(0, 0, 0, fa0, fb0);
+    int st = 0;
     for (int kt = 0; kt < nk; ++kt) {
-      rd(kt, 1, fa1, fb1);
+      rd(kt & 1, st, 1, fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
       mm(fa0, fb0);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's last fragments are in registers: its buffers may be refilled
-      __builtin_amdgcn_s_barrier();                        // ... and tile kt + 1 is complete (the producers waited for it)
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 2] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();  // tile kt + 1 is complete (the producers and the DMA waves waited for their parts of it)
       asm volatile("" ::: "memory");
-      if (kt + 1 < nk) rd(kt + 1, 0, fa0, fb0);
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 3] = __builtin_amdgcn_s_memtime();
+      st = st == NBS - 1 ? 0 : st + 1;
+      rd((kt + 1) & 1, st, 0, fa0, fb0);  // (past the end: a harmless re-read)
       __builtin_amdgcn_sched_barrier(0);
       mm(fa1, fb1);
       __builtin_amdgcn_sched_barrier(0);
     }
-  } else if (wave == 7) {
-    // ---- the DMA wave: B plane tiles L2 -> LDS, nothing else (a wave that also issued ds_write would be made to wait
-    // vmcnt(0) in front of every store: the compiler orders LDS accesses behind pending LDS-DMA of the same wave) ----
-    constexpr int IB = BST_B / 1024;  // 1-KiB pieces per stage
+  } else if (wave >= 8) {
+    // ---- DMA waves: this wave's IB pieces of every B stage ----
+    const int dw = wave - 8;
     const __bf16* Bp = reinterpret_cast<const __bf16*>(p.Bp);
-    // piece I = plane (I / PPP), sub-piece pc (I % PPP): LDS slot pc * 64 + lane of the plane image; its source chunk is
-    // the slot's chunk position XOR the row swizzle
-    constexpr int PPP = BP_B / 1024;
-    const unsigned char* pl[3];
-    long piece_step;
-    {
-      if constexpr (!B_KM) {  // slot -> (row = slot >> 2, cp = slot & 3): 16 rows per piece; (row >> 2) & 3 = (lane >> 4) & 3
-        const int row = lane >> 2, cp = lane & 3;
+    const unsigned char* pb[IB];
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
-          pl[q] = reinterpret_cast<const unsigned char*>(Bp + q * p.bp_stride + (long)(n0 + row) * p.ldb + kbeg) + ((cp ^ ((row >> 2) & 3)) << 4);
-        piece_step = (long)16 * p.ldb * 2;
-      } else {  // slot -> (row = slot >> 4, cp = slot & 15): 4 rows per piece; km_swz(row) depends on row & 15 = 4 (pc & 3) + (lane >> 4)
-        const int row = lane >> 4, cp = lane & 15;
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          pl[q] = reinterpret_cast<const unsigned char*>(Bp + q * p.bp_stride + (long)(kbeg + row) * p.ldb + n0) + (cp << 4);
-        piece_step = (long)4 * p.ldb * 2;
+    for (int i = 0; i < IB; ++i) {
+      const int I = dw * IB + i, plane = I / PPP, slot = (I % PPP) * 64 + lane;
+      if constexpr (!B_KM) {
+        const int row = slot >> 2, cp = slot & 3;
+        pb[i] = reinterpret_cast<const unsigned char*>(Bp + plane * p.bp_stride + (long)(n0 + row) * p.ldb + kbeg) + ((cp ^ ((row >> 2) & 3)) << 4);
+      } else {
+        const int row = slot >> 4, cp = slot & 15;
+        pb[i] = reinterpret_cast<const unsigned char*>(Bp + plane * p.bp_stride + (long)(kbeg + row) * p.ldb + n0) + ((cp ^ km_swz(row)) << 4);
       }
     }
-    const long stepB = B_KM ? (long)BK * p.ldb * 2 : BK * 2;
-    const int cpos = (lane & 15) << 4, r4 = lane >> 4;
-    int b_issued = 0;
-    // (requests past the end fetch the LAST tile again -- into a stage nobody reads any more -- so that every step issues the
-    // same number of DMA instructions and the counted waits hold to the end)
+    const long stepB = B_KM ? (long)BK * p.ldb * 2 : (long)BK * 2;
     auto issueB = [&](int stage) __attribute__((always_inline)) {
-      unsigned char* dst = sB + stage * BST_B;
-      const long o = (long)min(b_issued, nk - 1) * stepB;
-      ++b_issued;
+      unsigned char* dst = sB + stage * BST_B + dw * IB * 1024;
 #pragma unroll
-      for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int pc = 0; pc < PPP; ++pc) {
-          const unsigned char* src = pl[q] + o + pc * piece_step;
-          if constexpr (B_KM) src += (cpos ^ (km_swz(4 * (pc & 3) + r4) << 4)) - cpos;  // (cp ^ km_swz(row)) << 4 for row = 4 pc + r4
-          glds16x(src, dst + (q * PPP + pc) * 1024);
-        }
+      for (int i = 0; i < IB; ++i) {
+        glds16x(pb[i], dst + i * 1024);
+        pb[i] += stepB;
+      }
     };
     issueB(0);
-    issueB(1);
-    wait_vm<IB>();  // tile 0 landed; tile 1 may still be on its way
+    if (nk > 1) issueB(1);
+    if (nk > 1) wait_vm<IB>();  // tile 0 landed; tile 1 may still be on its way
+    else wait_vm<0>();
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     int st2 = 2;  // stage of tile kt + 2
     for (int kt = 0; kt < nk; ++kt) {
-      issueB(st2);  // into the stage tile kt - 1 left (everybody passed the barrier that ended step kt - 1)
+      if (kt + 2 < nk) issueB(st2);  // into the stage tile kt - 1 left (everybody passed the barrier that ended step kt - 1)
       st2 = st2 == NBS - 1 ? 0 : st2 + 1;
-      wait_vm<IB>();  // tile kt + 1 (requested one step ago) has landed; tile kt + 2 stays in flight across the barrier
-      __builtin_amdgcn_s_barrier();
-    }
-    wait_vm<0>();  // no piece may land after the epilogue has taken the LDS over (or the block has ended)
-  } else {
-    // ---- three A producers (192 threads): fp32 A tile -> registers (two k-tiles ahead, two register sets) -> three planes ->
-    // LDS.  1024 float4 per tile = 5 per thread + one more for producer wave 0 (a wave-uniform difference: two instantiations)
-    const int ptid = tid - 256, pw = wave - 4;
-    auto run = [&](auto ua_tag) __attribute__((always_inline)) {
-      constexpr int UA = decltype(ua_tag)::value;
-      f32x4 ra0[UA], ra1[UA];
-      auto gloadA = [&](int kt, f32x4* ra) __attribute__((always_inline)) {
-        const int k0 = kbeg + kt * BK;
-#pragma unroll
-        for (int i = 0; i < UA; ++i) {
-          const int idx = ptid + i * 192;
-          ra[i] = *reinterpret_cast<const f32x4*>(p.A + (long)(m0 + kc_row(idx >> 3)) * p.lda + k0 + (idx & 7) * 4);
-        }
-      };
-      auto stageA = [&](int buf, const f32x4* ra) __attribute__((always_inline)) {
-        __bf16* s = sA + buf * A_BUF;
-#pragma unroll
-        for (int i = 0; i < UA; ++i) {
-          const int idx = ptid + i * 192;
-          bf16x4 hh, mm_, ll;
-          split3(ra[i], hh, mm_, ll);
-          __bf16* d = s + kc_row(idx >> 3) * LDH + (idx & 7) * 4;
-          *reinterpret_cast<bf16x4*>(d) = hh;
-          *reinterpret_cast<bf16x4*>(d + A_SZ) = mm_;
-          *reinterpret_cast<bf16x4*>(d + 2 * A_SZ) = ll;
-        }
-      };
-      // step kt (the consumers multiply tile kt): planes of tile kt+1 from their register set into the other buffer, tile kt+3
-      // requested into the set (unconditionally: past the end the last tile again)
-      auto pstep = [&](int kt, f32x4* ra) __attribute__((always_inline)) {
-        stageA((kt + 1) & 1, ra);
-        gloadA(min(kt + 3, nk - 1), ra);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the plane stores are in the LDS
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      };
-      gloadA(0, ra0);
-      gloadA(min(1, nk - 1), ra1);
-      stageA(0, ra0);
-      gloadA(min(2, nk - 1), ra0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (kt + 2 < nk) wait_vm<IB>();  // tile kt + 1 (requested one step ago) has landed; tile kt + 2 stays in flight
+      else wait_vm<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      int kt = 0;
-      for (; kt + 1 < nk; kt += 2) {  // tile kt+1 sits in set 1, tile kt+2 in set 0
-        pstep(kt, ra1);
-        pstep(kt + 1, ra0);
+    }
+  } else {
+    // ---- A producers: the fp32 A tile only (half the staging work of the kernel above: B never passes through registers)
+    const int ptid = tid - 256;
+    constexpr int UA = Stage<BM, NP, false, BK>::NKC;
+    f32x4 ra0[UA], ra1[UA];
+    auto gloadA = [&](int kt, f32x4* ra) __attribute__((always_inline)) { g_load<BM, NP, false, BK>(ra, p.A, p.lda, m0, kbeg + kt * BK, ptid); };
+    auto stageA = [&](int buf, const f32x4* ra) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < UA; ++u) {
+        unsigned w[6];
+        convert_unit<false>(ra, u, w);
+        put_unit<NP, false, A_SZ, BK, BM>(w, u, sA + buf * A_BUF, ptid);
       }
-      if (kt < nk) pstep(kt, ra1);
     };
-    if (pw == 0) run(std::integral_constant<int, 6>{});
-    else run(std::integral_constant<int, 5>{});
+    auto pstep = [&](int kt, f32x4* ra) __attribute__((always_inline)) {
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 0] = __builtin_amdgcn_s_memtime();
+      stageA((kt + 1) & 1, ra);  // (past the end: a harmless copy of the last tile into the idle buffer)
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 1] = __builtin_amdgcn_s_memtime();
+      gloadA(min(kt + 3, nk - 1), ra);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the plane stores are in the LDS
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 2] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 3] = __builtin_amdgcn_s_memtime();
+    };
+    gloadA(0, ra0);
+    gloadA(min(1, nk - 1), ra1);
+    stageA(0, ra0);
+    gloadA(min(2, nk - 1), ra0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {  // tile kt+1 sits in set 1, tile kt+2 in set 0
+      pstep(kt, ra1);
+      pstep(kt + 1, ra0);
+    }
+    if (kt < nk) pstep(kt, ra1);
   }
   }  // nk > 0
 
-  // wide epilogue: as gemm_f32x3_ws_kernel (the image overlays the A buffers only)
+  if (tr && lane == 0) tr[8 * 64 * 4 + 1 + wave] = __builtin_amdgcn_s_memtime();
+  // wide epilogue: as gemm_f32x3_ws_kernel (the image overlays the A buffers only; every DMA piece has landed: the DMA waves'
+  // last wait was vmcnt(0))
   {
     constexpr int LDE = BN + 4, RP = 64, C4 = BN / 4;
     static_assert((size_t)RP * LDE * sizeof(float) <= (size_t)2 * A_BUF * sizeof(__bf16), "the epilogue image must not reach the B ring");
@@ -885,7 +878,7 @@ static int launch_x3_wp(const GemmArgs& a, int lb, dim3 grid, hipStream_t st) {
       if (e != hipSuccess) return (int)e;                                                                            \
       attr_set = true;                                                                                               \
     }                                                                                                                \
-    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);                                                          \
+    hipLaunchKernelGGL(kern, grid, dim3(768), smem, st, a);                                                          \
   } while (0)
   if (lb == 0) MTVAF_X3_WP(false);
   else MTVAF_X3_WP(true);

@@ -1306,7 +1306,7 @@ def test_gemm_f32_plane_operands_equal_the_in_kernel_split_bit_for_bit(hip, la, 
                             splits=sp, ktiles=(kl, kc))
             assert torch.equal(got, ref), f"k-tile list, splits {sp}"
     with pytest.raises(RuntimeError):  # shapes outside its cover are refused (the caller keeps the fp32-operand entry points)
-        hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got, M, N - 32, K)
+        hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got, M, N - 16, K)
 
 
 def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):

@@ -17,11 +17,14 @@ args = [int(a) for a in sys.argv[1:]]
 M, N, K = (args + [4096, 3072, 768])[:3] if len(args) >= 3 else (4096, 3072, 768)
 cfg = args[3] if len(args) > 3 else 5
 a, b, out = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.empty(M, N, device=dev)
+planes = hip.Planes(b) if os.environ.get("X3_TRACE_WP") == "1" else None  # (the B-planes kernel: wave 7 = the DMA wave)
+run = (lambda: hip.gemm(a, 0, b, 0, out, M, N, K, cfg=cfg, b_planes=(planes.img[0], planes.stride))) if planes is not None else \
+      (lambda: hip.gemm(a, 0, b, 0, out, M, N, K, compute="fp32x3", cfg=cfg))
 for _ in range(3):
-    hip.gemm(a, 0, b, 0, out, M, N, K, compute="fp32x3", cfg=cfg)
+    run()
 buf = torch.zeros(8 * 64 * 4 + 17, dtype=torch.int64, device=dev)
 hip.lib().mtvaf_f32x3_trace(hip._p(buf))
-hip.gemm(a, 0, b, 0, out, M, N, K, compute="fp32x3", cfg=cfg)
+run()
 torch.cuda.synchronize()
 hip.lib().mtvaf_f32x3_trace(None)
 t = buf.cpu()
