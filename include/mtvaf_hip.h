@@ -282,29 +282,6 @@ int mtvaf_gemm_f32x3(int layout_a, int layout_b, const float* A, int lda, const 
                      int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
                      mtvaf_stream_t stream);
 int mtvaf_f32_split(int on);
-/* Weights split ONCE: mtvaf_f32_split_planes writes the three bf16 planes of an fp32 tensor (dst[i + q * stride] = plane q of
- * src[i], the split the GEMM applies to fp32 tiles; n % 4 == 0, stride % 8 == 0, stride >= n); mtvaf_gemm_f32_wp is
- * mtvaf_gemm_f32 with the B operand's plane image beside it: in the split mode the 128x128 products of a row-major A take
- * their B tiles from the planes by LDS-DMA instead of splitting them again in every block -- bit-identical results (the
- * forward and dX products of modeling_bert.py:266, 283-284, 353, 420-421, 433, whose B is a weight).  mtvaf_f32_wplanes(0 / 1)
- * ignores / uses the images (default 1; MTVAF_F32_WPLANES=0); -1 queries. */
-int mtvaf_f32_split_planes(const float* src, void* dst, long n, long stride, mtvaf_stream_t stream);
-int mtvaf_gemm_f32_wp(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, const void* Bplanes,
-                      long plane_stride, float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
-                      int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
-                      mtvaf_stream_t stream);
-int mtvaf_f32_wplanes(int on);
-/* BOTH operands as plane images (csrc/gemm_f32p.hip): no operand is split inside the k-loop -- plane tiles travel L2 -> LDS by
- * LDS-DMA and the waves only read fragments and multiply.  Aplanes[i + q * a_stride] / Bplanes[i + q * b_stride] = plane q of
- * the fp32 operands in their own row-major layouts; C fp32 and / or Cplanes (the result's plane image, ldcp / c_stride: the
- * operand of the next product is born split); layouts KC x KC, KC x KM, KM x KM (+ klist / kcnt as mtvaf_gemm_f32_ktiles).
- * M % 128 == 0, N % 128 == 0 or N % 96 == 0, K % 32 == 0, ld / strides % 8 == 0: MTVAF_ERR_SHAPE / _ALIGN otherwise (no
- * fallback inside).  tile_n: 128 / 96 / -1 (planned).  Bit-identical to mtvaf_gemm_f32x3 on the fp32 operands.  Replaces
- * modeling_bert.py:266, 283-284, 353, 420-421, 433 and their autograd backward, as mtvaf_gemm_f32. */
-int mtvaf_gemm_f32p(int layout_a, int layout_b, const void* Aplanes, int lda, long a_stride, const void* Bplanes, int ldb,
-                    long b_stride, float* C, int ldc, void* Cplanes, int ldcp, long c_stride, int M, int N, int K, const float* bias,
-                    int epi, float* aux, int ldaux, int accumulate, int allow_split, void* workspace, size_t workspace_bytes,
-                    int tile_n, int splits, const int* klist, const int* kcnt, mtvaf_stream_t stream);
 /* profiling hook (tools/x3_trace.py): block 0 of every following wave-specialised split launch stores per wave and k-tile the
  * shader clock around the tile barrier into buf ([8 waves][64 k-tiles][4] + 17 int64 on the device); NULL switches it off */
 int mtvaf_f32x3_trace(void* buf);

@@ -705,9 +705,6 @@ static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, int mode, hi
 
 int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, bool aligned, hipStream_t st);  // gemm_bf16.hip
 int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st);                // gemm_f32x3.hip
-int launch_gemm_f32x3_wp(int tile, const GemmArgs& a, int lb, dim3 grid, hipStream_t st);                    // gemm_f32x3.hip
-int launch_split_planes(const float* src, void* dst, long n, long stride, hipStream_t st);                   // gemm_f32x3.hip
-int launch_gemm_f32p(int bn, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st);                  // gemm_f32p.hip
 
 // ordered split-K slab reduction (+ bias / tanh / dtanh epilogue), shared with gemm_bf16kc.hip
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
@@ -798,7 +795,10 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       // (fewer operand bytes per flop), the 64x64 every-wave kernel well behind both
       const double e = compute == 2 ? (c == 5 ? 0.70 : (c == 6 ? 0.68 : 0.45)) : ((c >= 16 && tiles * s <= 256) ? 1.0 : eff[c]);
       double cost = (double)rounds * bm * bn * kc / 128.0 / (e * occ2);
-      cost += 3000.0;  // fill/drain + launch
+      // fill/drain + launch.  Split kernels: one block per CU, nothing overlaps a tile's prologue + epilogue (traced:
+      // 3.7 + 2.5 us per tile, tools/x3_trace.py) -- charged per ROUND, which is what decides between e.g. 144 tiles x 3
+      // splits (two rounds of 1376-deep reductions: 131-139 us measured for the FFN weight gradients) and x 5 (three rounds)
+      cost += compute == 2 ? 28000.0 * rounds : 3000.0;
       if (s > 1) {
         // slabs: s*M*N floats written then read once (plus the final write) at ~4 TB/s ~ 1.7 KB/clk chip-wide
         cost += ((double)s * 2.0 + 1.0) * M * N * 4.0 / 1700.0 + 8000.0;
@@ -840,17 +840,17 @@ int mtvaf_prof_stop(int* n_out, int* keys, float* ms, int max_records) {
   if (!g_prof || !n_out) return MTVAF_ERR_ARG;
   const int n = g_prof_n < max_records ? g_prof_n : max_records;
   for (int i = 0; i < n; ++i) {
-    hipEventSynchronize(g_prof[i].e1);
+    (void)hipEventSynchronize(g_prof[i].e1);
     float t = 0.f;
-    hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1);
+    (void)hipEventElapsedTime(&t, g_prof[i].e0, g_prof[i].e1);
     if (ms) ms[i] = t;
     if (keys)
       for (int j = 0; j < 8; ++j) keys[i * 8 + j] = g_prof[i].key[j];
   }
   *n_out = n;
   for (int i = 0; i < g_prof_cap; ++i) {
-    hipEventDestroy(g_prof[i].e0);
-    hipEventDestroy(g_prof[i].e1);
+    (void)hipEventDestroy(g_prof[i].e0);
+    (void)hipEventDestroy(g_prof[i].e1);
   }
   delete[] g_prof;
   g_prof = nullptr;
@@ -876,14 +876,10 @@ int mtvaf_gemm_f32_plan(int layout_a, int layout_b, int M, int N, int K, int epi
 static long long* g_x3_trace = nullptr;
 static int g_x3_tile_walk = [] { const char* e = getenv("MTVAF_X3_TILE_WALK"); return e ? atoi(e) : 0; }();
 
-// weight-plane images (mtvaf_gemm_f32_wp) are used / ignored: MTVAF_F32_WPLANES=0 or mtvaf_f32_wplanes(0) switches them off
-static int g_f32_wplanes = [] { const char* e = getenv("MTVAF_F32_WPLANES"); return (e && atoi(e) == 0) ? 0 : 1; }();
-
 static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
                          int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
-                         hipStream_t stream, const int* klist = nullptr, const int* kcnt = nullptr, const void* Bplanes = nullptr,
-                         long plane_stride = 0) {
+                         hipStream_t stream, const int* klist = nullptr, const int* kcnt = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_SHAPE;
   if (compute == 1) {
     // the bf16 kernels need k-aligned, vector-loadable operands; anything else runs the fp32 kernels
@@ -901,7 +897,11 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     // kernel: the fp32 pipe's 64x64 tiles are faster there, measured 4.37 vs 4.53 ms per C1 step)
     const bool forced = cfg == 5 || cfg == 6 || cfg == 3;
     const long tiles96 = (M % 128 == 0 && N % 96 == 0) ? (long)(M / 128) * (N / 96) : 0;
-    if (!ok || (!forced && std::max((long)(M / 128) * (N / 128), tiles96) < 96)) compute = 0;
+    const long tiles = std::max((long)(M / 128) * (N / 128), tiles96);
+    // ... unless the reduction is deep enough for split-K to fill the chip anyway (the [768 x 768] weight gradient over 4096
+    // token rows: 36 tiles x 7 splits, 38-41 us against 46-51 on the fp32 pipe)
+    const bool deep = allow_split && splittable(epi) && K >= 2048 && tiles * std::min(16, K / 256) >= 192;
+    if (!ok || (!forced && tiles < 96 && !deep)) compute = 0;
     if (compute == 2 && !((cfg == 5 && M % 128 == 0 && N % 128 == 0) || (cfg == 6 && M % 128 == 0 && N % 96 == 0) ||
                           (cfg == 3 && N % 64 == 0))) cfg = -1;
   }
@@ -920,8 +920,6 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   }
   GemmArgs a;
   a.klist = nullptr; a.kcnt = nullptr; a.ngrp = 0;
-  a.Bp = nullptr; a.bp_stride = 0;
-  a.Ap = nullptr; a.ap_stride = 0; a.Cp = nullptr; a.cp_stride = 0; a.ldcp = 0;
   a.trace = g_x3_trace;
   a.tile_walk = g_x3_tile_walk;
   a.A = A; a.B = B; a.bias = bias; a.aux = aux;
@@ -966,22 +964,12 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     // (key[3]: alignment mode 0..2, +8 when the launch walks a k-tile list: its flops are 2 M N 32 (*kcnt), not 2 M N K)
     const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + (((cfg == 5 || cfg == 6) && a.wide) ? 20 : 0) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
-    hipEventRecord(pr->e0, stream);
+    (void)hipEventRecord(pr->e0, stream);
   }
   int rc;
   if (compute == 1) {
     rc = launch_gemm_bf16(cfg == 6 ? 0 : (cfg == 5 ? 1 : 2), a, layout_a, layout_b, grid, aligned, stream);
   } else if (compute == 2) {
-    // B from a plane image split once (weights): 128x128 whole tiles, A row-major, DMA-able planes; anything else splits B
-    // in-kernel from fp32 -- the same planes, the same MFMA sequence: bit-identical results either way
-    const bool planes = Bplanes && cfg == 5 && a.wide && layout_a == 0 && (ldb % 8 == 0) && (plane_stride % 8 == 0) &&
-                        (((uintptr_t)Bplanes & 15) == 0) && g_f32_wplanes != 0;
-    if (planes) {
-      a.Bp = Bplanes;
-      a.bp_stride = plane_stride;
-      if (pr) pr->key[0] += 2000;  // (profiler key 2225: gemm_f32x3_wp_kernel)
-      rc = launch_gemm_f32x3_wp(4, a, layout_b, grid, stream);
-    } else
     // 128x128 / 128x96: the wave-specialised kernel; without the wide epilogue's alignment the every-wave-does-everything form
     rc = launch_gemm_f32x3(cfg == 5 ? (a.wide ? 4 : 1) : (cfg == 6 ? (a.wide ? 5 : 3) : 2), a, layout_a, layout_b, grid, stream);
   } else
@@ -1005,7 +993,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     case 7: rc = launch_cfg<128, 192, 2, 2, 16>(a, layout_a, layout_b, grid, mode, stream); break;
     default: rc = launch_cfg<128, 192, 2, 2, 32>(a, layout_a, layout_b, grid, mode, stream); break;
   }
-  if (pr) hipEventRecord(pr->e1, stream);
+  if (pr) (void)hipEventRecord(pr->e1, stream);
   if (rc != MTVAF_OK) return rc;
   if (splits > 1)
     return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
@@ -1023,11 +1011,6 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
 int mtvaf_f32x3_trace(void* buf) {
   g_x3_trace = static_cast<long long*>(buf);
   return MTVAF_OK;
-}
-
-int mtvaf_f32_wplanes(int on) {
-  if (on >= 0) g_f32_wplanes = on ? 1 : 0;
-  return g_f32_wplanes;
 }
 
 static int g_f32_split = -1;
@@ -1054,91 +1037,6 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
                    hipStream_t stream) {
   return gemm_dispatch(mtvaf_f32_split(-1) ? 2 : 0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
                        allow_split, workspace, workspace_bytes, cfg, splits, stream);
-}
-
-// mtvaf_gemm_f32 whose B operand (a WEIGHT: unchanged between optimizer steps) also exists as the three bf16 planes of its
-// split, written once by mtvaf_f32_split_planes: Bplanes[i + q * plane_stride] = plane q of B[i] (same offsets / ldb as B).  In
-// the split mode the 128x128 products take their B tiles from the planes by LDS-DMA instead of splitting them again in every
-// block (csrc/gemm_f32x3.hip: gemm_f32x3_wp_kernel); results are bit-identical to mtvaf_gemm_f32 on B.  Bplanes == NULL, the
-// fp32 pipe (mtvaf_f32_split(0)), other tiles / layouts: exactly mtvaf_gemm_f32.
-int mtvaf_gemm_f32_wp(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, const void* Bplanes,
-                      long plane_stride, float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
-                      int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
-                      hipStream_t stream) {
-  return gemm_dispatch(mtvaf_f32_split(-1) ? 2 : 0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
-                       allow_split, workspace, workspace_bytes, cfg, splits, stream, nullptr, nullptr, Bplanes, plane_stride);
-}
-
-// dst[i + q * stride] = bf16 plane q (q = 0, 1, 2) of src[i]: x = x1 + x2 + x3 with RNE at every level, exactly the split the
-// GEMM producers apply to fp32 tiles.  n % 4 == 0, stride % 8 == 0, 16-byte aligned pointers.  HBM-bound: 10 bytes per element.
-int mtvaf_f32_split_planes(const float* src, void* dst, long n, long stride, hipStream_t stream) {
-  if (!src || !dst || n <= 0 || (n & 3) || (stride & 7) || stride < n) return MTVAF_ERR_ARG;
-  if (((uintptr_t)src | (uintptr_t)dst) & 15) return MTVAF_ERR_ALIGN;
-  return launch_split_planes(src, dst, n, stride, stream);
-}
-
-// Both operands as plane images (gemm_f32p.hip): C[M,N] (fp32, and / or its own plane image Cplanes) = opA . opB with
-// Aplanes[i + q * a_stride] / Bplanes[i + q * b_stride] = bf16 plane q of the fp32 operands (mtvaf_f32_split_planes, or a
-// producing kernel's plane output), in the operands' own row-major layouts (lda / ldb in elements).  Layouts KC x KC, KC x KM,
-// KM x KM (+ k-tile list).  M % 128 == 0, N % 128 == 0 or N % 96 == 0, K % 32 == 0, leading dimensions and strides % 8 == 0,
-// 16-byte aligned pointers: MTVAF_ERR_SHAPE / _ALIGN otherwise (no fallback inside: the caller keeps the fp32-operand entry
-// points for everything else).  Bit-identical to mtvaf_gemm_f32x3 on the fp32 operands the planes were split from (same tile
-// and split plan).  C may be NULL when Cplanes is given (the result exists as planes only; not with split-K).
-int mtvaf_gemm_f32p(int layout_a, int layout_b, const void* Aplanes, int lda, long a_stride, const void* Bplanes, int ldb,
-                    long b_stride, float* C, int ldc, void* Cplanes, int ldcp, long c_stride, int M, int N, int K, const float* bias,
-                    int epi, float* aux, int ldaux, int accumulate, int allow_split, void* workspace, size_t workspace_bytes,
-                    int tile_n, int splits, const int* klist, const int* kcnt, hipStream_t stream) {
-  if (M <= 0 || N <= 0 || K <= 0 || !Aplanes || !Bplanes || (!C && !Cplanes)) return MTVAF_ERR_ARG;
-  if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1 || (layout_a == 1 && layout_b == 0)) return MTVAF_ERR_ARG;
-  if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
-  if (M % 128 || K % 32 || (N % 128 && N % 96)) return MTVAF_ERR_SHAPE;
-  if ((lda % 8) || (ldb % 8) || (a_stride % 8) || (b_stride % 8) || (C && ldc % 4) || (Cplanes && ((ldcp % 4) || (c_stride % 4))) ||
-      (aux && ldaux % 4))
-    return MTVAF_ERR_ALIGN;
-  if ((((uintptr_t)Aplanes | (uintptr_t)Bplanes | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15) || ((uintptr_t)Cplanes & 7))
-    return MTVAF_ERR_ALIGN;
-  if (accumulate && !C) return MTVAF_ERR_ARG;
-  const bool can_split = allow_split && splittable(epi) && !Cplanes && C;
-  int cfg, s_auto;
-  choose(M, N, K, can_split, layout_a, layout_b, epi, &cfg, &s_auto, 2);
-  if (tile_n == 128 && N % 128 == 0) cfg = 5;
-  else if (tile_n == 96 && N % 96 == 0) cfg = 6;
-  if (cfg != 5 && cfg != 6) cfg = (N % 128 == 0) ? 5 : 6;  // (the planner's 64 x 64 tile does not exist here)
-  if (splits <= 0) splits = s_auto;
-  if (!can_split) splits = 1;
-  if (splits > 1 && (size_t)splits * M * N * sizeof(float) > workspace_bytes) {
-    splits = (int)(workspace_bytes / ((size_t)M * N * sizeof(float)));
-    if (splits < 1) splits = 1;
-  }
-  GemmArgs a = {};
-  a.Ap = Aplanes; a.ap_stride = a_stride; a.Bp = Bplanes; a.bp_stride = b_stride;
-  a.tile_walk = g_x3_tile_walk;
-  a.bias = bias; a.aux = aux; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldaux = ldaux;
-  a.epi = epi; a.accumulate = accumulate; a.a_vec = a.b_vec = 1;
-  int kc = (int)cdiv(cdiv(K, splits), 32) * 32;
-  splits = (int)cdiv(K, kc);
-  a.k_chunk = kc;
-  if (splits > 1) {
-    a.C = (float*)workspace; a.ldc = N; a.slab_stride = (long)M * N;
-    if ((uintptr_t)workspace & 15) return MTVAF_ERR_ALIGN;
-  } else {
-    a.C = C; a.ldc = ldc; a.slab_stride = 0;
-    a.Cp = Cplanes; a.cp_stride = c_stride; a.ldcp = ldcp;
-  }
-  const int bn = cfg == 5 ? 128 : 96;
-  a.tiles_n = N / bn;
-  a.wide = 1;
-  if (klist && kcnt && layout_a == 1 && layout_b == 1) { a.klist = klist; a.kcnt = kcnt; }
-  dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
-  // (profiler key 3000 + tile cfg: gemm_f32p_kernel; fast bit 8 = the launch walks a k-tile list)
-  const int key[8] = {3000 + cfg, layout_a, layout_b, 2 + (a.klist ? 8 : 0), M, N, K, splits};
-  const int rec = prof_begin(key, stream);
-  const int rc = launch_gemm_f32p(bn, a, layout_a, layout_b, grid, stream);
-  prof_end(rec, stream);
-  if (rc != MTVAF_OK) return rc;
-  if (splits > 1)
-    return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
-  return MTVAF_OK;
 }
 
 // mtvaf_gemm_f32 for a weight-gradient product (layouts KM x KM: C[M,N] = A[K,M]^T . B[K,N], the reduction index is the

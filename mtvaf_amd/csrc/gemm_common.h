@@ -40,16 +40,6 @@ struct GemmArgs {
   int ngrp;
   int grp_tile_begin[4];
   GemmProb grp[4];
-  // split-fp32 kernels: the B operand's three bf16 planes, split once (mtvaf_f32_split_planes: plane q of element i at
-  // Bp[i + q * bp_stride]; same offsets / leading dimension as B), or NULL (B is split in-kernel from fp32)
-  const void* Bp;
-  long bp_stride;
-  // gemm_f32p.hip: A as a plane image too, and (optionally) the RESULT's plane image written by the epilogue
-  const void* Ap;
-  long ap_stride;
-  void* Cp;
-  long cp_stride;
-  int ldcp;
   // profiling hook of the wave-specialised split kernel (mtvaf_f32x3_trace): block 0 stores, per wave and k-tile, the shader
   // clock where it arrives at / leaves the tile barrier -- [8 waves][64 k-tiles][4] int64 -- or NULL (no cost but the test)
   long long* trace;

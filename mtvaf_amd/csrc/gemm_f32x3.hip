@@ -14,12 +14,11 @@
 // buffer of 3 planes x (BM + BN) rows x 80 B (conflict-free ds_read_b128 fragments, as gemm_bf16.hip), the next k-tile
 // prefetched into registers during the MFMA phase, two blocks per CU -- the first form built (headline 18.55 -> 16.15 ms),
 // kept for the 64 x 64 tile and for results without the wide epilogue's alignment.
-#include <type_traits>
-
-#include "gemm_bf16x.h"  // (gemm_common.h + the LDS-DMA / transposing-read helpers of the bf16-operand kernels)
+#include "gemm_common.h"
 
 namespace mtvaf {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 // MFMA operand fragments travel as four dwords: a loop-carried / conditional value of type <8 x bf16> is legalised piece by
 // piece (48 v_perm_b32 + 48 v_lshrrev_b32 per k-tile in the consumer loop, found in round 4), a <4 x i32> is not
@@ -590,316 +589,6 @@ static int launch_x3_ws(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_
   return MTVAF_OK;
 }
 
-
-// ---- weights split ONCE (round 4) --------------------------------------------------------------------------------------
-// The wave-specialised kernel above is bound by its producers (measured: a 128 x 96 tile, 3/4 of the matrix work per k-tile,
-// takes 0.92 of the 128 x 128 tile's time; ~200 vector instructions per producer wave and k-tile for the two operand tiles
-// beside 36-48 MFMAs per consumer wave).  Half of that work splits WEIGHT tiles -- the same 128 x 32 values again in every
-// one of the 32 row tiles of a 4096-token product, in the forward and in the dX product, although a weight changes once per
-// optimizer step.  mtvaf_f32_split_planes writes the three bf16 planes of an fp32 tensor once ([3][n] bf16, the planes of
-// element i at i, i + stride, i + 2 stride: the same RNE split as split3 above, so the planes equal what the producers would
-// form); gemm_f32x3_wp_kernel takes its B operand from such an image: the producers copy plane tiles global -> registers -> LDS
-// in 16-byte pieces (no vector work; as LDS-DMA the requests measured slower, see the kernel); A (activations / gradients:
-// fp32, new in every call) is split in-kernel as before.  Bytes from L2 per k-tile: 16 KiB (A, fp32) + 24 KiB (B
-// planes) = 40 KiB against 32 KiB.  Same MFMA sequence and k order as the kernel above: results are bit-identical to it.
-//
-// B images (lane-linear LDS-DMA, so both swizzles sit on the per-lane SOURCE address and again on the read):
-//   KC (forward: W[n][k]): per plane BN rows x 64 B (32 k), unpadded; 16-byte chunk c of row r at c ^ ((r >> 2) & 3):
-//      conflict-free for the ds_read_b128 fragments of v_mfma_f32_32x32x16_bf16 (lane -> row l & 31, chunk 2 ks + (l >> 5)).
-//   KM (dX: W[n][k] with the reduction index n as the ROW): per plane 32 rows x 256 B (128 output columns), chunk c of row r at
-//      c ^ km_swz(r), fragments by two ds_read_b64_tr_b16 (gemm_bf16x.hip's image, 32 rows deep).
-__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n4,
-                                                           long stride) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
-    bf16x4 h, m, l;
-    x3::split3(v, h, m, l);
-    *reinterpret_cast<bf16x4*>(dst + 4 * i) = h;
-    *reinterpret_cast<bf16x4*>(dst + stride + 4 * i) = m;
-    *reinterpret_cast<bf16x4*>(dst + 2 * stride + 4 * i) = l;
-  }
-}
-
-template <bool B_KM, int BN>
-__global__ __launch_bounds__(768, 1) void gemm_f32x3_wp_kernel(GemmArgs p) {
-  using namespace x3;
-  static_assert(BN == 128, "plane images exist for 128-column tiles");
-  constexpr int BM = 128, BK = 32, LDH = BK + 8, NP = 256, NT = 768;
-  constexpr int WN = 2, TM = 2, TN = 2;
-  constexpr int A_SZ = BM * LDH;             // bf16 elements of one A plane
-  constexpr int A_BUF = 3 * A_SZ;            // elements of one A buffer (three planes)
-  constexpr int BP_B = BN * 64;              // bytes of one B plane tile (KC: BN rows x 64 B; KM: 32 rows x 2 BN B)
-  constexpr int BST_B = 3 * BP_B;            // bytes of one B stage
-  constexpr int NBS = 3;                     // B stages: a tile has two k-steps to land
-  constexpr int PPP = BP_B / 1024;           // 1-KiB DMA pieces per plane tile
-  constexpr int IB = 3 * PPP / 4;            // pieces per DMA wave and stage: 6
-  static_assert((3 * PPP) % 4 == 0, "whole DMA pieces per DMA wave");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  __bf16* sA = reinterpret_cast<__bf16*>(smem_raw);                  // [2][3][A_SZ]
-  unsigned char* sB = smem_raw + 2 * A_BUF * sizeof(__bf16);         // [NBS][3][BP_B]
-
-  // twelve waves, three per SIMD: 0-3 consumers (fragment reads + MFMAs), 4-7 A producers (fp32 tile -> registers -> three
-  // planes -> LDS), 8-11 DMA waves (B plane tiles L2 -> LDS, nothing else).  Why separate DMA waves: a global_load_lds request
-  // costs the issuing wave 80-95 cycles beside the matrix stream and a wave issues in order (with the requests in the consumers
-  // a k-tile took +460 cycles); and a wave that also issues ds_write is made to wait vmcnt(0) in front of every store -- the
-  // compiler orders LDS stores behind pending LDS-DMA of the same wave, __restrict__ regions or not -- so not the producers.
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool consumer = wave < 4;
-  const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
-  const int li = lane & 31, h = lane >> 5;
-  const int bid = p.tile_walk > 0 ? xcd_remap_cols(blockIdx.x, gridDim.x, p.tiles_n, p.tile_walk) : xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / p.tiles_n) * BM;
-  const int n0 = (bid % p.tiles_n) * BN;
-  const int kbeg = blockIdx.z * p.k_chunk;
-  const int kend = min(p.K, kbeg + p.k_chunk);
-  const int nk = (kend - kbeg) / BK;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  long long* const tr = (p.trace && blockIdx.x == 0 && blockIdx.z == 0 && wave < 8) ? p.trace : nullptr;  // (wave-uniform)
-  if (tr && tid == 0) tr[8 * 64 * 4] = __builtin_amdgcn_s_memtime();
-  if (nk > 0) {  // (block-uniform: an empty k-chunk writes a zero slab)
-  if (consumer) {
-    int offB[TN][2];
-    {
-      const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (!B_KM) {
-          const int row = (wn * TN + j) * 32 + li;
-          offB[j][0] = row * 64;
-          offB[j][1] = (row >> 2) & 3;
-        } else {
-          const int ns = wn * TN + j;
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
-            offB[j][jj] = 256 * (8 * (g >> 1) + 4 * jj + q) +
-                          16 * ((((ns ^ q) & 3) << 2) | ((2 * (g & 1) + (pp >> 1)) ^ ((2 * (g >> 1) + jj) & 3))) + 8 * (pp & 1);
-        }
-      }
-    }
-    frag_t fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
-    auto rd = [&](int abuf, int bst, int ks, frag_t (&fa)[3][TM], frag_t (&fb)[3][TN]) __attribute__((always_inline)) {
-      const __bf16* a = sA + abuf * A_BUF;
-      const unsigned char* b = sB + bst * BST_B;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          fa[q][i] = *reinterpret_cast<const frag_t*>(a + q * A_SZ + ((wm * TM + i) * 32 + li) * LDH + 16 * ks + 8 * h);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (!B_KM) fb[q][j] = *reinterpret_cast<const frag_t*>(b + q * BP_B + offB[j][0] + (((2 * ks + h) ^ offB[j][1]) << 4));
-          else fb[q][j] = __builtin_bit_cast(frag_t, tr_read8(b + q * BP_B + offB[j][0] + 4096 * ks, b + q * BP_B + offB[j][1] + 4096 * ks));
-        }
-      }
-    };
-    auto mm = [&](const frag_t (&fa)[3][TM], const frag_t (&fb)[3][TN]) __attribute__((always_inline)) {
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first (as the kernel above)
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MTVAF_FRAG(fa[PA[t]][i]), MTVAF_FRAG(fb[PB[t]][j]), acc[i][j], 0, 0, 0);
-    };
-    __builtin_amdgcn_s_setprio(2);
-    __builtin_amdgcn_s_barrier();  // k-tile 0: A planes in buffer 0 (producers), B planes in stage 0 (DMA waves)
-    asm volatile("" ::: "memory");
-    rd(0, 0, 0, fa0, fb0);
-    int st = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-      rd(kt & 1, st, 1, fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this tile's last fragments are in registers: its buffers may be refilled
-      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 2] = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();  // tile kt + 1 is complete (the producers and the DMA waves waited for their parts of it)
-      asm volatile("" ::: "memory");
-      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 3] = __builtin_amdgcn_s_memtime();
-      st = st == NBS - 1 ? 0 : st + 1;
-      rd((kt + 1) & 1, st, 0, fa0, fb0);  // (past the end: a harmless re-read)
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa1, fb1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else if (wave >= 8) {
-    // ---- DMA waves: this wave's IB pieces of every B stage ----
-    const int dw = wave - 8;
-    const __bf16* Bp = reinterpret_cast<const __bf16*>(p.Bp);
-    const unsigned char* pb[IB];
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-      const int I = dw * IB + i, plane = I / PPP, slot = (I % PPP) * 64 + lane;
-      if constexpr (!B_KM) {
-        const int row = slot >> 2, cp = slot & 3;
-        pb[i] = reinterpret_cast<const unsigned char*>(Bp + plane * p.bp_stride + (long)(n0 + row) * p.ldb + kbeg) + ((cp ^ ((row >> 2) & 3)) << 4);
-      } else {
-        const int row = slot >> 4, cp = slot & 15;
-        pb[i] = reinterpret_cast<const unsigned char*>(Bp + plane * p.bp_stride + (long)(kbeg + row) * p.ldb + n0) + ((cp ^ km_swz(row)) << 4);
-      }
-    }
-    const long stepB = B_KM ? (long)BK * p.ldb * 2 : (long)BK * 2;
-    auto issueB = [&](int stage) __attribute__((always_inline)) {
-      unsigned char* dst = sB + stage * BST_B + dw * IB * 1024;
-#pragma unroll
-      for (int i = 0; i < IB; ++i) {
-        glds16x(pb[i], dst + i * 1024);
-        pb[i] += stepB;
-      }
-    };
-    issueB(0);
-    if (nk > 1) issueB(1);
-    if (nk > 1) wait_vm<IB>();  // tile 0 landed; tile 1 may still be on its way
-    else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int st2 = 2;  // stage of tile kt + 2
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 2 < nk) issueB(st2);  // into the stage tile kt - 1 left (everybody passed the barrier that ended step kt - 1)
-      st2 = st2 == NBS - 1 ? 0 : st2 + 1;
-      if (kt + 2 < nk) wait_vm<IB>();  // tile kt + 1 (requested one step ago) has landed; tile kt + 2 stays in flight
-      else wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-    }
-  } else {
-    // ---- A producers: the fp32 A tile only (half the staging work of the kernel above: B never passes through registers)
-    const int ptid = tid - 256;
-    constexpr int UA = Stage<BM, NP, false, BK>::NKC;
-    f32x4 ra0[UA], ra1[UA];
-    auto gloadA = [&](int kt, f32x4* ra) __attribute__((always_inline)) { g_load<BM, NP, false, BK>(ra, p.A, p.lda, m0, kbeg + kt * BK, ptid); };
-    auto stageA = [&](int buf, const f32x4* ra) __attribute__((always_inline)) {
-#pragma unroll
-      for (int u = 0; u < UA; ++u) {
-        unsigned w[6];
-        convert_unit<false>(ra, u, w);
-        put_unit<NP, false, A_SZ, BK, BM>(w, u, sA + buf * A_BUF, ptid);
-      }
-    };
-    auto pstep = [&](int kt, f32x4* ra) __attribute__((always_inline)) {
-      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 0] = __builtin_amdgcn_s_memtime();
-      stageA((kt + 1) & 1, ra);  // (past the end: a harmless copy of the last tile into the idle buffer)
-      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 1] = __builtin_amdgcn_s_memtime();
-      gloadA(min(kt + 3, nk - 1), ra);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the plane stores are in the LDS
-      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 2] = __builtin_amdgcn_s_memtime();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 3] = __builtin_amdgcn_s_memtime();
-    };
-    gloadA(0, ra0);
-    gloadA(min(1, nk - 1), ra1);
-    stageA(0, ra0);
-    gloadA(min(2, nk - 1), ra0);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {  // tile kt+1 sits in set 1, tile kt+2 in set 0
-      pstep(kt, ra1);
-      pstep(kt + 1, ra0);
-    }
-    if (kt < nk) pstep(kt, ra1);
-  }
-  }  // nk > 0
-
-  if (tr && lane == 0) tr[8 * 64 * 4 + 1 + wave] = __builtin_amdgcn_s_memtime();
-  // wide epilogue: as gemm_f32x3_ws_kernel (the image overlays the A buffers only; every DMA piece has landed: the DMA waves'
-  // last wait was vmcnt(0))
-  {
-    constexpr int LDE = BN + 4, RP = 64, C4 = BN / 4;
-    static_assert((size_t)RP * LDE * sizeof(float) <= (size_t)2 * A_BUF * sizeof(__bf16), "the epilogue image must not reach the B ring");
-    float* smem = reinterpret_cast<float*>(smem_raw);
-    float* C = p.C + (long)blockIdx.z * p.slab_stride;
-    const bool split = gridDim.z > 1;
-    const int wrow = wm * TM * 32;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      __syncthreads();
-      if (consumer && wrow / RP == pass) {
-        const int rofs = wrow % RP;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              smem[(rofs + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
-      }
-      __syncthreads();
-#pragma unroll 2
-      for (int idx = tid; idx < RP * C4; idx += NT) {
-        const int r = idx / C4, c = (idx % C4) * 4;
-        f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
-        const long row = m0 + pass * RP + r;
-        const int col = n0 + c;
-        if (!split) {
-          if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-          if (p.epi == EPI_GELU) {
-            *reinterpret_cast<f32x4*>(p.aux + row * p.ldaux + col) = v;
-            v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
-          } else if (p.epi == EPI_TANH) {
-            v = f32x4{tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w)};
-          } else if (p.epi == EPI_DGELU) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
-            v = f32x4{v.x * gelu_erf_grad(a.x), v.y * gelu_erf_grad(a.y), v.z * gelu_erf_grad(a.z), v.w * gelu_erf_grad(a.w)};
-          } else if (p.epi == EPI_DTANH) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
-            v = v * (1.f - t * t);
-          }
-          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * p.ldc + col);
-        }
-        *reinterpret_cast<f32x4*>(C + row * p.ldc + col) = v;
-      }
-    }
-  }
-}
-
-template <int BN>
-static int launch_x3_wp(const GemmArgs& a, int lb, dim3 grid, hipStream_t st) {
-  if (!a.wide || !a.Bp) return MTVAF_ERR_ALIGN;
-  const size_t smem = (size_t)2 * 3 * 128 * 40 * sizeof(__bf16) + (size_t)3 * 3 * BN * 64;  // 61440 + 73728
-#define MTVAF_X3_WP(BKM)                                                                                             \
-  do {                                                                                                               \
-    auto kern = gemm_f32x3_wp_kernel<BKM, BN>;                                                                       \
-    static bool attr_set = false;                                                                                    \
-    if (!attr_set) {                                                                                                 \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
-      if (e != hipSuccess) return (int)e;                                                                            \
-      attr_set = true;                                                                                               \
-    }                                                                                                                \
-    hipLaunchKernelGGL(kern, grid, dim3(768), smem, st, a);                                                          \
-  } while (0)
-  if (lb == 0) MTVAF_X3_WP(false);
-  else MTVAF_X3_WP(true);
-#undef MTVAF_X3_WP
-  MTVAF_LAUNCH_CHECK();
-  return MTVAF_OK;
-}
-
-// B from a plane image (a.Bp / a.bp_stride), A fp32 KC; tile 4 = 128 x 128.  Called by gemm.hip's dispatcher.
-int launch_gemm_f32x3_wp(int tile, const GemmArgs& a, int lb, dim3 grid, hipStream_t st) {
-  if (tile != 4) return MTVAF_ERR_ARG;
-  return launch_x3_wp<128>(a, lb, grid, st);
-}
-
-int launch_split_planes(const float* src, void* dst, long n, long stride, hipStream_t st) {
-  const long n4 = n / 4;
-  const int blocks = (int)std::min<long>((n4 + 255) / 256, 4096);
-  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, st, src, static_cast<__bf16*>(dst), n4, stride);
-  MTVAF_LAUNCH_CHECK();
-  return MTVAF_OK;
-}
 
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_x3_tile(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {

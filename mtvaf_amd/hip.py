@@ -34,12 +34,7 @@ _SIGS = {
     "mtvaf_gemm_f32": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_gemm_f32x3": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_f32_split": (c_int, [I]),
-    "mtvaf_f32_wplanes": (c_int, [I]),
     "mtvaf_f32x3_trace": (c_int, [P]),
-    "mtvaf_gemm_f32p": (c_int, [I, I, P, I, ctypes.c_long, P, I, ctypes.c_long, P, I, P, I, ctypes.c_long, I, I, I, P, I, P, I, I, I, P, SZ,
-                                I, I, P, P, P]),
-    "mtvaf_f32_split_planes": (c_int, [P, P, ctypes.c_long, ctypes.c_long, P]),
-    "mtvaf_gemm_f32_wp": (c_int, [I, I, P, I, P, I, P, ctypes.c_long, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -237,10 +232,6 @@ def kernel_symbol(cfg, la, lb, fast):
             16: (64, 64, 2, 2), 17: (64, 64, 2, 2)}.get(cfg)
     b = lambda x: "true" if x else "false"
     klist, fast = bool(fast & 8), fast & 7  # (+8: the launch walked a k-tile list)
-    if cfg >= 3000:  # both operands as plane images (csrc/gemm_f32p.hip)
-        return f"gemm_f32p_kernel<{b(la)}, {b(lb)}, {b(klist)}, {128 if cfg == 3005 else 96}>"
-    if cfg >= 2000:  # split-fp32 kernel with the B operand from a plane image split once (mtvaf_gemm_f32_wp)
-        return f"gemm_f32x3_wp_kernel<{b(lb)}, 128>"
     if cfg >= 1000:  # the grouped weight-gradient launch of the fp32 LDS-DMA kernel (mtvaf_gemm_f32_dw_group)
         return f"gemm_f32_dma_group_kernel<128, 96, 4, 1, 2, {b(klist)}>"
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>
@@ -290,55 +281,6 @@ def f32_split(on=None) -> bool:
     return bool(lib().mtvaf_f32_split(-1 if on is None else int(bool(on))))
 
 
-def f32_wplanes(on=None) -> bool:
-    """Split mode: products whose B operand comes with a plane image (gemm(..., b_planes=)) read it / ignore it (split B
-    in-kernel again).  Default on (MTVAF_F32_WPLANES=0 off); None queries.  Results are bit-identical either way."""
-    return bool(lib().mtvaf_f32_wplanes(-1 if on is None else int(bool(on))))
-
-
-def split_planes(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
-    """dst [3, n] bf16 <- the three bf16 planes of the flat fp32 tensor src [n] (x = x1 + x2 + x3, RNE at every level: the split
-    the GEMM producers apply to fp32 tiles).  n % 8 == 0."""
-    n = src.numel()
-    if src.dtype != torch.float32 or dst.dtype != torch.bfloat16 or dst.numel() != 3 * n or n % 8:
-        raise ValueError("split_planes: src fp32 [n], dst bf16 [3, n], n % 8 == 0")
-    _ck(lib().mtvaf_f32_split_planes(_p(src), _p(dst), n, n, _st()), "mtvaf_f32_split_planes")
-    return dst
-
-
-class Planes:
-    """The three bf16 planes of an fp32 tensor: `img` [3, n] bf16 (n = numel of the flat fp32 tensor, or of a larger buffer the
-    tensor is a view of), `view(t)` = plane 0 of the sub-tensor t at t's offsets; `stride` = elements between planes."""
-    __slots__ = ("img", "stride", "base")
-
-    def __init__(self, src: torch.Tensor, img: Optional[torch.Tensor] = None):
-        flat = src.reshape(-1)
-        n = flat.numel()
-        self.img = img if img is not None else torch.empty(3, n, dtype=torch.bfloat16, device=src.device)
-        self.stride, self.base = n, flat.data_ptr()
-        split_planes(flat, self.img)
-
-    def view(self, t: torch.Tensor) -> torch.Tensor:
-        o = (t.data_ptr() - self.base) // 4
-        return self.img[0, o:o + t.numel()]
-
-
-def gemm_planes(a_pl, layout_a, lda, a_stride, b_pl, layout_b, ldb, b_stride, out, M, N, K, bias=None, epi=EPI_NONE, aux=None,
-                accumulate=False, allow_split=False, out_planes=None, ldcp=0, c_stride=0, tile_n=-1, splits=-1, ktiles=None):
-    """out[M,N] (fp32, may be None with out_planes) = opA . opB with both operands given as plane images (plane 0 tensors +
-    the element distance between planes): mtvaf_gemm_f32p."""
-    ws, wsb = None, 0
-    if allow_split:
-        wsb = lib().mtvaf_gemm_f32_workspace_bytes(M, N, K, 1)
-        ws = workspace(wsb, a_pl.device)
-    kl, kc = ktiles if ktiles is not None else (None, None)
-    _ck(lib().mtvaf_gemm_f32p(layout_a, layout_b, _p(a_pl), lda, a_stride, _p(b_pl), ldb, b_stride, _p(out),
-                              out.stride(0) if out is not None else 0, _p(out_planes), ldcp, c_stride, M, N, K, _p(bias), epi, _p(aux),
-                              aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws), wsb, tile_n, splits,
-                              _p(kl), _p(kc), _st()), "mtvaf_gemm_f32p")
-    return out
-
-
 def set_compute_dtype(dtype: str):
     global COMPUTE
     if dtype not in ("fp32", "bf16"):
@@ -349,9 +291,8 @@ def set_compute_dtype(dtype: str):
 def gemm(a: torch.Tensor, layout_a: int, b: torch.Tensor, layout_b: int, out: torch.Tensor, M: int, N: int, K: int,
          bias: Optional[torch.Tensor] = None, epi: int = EPI_NONE, aux: Optional[torch.Tensor] = None,
          accumulate: bool = False, allow_split: bool = False, lda: Optional[int] = None, ldb: Optional[int] = None,
-         ldc: Optional[int] = None, cfg: int = -1, splits: int = -1, compute: Optional[str] = None, b_planes=None):
-    """out[M,N] = opA[M,K] . opB[K,N] (+bias, epilogue).  KC: reduction index contiguous; KM: k-major.
-    b_planes = (bf16 tensor holding plane 0 of b at b's offsets, elements between planes): mtvaf_gemm_f32_wp."""
+         ldc: Optional[int] = None, cfg: int = -1, splits: int = -1, compute: Optional[str] = None):
+    """out[M,N] = opA[M,K] . opB[K,N] (+bias, epilogue).  KC: reduction index contiguous; KM: k-major."""
     _f32(a, b, out, bias, aux)
     lda = a.stride(0) if lda is None else lda
     ldb = b.stride(0) if ldb is None else ldb
@@ -365,14 +306,6 @@ def gemm(a: torch.Tensor, layout_a: int, b: torch.Tensor, layout_b: int, out: to
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     mode = compute or COMPUTE
-    if b_planes is not None and mode == "fp32":
-        _ck(lib().mtvaf_gemm_f32_wp(layout_a, layout_b, _p(a), lda, _p(b), ldb, _p(b_planes[0]), int(b_planes[1]), _p(out), ldc, M, N, K,
-                                    _p(bias), epi, _p(aux), aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split),
-                                    _p(ws), wsb, cfg, splits, _st()), "mtvaf_gemm_f32_wp")
-        if prof is not None:
-            e1.record()
-            prof.append(((layout_a, layout_b, M, N, K, epi, int(allow_split)), e0, e1))
-        return out
     fn = lib().mtvaf_gemm_bf16 if mode == "bf16" else (lib().mtvaf_gemm_f32x3 if mode == "fp32x3" else lib().mtvaf_gemm_f32)
     _ck(fn(layout_a, layout_b, _p(a), lda, _p(b), ldb, _p(out), ldc, M, N, K, _p(bias), epi, _p(aux),
            aux.stride(0) if aux is not None else 0, int(accumulate), int(allow_split), _p(ws), wsb, cfg, splits, _st()),

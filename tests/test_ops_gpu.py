@@ -1161,154 +1161,6 @@ def test_gemm_f32_split_adversarial(hip, la, lb, case):
     assert float(e_spl.pow(2).mean().sqrt()) <= 1.25 * float(e_nat.pow(2).mean().sqrt()) + 2.0 ** -26
 
 
-def test_split_planes_are_the_rne_three_way_split(hip):
-    """mtvaf_f32_split_planes: plane 1 = RNE_bf16(x), plane 2 = RNE_bf16(x - p1), plane 3 = RNE_bf16(x - p1 - p2), bit for bit
-    (torch's own bf16 rounding as the model), over magnitudes 2^+-40, zeros and negative values."""
-    g = torch.Generator().manual_seed(3)
-    x = torch.randn(8 * 1031, generator=g) * torch.exp2(torch.randint(-40, 41, (8 * 1031,), generator=g).float())
-    x[::97] = 0.0
-    d = torch.empty(3, x.numel(), dtype=torch.bfloat16, device=DEV)
-    hip.split_planes(x.to(DEV), d)
-    p1 = x.bfloat16()
-    r1 = x - p1.float()
-    p2 = r1.bfloat16()
-    p3 = (r1 - p2.float()).bfloat16()
-    for got, want in zip(d.cpu(), (p1, p2, p3)):
-        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
-    rec = d.cpu().double().sum(0)
-    assert float(((rec - x.double()).abs() / x.double().abs().clamp_min(1e-300)).max()) <= 2.0 ** -25
-
-
-@pytest.mark.parametrize("lb", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(512, 768, 768), (256, 3072, 768), (384, 768, 3072), (128, 128, 32), (256, 256, 96)])
-def test_gemm_f32_weight_planes_equal_the_in_kernel_split_bit_for_bit(hip, lb, M, N, K):
-    """mtvaf_gemm_f32_wp (B = a weight whose three bf16 planes were split once, tiles fetched by LDS-DMA: gemm_f32x3_wp_kernel)
-    against the kernel that splits B in every block: the same planes, the same MFMA sequence and k order -> identical bits.
-    Forward (B row-major [N][K]) and dX (B [K][N]: the reduction index is the row) layouts, one to 96 k-tiles, every epilogue of
-    the path, split-K; the switch mtvaf_f32_wplanes(0) and a NULL image fall back to the in-kernel split."""
-    g = torch.Generator().manual_seed(M + N + K + lb)
-    A = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-8, 9, (M, 1), generator=g).float())).to(DEV)
-    W = (torch.randn(N, K, generator=g) if lb == 0 else torch.randn(K, N, generator=g)).to(DEV)
-    # the planes live in a larger flat image at an offset, as a layer's weights do (same offsets as the fp32 flat buffer)
-    off, total = 4096, 4096 + W.numel() + 512
-    flat = torch.zeros(total, device=DEV)
-    flat[off:off + W.numel()] = W.view(-1)
-    Wf = flat[off:off + W.numel()].view(W.shape)
-    img = torch.empty(3, total, dtype=torch.bfloat16, device=DEV)
-    hip.split_planes(flat, img)
-    planes = (img[0, off:off + W.numel()], total)
-    bias = torch.randn(N, generator=g).to(DEV)
-    aux_ref, aux_got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-    pre = torch.randn(M, N, generator=g).to(DEV)
-    ref, got = torch.empty(M, N, device=DEV), torch.full((M, N), float("nan"), device=DEV)
-
-    def both(**kw):
-        hip.gemm(A, 0, Wf, lb, ref, M, N, K, cfg=5, **{k: (aux_ref if (k == "aux" and v is None) else v) for k, v in kw.items()})
-        got.fill_(float("nan"))
-        hip.prof_start(4)
-        hip.gemm(A, 0, Wf, lb, got, M, N, K, cfg=5, b_planes=planes, **{k: (aux_got if (k == "aux" and v is None) else v) for k, v in kw.items()})
-        rec = hip.prof_stop(4)
-        return rec[0][0]["cfg"]
-    assert hip.f32_split() and hip.f32_wplanes()
-    assert both() == 2225, "the plane kernel must have run"
-    assert torch.equal(got, ref)
-    close(got, A.double().cpu() @ (W.double().cpu().t() if lb == 0 else W.double().cpu()), rtol=3e-6, name="planes product")
-    assert both(bias=bias) == 2225 and torch.equal(got, ref)
-    if lb == 0:
-        assert both(bias=bias, epi=hip.EPI_GELU, aux=None) == 2225 and torch.equal(got, ref) and torch.equal(aux_got, aux_ref)
-    else:
-        assert both(epi=hip.EPI_DGELU, aux=pre) == 2225 and torch.equal(got, ref)
-    ref.normal_()
-    got.copy_(ref)
-    base = ref.clone()
-    hip.gemm(A, 0, Wf, lb, ref, M, N, K, cfg=5, accumulate=True)
-    hip.gemm(A, 0, Wf, lb, got, M, N, K, cfg=5, accumulate=True, b_planes=planes)
-    assert torch.equal(got, ref) and not torch.equal(got, base)
-    if K >= 768:
-        assert both(bias=bias, allow_split=True, splits=3) == 2225 and torch.equal(got, ref)
-    hip.f32_wplanes(False)
-    try:
-        assert both() == 225 and torch.equal(got, ref)
-    finally:
-        hip.f32_wplanes(True)
-
-
-@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
-@pytest.mark.parametrize("M,N,K,bn", [(512, 768, 768, 128), (512, 768, 768, 96), (256, 3072, 768, 128), (384, 2304, 3072, 96), (128, 128, 32, 128),
-                                      (128, 96, 64, 96), (256, 384, 96, 128)])
-def test_gemm_f32_plane_operands_equal_the_in_kernel_split_bit_for_bit(hip, la, lb, M, N, K, bn):
-    """mtvaf_gemm_f32p (csrc/gemm_f32p.hip: BOTH operands as plane images, tiles by LDS-DMA, nothing split in the k-loop)
-    against mtvaf_gemm_f32x3 on the fp32 operands the planes were split from: same planes, same MFMA sequence, same k order ->
-    identical bits.  All three operand layouts of the path, both tiles, one to 96 k-tiles, every epilogue, split-K, a k-tile
-    list, and the result's own plane image (equal to the split of the fp32 result)."""
-    cfg = 5 if bn == 128 else 6
-    g = torch.Generator().manual_seed(M + N + K + 3 * la + lb)
-    A = torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-8, 9, (M, 1), generator=g).float())
-    B = torch.randn(K, N, generator=g) * torch.exp2(torch.randint(-8, 9, (1, N), generator=g).float())
-    a = (A if la == 0 else A.t().contiguous()).to(DEV)
-    b = (B.t().contiguous() if lb == 0 else B).to(DEV)
-    pa, pb = hip.Planes(a), hip.Planes(b)
-    lda, ldb = a.stride(0), b.stride(0)
-    bias, pre = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
-    ref, got = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-    aux_r, aux_g = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
-
-    def run(**kw):
-        kr = {k: (aux_r if (k == "aux" and v is None) else v) for k, v in kw.items()}
-        kg = {k: (aux_g if (k == "aux" and v is None) else v) for k, v in kw.items()}
-        hip.gemm(a, la, b, lb, ref, M, N, K, compute="fp32x3", cfg=cfg, **kr)
-        got.fill_(float("nan"))
-        hip.prof_start(4)
-        hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got, M, N, K, tile_n=bn, **kg)
-        rec = hip.prof_stop(4)
-        assert rec[0][0]["cfg"] == 3000 + cfg
-    run()
-    assert torch.equal(got, ref)
-    close(got, A.double() @ B.double(), rtol=3e-6, name="plane operands")
-    run(bias=bias)
-    assert torch.equal(got, ref)
-    run(bias=bias, epi=hip.EPI_GELU, aux=None)
-    assert torch.equal(got, ref) and torch.equal(aux_g, aux_r)
-    run(epi=hip.EPI_DGELU, aux=pre)
-    assert torch.equal(got, ref)
-    run(bias=bias, epi=hip.EPI_TANH)
-    assert torch.equal(got, ref)
-    ref.normal_()
-    base = ref.clone()
-    got2 = base.clone()
-    hip.gemm(a, la, b, lb, ref, M, N, K, compute="fp32x3", cfg=cfg, accumulate=True)
-    hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got2, M, N, K, tile_n=bn, accumulate=True)
-    assert torch.equal(got2, ref)
-    if K >= 768:
-        run(bias=bias if la == 0 else None, allow_split=True, splits=3)
-        assert torch.equal(got, ref)
-    # the result's own plane image, beside and instead of the fp32 result
-    img = torch.empty(3, M * N, dtype=torch.bfloat16, device=DEV)
-    hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got, M, N, K, tile_n=bn, bias=bias, epi=hip.EPI_GELU,
-                    aux=aux_g, out_planes=img, ldcp=N, c_stride=M * N)
-    want = hip.Planes(got)
-    assert torch.equal(img.view(torch.int16), want.img.view(torch.int16))
-    img2 = torch.zeros_like(img)
-    hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, None, M, N, K, tile_n=bn, bias=bias, epi=hip.EPI_GELU,
-                    aux=aux_g, out_planes=img2, ldcp=N, c_stride=M * N)
-    assert torch.equal(img2.view(torch.int16), img.view(torch.int16))
-    if la == 1 and K >= 96:  # weight gradient over a k-tile list: A exactly zero outside the listed 32-row tiles
-        valid = torch.ones(K, dtype=torch.bool)
-        valid[32:64] = False
-        az = (a * valid[:, None].to(DEV)).contiguous()
-        paz = hip.Planes(az)
-        tiles = sorted(set(int(r) // 32 for r in torch.nonzero(valid).flatten()))
-        kl, kc = torch.tensor(tiles, dtype=torch.int32, device=DEV), torch.tensor([len(tiles)], dtype=torch.int32, device=DEV)
-        for sp in (1, 2):
-            hip.gemm_ktiles(az, b, ref, M, N, K, kl, kc, splits=sp, cfg=cfg)
-            got.fill_(float("nan"))
-            hip.gemm_planes(paz.img[0], 1, lda, paz.stride, pb.img[0], 1, ldb, pb.stride, got, M, N, K, tile_n=bn, allow_split=True,
-                            splits=sp, ktiles=(kl, kc))
-            assert torch.equal(got, ref), f"k-tile list, splits {sp}"
-    with pytest.raises(RuntimeError):  # shapes outside its cover are refused (the caller keeps the fp32-operand entry points)
-        hip.gemm_planes(pa.img[0], la, lda, pa.stride, pb.img[0], lb, ldb, pb.stride, got, M, N - 16, K)
-
-
 def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
     """The split kernel behind the fp32 entry points: every epilogue of the path (bias, bias + GELU with the saved
     pre-activation, GELU', tanh, accumulate), forced split-K, a k-tile list (weight gradient: dY exactly zero outside the listed

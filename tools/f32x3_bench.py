@@ -55,24 +55,6 @@ def main():
             tot[mode] += us
             line += f" | {mode:7s} {us:6.1f} us {fl / us / 1e6:5.1f} TF err {emax:.1e}/{erms:.1e}"
         hip.f32_split(True)
-        if tiles:  # both operands as plane images (mtvaf_gemm_f32p): nothing is split in the k-loop
-            pa_, pb_ = hip.Planes(a), hip.Planes(b)
-            for bn in (128, 96):
-                if n % bn:
-                    continue
-                for sp in ((-1,) if la == KC else (-1, 2, 3, 4, 6)):
-                    run = lambda: hip.gemm_planes(pa_.img[0], la, a.stride(0), pa_.stride, pb_.img[0], lb, b.stride(0), pb_.stride, out, m, n, k,
-                                                  allow_split=True, tile_n=bn, splits=sp)
-                    run()
-                    line += f" | P{bn}{'' if sp < 0 else '/s' + str(sp)} {t(run):6.1f}"
-            line += f" (split passes: A {t(lambda: hip.split_planes(a.reshape(-1), pa_.img)):.1f}, B {t(lambda: hip.split_planes(b.reshape(-1), pb_.img)):.1f})"
-        if tiles and la == KC:  # B = a weight: its planes split once (mtvaf_gemm_f32_wp), 128x128 tile
-            img = torch.empty(3, b.numel(), dtype=torch.bfloat16, device=dev)
-            hip.split_planes(b.reshape(-1), img)
-            tsp = t(lambda: hip.split_planes(b.reshape(-1), img))
-            run = lambda: hip.gemm(a, la, b, lb, out, m, n, k, allow_split=True, cfg=5, b_planes=(img[0], b.numel()))
-            run()
-            line += f" | planes128 {t(run):6.1f} (split pass {tsp:.1f})"
         if tiles:
             for cfg in (5, 6):
                 if n % (128 if cfg == 5 else 96):

@@ -17,9 +17,7 @@ args = [int(a) for a in sys.argv[1:]]
 M, N, K = (args + [4096, 3072, 768])[:3] if len(args) >= 3 else (4096, 3072, 768)
 cfg = args[3] if len(args) > 3 else 5
 a, b, out = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.empty(M, N, device=dev)
-planes = hip.Planes(b) if os.environ.get("X3_TRACE_WP") == "1" else None  # (the B-planes kernel: wave 7 = the DMA wave)
-run = (lambda: hip.gemm(a, 0, b, 0, out, M, N, K, cfg=cfg, b_planes=(planes.img[0], planes.stride))) if planes is not None else \
-      (lambda: hip.gemm(a, 0, b, 0, out, M, N, K, compute="fp32x3", cfg=cfg))
+run = lambda: hip.gemm(a, 0, b, 0, out, M, N, K, compute="fp32x3", cfg=cfg)
 for _ in range(3):
     run()
 buf = torch.zeros(8 * 64 * 4 + 17, dtype=torch.int64, device=dev)
