@@ -795,10 +795,9 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       // (fewer operand bytes per flop), the 64x64 every-wave kernel well behind both
       const double e = compute == 2 ? (c == 5 ? 0.70 : (c == 6 ? 0.68 : 0.45)) : ((c >= 16 && tiles * s <= 256) ? 1.0 : eff[c]);
       double cost = (double)rounds * bm * bn * kc / 128.0 / (e * occ2);
-      // fill/drain + launch.  Split kernels: one block per CU, nothing overlaps a tile's prologue + epilogue (traced:
-      // 3.7 + 2.5 us per tile, tools/x3_trace.py) -- charged per ROUND, which is what decides between e.g. 144 tiles x 3
-      // splits (two rounds of 1376-deep reductions: 131-139 us measured for the FFN weight gradients) and x 5 (three rounds)
-      cost += compute == 2 ? 28000.0 * rounds : 3000.0;
+      cost += 3000.0;  // fill/drain + launch  (charging the split kernels' traced 6.2 us of prologue + epilogue per ROUND instead
+                       // was tried in round 4: with the k-tile lists of the bench batch the weight gradients then take 4
+                       // splits and 110 us where this model's 5 splits take 96)
       if (s > 1) {
         // slabs: s*M*N floats written then read once (plus the final write) at ~4 TB/s ~ 1.7 KB/clk chip-wide
         cost += ((double)s * 2.0 + 1.0) * M * N * 4.0 / 1700.0 + 8000.0;
