@@ -25,10 +25,15 @@
 
 namespace mtvaf {
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE, bool KLIST = false>
-__global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN == 8) ? 2 : (NSTAGE >= 3 ? 1 : 2))) void gemm_bf16x_kernel(GemmArgsX p) {
+// DW (round 4; four-wave tiles): NW more waves that do nothing but issue the LDS-DMA requests.  A global_load_lds request
+// costs the issuing wave 80-95 cycles of issue beside the matrix stream (traced on the split-fp32 kernels, tools/x3_trace.py),
+// and a wave issues in order: with 7-8 requests per wave and k-tile in the MFMA waves, the requests took as long as the
+// tile's 16 MFMAs -- which is what SQ_VALU_MFMA_BUSY 0.15-0.22 of these rings showed, not (only) the L2 -> LDS rate.
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE, bool KLIST = false, bool DW = false>
+__global__ __launch_bounds__((DW ? 2 : 1) * WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN == 8) ? 2 : ((NSTAGE >= 3 ? 1 : 2) * (DW ? 2 : 1)))) void gemm_bf16x_kernel(GemmArgsX p) {
+  static_assert(!DW || WM * WN == 4, "DMA waves: four-wave tiles");
   constexpr int BK = 64;  // bf16 elements per k-tile
-  constexpr int NW = WM * WN, NT = NW * 64;
+  constexpr int NW = WM * WN, NT = (DW ? 2 : 1) * NW * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int A_B = BM * 128, B_B = BN * 128, STAGE_B = A_B + B_B;  // bytes (KC: BM rows x 128 B; KM: 64 rows x 2*BM B)
   constexpr int IA = A_B / 1024 / NW, IB = B_B / 1024 / NW;          // 1-KiB DMA instructions per wave
@@ -41,7 +46,9 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool dma_wave = DW && wave_all >= NW;  // (wave-uniform)
+  const int wave = DW ? wave_all % NW : wave_all;  // MFMA wave index / owner index of a DMA wave's pieces
   const int wm = wave / WN, wn = wave % WN;
   const int li = lane & 31, h = lane >> 5;
   const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -184,23 +191,47 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
   };
+  if (!DW || dma_wave) {
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nk) issue(s);
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nk) issue(s);
+  }
   int st = 0;
+  if (dma_wave) {  // the same barriers as the MFMA waves: one per k-tile
+    for (int kt = 0; kt < nk; ++kt) {
+      const int ahead = min(NSTAGE - 2, nk - 1 - kt);
+      if (NSTAGE >= 5 && ahead == 3) wait_vm<3 * (IA + IB)>();
+      else if (NSTAGE >= 4 && ahead == 2) wait_vm<2 * (IA + IB)>();
+      else if (NSTAGE >= 3 && ahead == 1) wait_vm<IA + IB>();
+      else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (kt + NSTAGE - 1 < nk) {
+        int si = st + NSTAGE - 1;
+        if (si >= NSTAGE) si -= NSTAGE;
+        issue(si);
+      }
+      st = st + 1 == NSTAGE ? 0 : st + 1;
+    }
+    nk = 0;  // (no products in this wave)
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's pieces of tile kt have landed; the (up to NSTAGE - 2) tiles issued after it stay in flight
-    const int ahead = min(NSTAGE - 2, nk - 1 - kt);
-    if (NSTAGE >= 5 && ahead == 3) wait_vm<3 * (IA + IB)>();
-    else if (NSTAGE >= 4 && ahead == 2) wait_vm<2 * (IA + IB)>();
-    else if (NSTAGE >= 3 && ahead == 1) wait_vm<IA + IB>();
-    else wait_vm<0>();
+    if constexpr (!DW) {
+      // this wave's pieces of tile kt have landed; the (up to NSTAGE - 2) tiles issued after it stay in flight
+      const int ahead = min(NSTAGE - 2, nk - 1 - kt);
+      if (NSTAGE >= 5 && ahead == 3) wait_vm<3 * (IA + IB)>();
+      else if (NSTAGE >= 4 && ahead == 2) wait_vm<2 * (IA + IB)>();
+      else if (NSTAGE >= 3 && ahead == 1) wait_vm<IA + IB>();
+      else wait_vm<0>();
+    }
     __builtin_amdgcn_s_barrier();  // ... and everybody else's; every wave is done reading tile kt-1
     asm volatile("" ::: "memory");
-    if (kt + NSTAGE - 1 < nk) {
-      int si = st + NSTAGE - 1;
-      if (si >= NSTAGE) si -= NSTAGE;
-      issue(si);  // into the stage tile kt-1 occupied
+    if constexpr (!DW) {
+      if (kt + NSTAGE - 1 < nk) {
+        int si = st + NSTAGE - 1;
+        if (si >= NSTAGE) si -= NSTAGE;
+        issue(si);  // into the stage tile kt-1 occupied
+      }
     }
     const unsigned char* a = smem_b + st * STAGE_B;
     const unsigned char* b = a + A_B;
@@ -230,7 +261,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
     __builtin_amdgcn_sched_barrier(0);
     st = st + 1 == NSTAGE ? 0 : st + 1;
   }
-  if (nk > 0) mm(fa1, fb1);  // slice 3 of the last tile
+  if (nk > 0) mm(fa1, fb1);  // slice 3 of the last tile (MFMA waves)
 
   // ---- epilogue: accumulator tile -> LDS (transposed to row-major) -> 8 columns per lane ----
   // in passes of 128 rows (one pass for the 128-row tiles): a [256][BN + 4] fp32 image does not fit the LDS at BN = 192,
@@ -246,7 +277,7 @@ __global__ __launch_bounds__(WM* WN * 64, (BM * BN > 256 * 128) ? 1 : ((WM * WN 
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {
     __syncthreads();
-    if (wm / WPP == pass) {
+    if (!dma_wave && wm / WPP == pass) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -389,21 +420,31 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE, bool KLIST = false>
+static int g_bf16x_dma_waves = [] { const char* e = getenv("MTVAF_BF16X_DMA_WAVES"); return (e && atoi(e) == 0) ? 0 : 1; }();
+
+// DMA waves pay where a product is at most two tiles per CU (measured, tools/bf16x_bench.py + bench.py: C3, 4096 token rows,
+// 4252 -> 4668 sentences/s; with more tiles per CU the co-resident blocks already hide the requests, and the doubled block
+// size costs: C4 at 8192 rows 5700 -> 5568 with the waves everywhere)
+static bool bf16x_use_dma_waves(dim3 grid) { return g_bf16x_dma_waves && (long)grid.x * grid.z <= 512; }
+
+template <int BM, int BN, int WM, int WN, bool A_KM, bool B_KM, int NSTAGE, bool KLIST = false, bool DW = false>
 static int launch_x(const GemmArgsX& a, dim3 grid, hipStream_t st) {
   if constexpr (A_KM && B_KM && !KLIST && NSTAGE == 2) {  // (the k-tile list: 2-stage weight-gradient kernels only)
-    if (a.klist) return launch_x<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, true>(a, grid, st);
+    if (a.klist) return launch_x<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, true, DW>(a, grid, st);
+  }
+  if constexpr (WM * WN == 4 && !DW && NSTAGE <= 3) {  // four-wave tiles: the requests in waves of their own (MTVAF_BF16X_DMA_WAVES=0: off)
+    if (bf16x_use_dma_waves(grid)) return launch_x<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST, true>(a, grid, st);
   }
   size_t smem = (size_t)NSTAGE * (BM + BN) * 128;
   smem = std::max(smem, (size_t)128 * (BN + 4) * sizeof(float));  // epilogue image (one 128-row pass)
-  auto kern = gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>;
+  auto kern = gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST, DW>;
   static bool attr_set = false;
   if (smem > 64 * 1024 && !attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), smem, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3((DW ? 2 : 1) * WM * WN * 64), smem, st, a);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -614,7 +655,11 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
   a.tiles_n = N / bn;
   // measured (tools/bf16x_bench.py): with 4-wave blocks two co-resident blocks beat the deeper ring on every shape of the
   // path; the 8-wave 256x128 block (one per CU) wants the 3-deep ring
-  if (stages < 2 || stages > 5) stages = bm == 256 ? 3 : 2;
+  // ... WITHOUT the DMA waves.  With them (round 4) a product of at most one tile per CU takes the 3-deep ring: nothing
+  // co-resides anyway, and two k-tiles in flight feed the MFMA waves that no longer stop to issue requests (M = 4096, 128x96:
+  // FFN-2 forward 35.9 -> 25.6 us, FFN-1 dX 35.1 -> 25.4, QKV dX 27.9 -> 20.7; with several tiles per CU the two co-resident
+  // blocks of the 2-deep ring stay ahead: FFN-1 forward 35.3 vs 46.6)
+  if (stages < 2 || stages > 5) stages = bm == 256 ? 3 : ((g_bf16x_dma_waves && !a.klist && tiles * splits <= 256) ? 3 : 2);
   if (bn == 192) stages = 2;  // (the only ring that fits: 2 x 56 KB)
   if (bn == 256) { stages = 2; a.klist = a.kcnt = nullptr; }
   if (a.klist && stages != 2) a.klist = a.kcnt = nullptr;  // (list mode exists for the 2-stage kernels: otherwise reduce over everything)
