@@ -774,8 +774,11 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
   for (int c = 0; c < kNumCfgs; ++c) {
     if (eff[c] <= 0.0) continue;
     if (compute == 1 && !(c == 6 || c == 5 || c == 3)) continue;  // bf16 kernels exist for 128x96, 128x128, 64x64
-    if (compute == 2 && !((c == 5 && M % 128 == 0 && N % 128 == 0) || (c == 6 && M % 128 == 0 && N % 96 == 0) ||
-                          (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
+    // (the 128x96 split tile: forward products only by default -- with a k-major B operand or as a weight gradient it
+    // measured level or behind 128x128 + split-K in the bench step; MTVAF_X3_TILE96 = 0 never, 2 every layout)
+    static const int tile96 = [] { const char* e = getenv("MTVAF_X3_TILE96"); return e ? atoi(e) : 1; }();
+    const bool c6_ok = M % 128 == 0 && N % 96 == 0 && (tile96 == 2 || (tile96 == 1 && la == 0 && lb == 0));
+    if (compute == 2 && !((c == 5 && M % 128 == 0 && N % 128 == 0) || (c == 6 && c6_ok) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute != 0 ? 32 : kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
     const int max_s = allow_split ? 16 : 1;
