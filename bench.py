@@ -121,6 +121,31 @@ def cpu_baseline(B, S, n_aux, seconds_budget=40.0, min_steps=3):
             "seconds_per_step": round(med, 3)}
 
 
+def frontend_cache_throughput(device, batch=32, n_aux=3, hw=224, reps=3):
+    """Row f1 (the step before the path): images/s of building the region-feature cache -- the frozen ResNet-50 pyramid of
+    `ImageModel` (reference: models/bert_model.py:63-111; torch / MIOpen, random weights: the reference's .pth files are not
+    in the image) run once per image in inference mode by `RegionFeatureCache.extract` on `batch` sentences of 1 + n_aux
+    images of hw x hw.  A detail figure (bench_detail.json), never part of `value`."""
+    from mtvaf_amd.features import RegionFeatureCache
+    from mtvaf_amd.models.bert_model import ImageModel
+    torch.manual_seed(5)
+    im = ImageModel(resnet_root="random").to(device).eval()
+    cache = RegionFeatureCache(im)
+    x = torch.randn(batch, 3, hw, hw, device=device)
+    aux = torch.randn(batch, n_aux, 3, hw, hw, device=device)
+    cache.extract(x, aux)  # (MIOpen picks its algorithms here)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        feats, fa = cache.extract(x, aux)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    n_img = batch * (1 + n_aux)
+    return {"images_per_s": round(n_img / dt, 1), "sentences_per_s": round(batch / dt, 1), "ms_per_batch": round(1e3 * dt, 2),
+            "what": f"RegionFeatureCache.extract, ResNet-50 pyramid (random weights), {batch} sentences x (1 + {n_aux}) images of "
+                    f"{hw}x{hw}, fp32, eval-mode BatchNorm; output {tuple(feats.shape)} + {tuple(fa.shape)}"}
+
+
 def pmc_traffic(symbol, dtype="fp32", batch=32, seq=128):
     """HBM-side bytes per launch of `symbol` from the committed rocprofv3 PMC passes (profiles/pmc_gemm.json, written by
     tools/pmc_to_json.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane streams, plus
@@ -760,6 +785,11 @@ def main():
                 res["ms_per_step_" + tag_] = sp["ms_per_step"]
                 res["roofline_" + tag_] = sp.get("roofline")
         log("secondary configurations done")
+    if rank == 0 and world == 1 and not a.no_secondary and not a.no_cpu_baseline:
+        try:  # (detail only; must never cost the line)
+            res["frontend_cache_build"] = frontend_cache_throughput(device)
+        except Exception as e:
+            res["frontend_cache_build"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(B, S, a.aux)
         if (B, S, a.aux) == (32, 128, 8):  # second entry: the reference's own CPU-runnable configuration (configs[0])

@@ -749,6 +749,11 @@ void prof_end(int i, hipStream_t stream) {
 // Cost model (units: fp32 MFMA cycles of one CU).  The MFMA pipe of a CU is shared by its resident
 // blocks, so time ~ rounds over the 256 CUs x work per tile / efficiency of that tile shape (calibrated
 // with tools/gemm_sweep.py on MI355X at M = 4096), plus, for split-K, the slab write + ordered reduce.
+static bool x3_tile96_ok(int M, int N, int la, int lb) {
+  static const int tile96 = [] { const char* e = getenv("MTVAF_X3_TILE96"); return e ? atoi(e) : 1; }();
+  return M % 128 == 0 && N % 96 == 0 && (tile96 == 2 || (tile96 == 1 && la == 0 && lb == 0));
+}
+
 static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi, int* cfg_out, int* splits_out,
                    int compute = 0) {
   //                                  128x128 128x96 128x288 64x64 128x64 128x128x32 128x96x32 128x192 128x192x32
@@ -776,8 +781,7 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
     if (compute == 1 && !(c == 6 || c == 5 || c == 3)) continue;  // bf16 kernels exist for 128x96, 128x128, 64x64
     // (the 128x96 split tile: forward products only by default -- with a k-major B operand or as a weight gradient it
     // measured level or behind 128x128 + split-K in the bench step; MTVAF_X3_TILE96 = 0 never, 2 every layout)
-    static const int tile96 = [] { const char* e = getenv("MTVAF_X3_TILE96"); return e ? atoi(e) : 1; }();
-    const bool c6_ok = M % 128 == 0 && N % 96 == 0 && (tile96 == 2 || (tile96 == 1 && la == 0 && lb == 0));
+    const bool c6_ok = x3_tile96_ok(M, N, la, lb);
     if (compute == 2 && !((c == 5 && M % 128 == 0 && N % 128 == 0) || (c == 6 && c6_ok) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute != 0 ? 32 : kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
@@ -893,19 +897,21 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   }
   if (compute == 2) {
     // the split kernels take whole 64x64 tiles of k-aligned, vector-loadable operands; anything else runs the fp32 pipe
-    const bool ok = (K % 32 == 0) && (M % 64 == 0) && (N % 64 == 0 || (M % 128 == 0 && N % 96 == 0)) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
+    const bool can5 = M % 128 == 0 && N % 128 == 0, can3 = M % 64 == 0 && N % 64 == 0;
+    const bool can6 = M % 128 == 0 && N % 96 == 0;  // (forced; the planner takes it where x3_tile96_ok says so)
+    const bool forced = (cfg == 5 && can5) || (cfg == 6 && can6) || (cfg == 3 && can3);
+    const bool plannable = can5 || can3 || x3_tile96_ok(M, N, layout_a, layout_b);
+    const bool ok = (K % 32 == 0) && (forced || plannable) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
                     (((uintptr_t)B & 15) == 0) && !(layout_a == 1 && layout_b == 0);
     // (few output tiles -- the 256-token products of BASELINE configs[0] -- leave most CUs without a block of the 128x128
     // kernel: the fp32 pipe's 64x64 tiles are faster there, measured 4.37 vs 4.53 ms per C1 step)
-    const bool forced = cfg == 5 || cfg == 6 || cfg == 3;
-    const long tiles96 = (M % 128 == 0 && N % 96 == 0) ? (long)(M / 128) * (N / 96) : 0;
+    const long tiles96 = can6 ? (long)(M / 128) * (N / 96) : 0;
     const long tiles = std::max((long)(M / 128) * (N / 128), tiles96);
     // ... unless the reduction is deep enough for split-K to fill the chip anyway (the [768 x 768] weight gradient over 4096
     // token rows: 36 tiles x 7 splits, 38-41 us against 46-51 on the fp32 pipe)
     const bool deep = allow_split && splittable(epi) && K >= 2048 && tiles * std::min(16, K / 256) >= 192;
     if (!ok || (!forced && tiles < 96 && !deep)) compute = 0;
-    if (compute == 2 && !((cfg == 5 && M % 128 == 0 && N % 128 == 0) || (cfg == 6 && M % 128 == 0 && N % 96 == 0) ||
-                          (cfg == 3 && N % 64 == 0))) cfg = -1;
+    if (compute == 2 && !forced) cfg = -1;
   }
   if (!A || !B || !C) return MTVAF_ERR_ARG;
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
