@@ -598,8 +598,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if rank == 0:
+        log("model and batch built")
     for _ in range(a.warmup):
         step()
+    if rank == 0:
+        log(f"{a.warmup} warm-up steps enqueued")
     import gc
     gc.collect()  # (set-up garbage -- model construction, warm-up graphs -- is collected here, not inside a timed step)
     barrier()

@@ -289,8 +289,11 @@ int mtvaf_f32x3_trace(void* buf);
 /* The (up to four) weight-gradient products of one encoder layer in fp32, dW_i[M_i,N_i] = A_i^T . B_i with A_i [K,M_i], B_i [K,N_i]
  * row-major, as ONE launch of the 128x96 LDS-DMA kernel (autograd backward of modeling_bert.py:266, 283-284, 353, 420-421, 433);
  * klist / kcnt as mtvaf_gemm_f32_ktiles (NULL: the whole reduction); deterministic split-K through per-product slabs in
- * `workspace` (splits <= 0: planned).  M_i % 128 == 0, N_i % 96 == 0, K % 32 == 0.  mtvaf_dw_group_rows: the executor uses it for
- * layers of at most that many token rows (default 1024, MTVAF_DW_GROUP_ROWS; rows >= 0 sets, -1 queries). */
+ * `workspace` (splits <= 0: planned).  M_i % 128 == 0, N_i % 96 == 0, K % 32 == 0.  Under the split arithmetic (mtvaf_f32_split),
+ * for K > 1024 and M_i, N_i % 128 == 0, the launch is the GROUP form of the wave-specialised split kernel on 128x128 tiles
+ * instead (unsplit once the tiles cover three quarters of the CUs: 432 tiles at BERT-base).  mtvaf_dw_group_rows: the executor
+ * groups layers of at most that many token rows on the fp32 pipe's ring (default 1024, MTVAF_DW_GROUP_ROWS; rows >= 0 sets,
+ * -1 queries); mtvaf_dw_group_wanted(rows, H, I): the executor's whole rule (1: this layer's weight gradients go out grouped). */
 int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
                             const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
                             void* workspace, size_t workspace_bytes, int splits, mtvaf_stream_t stream);
@@ -298,6 +301,7 @@ int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const 
  * never a silently different plan) */
 size_t mtvaf_gemm_f32_dw_group_workspace_bytes(int n, const int* M, const int* N, int K, int splits);
 int mtvaf_dw_group_rows(int rows);
+int mtvaf_dw_group_wanted(int rows, int H, int I);
 
 /* Stream-K form of the 256x256 eight-phase bf16 kernel (csrc/gemm_bf16p.hip; tile 5 = tile-per-block, tile 6 = stream-K forced,
  * tile 0 = the planner decides): one block per CU walks an equal run of the k-tile steps of all output tiles; a tile whose

@@ -219,6 +219,19 @@ int mtvaf_dw_group_rows(int rows) {
   return g_dw_group_rows;
 }
 
+// 1: a layer of `rows` token rows sends its four weight-gradient products as ONE grouped launch (mtvaf_gemm_f32_dw_group):
+// few-token layers on the fp32 pipe's grouped ring (above), and -- under the split arithmetic, round 4 -- longer ones as one
+// UNSPLIT launch of the wave-specialised split kernel's GROUP form when every product is whole 128 x 128 tiles (432 tiles at
+// BERT-base: 1.7 rounds of the CUs; MTVAF_X3_DW_GROUP=0 keeps one launch + one slab reduction per product).  The Python
+// orchestration asks the same function.
+int mtvaf_f32_split(int on);
+int mtvaf_dw_group_wanted(int rows, int H, int I) {
+  static const int x3_group = [] { const char* e = getenv("MTVAF_X3_DW_GROUP"); return e ? atoi(e) : 1; }();
+  if (rows <= 0 || rows % 32 || H % 128 || I % 128) return 0;
+  if (rows <= mtvaf_dw_group_rows(-1) && H % 96 == 0 && I % 96 == 0) return 1;
+  return (x3_group && rows > 1024 && mtvaf_f32_split(-1)) ? 1 : 0;
+}
+
 // Backward of one layer.  g->dh holds d loss / d h2 on entry and d loss / d x on return.  `settle` != 0: the second stream
 // additionally waits for the layer's LAST main-stream kernel (an optimizer update hanging off the caller's hook must be
 // behind every product that still reads the weights).
@@ -283,7 +296,7 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     const float* cx = static_cast<const float*>(L->cx);
     float* pre = static_cast<float*>(L->pre);
     const float* act = static_cast<const float*>(L->act);
-    const bool grp = M <= mtvaf_dw_group_rows(-1) && M % 32 == 0 && H % 128 == 0 && I % 128 == 0 && H % 96 == 0 && I % 96 == 0;
+    const bool grp = mtvaf_dw_group_wanted(M, H, I) != 0;
     MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0, M, H,
                                        L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, nullptr, mainS));
     MTVAF_TRY(fork_to(mainS, side));

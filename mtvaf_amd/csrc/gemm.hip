@@ -705,6 +705,7 @@ static int launch_cfg(const GemmArgs& a, int la, int lb, dim3 grid, int mode, hi
 
 int launch_gemm_bf16(int tile, const GemmArgs& a, int la, int lb, dim3 grid, bool aligned, hipStream_t st);  // gemm_bf16.hip
 int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st);                // gemm_f32x3.hip
+int launch_gemm_f32x3_group(const GemmArgs& a, dim3 grid, hipStream_t st);                                      // gemm_f32x3.hip
 
 // ordered split-K slab reduction (+ bias / tanh / dtanh epilogue), shared with gemm_bf16kc.hip
 int launch_splitk_reduce(const float* slabs, int splits, float* C, int M, int N, int ldc, const float* bias, int accumulate,
@@ -1082,10 +1083,41 @@ static int dw_group_plan(long tiles, int K, int requested) {
   return (int)cdiv(K, kc);
 }
 
+// The grouped launch on the split kernel (gemm_f32x3_ws_kernel<.., GROUP>): split arithmetic in force, every product whole
+// 128 x 128 tiles, and a reduction longer than the few-token case the fp32 pipe's grouped ring was tuned for (K <= 1024: kept)
+static bool dw_group_on_split_kernel(int n, const int* M, const int* N, int K) {
+  if (!mtvaf_f32_split(-1) || K <= 1024) return false;
+  for (int i = 0; i < n; ++i)
+    if (M[i] % 128 || N[i] % 128) return false;
+  return true;
+}
+// its splits: none once the tiles alone cover three quarters of the CUs (the second stream shares the chip with the main one:
+// what counts is CU time, and an unsplit block pays the ~6 us of prologue + epilogue once), otherwise enough to get there
+static int dw_group_plan_x3(long tiles, int K, int requested) {
+  const int ktiles = K / 32;
+  int splits = requested;
+  if (splits <= 0) {
+    splits = 1;
+    while (tiles * splits < 192 && ktiles / (splits + 1) >= 16 && splits < 8) ++splits;
+  }
+  while (splits > 1 && ktiles / splits < 4) --splits;
+  const int kc = (int)cdiv(cdiv(K, splits), 32) * 32;
+  return (int)cdiv(K, kc);
+}
+
 // Bytes of split-K slabs mtvaf_gemm_f32_dw_group needs for these products (0: no split planned).
 size_t mtvaf_gemm_f32_dw_group_workspace_bytes(int n, const int* M, const int* N, int K, int splits) {
   if (n < 1 || n > 4 || K <= 0 || K % 32 || !M || !N) return 0;
   long tiles = 0, outs = 0;
+  if (dw_group_on_split_kernel(n, M, N, K)) {
+    for (int i = 0; i < n; ++i) {
+      if (M[i] <= 0 || N[i] <= 0) return 0;
+      tiles += (long)(M[i] / 128) * (N[i] / 128);
+      outs += (long)M[i] * N[i];
+    }
+    const int s = dw_group_plan_x3(tiles, K, splits);
+    return s > 1 ? (size_t)s * outs * sizeof(float) : 0;
+  }
   for (int i = 0; i < n; ++i) {
     if (M[i] <= 0 || N[i] <= 0 || M[i] % 128 || N[i] % 96) return 0;
     tiles += (long)(M[i] / 128) * (N[i] / 96);
@@ -1101,6 +1133,50 @@ int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const 
   if (n < 1 || n > 4 || K <= 0 || K % 32) return MTVAF_ERR_SHAPE;
   GemmArgs a = {};
   long tiles = 0, outs = 0;
+  for (int i = 0; i < n; ++i)
+    if (M[i] <= 0 || N[i] <= 0) return MTVAF_ERR_SHAPE;
+  if (dw_group_on_split_kernel(n, M, N, K)) {
+    for (int i = 0; i < n; ++i) {
+      if (lda[i] % 4 || ldb[i] % 4 || ldc[i] % 4 || (((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C[i]) & 15)) return MTVAF_ERR_ALIGN;
+      a.grp_tile_begin[i] = (int)tiles;
+      tiles += (long)(M[i] / 128) * (N[i] / 128);
+      outs += (long)M[i] * N[i];
+    }
+    for (int i = n; i < 4; ++i) a.grp_tile_begin[i] = INT_MAX;
+    splits = dw_group_plan_x3(tiles, K, splits);
+    if (splits > 1 && (size_t)splits * outs * sizeof(float) > workspace_bytes) return MTVAF_ERR_WORKSPACE;
+    float* slab = static_cast<float*>(workspace);
+    for (int i = 0; i < n; ++i) {
+      GemmProb& g = a.grp[i];
+      g.A = A[i]; g.B = B[i]; g.lda = lda[i]; g.ldb = ldb[i]; g.tiles_n = N[i] / 128;
+      if (splits > 1) {
+        g.C = slab; g.ldc = N[i]; g.slab_stride = (long)M[i] * N[i];
+        slab += (long)splits * M[i] * N[i];
+      } else {
+        g.C = C[i]; g.ldc = ldc[i]; g.slab_stride = 0;
+      }
+    }
+    a.ngrp = n;
+    a.A = a.grp[0].A; a.B = a.grp[0].B; a.C = a.grp[0].C;
+    a.M = M[0]; a.N = N[0]; a.K = K; a.lda = lda[0]; a.ldb = ldb[0]; a.ldc = a.grp[0].ldc;
+    a.k_chunk = (int)cdiv(cdiv(K, splits), 32) * 32;
+    a.epi = EPI_NONE; a.a_vec = a.b_vec = 1; a.tiles_n = a.grp[0].tiles_n;
+    a.klist = (klist && kcnt) ? klist : nullptr;
+    a.kcnt = a.klist ? kcnt : nullptr;
+    a.wide = 1;
+    a.trace = nullptr; a.tile_walk = 0;
+    const int key[8] = {1225, 1, 1, a.klist ? 10 : 2, (int)(outs / 768), 768, K, splits};  // (1000 + 225: the GROUP instantiation)
+    const int rec = prof_begin(key, stream);
+    const int rc = launch_gemm_f32x3_group(a, dim3((unsigned)tiles, 1, (unsigned)splits), stream);
+    prof_end(rec, stream);
+    if (rc != MTVAF_OK) return rc;
+    if (splits > 1)
+      for (int i = 0; i < n; ++i) {
+        const int r2 = launch_splitk_reduce(a.grp[i].C, splits, C[i], M[i], N[i], ldc[i], nullptr, 0, EPI_NONE, nullptr, 0, stream);
+        if (r2 != MTVAF_OK) return r2;
+      }
+    return MTVAF_OK;
+  }
   for (int i = 0; i < n; ++i) {
     if (M[i] <= 0 || N[i] <= 0 || M[i] % 128 || N[i] % 96) return MTVAF_ERR_SHAPE;
     if (lda[i] % 4 || ldb[i] % 4 || ldc[i] % 4 || (((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C[i]) & 15)) return MTVAF_ERR_ALIGN;

@@ -368,11 +368,17 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32x3_kernel(GemmArgs p) 
 // BN = 128: consumers as 2 x 2 wave tiles of 64 x 64.  BN = 96 (round 4): consumers as 4 x 1 wave tiles of 32 x 96 -- the tile of
 // the N = 768 / 2304 results of 4096 token rows (256 / 768 tiles = whole rounds of the 256 CUs, where 128 x 128 tiles are 192 /
 // 576: three quarters of the chip idle in the last round).
-template <bool A_KM, bool B_KM, bool KLIST, int BN>
+// GROUP (round 4): blockIdx.x walks the 128 x 128 tiles of up to four products that share the reduction axis -- the four weight
+// gradients of an encoder layer (36 + 144 + 144 + 108 tiles at BERT-base) -- back to back (GemmArgs::grp, as the fp32 pipe's
+// gemm_f32_dma_group_kernel): at 4096 token rows they fill 1.7 rounds of the CUs UNSPLIT, where one launch per product needs
+// 2 - 7 splits each to reach the idle CUs, pays the 6 us of prologue + epilogue per block that many times over and a slab
+// reduction launch per product on top.
+template <bool A_KM, bool B_KM, bool KLIST, int BN, bool GROUP = false>
 __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   using namespace x3;
   static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
   static_assert(BN == 128 || BN == 96, "consumer layouts exist for 128 x 128 and 128 x 96");
+  static_assert(!GROUP || (A_KM && B_KM && BN == 128), "grouped launches are weight gradients on 128 x 128 tiles");
   constexpr int BM = 128, BK = 32, LDH = BK + 8, NP = 256, NT = 512;
   constexpr int WN = BN == 128 ? 2 : 1, TM = BN == 128 ? 2 : 1, TN = BN == 128 ? 2 : 3;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH, BUF = 3 * (A_SZ + B_SZ);
@@ -385,9 +391,23 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   const bool consumer = wave < 4;
   const int wm = (wave & 3) / WN, wn = (wave & 3) % WN;
   const int li = lane & 31, h = lane >> 5;
-  const int bid = p.tile_walk > 0 ? xcd_remap_cols(blockIdx.x, gridDim.x, p.tiles_n, p.tile_walk) : xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / p.tiles_n) * BM;
-  const int n0 = (bid % p.tiles_n) * BN;
+  int bid = (!GROUP && p.tile_walk > 0) ? xcd_remap_cols(blockIdx.x, gridDim.x, p.tiles_n, p.tile_walk) : xcd_remap(blockIdx.x, gridDim.x);
+  const float* __restrict__ Ap = p.A;
+  const float* __restrict__ Bp = p.B;
+  float* Cp = p.C;
+  int lda = p.lda, ldb = p.ldb, ldc = p.ldc, tiles_n = p.tiles_n;
+  long slab_stride = p.slab_stride;
+  if constexpr (GROUP) {
+    // (a run-time index into the kernel-argument segment: scalar loads on demand)
+    const int q = (bid >= p.grp_tile_begin[1]) + (bid >= p.grp_tile_begin[2]) + (bid >= p.grp_tile_begin[3]);
+    const GemmProb& pb = p.grp[q];
+    bid -= p.grp_tile_begin[q];
+    Ap = pb.A; Bp = pb.B; Cp = pb.C;
+    lda = pb.lda; ldb = pb.ldb; ldc = pb.ldc; tiles_n = pb.tiles_n;
+    slab_stride = pb.slab_stride;
+  }
+  const int m0 = (bid / tiles_n) * BM;
+  const int n0 = (bid % tiles_n) * BN;
   int kbeg = blockIdx.z * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
   int nk = (kend - kbeg) / BK;
@@ -468,8 +488,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
       int k0;
       if constexpr (KLIST) k0 = p.klist[lbeg + kt] * BK;
       else k0 = kbeg + kt * BK;
-      g_load<BM, NP, A_KM, BK>(ra, p.A, p.lda, m0, k0, ptid);
-      g_load<BN, NP, B_KM, BK>(rb, p.B, p.ldb, n0, k0, ptid);
+      g_load<BM, NP, A_KM, BK>(ra, Ap, lda, m0, k0, ptid);
+      g_load<BN, NP, B_KM, BK>(rb, Bp, ldb, n0, k0, ptid);
     };
     auto stage_all = [&](int buf, const f32x4* ra, const f32x4* rb) __attribute__((always_inline)) {
 #pragma unroll
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   {
     constexpr int LDE = BN + 4, RP = 64, C4 = BN / 4;
     float* smem = reinterpret_cast<float*>(smem_raw);
-    float* C = p.C + (long)blockIdx.z * p.slab_stride;
+    float* C = Cp + (long)blockIdx.z * slab_stride;
     const bool split = gridDim.z > 1;
     const int wrow = wm * TM * 32;  // first result row of this consumer wave inside the tile
 #pragma unroll
@@ -556,9 +576,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
             v = v * (1.f - t * t);
           }
-          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * p.ldc + col);
+          if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * ldc + col);
         }
-        *reinterpret_cast<f32x4*>(C + row * p.ldc + col) = v;
+        *reinterpret_cast<f32x4*>(C + row * ldc + col) = v;
       }
     }
   }
@@ -589,6 +609,27 @@ static int launch_x3_ws(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_
   return MTVAF_OK;
 }
 
+
+// the grouped weight-gradient launch (GemmArgs::grp filled by mtvaf_gemm_f32_dw_group; no bias / activation)
+int launch_gemm_f32x3_group(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  const size_t smem = (size_t)2 * 3 * (128 + 128) * 40 * sizeof(__bf16);
+#define MTVAF_X3_GRP(KL)                                                                                             \
+  do {                                                                                                               \
+    auto kern = gemm_f32x3_ws_kernel<true, true, KL, 128, true>;                                                     \
+    static bool attr_set = false;                                                                                    \
+    if (!attr_set) {                                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);  \
+      if (e != hipSuccess) return (int)e;                                                                            \
+      attr_set = true;                                                                                               \
+    }                                                                                                                \
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);                                                          \
+  } while (0)
+  if (a.klist) MTVAF_X3_GRP(true);
+  else MTVAF_X3_GRP(false);
+#undef MTVAF_X3_GRP
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
 
 template <int BM, int BN, int WM, int WN, int BK>
 static int launch_x3_tile(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {

@@ -806,7 +806,7 @@ class EncoderFunction(torch.autograd.Function):
                                        off + 2, dbias_x=G[13])
                 dpre = _empty(M, I, like=dev_like)
                 # (few token rows: the layer's four weight gradients as ONE launch -- the same rule as csrc/executor.hip)
-                grp = M <= hip.dw_group_rows() and M % 32 == 0 and H % 128 == 0 and I % 128 == 0 and H % 96 == 0 and I % 96 == 0
+                grp = hip.dw_group_wanted(M, H, I)
                 if not grp:
                     on_side((df,), lambda: hip.linear_bwd_weight(df, act, G[12], ktiles=ktiles))
                 hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)

@@ -90,6 +90,7 @@ _SIGS = {
     "mtvaf_gemm_f32_dw_group": (c_int, [I, P, P, P, P, P, P, P, P, I, P, P, P, SZ, I, P]),
     "mtvaf_gemm_f32_dw_group_workspace_bytes": (SZ, [I, P, P, I, I]),
     "mtvaf_dw_group_rows": (c_int, [I]),
+    "mtvaf_dw_group_wanted": (c_int, [I, I, I]),
     "mtvaf_streamk_attach": (c_int, [P, SZ, P]),
     "mtvaf_streamk_scratch_bytes": (SZ, [I]),
     "mtvaf_streamk_attached": (c_int, [P]),
@@ -232,6 +233,8 @@ def kernel_symbol(cfg, la, lb, fast):
             16: (64, 64, 2, 2), 17: (64, 64, 2, 2)}.get(cfg)
     b = lambda x: "true" if x else "false"
     klist, fast = bool(fast & 8), fast & 7  # (+8: the launch walked a k-tile list)
+    if cfg == 1225:  # the grouped weight-gradient launch of the wave-specialised split kernel (mtvaf_gemm_f32_dw_group)
+        return f"gemm_f32x3_ws_kernel<true, true, {b(klist)}, 128, true>"
     if cfg >= 1000:  # the grouped weight-gradient launch of the fp32 LDS-DMA kernel (mtvaf_gemm_f32_dw_group)
         return f"gemm_f32_dma_group_kernel<128, 96, 4, 1, 2, {b(klist)}>"
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>
@@ -242,7 +245,7 @@ def kernel_symbol(cfg, la, lb, fast):
         return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}, {b(klist)}>"
     if cfg >= 200:  # split-fp32 kernels (csrc/gemm_f32x3.hip): +20 the wave-specialised kernel
         if cfg in (225, 226):
-            return f"gemm_f32x3_ws_kernel<{b(la)}, {b(lb)}, {b(klist)}, {128 if cfg == 225 else 96}>"
+            return f"gemm_f32x3_ws_kernel<{b(la)}, {b(lb)}, {b(klist)}, {128 if cfg == 225 else 96}, false>"
         d = (64, 64, 2, 2) if cfg == 203 else ((128, 96, 4, 1) if cfg == 206 else (128, 128, 2, 2))
         return f"gemm_f32x3_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(klist)}, 32>"
     if cfg >= 100:
@@ -656,6 +659,13 @@ def dw_group_rows(rows: int = -1) -> int:
     """fp32 mode: layers of at most this many token rows send their four weight-gradient products as one grouped launch
     (csrc/executor.hip: mtvaf_dw_group_rows; default 1024, MTVAF_DW_GROUP_ROWS).  rows >= 0 sets it."""
     return lib().mtvaf_dw_group_rows(rows)
+
+
+def dw_group_wanted(rows: int, H: int, I: int) -> bool:
+    """fp32 mode: does a layer of `rows` token rows send its four weight gradients as one grouped launch?  (The rule of
+    csrc/executor.hip: few-token layers on the fp32 pipe's grouped ring; under the split arithmetic also longer ones, unsplit,
+    on the split kernel's GROUP form.)"""
+    return bool(lib().mtvaf_dw_group_wanted(rows, H, I))
 
 
 def gemm_f32_dw_group(items, K, ktiles=None, splits=-1):

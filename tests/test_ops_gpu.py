@@ -1076,6 +1076,25 @@ def test_gemm_f32_dw_group(hip, T):
         hip.gemm_f32_dw_group(two, T, ktiles=kt)
         close(two[0][2], refs[2], rtol=2e-5, name="two products: first")
         close(two[1][2], refs[1], rtol=2e-5, name="two products: second")
+    # which kernel: long reductions under the split arithmetic go to the split kernel's GROUP form, unsplit by plan at these
+    # 432 tiles; few-token layers and the fp32 pipe keep the LDS-DMA ring -- and both produce the products above
+    was = hip.f32_split()
+    try:
+        for mode in (True, False):
+            hip.f32_split(mode)
+            hip.prof_start(8)
+            hip.gemm_f32_dw_group(items, T, ktiles=kt)
+            recs = hip.prof_stop(8)
+            assert len(recs) == 1
+            on_split = mode and T > 1024
+            assert recs[0][0]["cfg"] == (1225 if on_split else 1012), recs
+            if on_split:
+                assert recs[0][0]["splits"] == 1
+            for (_, _, o), r in zip(items, refs):
+                close(o, r, rtol=2e-5, name=f"dW {tuple(o.shape)} over {T} rows, split arithmetic {mode}")
+            assert hip.dw_group_wanted(T, H, I) == (T <= 1024 or mode)
+    finally:
+        hip.f32_split(was)
     with pytest.raises(RuntimeError):
         hip.gemm_f32_dw_group([(d[0][:, :64], d[3], torch.empty(64, H, device=DEV))], T)  # M % 128 != 0
     with pytest.raises(RuntimeError):
