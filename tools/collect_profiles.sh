@@ -29,6 +29,8 @@ python bench.py --steps 5 --warmup 4 --batch 128 --seq 512 --no-cpu-baseline --n
 python tools/f32x3_bench.py > $O/${T}_f32x3_microbench.txt 2>/dev/null
 python tools/x3_trace.py 4096 3072 768 5 > $O/${T}_x3_trace.txt 2>/dev/null
 python tools/x3_trace.py 4096 768 768 6 >> $O/${T}_x3_trace.txt 2>/dev/null
+# sustained bf16 MFMA rate of the whole chip (hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 tools/micro/mfma_bf16_rate.hip)
+[ -x tools/micro/mfma_bf16_rate ] && tools/micro/mfma_bf16_rate > $O/${T}_mfma_bf16_rate.txt 2>&1
 fi
 if [ $PHASE = stats ]; then
 stats fp32 MTVAF_DW_STREAM=1
