@@ -755,8 +755,15 @@ static bool x3_tile96_ok(int M, int N, int la, int lb) {
   return M % 128 == 0 && N % 96 == 0 && (tile96 == 2 || (tile96 == 1 && la == 0 && lb == 0));
 }
 
+// 128x128 tiles of the wave-specialised split kernel may hang over the result (clamped loads, guarded stores): any M, N that
+// are multiples of 4 and at least one tile -- the prompt generator's N = 800 (MTVAF_X3_RAGGED=0: whole tiles only)
+static bool x3_ragged_ok(int M, int N) {
+  static const int on = [] { const char* e = getenv("MTVAF_X3_RAGGED"); return e ? atoi(e) : 1; }();
+  return on && M % 4 == 0 && N % 4 == 0 && M >= 128 && N >= 128;
+}
+
 static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi, int* cfg_out, int* splits_out,
-                   int compute = 0) {
+                   int compute = 0, int ragged5 = 0) {
   //                                  128x128 128x96 128x288 64x64 128x64 128x128x32 128x96x32 128x192 128x192x32
   static const double eff_base[kNumCfgs] = {0.80, 0.86, 0.72, 0.45, 0.80, 0.70, 1.00, 0.92, 0.78,
                                             1.18, 1.00, 0.85,   // 9..11: LDS-DMA pipeline
@@ -783,7 +790,7 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
     // (the 128x96 split tile: forward products only by default -- with a k-major B operand or as a weight gradient it
     // measured level or behind 128x128 + split-K in the bench step; MTVAF_X3_TILE96 = 0 never, 2 every layout)
     const bool c6_ok = x3_tile96_ok(M, N, la, lb);
-    if (compute == 2 && !((c == 5 && M % 128 == 0 && N % 128 == 0) || (c == 6 && c6_ok) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
+    if (compute == 2 && !((c == 5 && ((M % 128 == 0 && N % 128 == 0) || ragged5)) || (c == 6 && c6_ok) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute != 0 ? 32 : kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
     const int max_s = allow_split ? 16 : 1;
@@ -896,29 +903,34 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     if (!ok) compute = 0;
     if (compute == 1 && !(cfg == 6 || cfg == 5 || cfg == 3)) cfg = -1;
   }
+  bool rag5 = false;
   if (compute == 2) {
     // the split kernels take whole 64x64 tiles of k-aligned, vector-loadable operands; anything else runs the fp32 pipe
     const bool can5 = M % 128 == 0 && N % 128 == 0, can3 = M % 64 == 0 && N % 64 == 0;
     const bool can6 = M % 128 == 0 && N % 96 == 0;  // (forced; the planner takes it where x3_tile96_ok says so)
-    const bool forced = (cfg == 5 && can5) || (cfg == 6 && can6) || (cfg == 3 && can3);
-    const bool plannable = can5 || can3 || x3_tile96_ok(M, N, layout_a, layout_b);
+    // 128x128 tiles that hang over the result: the wave-specialised kernel only (it needs the wide epilogue's alignment)
+    rag5 = !can5 && x3_ragged_ok(M, N) && (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) &&
+           (!aux || ((ldaux % 4 == 0) && (((uintptr_t)aux & 15) == 0))) && (!bias || (((uintptr_t)bias & 15) == 0));
+    const bool forced = (cfg == 5 && (can5 || rag5)) || (cfg == 6 && can6) || (cfg == 3 && can3);
+    const bool plannable = can5 || rag5 || can3 || x3_tile96_ok(M, N, layout_a, layout_b);
     const bool ok = (K % 32 == 0) && (forced || plannable) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
                     (((uintptr_t)B & 15) == 0) && !(layout_a == 1 && layout_b == 0);
     // (few output tiles -- the 256-token products of BASELINE configs[0] -- leave most CUs without a block of the 128x128
     // kernel: the fp32 pipe's 64x64 tiles are faster there, measured 4.37 vs 4.53 ms per C1 step)
     const long tiles96 = can6 ? (long)(M / 128) * (N / 96) : 0;
-    const long tiles = std::max((long)(M / 128) * (N / 128), tiles96);
+    const long tiles = std::max(rag5 ? cdiv(M, 128) * cdiv(N, 128) : (long)(M / 128) * (N / 128), tiles96);
     // ... unless the reduction is deep enough for split-K to fill the chip anyway (the [768 x 768] weight gradient over 4096
     // token rows: 36 tiles x 7 splits, 38-41 us against 46-51 on the fp32 pipe)
     const bool deep = allow_split && splittable(epi) && K >= 2048 && tiles * std::min(16, K / 256) >= 192;
     if (!ok || (!forced && tiles < 96 && !deep)) compute = 0;
     if (compute == 2 && !forced) cfg = -1;
+    if (compute != 2) rag5 = false;
   }
   if (!A || !B || !C) return MTVAF_ERR_ARG;
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
   if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1) return MTVAF_ERR_ARG;
   int c_auto, s_auto;
-  choose(M, N, K, allow_split && splittable(epi), layout_a, layout_b, epi, &c_auto, &s_auto, compute);
+  choose(M, N, K, allow_split && splittable(epi), layout_a, layout_b, epi, &c_auto, &s_auto, compute, rag5);
   const bool cfg_forced = cfg >= 0 && cfg < kNumCfgs;
   if (!cfg_forced) cfg = c_auto;
   if (splits <= 0) splits = s_auto;
@@ -953,9 +965,11 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
                     (layout_b == 0 || N % 4 == 0) && M >= 4 && N >= 4;
   const bool aligned = fast && (M % bm == 0) && (N % bn == 0);
   const int mode = aligned ? 2 : (fast ? 1 : 0);
-  a.wide = aligned && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) &&
+  // (rag5: the wave-specialised kernel guards its stores, so the wide epilogue does not need whole tiles there)
+  a.wide = (aligned || (rag5 && cfg == 5 && fast)) && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) &&
            (!aux || ((ldaux % 4 == 0) && (((uintptr_t)aux & 15) == 0))) && (!bias || (((uintptr_t)bias & 15) == 0)) &&
            (a.slab_stride % 4 == 0);
+  if (compute == 2 && cfg == 5 && rag5 && !a.wide) return MTVAF_ERR_ALIGN;  // (only the guarded epilogue may hang over the result)
   if (compute == 0 && cfg >= kFirstDma && !(aligned && !(layout_a == 1 && layout_b == 0))) {
     if (cfg_forced) return MTVAF_ERR_SHAPE;
     static const int staged_twin[9] = {6, 5, 8, 6, 5, 4, 4, 3, 3};  // same tile, register-staged kernel (handles any alignment)

@@ -88,14 +88,17 @@ __device__ __forceinline__ void km_unit(int u, int& kq, int& c4) {
 
 // global -> registers (whole tiles only: the launcher checks alignment).  KC: float4 idx -> (row = idx / (BK/4), k = (idx %
 // (BK/4)) * 4).  KM: unit u -> (k quad kq, 4 rows c4; km_unit): four float4 (the same 4 rows at k .. k + 3).
+// rlim: the last row a load may start at (KC: rows - 1, KM: rows - 4; default: no limit) -- tiles that hang over the operand
+// (ragged results of the wave-specialised kernel) re-read its last rows, finite values whose products are never stored; the
+// clamp is loop-invariant (only k0 moves), so the k-loop does not see it.
 template <int ROWS, int NT, bool KM, int BK>
-__device__ __forceinline__ void g_load(f32x4* reg, const float* base, int ld, int r0, int k0, int tid) {
+__device__ __forceinline__ void g_load(f32x4* reg, const float* base, int ld, int r0, int k0, int tid, int rlim = 0x7fffffff) {
   if constexpr (!KM) {
 #pragma unroll
     for (int i = 0; i < Stage<ROWS, NT, KM, BK>::NKC; ++i) {
       const int idx = tid + i * NT;
       const int row = BK == 32 ? kc_row(idx >> 3) : idx / (BK / 4);
-      reg[i] = *reinterpret_cast<const f32x4*>(base + (long)(r0 + row) * ld + k0 + (idx % (BK / 4)) * 4);
+      reg[i] = *reinterpret_cast<const f32x4*>(base + (long)min(r0 + row, rlim) * ld + k0 + (idx % (BK / 4)) * 4);
     }
   } else {
 #pragma unroll
@@ -104,7 +107,7 @@ __device__ __forceinline__ void g_load(f32x4* reg, const float* base, int ld, in
       if (Stage<ROWS, NT, KM, BK>::UNITS % NT != 0 && u >= Stage<ROWS, NT, KM, BK>::UNITS) continue;
       int kq, c4;
       km_unit<BK>(u, kq, c4);
-      const float* q = base + (long)(k0 + 4 * kq) * ld + r0 + c4;
+      const float* q = base + (long)(k0 + 4 * kq) * ld + min(r0 + c4, rlim);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) reg[4 * i + kk] = *reinterpret_cast<const f32x4*>(q + (long)kk * ld);
     }
@@ -488,8 +491,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
       int k0;
       if constexpr (KLIST) k0 = p.klist[lbeg + kt] * BK;
       else k0 = kbeg + kt * BK;
-      g_load<BM, NP, A_KM, BK>(ra, Ap, lda, m0, k0, ptid);
-      g_load<BN, NP, B_KM, BK>(rb, Bp, ldb, n0, k0, ptid);
+      g_load<BM, NP, A_KM, BK>(ra, Ap, lda, m0, k0, ptid, GROUP ? 0x7fffffff : p.M - (A_KM ? 4 : 1));
+      g_load<BN, NP, B_KM, BK>(rb, Bp, ldb, n0, k0, ptid, GROUP ? 0x7fffffff : p.N - (B_KM ? 4 : 1));
     };
     auto stage_all = [&](int buf, const f32x4* ra, const f32x4* rb) __attribute__((always_inline)) {
 #pragma unroll
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
         f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
         const long row = m0 + pass * RP + r;
         const int col = n0 + c;
+        if (!GROUP && (row >= p.M || col >= p.N)) continue;  // (a tile that hangs over the result: N, ldc multiples of 4)
         if (!split) {
           if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
           if (p.epi == EPI_GELU) {

@@ -1117,7 +1117,8 @@ def _x3_operands(M, N, K, la, lb, seed, spread=0):
 @pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K,spread,tile", [(512, 768, 768, 0, 5), (256, 384, 3072, 12, 5), (128, 128, 32, 30, 5), (192, 320, 96, 6, 3),
                                                (1024, 1536, 256, 3, 5), (512, 768, 768, 0, 6), (256, 384, 3072, 12, 6),
-                                               (128, 96, 32, 30, 6), (1024, 1536, 256, 3, 6)])
+                                               (128, 96, 32, 30, 6), (1024, 1536, 256, 3, 6),
+                                               (1152, 800, 384, 3, 5), (132, 388, 96, 12, 5)])  # (tiles that hang over the result)
 def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread, tile):
     """fp32 GEMM by three-way bf16 operand splitting (mtvaf_gemm_f32x3, csrc/gemm_f32x3.hip) is an fp32 GEMM: against the fp64
     product its error is bounded element-wise by a few fp32 roundings of |A|.|B| (the six partial products are exact, the
@@ -1137,6 +1138,43 @@ def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread, tile):
     assert float(e_spl.max()) <= 2.0 ** -24 * (4 + K ** 0.5), (float(e_spl.max()), float(e_nat.max()))
     assert float(e_spl.max()) <= 1.25 * float(e_nat.max()) + 2.0 ** -25, (float(e_spl.max()), float(e_nat.max()))
     assert float(e_spl.pow(2).mean().sqrt()) <= 1.1 * float(e_nat.pow(2).mean().sqrt()) + 2.0 ** -27
+
+
+@pytest.mark.parametrize("la,lb,M,N,K", [(0, 0, 1152, 800, 3840), (0, 1, 1152, 800, 6144), (1, 1, 6144, 800, 1152), (1, 1, 800, 3840, 1152),
+                                          (0, 0, 260, 132, 64)])
+def test_gemm_f32_split_ragged_tiles(hip, la, lb, M, N, K):
+    """128 x 128 tiles of the wave-specialised split kernel that hang over the result (M, N multiples of 4: the prompt
+    generator's 800-wide hidden layer, `models/bert_model.py:63-111`): clamped operand loads, guarded stores.  The library picks
+    the kernel by itself for the four prompt-generator products; every epilogue and a split reduction give the values of the
+    fp64 product; nothing is written outside the result (guard bands around a strided output stay NaN)."""
+    a, b, ref, _ = _x3_operands(M, N, K, la, lb, seed=3 * M + N + K)
+    bias = rnd(N, seed=5).to(DEV)
+    was = hip.f32_split()
+    try:
+        hip.f32_split(True)
+        big = torch.full((M + 8, N + 8), float("nan"), device=DEV)  # the result inside a wider, taller buffer (ldc = N + 8)
+        rows = big[4:4 + M]
+        hip.prof_start(4)
+        hip.gemm(a, la, b, lb, rows, M, N, K, bias=bias, allow_split=True, ldc=N + 8)
+        recs = hip.prof_stop(4)
+        if M * N >= 96 * 128 * 128:
+            assert recs[0][0]["cfg"] == 225, recs  # (chosen by the library, not forced)
+        close(rows[:, :N], ref + bias.double().cpu(), rtol=3e-6, name="ragged, bias")
+        guard = big.clone()
+        guard[4:4 + M, :N] = float("nan")
+        assert bool(torch.isnan(guard).all())  # nothing outside the result was written
+        for sp in (1, 3):
+            aux = torch.full((M, N), float("nan"), device=DEV)
+            out2 = torch.full((M, N), float("nan"), device=DEV)
+            hip.gemm(a, la, b, lb, out2, M, N, K, bias=bias, epi=hip.EPI_GELU, aux=aux, allow_split=True, splits=sp, compute="fp32x3", cfg=5)
+            close(aux, ref + bias.double().cpu(), rtol=3e-6, name=f"ragged, saved pre-activation, splits {sp}")
+            close(out2, torch.nn.functional.gelu(ref + bias.double().cpu()), rtol=3e-6, name=f"ragged, GELU, splits {sp}")
+        acc0 = rnd(M, N, seed=6).to(DEV)
+        out3 = acc0.clone()
+        hip.gemm(a, la, b, lb, out3, M, N, K, accumulate=True, compute="fp32x3", cfg=5)
+        close(out3, ref + acc0.double().cpu(), rtol=3e-6, name="ragged, accumulate")
+    finally:
+        hip.f32_split(was)
 
 
 @pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])

@@ -1,40 +1,52 @@
-"""Host enqueue time vs GPU time of a training step: is a configuration launch-bound?
-    python tools/host_time.py [--dtype bf16] [--batch 32] [--seq 128] [--aux 8]
-Enqueues N steps WITHOUT reading the tags (no host sync), measures the Python time to enqueue them and the GPU time to
-drain them; also a cProfile of the enqueue loop."""
-import argparse, cProfile, os, pstats, sys, time, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import bench
-ap = argparse.ArgumentParser()
-ap.add_argument("--dtype", default="fp32"); ap.add_argument("--batch", type=int, default=32)
-ap.add_argument("--seq", type=int, default=128); ap.add_argument("--aux", type=int, default=8)
-ap.add_argument("--profile", action="store_true")
-a = ap.parse_args()
-from mtvaf_amd import hip
-from mtvaf_amd.optim import AdamW
-hip.set_compute_dtype(a.dtype)
-dev = "cuda"
-model, cfg = bench.build_model(dev, "bert", a.seq)
+"""Host time to ENQUEUE the phases of one training step of the bench workload (no synchronisation inside the loop) against
+the GPU's time per step: is the step GPU-bound, and how far ahead does the host run?
+
+    python tools/host_time.py [steps]
+"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from mtvaf_amd.optim import AdamW  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+dev = torch.device("cuda:0")
+model, cfg = bench.build_model(dev, "bert", 128)
 model.train()
-ids, mask, tt, labels, feats, aux = bench.synthetic_batch(a.batch, a.seq, a.aux, cfg.vocab_size, 0, dev)
-opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, model=model, overlap=True)
-def step():
-    out = model(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
-    out.loss.backward(); opt.step(); opt.zero_grad(set_to_none=True)
-    return out
-for _ in range(5): step()
+opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model, overlap=True)
+ids, mask, tt, labels, feats, aux = bench.synthetic_batch(32, 128, 8, cfg.vocab_size, 1234, dev)
+kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None, images=feats, aux_imgs=aux)
+acc = [0.0] * 5
+
+
+def step(timed):
+    t = [time.perf_counter()]
+    out = model(**kw); t.append(time.perf_counter())
+    out.loss.backward(); t.append(time.perf_counter())
+    opt.step(); t.append(time.perf_counter())
+    opt.zero_grad(set_to_none=True); t.append(time.perf_counter())
+    n = len(out.logits); t.append(time.perf_counter())  # waits for this step's Viterbi copy (the trainer reads the tags)
+    assert n == 32
+    if timed:
+        for i in range(5):
+            acc[i] += t[i + 1] - t[i]
+
+
+for _ in range(5):
+    step(False)
 torch.cuda.synchronize()
-N = 10
 t0 = time.perf_counter()
-outs = [step() for _ in range(N)]
-t1 = time.perf_counter()
+for _ in range(steps):
+    step(True)
+t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f"{a.dtype} B={a.batch} S={a.seq}: host enqueue {1e3 * (t1 - t0) / N:.2f} ms/step, drained after {1e3 * (t2 - t0) / N:.2f} ms/step "
-      f"({'HOST-bound' if (t2 - t1) < 0.1 * (t1 - t0) else 'GPU-bound'})")
-if a.profile:
-    pr = cProfile.Profile(); pr.enable()
-    for _ in range(10): step()
-    pr.disable(); torch.cuda.synchronize()
-    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
+t_all = time.perf_counter() - t0
+names = ["forward", "backward", "optimizer.step", "zero_grad", "wait for the tags"]
+print(f"{steps} steps: {1e3 * t_all / steps:.3f} ms per step on the GPU's clock; host loop {1e3 * t_host / steps:.3f} ms per step, of which")
+for n, a in zip(names, acc):
+    print(f"  {n:18s} {1e3 * a / steps:7.3f} ms")
+print(f"  host work without the wait: {1e3 * sum(acc[:4]) / steps:.3f} ms")
