@@ -161,6 +161,16 @@ int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res
                              float* dgamma, float* dbeta, float* dbias_x, int accumulate, int M, int H, float p_drop,
                              uint64_t seed, uint64_t offset, void* workspace, size_t workspace_bytes,
                              void* dx_bf16 /* nullable: dx rounded to bf16; dx may then be NULL */, mtvaf_stream_t stream);
+/* The two halves of mtvaf_dropout_res_ln_bwd as separate calls: _rows writes dx / dres and per-block partial sums into `part`
+ * (mtvaf_ln_bwd_workspace_bytes(M, H) bytes, the caller's until _finish has run); _finish reduces them, in fixed order, into
+ * dgamma / dbeta / dbias_x.  The layer executor runs _finish on its weight-gradient stream: the sums feed parameter
+ * gradients only (autograd backward of modeling_bert.py:354-355, 434-435). */
+int mtvaf_dropout_res_ln_bwd_rows(const float* dout, const float* x, const float* res, const float* gamma, const float* mean,
+                                  const float* rstd, float* dx, float* dres, int dres_accumulate, int M, int H, float p_drop,
+                                  uint64_t seed, uint64_t offset, float* part, void* dx_bf16 /* nullable */,
+                                  mtvaf_stream_t stream);
+int mtvaf_dropout_res_ln_bwd_finish(const float* part, int M, int H, float* dgamma, float* dbeta, float* dbias_x /* nullable */,
+                                    int accumulate, mtvaf_stream_t stream);
 
 /* ---- small reductions / elementwise ---------------------------------------------------------------------
  * bias gradients (column sums of dY) and nn.Dropout on the sequence output (bert_model.py:506). */
@@ -393,6 +403,9 @@ typedef struct {
    * mode, 64-row tiles in bf16 mode) */
   const int* klist;
   const int* kcnt;
+  /* optional (both or neither): the layer's own LayerNorm-backward partials of the FFN / attention block,
+   * mtvaf_ln_bwd_workspace_bytes(M, H) each -- their column sums then run on `side` instead of the main chain */
+  float *lnpart2, *lnpart1;
 } mtvaf_layer_grads_t;
 
 int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* layer, mtvaf_stream_t stream);

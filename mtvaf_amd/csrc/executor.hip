@@ -70,6 +70,11 @@ int mtvaf_prefix_attn_bf16_varlen_bwd(const void* dctx16, const void* qkv16, con
 int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                              float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
                              uint64_t offset, void* out_bf16, hipStream_t st);
+int mtvaf_dropout_res_ln_bwd_rows(const float* dout, const float* x, const float* res, const float* gamma, const float* mean,
+                                  const float* rstd, float* dx, float* dres, int dres_accumulate, int M, int H, float p_drop,
+                                  uint64_t seed, uint64_t offset, float* part, void* dx_bf16, hipStream_t st);
+int mtvaf_dropout_res_ln_bwd_finish(const float* part, int M, int H, float* dgamma, float* dbeta, float* dbias_x, int accumulate,
+                                    hipStream_t st);
 int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma, const float* mean,
                              const float* rstd, float* dx, float* dres, int dres_accumulate, float* dgamma, float* dbeta,
                              float* dbias_x, int accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset,
@@ -149,6 +154,8 @@ struct mtvaf_layer_grads_t {
   void* ws_side; size_t ws_side_bytes;         // scratch of the second stream (split-K slabs, column-sum partials)
   const int* klist;                            // optional: k-tile list of the token axis for the dW products (32-row tiles in fp32 mode, 64 in bf16)
   const int* kcnt;
+  float *lnpart2, *lnpart1;                    // optional (both or neither): per-layer LayerNorm-backward partials of the FFN / attention
+                                               // block (mtvaf_ln_bwd_workspace_bytes each) -- their column sums then run on `side`
 };
 
 int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
@@ -232,6 +239,22 @@ int mtvaf_dw_group_wanted(int rows, int H, int I) {
   return (x3_group && rows > 1024 && mtvaf_f32_split(-1)) ? 1 : 0;
 }
 
+// LayerNorm backward of one block of the layer, then the fork the weight gradients behind it need anyway.  With per-layer
+// partial buffers (g->lnpart*) and a second stream, the column sums (dgamma, dbeta, the dense bias gradient: parameter
+// gradients only) run THERE: 24 launches of ~12 us leave the main chain of a step.
+static int ln_bwd_forked(const float* dout, const float* x, const float* res, const float* gamma, const float* mean, const float* rstd,
+                         float* dx, float* dres, float* dgamma, float* dbeta, float* dbias, int M, int H, float p_drop, uint64_t seed,
+                         uint64_t offset, float* part, void* ws, size_t ws_bytes, void* dx16, hipStream_t mainS, hipStream_t side) {
+  if (part && side != mainS) {
+    MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows(dout, x, res, gamma, mean, rstd, dx, dres, 0, M, H, p_drop, seed, offset, part, dx16, mainS));
+    MTVAF_TRY(fork_to(mainS, side));
+    return mtvaf_dropout_res_ln_bwd_finish(part, M, H, dgamma, dbeta, dbias, 0, side);
+  }
+  MTVAF_TRY(mtvaf_dropout_res_ln_bwd(dout, x, res, gamma, mean, rstd, dx, dres, 0, dgamma, dbeta, dbias, 0, M, H, p_drop, seed, offset, ws,
+                                     ws_bytes, dx16, mainS));
+  return fork_to(mainS, side);
+}
+
 // Backward of one layer.  g->dh holds d loss / d h2 on entry and d loss / d x on return.  `settle` != 0: the second stream
 // additionally waits for the layer's LAST main-stream kernel (an optimizer update hanging off the caller's hook must be
 // behind every product that still reads the weights).
@@ -244,9 +267,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     // tokens cut in two, combined inside the launch) when a stream-K scratch is attached to the second stream: 36 + 36 + 27 + 9
     // output tiles fill 256 CUs together, not one product at a time.  Enqueued behind the last of their operands (dqkv).
     const bool grp = mtvaf_streamk_attached(side) > 0 && !g->klist && M % 256 == 0 && H % 256 == 0 && I % 256 == 0;
-    MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0,
-                                       M, H, L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, g->df, mainS));
-    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(ln_bwd_forked(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, g->dg2, g->db2, g->dbi2, M, H, L->p_hidden,
+                            L->seed, L->offset + 2, g->lnpart2, g->ws_main, g->ws_main_bytes, g->df, mainS, side));
     if (!grp) MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->df, H, L->act, I, g->dw2, I, nullptr, 0, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->df, H, L->w2_h, I, nullptr, 0, g->dpre, I, M, I, H, nullptr, X_EPI_DGELU, L->pre, I, 0,
@@ -257,9 +279,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
                                nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->dpre, I, L->w1_h, H, g->dh1, H, nullptr, 0, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1,
                                nullptr, 0, nullptr, 0, 0, -1, 0, mainS));
-    MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, nullptr, g->dh, 0, g->dg1, g->db1, g->dbo, 0, M,
-                                       H, L->p_hidden, L->seed, L->offset + 1, g->ws_main, g->ws_main_bytes, g->da, mainS));
-    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(ln_bwd_forked(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, nullptr, g->dh, g->dg1, g->db1, g->dbo, M, H, L->p_hidden,
+                            L->seed, L->offset + 1, g->lnpart1, g->ws_main, g->ws_main_bytes, g->da, mainS, side));
     if (!grp) MTVAF_TRY(mtvaf_gemm_bf16x_ktiles(X_KM, X_KM, g->da, H, L->cx, H, g->dwo, H, nullptr, 0, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0,
                                nullptr, 1, g->ws_side, g->ws_side_bytes, 0, -1, 0, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_bf16x(X_KC, X_KM, g->da, H, L->wo_h, H, nullptr, 0, g->dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0,
@@ -297,9 +318,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     float* pre = static_cast<float*>(L->pre);
     const float* act = static_cast<const float*>(L->act);
     const bool grp = mtvaf_dw_group_wanted(M, H, I) != 0;
-    MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, 0, g->dg2, g->db2, g->dbi2, 0, M, H,
-                                       L->p_hidden, L->seed, L->offset + 2, g->ws_main, g->ws_main_bytes, nullptr, mainS));
-    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(ln_bwd_forked(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, g->dg2, g->db2, g->dbi2, M, H, L->p_hidden, L->seed,
+                            L->offset + 2, g->lnpart2, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
     if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, df, H, act, I, g->dw2, I, H, I, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, df, H, L->w2, I, dpre, I, M, I, H, nullptr, X_EPI_DGELU, pre, I, 0, 1, g->ws_main, g->ws_main_bytes, -1, -1,
@@ -310,9 +330,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dpre, I, L->w1, H, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, 1, g->ws_main,
                              g->ws_main_bytes, -1, -1, mainS));
-    MTVAF_TRY(mtvaf_dropout_res_ln_bwd(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, 0, g->dg1, g->db1, g->dbo, 0, M, H,
-                                       L->p_hidden, L->seed, L->offset + 1, g->ws_main, g->ws_main_bytes, nullptr, mainS));
-    MTVAF_TRY(fork_to(mainS, side));
+    MTVAF_TRY(ln_bwd_forked(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, g->dg1, g->db1, g->dbo, M, H, L->p_hidden, L->seed,
+                            L->offset + 1, g->lnpart1, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
     if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, da, H, cx, H, g->dwo, H, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, da, H, L->wo, H, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_main,

@@ -589,6 +589,33 @@ int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamm
 // dgamma/dbeta: overwritten (accumulate = 0) or added to.  dres_accumulate: dres += instead of =.
 // dbias_x (nullable): column sums of dx, i.e. the bias gradient of the dense layer whose output is x.
 // dx_bf16 (nullable): dx rounded to bf16 (mixed-precision mode: dx is only a GEMM operand downstream); dx may then be NULL.
+// The two halves of mtvaf_dropout_res_ln_bwd as separate calls (the executor runs the second on its weight-gradient stream: the
+// column sums feed parameter gradients only, nothing on the main chain waits for them): _rows writes dx / dres and the
+// per-block partial sums into `part` (mtvaf_ln_bwd_workspace_bytes(M, H) bytes, owned by the caller until _finish has run);
+// _finish reduces them into dgamma / dbeta / dbias_x in fixed order.
+int mtvaf_dropout_res_ln_bwd_rows(const float* dout, const float* x, const float* res, const float* gamma, const float* mean,
+                                  const float* rstd, float* dx, float* dres, int dres_accumulate, int M, int H, float p_drop,
+                                  uint64_t seed, uint64_t offset, float* part, void* dx_bf16, hipStream_t st) {
+  if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
+  if ((!dx && !dx_bf16) || !part) return MTVAF_ERR_ARG;
+  const int g = row_grid_bwd(M);
+  hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
+                     offset, static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+int mtvaf_dropout_res_ln_bwd_finish(const float* part, int M, int H, float* dgamma, float* dbeta, float* dbias_x, int accumulate,
+                                    hipStream_t st) {
+  if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
+  if (!part) return MTVAF_ERR_ARG;
+  OutPtrs outs{{dgamma, dbeta, dbias_x, nullptr}};
+  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((3 * H + 31) / 32), dim3(256), 0, st, part, row_grid_bwd(M), H, 3, outs,
+                     accumulate);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
 int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma,
                              const float* mean, const float* rstd, float* dx, float* dres, int dres_accumulate,
                              float* dgamma, float* dbeta, float* dbias_x, int accumulate, int M, int H, float p_drop,
@@ -596,18 +623,11 @@ int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res
                              hipStream_t st) {
   if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
   if (!dx && !dx_bf16) return MTVAF_ERR_ARG;
-  const int g = row_grid_bwd(M);
-  if (workspace_bytes < (size_t)g * 3 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
-  float* part = (float*)workspace;
-  hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
-                     offset, static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
-  MTVAF_LAUNCH_CHECK();
-  OutPtrs outs{{dgamma, dbeta, dbias_x, nullptr}};
-  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((3 * H + 31) / 32), dim3(256), 0, st, part, g, H, 3, outs,
-                     accumulate);
-  MTVAF_LAUNCH_CHECK();
-  return MTVAF_OK;
+  if (workspace_bytes < (size_t)row_grid_bwd(M) * 3 * H * sizeof(float)) return MTVAF_ERR_WORKSPACE;
+  const int rc = mtvaf_dropout_res_ln_bwd_rows(dout, x, res, gamma, mean, rstd, dx, dres, dres_accumulate, M, H, p_drop, seed, offset,
+                                               static_cast<float*>(workspace), dx_bf16, st);
+  if (rc != MTVAF_OK) return rc;
+  return mtvaf_dropout_res_ln_bwd_finish(static_cast<const float*>(workspace), M, H, dgamma, dbeta, dbias_x, accumulate, st);
 }
 
 // 0 (default): deterministic scatter-add of the word / position table gradients; 1: float atomics (MTVAF_EMBED_ATOMIC=1)

@@ -183,6 +183,9 @@ DW_SIDE_STREAM = os.environ.get("MTVAF_DW_STREAM", "1") != "0"
 # Below this many token rows the second stream loses (bs 4, 256 rows: 4.87 ms per step with it against 4.33-4.59 without, same
 # box): the products are short latency chains there and the cross-stream events cost more than the overlap returns.
 DW_STREAM_MIN_ROWS = int(os.environ.get("MTVAF_DW_STREAM_MIN_ROWS", "1024"))
+# LayerNorm backward's column sums (dgamma, dbeta, dense bias gradient) on the weight-gradient stream (MTVAF_LN_SUMS_SIDE=0: on
+# the main chain, as before round 4)
+LN_SUMS_ON_SIDE = os.environ.get("MTVAF_LN_SUMS_SIDE", "1") != "0"
 _side_streams = {}
 
 
@@ -331,7 +334,10 @@ def _bwd_layout(M, H, I, B, NH, S, Pn, use_h):
         lay = _layouts[key] = _layout([("dh1", M * H * 4), ("df", M * H * e), ("dpre", M * I * e), ("da", M * H * e),
                                        ("dctx", M * H * e), ("dqkv", M * 3 * H * e),
                                        ("part", (M // 128) * I * 4 if use_h else 0), ("partq", B * nqt * H * 4 if use_h else 0),
-                                       ("partkv", B * nkt * 2 * H * 4 if use_h else 0), ("delta", 0 if use_h else B * NH * S * 4)])
+                                       ("partkv", B * nkt * 2 * H * 4 if use_h else 0), ("delta", 0 if use_h else B * NH * S * 4),
+                                       # (the layer's own LayerNorm-backward partials: their column sums run on the second stream)
+                                       ("lnpart2", int(hip.lib().mtvaf_ln_bwd_workspace_bytes(M, H)) if LN_SUMS_ON_SIDE else 0),
+                                       ("lnpart1", int(hip.lib().mtvaf_ln_bwd_workspace_bytes(M, H)) if LN_SUMS_ON_SIDE else 0)])
     return lay
 
 

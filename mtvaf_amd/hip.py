@@ -56,6 +56,8 @@ _SIGS = {
                                    U64, P, P, SZ, P]),
     "mtvaf_dropout_res_ln_fwd": (c_int, [P, P, P, P, P, P, P, I, I, F, F, U64, U64, P, P]),
     "mtvaf_dropout_res_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, I, P, P, P, I, I, I, F, U64, U64, P, SZ, P, P]),
+    "mtvaf_dropout_res_ln_bwd_rows": (c_int, [P, P, P, P, P, P, P, P, I, I, I, F, U64, U64, P, P, P]),
+    "mtvaf_dropout_res_ln_bwd_finish": (c_int, [P, I, I, P, P, P, I, P]),
     "mtvaf_colsum_workspace_bytes": (SZ, [I, I]),
     "mtvaf_colsum": (c_int, [P, I, I, I, P, I, P, SZ, P]),
     "mtvaf_dropout": (c_int, [P, P, L, F, U64, U64, P]),
@@ -119,7 +121,8 @@ class LayerGradsStruct(ctypes.Structure):
                                          "dwqkv", "dbqkv", "dwo", "dbo", "dg1", "db1", "dw1", "dbi1", "dw2", "dbi2", "dg2",
                                          "db2", "dpk", "dpv", "ws_main")] + [("ws_main_bytes", c_size_t), ("ws_side", c_void_p),
                                                                             ("ws_side_bytes", c_size_t), ("klist", c_void_p),
-                                                                            ("kcnt", c_void_p)])
+                                                                            ("kcnt", c_void_p), ("lnpart2", c_void_p),
+                                                                            ("lnpart1", c_void_p)])
 
 
 _lib = None
