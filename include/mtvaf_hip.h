@@ -92,6 +92,14 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
                           const float* addmask, const float* ctx, const float* lse, float* delta, float* dqkv,
                           float* dpk, float* dpv, int B, int S, int P, int NH, int head_dim, float p_drop,
                           uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
+/* mtvaf_prefix_attn_bwd for callers that vouch (zero_tail != 0) that dctx is EXACTLY zero for the queries behind a sentence's
+ * last unmasked text position -- trailing padding nothing downstream reads: the contract under which the weight gradients
+ * walk k-tile lists.  Those queries have dQ = 0 and add nothing to dK / dV, so the query loops stop there; under the
+ * contract the results equal mtvaf_prefix_attn_bwd's bit for bit. */
+int mtvaf_prefix_attn_bwd_tail(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
+                               const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B,
+                               int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, int zero_tail,
+                               mtvaf_stream_t stream);
 
 /* The same attention over PACKED token rows (padding-free execution): cu [B+1] int32 -- sentence b owns rows
  * cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / dqkv (its unmasked tokens in order, at most S).  Every kept key is unmasked,

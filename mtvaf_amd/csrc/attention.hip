@@ -50,6 +50,10 @@ struct AttnArgs {
   // exist.  NULL: the padded [B, S] layout.  lse / delta / the dropout row ids keep the [B, NH, S] indexing either way.
   const int* cu;
   int pad_rows;  // packed rows: this many rows behind the last sentence pad the image; the z-slice b == B zero-fills them
+  // backward, padded layout: the caller vouches that dctx is EXACTLY zero for the queries behind the last unmasked text position
+  // of a sentence (trailing padding: nothing downstream reads those rows -- the contract of the k-tile lists of the weight
+  // gradients).  Their dQ is exactly zero and they add exactly nothing to dK / dV: the key side stops its query loop there.
+  int zero_tail;
 };
 
 struct Sent {
@@ -261,6 +265,15 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
   const int Tf = a.P + a.S;
   const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
   const bool qok = q < Sb;
+  if (a.zero_tail && !a.cu && qtile * 64 >= T - a.P) {  // (block-uniform) a tile of trailing padding: dQ = 0, nothing to read
+    if (qok) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(a.dqkv + (sn.tok0 + q) * 3 * a.H + h * D + 16 * dt + 4 * g) = z;
+      if (g == 0) a.delta[((long)b * a.NH + h) * a.S + q] = 0.f;
+    }
+    return;
+  }
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
@@ -464,8 +477,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
     }
     if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, Sb - 1)] * LOG2E;
   };
-  if (Sb > 0) fetch(0);
-  for (int q0 = 0; q0 < Sb; q0 += KT) {
+  // (zero_tail: queries from the last unmasked position on have dO = 0 exactly -- no contribution, see AttnArgs)
+  const int Sq = (a.zero_tail && !a.cu) ? min(Sb, T - a.P) : Sb;
+  if (Sq > 0) fetch(0);
+  for (int q0 = 0; q0 < Sq; q0 += KT) {
     float dsum[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -491,9 +506,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
       rh_s[threadIdx.x] = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), row_base + (uint32_t)qq);
     }
     __syncthreads();
-    if (q0 + KT < Sb) fetch(q0 + KT);
+    if (q0 + KT < Sq) fetch(q0 + KT);
     // a wave whose 16 keys all lie beyond T (last key tile) only takes part in the staging and the barriers
-    const int nsub = wave_live ? min(4, (Sb - q0 + 15) >> 4) : 0;
+    const int nsub = wave_live ? min(4, (Sq - q0 + 15) >> 4) : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i < nsub) {
@@ -631,12 +646,14 @@ static int attn_fwd_launch(const float* qkv, const float* pk, const float* pv, c
 
 static int attn_bwd_launch(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
                            const int* cu, int pad_rows, const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv,
-                           int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st) {
+                           int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st,
+                           int zero_tail = 0) {
   if (head_dim != D) return MTVAF_ERR_SHAPE;
   if (!cu && !addmask) return MTVAF_ERR_ARG;
   AttnArgs a{};
   a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.pad_rows = pad_rows; a.ctx = const_cast<float*>(ctx);
   a.lse = const_cast<float*>(lse); a.dctx = dctx; a.delta = delta; a.dqkv = dqkv; a.dpk = dpk; a.dpv = dpv;
+  a.zero_tail = zero_tail;
   fill_common(a, B, S, P, NH, p_drop, seed, offset);
   int rc = check(a);
   if (rc) return rc;
@@ -662,6 +679,16 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
                           uint64_t seed, uint64_t offset, hipStream_t st) {
   return attn_bwd_launch(dctx, qkv, pk, pv, addmask, nullptr, 0, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed,
                          offset, st);
+}
+
+// mtvaf_prefix_attn_bwd for callers that vouch that dctx is exactly zero for the queries behind a sentence's last unmasked text
+// position (zero_tail != 0; see AttnArgs): same results bit for bit under that contract, the query loops stop there.
+int mtvaf_prefix_attn_bwd_tail(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
+                               const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
+                               int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, int zero_tail,
+                               hipStream_t st) {
+  return attn_bwd_launch(dctx, qkv, pk, pv, addmask, nullptr, 0, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed,
+                         offset, st, zero_tail);
 }
 
 // The same attention over PACKED token rows (padding-free execution): cu [B+1] int32 row offsets -- sentence b owns rows

@@ -39,6 +39,10 @@ int mtvaf_colsum(const float* x, int rows, int cols, int ld, float* out, int acc
 int mtvaf_prefix_attn_fwd(const float* qkv, const float* pk, const float* pv, const float* addmask, float* ctx, float* lse,
                           int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
                           hipStream_t st);
+int mtvaf_prefix_attn_bwd_tail(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
+                               const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
+                               int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, int zero_tail,
+                               hipStream_t st);
 int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
                           const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B,
                           int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
@@ -239,6 +243,11 @@ int mtvaf_dw_group_wanted(int rows, int H, int I) {
   return (x3_group && rows > 1024 && mtvaf_f32_split(-1)) ? 1 : 0;
 }
 
+static bool attn_tail_on() {  // MTVAF_ATTN_TAIL=0: the attention backward keeps its full query loops under a k-tile list too
+  static const int on = [] { const char* e = getenv("MTVAF_ATTN_TAIL"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
 // LayerNorm backward of one block of the layer, then the fork the weight gradients behind it need anyway.  With per-layer
 // partial buffers (g->lnpart*) and a second stream, the column sums (dgamma, dbeta, the dense bias gradient: parameter
 // gradients only) run THERE: 24 launches of ~12 us leave the main chain of a step.
@@ -341,8 +350,11 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
                                              L->Mp - L->Mv, cx, L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn,
                                              L->seed, L->offset, mainS));
     } else {
-      MTVAF_TRY(mtvaf_prefix_attn_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx,
-                                      L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+      // (a k-tile list = the caller's word that masked token rows carry exactly-zero gradients: the query loops stop at the
+      // last unmasked position)
+      MTVAF_TRY(mtvaf_prefix_attn_bwd_tail(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx,
+                                           L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset,
+                                           (g->klist != nullptr && attn_tail_on()) ? 1 : 0, mainS));
     }
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));

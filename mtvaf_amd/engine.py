@@ -860,7 +860,7 @@ class EncoderFunction(torch.autograd.Function):
                 dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
                 hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
                                     delta, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, B, S, Pn, NH,
-                                    p_attn, seed, off)
+                                    p_attn, seed, off, zero_tail=ktiles is not None)
 
                 def qkv_grads():
                     hip.colsum(dqkv, dbqkv)

@@ -38,6 +38,7 @@ _SIGS = {
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_bwd_tail": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, I, P]),
     "mtvaf_prefix_attn_varlen_fwd": (c_int, [P, P, P, P, I, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_varlen_bwd": (c_int, [P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bf16_varlen_fwd": (c_int, [P, P, P, P, I, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -428,10 +429,12 @@ def prefix_attn_fwd(qkv, pk, pv, addmask, ctx, lse, B, S, Pn, NH, p, seed, offse
                                     seed, offset, _st()), "mtvaf_prefix_attn_fwd")
 
 
-def prefix_attn_bwd(dctx, qkv, pk, pv, addmask, ctx, lse, delta, dqkv, dpk, dpv, B, S, Pn, NH, p, seed, offset):
-    _ck(lib().mtvaf_prefix_attn_bwd(_p(dctx), _p(qkv), _p(pk), _p(pv), _p(addmask), _p(ctx), _p(lse), _p(delta), _p(dqkv),
-                                    _p(dpk), _p(dpv), B, S, Pn, NH, 64, float(p), seed, offset, _st()),
-        "mtvaf_prefix_attn_bwd")
+def prefix_attn_bwd(dctx, qkv, pk, pv, addmask, ctx, lse, delta, dqkv, dpk, dpv, B, S, Pn, NH, p, seed, offset, zero_tail=False):
+    """zero_tail: the caller vouches that dctx is exactly zero for the queries behind each sentence's last unmasked position
+    (the k-tile-list contract): same bits, the query loops stop there."""
+    _ck(lib().mtvaf_prefix_attn_bwd_tail(_p(dctx), _p(qkv), _p(pk), _p(pv), _p(addmask), _p(ctx), _p(lse), _p(delta), _p(dqkv),
+                                         _p(dpk), _p(dpv), B, S, Pn, NH, 64, float(p), seed, offset, int(bool(zero_tail)), _st()),
+        "mtvaf_prefix_attn_bwd_tail")
 
 
 def prefix_attn_varlen_fwd(qkv, pk, pv, cu, pad_rows, ctx, lse, B, S, Pn, NH, p, seed, offset):

@@ -264,6 +264,41 @@ def test_prefix_attention(hip, B, S, Pn, NH):
         close(dpv, vd.grad, rtol=5e-4, name="attn dpv")
 
 
+@pytest.mark.parametrize("B,S,Pn,NH,p", [(4, 128, 36, 12, 0.0), (4, 128, 36, 3, 0.1), (3, 200, 16, 2, 0.1), (3, 64, 0, 2, 0.0)])
+def test_prefix_attention_backward_zero_tail_contract(hip, B, S, Pn, NH, p):
+    """mtvaf_prefix_attn_bwd_tail: when the upstream gradient is exactly zero for the queries behind a sentence's last unmasked
+    position (what the masked CRF / the k-tile-list contract guarantees), stopping the query loops there gives the same bits
+    as the full loops -- ragged lengths incl. a full and a one-token sentence, holes in the mask, dropout live."""
+    H, T = NH * 64, Pn + S
+    qkv, pk, pv = rnd(B * S, 3 * H, seed=11), rnd(B, max(Pn, 1) * H, seed=12), rnd(B, max(Pn, 1) * H, seed=13)
+    lens = [S, 1, S // 2 + 3, max(2, S // 5)][:B]
+    mask = torch.zeros(B, T)
+    for b, Lb in enumerate(lens):
+        mask[b, : Pn + Lb] = 1
+    if B > 2:
+        mask[2, Pn + 4] = 0  # a hole before the last unmasked position stays inside the loops
+    addmask = (1 - mask) * -10000.0
+    dctx = rnd(B * S, H, seed=14).view(B, S, H)
+    for b, Lb in enumerate(lens):
+        dctx[b, Lb:] = 0.0  # the contract
+    g = lambda t: t.to(DEV)
+    gq, gk, gv, gm = g(qkv), g(pk) if Pn else None, g(pv) if Pn else None, g(addmask)
+    ctx, lse = torch.empty(B * S, H, device=DEV), torch.empty(B, NH, S, device=DEV)
+    hip.prefix_attn_fwd(gq, gk, gv, gm, ctx, lse, B, S, Pn, NH, p, 5, 9)
+    outs = []
+    for tail in (False, True):
+        delta = torch.full((B, NH, S), float("nan"), device=DEV)
+        dqkv = torch.full((B * S, 3 * H), float("nan"), device=DEV)
+        dpk = torch.full((B, max(Pn, 1) * H), float("nan"), device=DEV) if Pn else None
+        dpv = torch.full((B, max(Pn, 1) * H), float("nan"), device=DEV) if Pn else None
+        hip.prefix_attn_bwd(g(dctx.view(B * S, H)), gq, gk, gv, gm, ctx, lse, delta, dqkv, dpk, dpv, B, S, Pn, NH, p, 5, 9, zero_tail=tail)
+        assert bool(torch.isfinite(dqkv).all())
+        outs.append((dqkv, dpk, dpv))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if Pn:
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
 @pytest.mark.parametrize("B,S,Pn,NH", [(3, 16, 0, 2), (3, 16, 4, 2), (2, 128, 36, 12), (2, 100, 16, 3), (1, 200, 36, 2),
                                        (2, 64, 100, 1)])
 def test_prefix_attention_bf16(hip, B, S, Pn, NH):
