@@ -348,6 +348,8 @@ def compact_line(res):
         line["grad_sync"] = {k: v for k, v in res["grad_sync"].items() if k != "note"}
     if isinstance(res.get("padding_free"), dict):
         line["padding_free"] = {k: res["padding_free"][k] for k in ("value", "ms_per_step") if k in res["padding_free"]}
+    if isinstance(res.get("full_length"), dict):
+        line["full_length"] = {k: res["full_length"][k] for k in ("value", "ms_per_step") if k in res["full_length"]}
     if isinstance(res.get("fwd_bwd_without_optimizer"), dict):
         line["fwd_bwd_without_optimizer"] = res["fwd_bwd_without_optimizer"]
     if isinstance(res.get("secondary"), dict):
@@ -362,7 +364,7 @@ def compact_line(res):
         line["secondary"] = sec
     line["detail"] = "bench_detail.json (also on stderr)"
     # shrink until it fits: the contract's keys, roofline and cpu_baseline are never dropped
-    for drop in ("fwd_bwd_without_optimizer", "padding_free", "roofline_fp32_pipe", "grad_sync"):
+    for drop in ("fwd_bwd_without_optimizer", "full_length", "padding_free", "roofline_fp32_pipe", "grad_sync"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -696,6 +698,25 @@ def main():
                                 "tests/test_unpad_gpu.py); masked token rows are not computed; opt-in (`--unpad` / "
                                 "MTVAF_UNPAD=1), not the headline"}
 
+    full_length = None
+    if not a.full_length and not a.unpad and not a.graph and not a.no_secondary and world == 1:
+        # secondary figure: the same K steps on a batch whose sequences are ALL S tokens long -- nothing is masked, so neither the
+        # k-tile lists of the weight gradients nor padding-free execution have anything to skip: the floor of both
+        ragged = (ids, mask, tt, labels, feats, aux)
+        ids, mask, tt, labels, feats, aux = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, True)
+        try:
+            for _ in range(2):
+                step()
+            barrier()
+            t3 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            barrier()
+            dt3 = time.perf_counter() - t3
+        finally:
+            ids, mask, tt, labels, feats, aux = ragged
+        full_length = {"value": round(B * a.steps / dt3, 2), "ms_per_step": round(1e3 * dt3 / a.steps, 3)}
+
     res = {"metric": "training sentences/sec (fwd+bwd)", "value": round(value, 2), "unit": "sentences/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -719,7 +740,7 @@ def main():
                          "weight-gradient products skip the k-tiles of masked token rows (exact zeros): the roofline "
                          "object counts the flops those launches execute",
            "padding": "skipped (--unpad): the fraction below counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
-           "padding_free": padding_free}
+           "padding_free": padding_free, "full_length": full_length}
     res["rank_ms_spread"] = rank_ms_spread
     if rank_ms_spread is not None and rank_ms_spread >= 0.03:
         log(f"per-rank step times differ by {100 * rank_ms_spread:.1f} % (>= 3 %): the slowest rank sets `value`")

@@ -242,6 +242,8 @@ class Packing:
         _PENDING_PACK = None
         if not (UNPAD and addmask.is_cuda and addmask.dtype == torch.float32 and addmask.is_contiguous()):
             return
+        if torch.cuda.is_current_stream_capturing():
+            return  # (the row count cannot reach the host inside a capture: this step runs the padded layout)
         B, T = addmask.shape
         dev = addmask.device
         cu = torch.empty(B + 1, dtype=torch.int32, device=dev)

@@ -43,9 +43,16 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep needs the batch on the MI355X (no CPU fallback)")
         if "labels" not in tens:
             raise ValueError("a training step needs labels (loss.backward() is part of the graph)")
-        if engine.UNPAD:
-            raise RuntimeError("padding-free execution (engine.UNPAD) reads the packed row count on the host once per step: "
-                               "it cannot be captured into a HIP graph -- use the eager model")
+        # padding-free execution (engine.UNPAD) reads the packed row count on the host once per step, which a capture cannot
+        # contain: it steps aside -- the warm-up passes and the captured step run the padded layout (same loss, tags and
+        # parameter gradients; tests/test_unpad_gpu.py), the switch is restored for eager steps afterwards
+        unpad_was, engine.UNPAD = engine.UNPAD, False
+        try:
+            self._build(model, batch, tens, warmup)
+        finally:
+            engine.UNPAD = unpad_was
+
+    def _build(self, model, batch, tens, warmup):
         enc = getattr(getattr(model, "bert", model), "encoder", None)
         sink = getattr(enc, "_sink", None)
         if sink is not None and sink.on_layer_done is not None:

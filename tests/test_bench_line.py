@@ -43,6 +43,7 @@ def _worst_case():
             "fwd_bwd_without_optimizer": {"value": 2400.0, "ms_per_step": 13.3}, "real_token_rows": 0.5771,
             "flop_per_sentence_train_real_rows": 38600000000, "note_flops": "n" * 500, "padding": "p" * 80,
             "padding_free": {"value": 3000.0, "ms_per_step": 10.6, "mfma_fraction_of_step_executed_flops": 0.5, "note": "n" * 300},
+            "full_length": {"value": 1800.0, "ms_per_step": 17.76},
             "n_ranks_seen": 8, "backend": "nccl", "rank_ms_spread": 0.012,
             "grad_sync": {"wire": "bf16", "buckets": 4, "comm_stream_ms_per_step": 1.234, "exposed_tail_ms_per_step": 0.123, "note": "g" * 300},
             "roofline": _roofline(), "roofline_fp32_pipe": _roofline(), "value_fp32_pipe": 1723.0, "ms_per_step_fp32_pipe": 18.57,

@@ -162,18 +162,37 @@ def test_graphed_training_trajectory_equals_eager(dtype):
         hip.set_compute_dtype("fp32")
 
 
-def test_padding_free_execution_refuses_graph_capture():
-    """engine.UNPAD reads the packed row count on the host once per step, which a capture cannot contain: the documented
-    error, before anything is captured."""
-    import pytest as _pt
+def test_padding_free_execution_steps_aside_for_graph_capture():
+    """engine.UNPAD reads the packed row count on the host once per step, which a capture cannot contain: with the switch on,
+    GraphedTrainStep captures the PADDED step (same loss, tags and parameter gradients as the padding-free eager step) and
+    leaves the switch on for eager steps afterwards."""
     from mtvaf_amd import engine
     from mtvaf_amd.graph import GraphedTrainStep
+    cfg = P.BASE_BERT
+    sde, sdh, sdp, text, vis = _assembled_case(cfg, 4, 64, 3, seed=53)
+    m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
+    m.eval()
+    kw = _kw(text, vis)
     engine_unpad = engine.UNPAD
-    engine.UNPAD = True
     try:
-        with _pt.raises(RuntimeError, match="cannot be captured"):
-            GraphedTrainStep(torch.nn.Linear(2, 2).to("cuda"), {"input_ids": torch.zeros(2, 8, dtype=torch.long, device="cuda"),
-                                                                "labels": torch.zeros(2, 8, dtype=torch.long, device="cuda")})
+        engine.UNPAD = False
+        ploss, ptags, pgrads = _eager(m, kw)
+        engine.UNPAD = True
+        uloss, utags, ugrads = _eager(m, kw)  # the eager step under the switch (packs when that saves a 128-row tile)
+        g = GraphedTrainStep(m, kw)
+        try:
+            assert engine.UNPAD is True
+            m.zero_grad(set_to_none=True)
+            out = g(**{k: v for k, v in kw.items() if v is not None})
+            torch.cuda.synchronize()
+            assert float(out.loss) == ploss and list(out.logits) == ptags == utags  # the captured step is the padded one
+            assert abs(float(out.loss) - uloss) <= 1e-5 * abs(uloss)
+            named = dict(m.named_parameters())
+            for n, ge in pgrads.items():
+                if "word_embeddings" not in n:
+                    assert torch.equal(named[n].grad, ge), n
+        finally:
+            g.close()
     finally:
         engine.UNPAD = engine_unpad
 
