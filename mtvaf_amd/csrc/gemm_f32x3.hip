@@ -537,33 +537,32 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   }
 
   if (tr && lane == 0) tr[8 * 64 * 4 + 1 + wave] = __builtin_amdgcn_s_memtime();  // this wave's k-loop is over
-  // wide epilogue, 64 result rows per pass (the consumer waves that own them write their accumulators through the LDS), stores
-  // by all 512 threads
+  // wide epilogue: the four consumer waves write their accumulators through the LDS at once (the whole 128-row image, 66 KB
+  // at BN = 128, fits in the two operand buffers, both free behind the k-loop's last barrier), ONE barrier, stores by all 512
+  // threads.  (Until round 4 in two passes of 64 rows with three barriers; measured level with this form -- 1186-1188 vs
+  // 1188-1192 us over a layer's twelve products: the 4900 ticks of the epilogue are the stores, not the barriers.)
   {
-    constexpr int LDE = BN + 4, RP = 64, C4 = BN / 4;
+    constexpr int LDE = BN + 4, RP = BM, C4 = BN / 4;
     float* smem = reinterpret_cast<float*>(smem_raw);
     float* C = Cp + (long)blockIdx.z * slab_stride;
     const bool split = gridDim.z > 1;
     const int wrow = wm * TM * 32;  // first result row of this consumer wave inside the tile
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass) __syncthreads();  // the previous pass's image has been read (pass 0: the k-loop ended with a barrier)
-      if (consumer && wrow / RP == pass) {
-        const int rofs = wrow % RP;
+    {
+      if (consumer) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              smem[(rofs + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
+              smem[(wrow + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * LDE + (wn * TN + j) * 32 + li] = acc[i][j][r];
       }
       __syncthreads();
 #pragma unroll 2
       for (int idx = tid; idx < RP * C4; idx += NT) {
         const int r = idx / C4, c = (idx % C4) * 4;
         f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
-        const long row = m0 + pass * RP + r;
+        const long row = m0 + r;
         const int col = n0 + c;
         if (!GROUP && (row >= p.M || col >= p.N)) continue;  // (a tile that hangs over the result: N, ldc multiples of 4)
         if (!split) {
@@ -592,7 +591,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
 template <int BN>
 static int launch_x3_ws(const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   if (!a.wide) return MTVAF_ERR_ALIGN;
-  const size_t smem = (size_t)2 * 3 * (128 + BN) * 40 * sizeof(__bf16);  // 122880 / 107520 (the epilogue image of 64 x (BN + 4) floats fits inside)
+  const size_t smem = (size_t)2 * 3 * (128 + BN) * 40 * sizeof(__bf16);  // 122880 / 107520 (the epilogue image of 128 x (BN + 4) floats, 67584 / 51200 bytes, fits inside)
 #define MTVAF_X3_WS(AK, BKM, KL)                                                                                      \
   do {                                                                                                               \
     auto kern = gemm_f32x3_ws_kernel<AK, BKM, KL, BN>;                                                               \
