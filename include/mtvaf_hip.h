@@ -318,6 +318,15 @@ int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const 
 /* bytes of split-K slabs that call needs for these products (0: no split planned; too little workspace is MTVAF_ERR_WORKSPACE,
  * never a silently different plan) */
 size_t mtvaf_gemm_f32_dw_group_workspace_bytes(int n, const int* M, const int* N, int K, int splits);
+/* The same launch + the bias gradients that go with the weight gradients: dbias (nullable array of n nullable pointers),
+ * dbias[i][0 .. M_i) <- column sums of A_i over its K rows (A_i is the dY of the dense layer: autograd backward of the bias of
+ * modeling_bert.py:266, 283-284, 420-421), 16-byte aligned, overwritten.  The unsplit grouped launch of the split kernel
+ * takes them from the A tiles it stages anyway; any other plan runs mtvaf_colsum behind the products (workspace_bytes must
+ * then also cover mtvaf_colsum_workspace_bytes(K, M_i)). */
+int mtvaf_gemm_f32_dw_group_bias(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb,
+                                 float* const* C, const int* ldc, const int* M, const int* N, int K, const int* klist,
+                                 const int* kcnt, float* const* dbias, void* workspace, size_t workspace_bytes, int splits,
+                                 mtvaf_stream_t stream);
 int mtvaf_dw_group_rows(int rows);
 int mtvaf_dw_group_wanted(int rows, int H, int I);
 

@@ -26,6 +26,9 @@ int mtvaf_gemm_bf16x(int layout_a, int layout_b, const void* A, int lda, const v
 int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
                             const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
                             void* workspace, size_t workspace_bytes, int splits, hipStream_t stream);
+int mtvaf_gemm_f32_dw_group_bias(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                                 const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
+                                 float* const* dbias, void* workspace, size_t workspace_bytes, int splits, hipStream_t stream);
 int mtvaf_streamk_attached(hipStream_t stream);
 int mtvaf_gemm_bf16x_dw_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb, float* const* C32,
                               const int* ldc32, const int* M, const int* N, int K, hipStream_t stream);
@@ -334,7 +337,8 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, df, H, L->w2, I, dpre, I, M, I, H, nullptr, X_EPI_DGELU, pre, I, 0, 1, g->ws_main, g->ws_main_bytes, -1, -1,
                              mainS));
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
+    // (grouped weight gradients: the bias gradients dbi1 / dbqkv come out of that launch -- column sums of the dY tiles it stages)
+    if (!grp) MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
     if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dpre, I, L->h1, H, g->dw1, H, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dpre, I, L->w1, H, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, 1, g->ws_main,
@@ -357,7 +361,7 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
                                            (g->klist != nullptr && attn_tail_on()) ? 1 : 0, mainS));
     }
     MTVAF_TRY(fork_to(mainS, side));
-    MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
+    if (!grp) MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
     if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dqkv, 3 * H, L->x, H, g->dwqkv, H, 3 * H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1,
                              g->ws_side, g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     if (grp) {
@@ -366,7 +370,9 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
       float* const Cs[4] = {g->dw2, g->dw1, g->dwo, g->dwqkv};
       const int lda[4] = {H, I, H, 3 * H}, ldb[4] = {I, H, H, H}, ldc[4] = {I, H, H, H};
       const int Ms[4] = {H, I, H, 3 * H}, Ns[4] = {I, H, H, H};
-      MTVAF_TRY(mtvaf_gemm_f32_dw_group(4, As, lda, Bs, ldb, Cs, ldc, Ms, Ns, M, g->klist, g->kcnt, g->ws_side, g->ws_side_bytes, -1, side));
+      float* const dbs[4] = {nullptr, g->dbi1, nullptr, g->dbqkv};
+      MTVAF_TRY(mtvaf_gemm_f32_dw_group_bias(4, As, lda, Bs, ldb, Cs, ldc, Ms, Ns, M, g->klist, g->kcnt, dbs, g->ws_side, g->ws_side_bytes, -1,
+                                             side));
     }
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dqkv, 3 * H, L->wqkv, H, g->dh, H, M, H, 3 * H, nullptr, X_EPI_NONE, nullptr, 0, 1, 1,
                              g->ws_main, g->ws_main_bytes, -1, -1, mainS));

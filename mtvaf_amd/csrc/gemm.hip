@@ -1141,9 +1141,16 @@ size_t mtvaf_gemm_f32_dw_group_workspace_bytes(int n, const int* M, const int* N
   return s > 1 ? (size_t)s * outs * sizeof(float) : 0;
 }
 
-int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
-                            const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
-                            void* workspace, size_t workspace_bytes, int splits, hipStream_t stream) {
+int mtvaf_colsum(const float* x, int rows, int cols, int ld, float* out, int accumulate, void* workspace, size_t workspace_bytes,
+                 hipStream_t st);  // rowops.hip
+
+// dbias (nullable; entries nullable): dbias[i][0 .. M_i) = column sums of A_i over the reduction axis -- the bias gradient of the
+// dense layer whose weight gradient product i is (A_i = its dY).  The unsplit grouped launch of the split kernel takes them
+// from the A tiles it stages anyway (no extra pass over dY, no extra launch); every other plan runs mtvaf_colsum behind the
+// products (`workspace` is theirs again by then, in stream order).
+static int dw_group_impl(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                         const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt, float* const* dbias,
+                         void* workspace, size_t workspace_bytes, int splits, hipStream_t stream) {
   if (n < 1 || n > 4 || K <= 0 || K % 32) return MTVAF_ERR_SHAPE;
   GemmArgs a = {};
   long tiles = 0, outs = 0;
@@ -1169,6 +1176,8 @@ int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const 
       } else {
         g.C = C[i]; g.ldc = ldc[i]; g.slab_stride = 0;
       }
+      static const int fuse_bias = [] { const char* e = getenv("MTVAF_X3_DW_BIAS"); return e ? atoi(e) : 1; }();  // (0: always mtvaf_colsum)
+      g.colsum = (fuse_bias && splits == 1 && dbias && dbias[i] && (((uintptr_t)dbias[i] & 15) == 0)) ? dbias[i] : nullptr;
     }
     a.ngrp = n;
     a.A = a.grp[0].A; a.B = a.grp[0].B; a.C = a.grp[0].C;
@@ -1189,6 +1198,11 @@ int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const 
         const int r2 = launch_splitk_reduce(a.grp[i].C, splits, C[i], M[i], N[i], ldc[i], nullptr, 0, EPI_NONE, nullptr, 0, stream);
         if (r2 != MTVAF_OK) return r2;
       }
+    for (int i = 0; dbias && i < n; ++i)  // (the sums the launch did not take itself)
+      if (dbias[i] && !a.grp[i].colsum) {
+        const int r3 = mtvaf_colsum(A[i], K, M[i], lda[i], dbias[i], 0, workspace, workspace_bytes, stream);
+        if (r3 != MTVAF_OK) return r3;
+      }
     return MTVAF_OK;
   }
   for (int i = 0; i < n; ++i) {
@@ -1207,6 +1221,7 @@ int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const 
   float* slab = static_cast<float*>(workspace);
   for (int i = 0; i < n; ++i) {
     GemmProb& g = a.grp[i];
+    g.colsum = nullptr;
     g.A = A[i]; g.B = B[i]; g.lda = lda[i]; g.ldb = ldb[i]; g.tiles_n = N[i] / 96;
     if (splits > 1) {
       g.C = slab; g.ldc = N[i]; g.slab_stride = (long)M[i] * N[i];
@@ -1254,7 +1269,26 @@ int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const 
       if (rc != MTVAF_OK) return rc;
     }
   }
+  for (int i = 0; dbias && i < n; ++i)
+    if (dbias[i]) {
+      const int rc = mtvaf_colsum(A[i], K, M[i], lda[i], dbias[i], 0, workspace, workspace_bytes, stream);
+      if (rc != MTVAF_OK) return rc;
+    }
   return MTVAF_OK;
+}
+
+int mtvaf_gemm_f32_dw_group(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                            const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
+                            void* workspace, size_t workspace_bytes, int splits, hipStream_t stream) {
+  return dw_group_impl(n, A, lda, B, ldb, C, ldc, M, N, K, klist, kcnt, nullptr, workspace, workspace_bytes, splits, stream);
+}
+
+// mtvaf_gemm_f32_dw_group + the bias gradients that go with the weight gradients: dbias[i] (nullable) <- column sums of A_i
+// over the K rows ([M_i] floats, 16-byte aligned, overwritten).  workspace_bytes must also cover mtvaf_colsum_workspace_bytes.
+int mtvaf_gemm_f32_dw_group_bias(int n, const float* const* A, const int* lda, const float* const* B, const int* ldb, float* const* C,
+                                 const int* ldc, const int* M, const int* N, int K, const int* klist, const int* kcnt,
+                                 float* const* dbias, void* workspace, size_t workspace_bytes, int splits, hipStream_t stream) {
+  return dw_group_impl(n, A, lda, B, ldb, C, ldc, M, N, K, klist, kcnt, dbias, workspace, workspace_bytes, splits, stream);
 }
 
 // Same contract as mtvaf_gemm_f32 (fp32 operands and results in memory), but the products run on the bf16

@@ -14,6 +14,9 @@ struct GemmProb {
   float* C;  // result, or this product's split-K slabs
   int lda, ldb, ldc, tiles_n;
   long slab_stride;
+  // grouped launch of the wave-specialised split kernel, unsplit: column sums of A over the reduction axis -> colsum[0 .. M)
+  // (the bias gradient that belongs to this weight gradient: A is the dY of the dense layer), or NULL
+  float* colsum;
 };
 
 struct GemmArgs {

@@ -400,6 +400,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   float* Cp = p.C;
   int lda = p.lda, ldb = p.ldb, ldc = p.ldc, tiles_n = p.tiles_n;
   long slab_stride = p.slab_stride;
+  float* colsum = nullptr;  // GROUP: where this product's column sums of A go (its blocks with n0 == 0 take them), or NULL
   if constexpr (GROUP) {
     // (a run-time index into the kernel-argument segment: scalar loads on demand)
     const int q = (bid >= p.grp_tile_begin[1]) + (bid >= p.grp_tile_begin[2]) + (bid >= p.grp_tile_begin[3]);
@@ -408,6 +409,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     Ap = pb.A; Bp = pb.B; Cp = pb.C;
     lda = pb.lda; ldb = pb.ldb; ldc = pb.ldc; tiles_n = pb.tiles_n;
     slab_stride = pb.slab_stride;
+    colsum = pb.colsum;
   }
   const int m0 = (bid / tiles_n) * BM;
   const int n0 = (bid % tiles_n) * BN;
@@ -512,8 +514,20 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     // (the requests are UNCONDITIONAL -- past the end they fetch the last tile again: behind a conditional request hipcc
     // cannot count on the newer batch being in flight and waits for vmcnt(0), i.e. for the loads issued one step ago: every
     // step then lasted one global-load latency, ~1.6 us, whatever else overlapped)
+    // GROUP: the column sums of A over the reduction axis (the bias gradient that goes with this weight gradient), taken by
+    // the product's blocks with n0 == 0 from the A units they stage anyway -- every k-tile exactly once, in k order; a thread
+    // owns four consecutive columns at one k quad, the eight k quads of a column group are eight consecutive lanes
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    const bool do_sum = GROUP && colsum != nullptr && n0 == 0 && gridDim.z == 1;  // (block-uniform)
+    auto sum_a = [&](const f32x4* ra) __attribute__((always_inline)) {
+      if constexpr (GROUP) {
+        static_assert(!GROUP || UA == 1, "one A unit per producer thread");
+        if (do_sum) csum += (ra[0] + ra[1]) + (ra[2] + ra[3]);
+      }
+    };
     auto pstep = [&](int kt, f32x4* ra, f32x4* rb) __attribute__((always_inline)) {
       if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 0] = __builtin_amdgcn_s_memtime();
+      if (kt + 1 < nk) sum_a(ra);
       stage_all((kt + 1) & 1, ra, rb);  // (past the end: a harmless copy of the last tile into the idle buffer)
       if (tr && kt < 64 && lane == 0) tr[(wave * 64 + kt) * 4 + 1] = __builtin_amdgcn_s_memtime();
       gload(min(kt + 3, nk - 1), ra, rb);
@@ -524,6 +538,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     if (nk > 0) {
       gload(0, ra0, rb0);
       gload(min(1, nk - 1), ra1, rb1);
+      sum_a(ra0);
       stage_all(0, ra0, rb0);
       gload(min(2, nk - 1), ra0, rb0);
     }
@@ -534,6 +549,18 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
       pstep(kt + 1, ra0, rb0);
     }
     if (kt < nk) pstep(kt, ra1, rb1);
+    if constexpr (GROUP) {
+      if (do_sum) {
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+          csum.x += __shfl_xor(csum.x, d, 64);
+          csum.y += __shfl_xor(csum.y, d, 64);
+          csum.z += __shfl_xor(csum.z, d, 64);
+          csum.w += __shfl_xor(csum.w, d, 64);
+        }
+        if ((ptid & 7) == 0) *reinterpret_cast<f32x4*>(colsum + m0 + (ptid >> 3) * 4) = csum;
+      }
+    }
   }
 
   if (tr && lane == 0) tr[8 * 64 * 4 + 1 + wave] = __builtin_amdgcn_s_memtime();  // this wave's k-loop is over

@@ -820,8 +820,8 @@ class EncoderFunction(torch.autograd.Function):
                 hip.linear_bwd_input(df, w.w2, dpre, epi=hip.EPI_DGELU, aux=pre)
 
                 def ffn1_grads():
-                    hip.colsum(dpre, G[11])
-                    if not grp:
+                    if not grp:  # (grouped: the bias gradient comes out of the grouped launch, as in csrc/executor.hip)
+                        hip.colsum(dpre, G[11])
                         hip.linear_bwd_weight(dpre, h1, G[10], ktiles=ktiles)
                 on_side((dpre,), ffn1_grads)
                 hip.linear_bwd_input(dpre, w.w1, dh1, accumulate=True)
@@ -865,10 +865,11 @@ class EncoderFunction(torch.autograd.Function):
                                     p_attn, seed, off, zero_tail=ktiles is not None)
 
                 def qkv_grads():
-                    hip.colsum(dqkv, dbqkv)
                     if grp:
-                        hip.gemm_f32_dw_group([(df, act, G[12]), (dpre, h1, G[10]), (da, cx, G[6]), (dqkv, x, dwqkv)], M, ktiles=ktiles)
+                        hip.gemm_f32_dw_group([(df, act, G[12]), (dpre, h1, G[10]), (da, cx, G[6]), (dqkv, x, dwqkv)], M, ktiles=ktiles,
+                                              dbias=[None, G[11], None, dbqkv])
                     else:
+                        hip.colsum(dqkv, dbqkv)
                         hip.linear_bwd_weight(dqkv, x, dwqkv, ktiles=ktiles)
                 on_side((dqkv, df, dpre, da) if grp else (dqkv,), qkv_grads)
                 hip.linear_bwd_input(dqkv, w.wqkv, dh0, accumulate=True)

@@ -91,6 +91,7 @@ _SIGS = {
     "mtvaf_embed_scatter_mode": (c_int, [I]),
     "mtvaf_embed_ln_bwd_workspace_bytes": (SZ, [I, I, I, I]),
     "mtvaf_gemm_f32_dw_group": (c_int, [I, P, P, P, P, P, P, P, P, I, P, P, P, SZ, I, P]),
+    "mtvaf_gemm_f32_dw_group_bias": (c_int, [I, P, P, P, P, P, P, P, P, I, P, P, P, P, SZ, I, P]),
     "mtvaf_gemm_f32_dw_group_workspace_bytes": (SZ, [I, P, P, I, I]),
     "mtvaf_dw_group_rows": (c_int, [I]),
     "mtvaf_dw_group_wanted": (c_int, [I, I, I]),
@@ -674,20 +675,31 @@ def dw_group_wanted(rows: int, H: int, I: int) -> bool:
     return bool(lib().mtvaf_dw_group_wanted(rows, H, I))
 
 
-def gemm_f32_dw_group(items, K, ktiles=None, splits=-1):
-    """items: up to four (a [K,M] fp32, b [K,N] fp32, out [M,N] fp32): out = a^T . b for each, ONE launch of the 128x96 LDS-DMA
-    kernel (+ one ordered slab reduction per product when the reduction is split)."""
+def gemm_f32_dw_group(items, K, ktiles=None, splits=-1, dbias=None):
+    """items: up to four (a [K,M] fp32, b [K,N] fp32, out [M,N] fp32): out = a^T . b for each, ONE launch (the 128x96 LDS-DMA
+    kernel, or -- split arithmetic, K > 1024, whole 128x128 tiles -- the GROUP form of the wave-specialised split kernel) + one
+    ordered slab reduction per product when the reduction is split.  dbias: list of len(items) tensors / None -- dbias[i] [M]
+    <- column sums of a over its K rows (the bias gradient that goes with the weight gradient)."""
     n = len(items)
     vp = lambda ts: (ctypes.c_void_p * n)(*[_p(t) for t in ts])
     ia = lambda xs: (ctypes.c_int * n)(*xs)
     As, Bs, Cs = [i[0] for i in items], [i[1] for i in items], [i[2] for i in items]
     Ms, Ns = ia([t.shape[1] for t in As]), ia([t.shape[1] for t in Bs])
     wsb = int(lib().mtvaf_gemm_f32_dw_group_workspace_bytes(n, Ms, Ns, K, splits))  # the library's own plan, as the executor's call
+    if dbias is not None:
+        wsb = max(wsb, max(int(lib().mtvaf_colsum_workspace_bytes(K, t.shape[1])) for t in As))
     ws = workspace(max(wsb, 16), As[0].device)
     kl, kc = (ktiles if ktiles is not None else (None, None))
-    _ck(lib().mtvaf_gemm_f32_dw_group(n, vp(As), ia([t.stride(0) for t in As]), vp(Bs), ia([t.stride(0) for t in Bs]), vp(Cs),
-                                      ia([t.stride(0) for t in Cs]), Ms, Ns,
-                                      K, _p(kl), _p(kc), _p(ws), ws.numel(), splits, _st()), "mtvaf_gemm_f32_dw_group")
+    if dbias is None:
+        _ck(lib().mtvaf_gemm_f32_dw_group(n, vp(As), ia([t.stride(0) for t in As]), vp(Bs), ia([t.stride(0) for t in Bs]), vp(Cs),
+                                          ia([t.stride(0) for t in Cs]), Ms, Ns,
+                                          K, _p(kl), _p(kc), _p(ws), ws.numel(), splits, _st()), "mtvaf_gemm_f32_dw_group")
+    else:
+        assert len(dbias) == n
+        _f32(*[t for t in dbias if t is not None])
+        _ck(lib().mtvaf_gemm_f32_dw_group_bias(n, vp(As), ia([t.stride(0) for t in As]), vp(Bs), ia([t.stride(0) for t in Bs]), vp(Cs),
+                                               ia([t.stride(0) for t in Cs]), Ms, Ns, K, _p(kl), _p(kc), vp(dbias), _p(ws), ws.numel(),
+                                               splits, _st()), "mtvaf_gemm_f32_dw_group_bias")
 
 
 def gemm_bf16x_dw_group(items, K):

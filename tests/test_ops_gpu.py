@@ -1107,6 +1107,21 @@ def test_gemm_f32_dw_group(hip, T):
         hip.gemm_f32_dw_group(items, T, ktiles=kt, splits=3)
         for (_, _, o), f in zip(items, first):
             assert torch.equal(o, f)  # ordered slab reduction: the same bits every time
+        # the bias gradients that go with the weight gradients (column sums of the dY operands): out of the same call
+        dbs = [None, torch.full((I,), float("nan"), device=DEV), None, torch.full((3 * H,), float("nan"), device=DEV)]
+        for sp in (-1, 2):
+            for _, _, o in items:
+                o.fill_(float("nan"))
+            for t in (dbs[1], dbs[3]):
+                t.fill_(float("nan"))
+            hip.gemm_f32_dw_group(items, T, ktiles=kt, splits=sp, dbias=dbs)
+            for (_, _, o), r in zip(items, refs):
+                close(o, r, rtol=2e-5, name=f"dW {tuple(o.shape)} with bias sums, splits {sp}, list {use_list}")
+            close(dbs[1], d[1].double().cpu().sum(0), rtol=2e-5, name=f"bias gradient of product 1, splits {sp}, list {use_list}")
+            close(dbs[3], d[2].double().cpu().sum(0), rtol=2e-5, name=f"bias gradient of product 3, splits {sp}, list {use_list}")
+        again = [t.clone() for t in (dbs[1], dbs[3])]
+        hip.gemm_f32_dw_group(items, T, ktiles=kt, splits=2, dbias=dbs)
+        assert torch.equal(dbs[1], again[0]) and torch.equal(dbs[3], again[1])  # fixed summation order
         two = [(items[2][0], items[2][1], torch.empty(H, H, device=DEV)), (items[1][0], items[1][1], torch.empty(I, H, device=DEV))]
         hip.gemm_f32_dw_group(two, T, ktiles=kt)
         close(two[0][2], refs[2], rtol=2e-5, name="two products: first")
