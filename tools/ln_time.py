@@ -17,4 +17,13 @@ for M in (2048, 4096, 8192):
     e0.record()
     for _ in range(50): f()
     e1.record(); torch.cuda.synchronize()
-    print(M, "rows: ln_bwd + column sums", round(e0.elapsed_time(e1) / 50 * 1e3, 2), "us")
+    both = e0.elapsed_time(e1) / 50 * 1e3
+    part = torch.empty(int(hip.lib().mtvaf_ln_bwd_workspace_bytes(M, H)) // 4, device=dev)
+    rows = lambda: hip._ck(hip.lib().mtvaf_dropout_res_ln_bwd_rows(hip._p(dout), hip._p(x), hip._p(res), hip._p(gamma), hip._p(mean), hip._p(rstd),
+                                                                   hip._p(dx), hip._p(dres), 0, M, H, 0.1, 7, 3, hip._p(part), None, hip._st()), "rows")
+    for _ in range(5): rows()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50): rows()
+    e1.record(); torch.cuda.synchronize()
+    print(M, "rows: ln_bwd + column sums", round(both, 2), "us; the row kernel alone", round(e0.elapsed_time(e1) / 50 * 1e3, 2), "us")
