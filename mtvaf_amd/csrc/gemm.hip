@@ -793,10 +793,11 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
     if (compute == 2 && !((c == 5 && ((M % 128 == 0 && N % 128 == 0) || ragged5)) || (c == 6 && c6_ok) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute != 0 ? 32 : kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
-    // split kernel, dX products (KC x KM) of >= 128 tiles: at most 2 splits.  They run on the main chain of a backward pass
-    // while the grouped weight gradients share the chip on the second stream, so what a split costs is its CU time (6 us of
-    // prologue + epilogue per block, a slab pass) rather than what it saves in latency alone: 192 tiles x 4 splits measured
-    // 15.55-15.80 ms per step, x 2: 15.35-15.37, unsplit 15.59 (MTVAF_X3_DX_MAXSPLIT overrides)
+    // split kernel, dX products (KC x KM) of >= 128 tiles: at most 2 splits -- in effect none: the [4096 x 768] products over
+    // K = 2304 / 3072 now run as 192 unsplit tiles.  They sit on the main chain of a backward pass while the grouped weight
+    // gradients share the chip on the second stream, so what a split costs is its CU time (6 us of prologue + epilogue per
+    // block, a slab pass and a reduction launch) rather than what it saves in latency alone: 4 splits measured 15.20-15.26 ms
+    // per step, this cap 14.85-14.97 (MTVAF_X3_DX_MAXSPLIT overrides)
     static const int dx_max_s = [] { const char* e = getenv("MTVAF_X3_DX_MAXSPLIT"); return e ? atoi(e) : 2; }();
     const int max_s = allow_split ? ((compute == 2 && la == 0 && lb == 1 && tiles >= 128) ? dx_max_s : 16) : 1;
     for (int s = 1; s <= max_s; ++s) {
