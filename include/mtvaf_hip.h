@@ -359,6 +359,12 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
                                const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
                                float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
                                float p_drop, uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
+/* mtvaf_prefix_attn_bf16_bwd under the zero-tail contract of mtvaf_prefix_attn_bwd_tail (the key side's query loop stops at the
+ * last unmasked position; same bits) */
+int mtvaf_prefix_attn_bf16_bwd_tail(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16,
+                                    const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
+                                    float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
+                                    float p_drop, uint64_t seed, uint64_t offset, int zero_tail, mtvaf_stream_t stream);
 /* ... over PACKED token rows (padding-free execution, see mtvaf_prefix_attn_varlen_fwd): cu [B+1] int32, no mask read;
  * partq / partkv keep their padded row counts (blocks beyond a sentence write zeros). */
 int mtvaf_prefix_attn_bf16_varlen_fwd(const void* qkv16, const void* pk16, const void* pv16, const int* cu, int pad_rows, void* ctx16,
@@ -420,6 +426,9 @@ typedef struct {
    * mode, 64-row tiles in bf16 mode) */
   const int* klist;
   const int* kcnt;
+  /* the caller's word: token rows behind a sentence's last unmasked position carry exactly-zero gradients (what a k-tile list
+   * implies as well): the attention backward stops its query loops there (mtvaf_prefix_attn_bwd_tail) */
+  int zero_tail;
   /* optional (both or neither): the layer's own LayerNorm-backward partials of the FFN / attention block,
    * mtvaf_ln_bwd_workspace_bytes(M, H) each -- their column sums then run on `side` instead of the main chain */
   float *lnpart2, *lnpart1;

@@ -56,6 +56,8 @@ struct Args {
   const uint64_t* epoch;  // device-side dropout epoch (captured launches), or NULL
   const int* cu;          // PACKED token rows (see attention.hip): [B+1] row offsets of the sentences, or NULL
   int pad_rows;           // rows behind the last sentence that pad the packed image: zero-filled by the z-slice b == B
+  int zero_tail;          // backward, padded layout: dctx is exactly zero behind a sentence's last unmasked position (the caller's
+                          // word, as in attention.hip): the key side's query loop stops there
 };
 
 struct Sent {
@@ -461,8 +463,9 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
     }
     if (threadIdx.x < KT) lreg = a.lse[((long)b * a.NH + h) * a.S + min(q0 + (int)threadIdx.x, Sb - 1)] * LOG2E;
   };
-  if (Sb > 0) fetch(0);
-  for (int q0 = 0; q0 < Sb; q0 += KT) {
+  const int Sq = (a.zero_tail && !a.cu) ? min(Sb, T - a.P) : Sb;  // (queries behind it have dO = 0: they add exactly nothing)
+  if (Sq > 0) fetch(0);
+  for (int q0 = 0; q0 < Sq; q0 += KT) {
     float dsum[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) dsum[i] = dot8(orr[i], ofw[i]);
@@ -486,9 +489,9 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
       rh_s[threadIdx.x] = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), row_base + (uint32_t)qq);
     }
     __syncthreads();
-    if (q0 + KT < Sb) fetch(q0 + KT);
+    if (q0 + KT < Sq) fetch(q0 + KT);
     // a wave whose 16 keys all lie beyond T (last key tile) only takes part in the staging and the barriers
-    const int nsub = wave_live ? min(4, (Sb - q0 + 15) >> 4) : 0;
+    const int nsub = wave_live ? min(4, (Sq - q0 + 15) >> 4) : 0;
     f32x4 pd[4], ds[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -645,9 +648,10 @@ static int attn16_fwd_launch(const void* qkv16, const void* pk16, const void* pv
 static int attn16_bwd_launch(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const float* addmask,
                              const int* cu, int pad_rows, const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
                              float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
-                             hipStream_t st) {
+                             hipStream_t st, int zero_tail = 0) {
   if (head_dim != ab::D) return MTVAF_ERR_SHAPE;
   ab::Args a{};
+  a.zero_tail = zero_tail;
   a.qkv = static_cast<const __bf16*>(qkv16); a.pk = static_cast<const __bf16*>(pk16); a.pv = static_cast<const __bf16*>(pv16);
   a.addmask = addmask; a.cu = cu; a.pad_rows = pad_rows; a.ctx = static_cast<__bf16*>(const_cast<void*>(ctx16)); a.lse = const_cast<float*>(lse);
   a.dctx = static_cast<const __bf16*>(dctx16); a.dqkv = static_cast<__bf16*>(dqkv16); a.dpk = dpk; a.dpv = dpv;
@@ -687,6 +691,17 @@ int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void
   if (!addmask) return MTVAF_ERR_ARG;
   return attn16_bwd_launch(dctx16, qkv16, pk16, pv16, addmask, nullptr, 0, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, P, NH,
                            head_dim, p_drop, seed, offset, st);
+}
+
+// mtvaf_prefix_attn_bf16_bwd for callers that vouch (zero_tail != 0) that dctx is exactly zero behind each sentence's last
+// unmasked position (see mtvaf_prefix_attn_bwd_tail): same bits, the key side's query loop stops there.
+int mtvaf_prefix_attn_bf16_bwd_tail(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const float* addmask,
+                                    const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                                    float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                    uint64_t offset, int zero_tail, hipStream_t st) {
+  if (!addmask) return MTVAF_ERR_ARG;
+  return attn16_bwd_launch(dctx16, qkv16, pk16, pv16, addmask, nullptr, 0, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, P, NH,
+                           head_dim, p_drop, seed, offset, st, zero_tail);
 }
 
 // PACKED token rows (padding-free execution; see mtvaf_prefix_attn_varlen_fwd): cu [B+1] int32 row offsets, no mask read;

@@ -52,6 +52,10 @@ int mtvaf_prefix_attn_bwd(const float* dctx, const float* qkv, const float* pk, 
 int mtvaf_prefix_attn_bf16_fwd(const void* qkv16, const void* pk16, const void* pv16, const float* addmask, void* ctx16,
                                float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
                                uint64_t offset, hipStream_t st);
+int mtvaf_prefix_attn_bf16_bwd_tail(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16, const float* addmask,
+                                    const void* ctx16, const float* lse, void* dqkv16, float* dpk, float* dpv, float* partq,
+                                    float* partkv, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                    uint64_t offset, int zero_tail, hipStream_t st);
 int mtvaf_prefix_attn_bf16_bwd(const void* dctx16, const void* qkv16, const void* pk16, const void* pv16,
                                const float* addmask, const void* ctx16, const float* lse, void* dqkv16, float* dpk,
                                float* dpv, float* partq, float* partkv, int B, int S, int P, int NH, int head_dim,
@@ -161,6 +165,8 @@ struct mtvaf_layer_grads_t {
   void* ws_side; size_t ws_side_bytes;         // scratch of the second stream (split-K slabs, column-sum partials)
   const int* klist;                            // optional: k-tile list of the token axis for the dW products (32-row tiles in fp32 mode, 64 in bf16)
   const int* kcnt;
+  int zero_tail;                               // the caller's word: token rows behind a sentence's last unmasked position carry exactly-zero
+                                               // gradients (what a k-tile list implies): attention backward stops its query loops there
   float *lnpart2, *lnpart1;                    // optional (both or neither): per-layer LayerNorm-backward partials of the FFN / attention
                                                // block (mtvaf_ln_bwd_workspace_bytes each) -- their column sums then run on `side`
 };
@@ -301,8 +307,9 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
       MTVAF_TRY(mtvaf_prefix_attn_bf16_varlen_bwd(g->dctx, L->qkv, L->pk, L->pv, L->cu, L->Mp - L->Mv, L->cx, L->lse, g->dqkv, g->dpk,
                                                   g->dpv, g->partq, g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
     } else {
-      MTVAF_TRY(mtvaf_prefix_attn_bf16_bwd(g->dctx, L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, g->dqkv, g->dpk, g->dpv, g->partq,
-                                           g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset, mainS));
+      MTVAF_TRY(mtvaf_prefix_attn_bf16_bwd_tail(g->dctx, L->qkv, L->pk, L->pv, L->addmask, L->cx, L->lse, g->dqkv, g->dpk, g->dpv, g->partq,
+                                                g->partkv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset,
+                                                ((g->klist != nullptr || g->zero_tail) && attn_tail_on()) ? 1 : 0, mainS));
     }
     MTVAF_TRY(fork_to(mainS, side));
     MTVAF_TRY(mtvaf_colsum_small(g->partq, B * ((S + 63) / 64), H, g->dbqkv, 0, side));
@@ -358,7 +365,7 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
       // last unmasked position)
       MTVAF_TRY(mtvaf_prefix_attn_bwd_tail(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx,
                                            L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn, L->seed, L->offset,
-                                           (g->klist != nullptr && attn_tail_on()) ? 1 : 0, mainS));
+                                           ((g->klist != nullptr || g->zero_tail) && attn_tail_on()) ? 1 : 0, mainS));
     }
     MTVAF_TRY(fork_to(mainS, side));
     if (!grp) MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));

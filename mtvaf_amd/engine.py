@@ -508,6 +508,7 @@ def _native_backward(ctx, douts):
     am_ptr = addmask.data_ptr()
     settle = int(grad_sink is not None and side is not None and grad_sink.on_layer_done is not None and grad_sink.settle_params)
     klist = kcnt = None
+    zero_tail = bool(SKIP_PAD_DW and pack is None and len(cfg) > 5 and cfg[5] and addmask.dtype == torch.float32 and addmask.is_contiguous())
     bk = 64 if use_h else 32  # k-tile of the dW kernels
     # (mixed-precision mode: measured SLOWER with the list -- 7.85 vs 7.56 ms at C3, 11.71 vs 11.60 at C4: 64-row tiles skip
     # only ~19 % of a 33-us product and the device-side count delays its first loads -- so the list is an fp32-mode lever;
@@ -576,6 +577,9 @@ def _native_backward(ctx, douts):
         gs.ws_main, gs.ws_main_bytes = ws_main.data_ptr(), ws_main.numel()
         gs.ws_side, gs.ws_side_bytes = ws_side.data_ptr(), ws_side.numel()
         gs.klist, gs.kcnt = (klist.data_ptr(), kcnt.data_ptr()) if klist is not None else (None, None)
+        # (the caller vouches that masked token rows carry exactly-zero gradients -- cfg[5], BertModel.allow_unpad: the contract of
+        # the k-tile lists, which the bf16 kernels do not take by default)
+        gs.zero_tail = int(zero_tail)
         hip._ck(fn(ctypes.byref(st), ctypes.byref(gs), main_h, side_h, settle), "mtvaf_encoder_layer_bwd")
         if gviews is None:
             G[0], G[2], G[4] = dwqkv[:H], dwqkv[H:2 * H], dwqkv[2 * H:]
@@ -751,6 +755,8 @@ class EncoderFunction(torch.autograd.Function):
             for t in reads:  # temporaries freed before the join below: the allocator must wait for the side stream
                 t.record_stream(side)
 
+        # (the same contract flag as the native executor's: the two paths must stay bit-identical)
+        zero_tail = bool(SKIP_PAD_DW and len(cfg) > 5 and cfg[5] and addmask.dtype == torch.float32 and addmask.is_contiguous())
         ktiles = None  # (the native executor's k-tile list: the two paths must stay bit-identical)
         if (SKIP_PAD_DW and (not use_h or SKIP_PAD_DW_BF16) and need_param_grads and len(cfg) > 5 and cfg[5] and M % (64 if use_h else 32) == 0
                 and addmask.dtype == torch.float32 and addmask.is_contiguous()):
@@ -839,7 +845,7 @@ class EncoderFunction(torch.autograd.Function):
                 partq, partkv = _empty(B * nqt, H, like=dev_like), _empty(B * nkt, 2 * H, like=dev_like)
                 hip.prefix_attn_bf16_bwd(dctx, qkv, pkv16[li, 0] if Pn else None, pkv16[li, 1] if Pn else None, addmask, cx,
                                          lse, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, partq, partkv,
-                                         B, S, Pn, NH, p_attn, seed, off)
+                                         B, S, Pn, NH, p_attn, seed, off, zero_tail=zero_tail or ktiles is not None)
 
                 def qkv_grads():
                     (hip.colsum_small if partq.shape[0] <= 256 else hip.colsum)(partq, dbqkv[:H])
@@ -862,7 +868,7 @@ class EncoderFunction(torch.autograd.Function):
                 dqkv, delta = _empty(M, 3 * H, like=dev_like), _empty(B, NH, S, like=dev_like)
                 hip.prefix_attn_bwd(dctx, qkv, pkv[li, 0] if Pn else None, pkv[li, 1] if Pn else None, addmask, cx, lse,
                                     delta, dqkv, dpkv[li, 0] if Pn else None, dpkv[li, 1] if Pn else None, B, S, Pn, NH,
-                                    p_attn, seed, off, zero_tail=ktiles is not None)
+                                    p_attn, seed, off, zero_tail=zero_tail or ktiles is not None)
 
                 def qkv_grads():
                     if grp:

@@ -50,6 +50,7 @@ _SIGS = {
     "mtvaf_zero_f32": (c_int, [P, L, P]),
     "mtvaf_prefix_attn_bf16_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bf16_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_bf16_bwd_tail": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, I, P]),
     "mtvaf_ln_bwd_workspace_bytes": (SZ, [I, I]),
     "mtvaf_roberta_position_ids": (c_int, [P, P, I, I, I, P]),
     "mtvaf_embed_ln_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, F, F, U64, U64, P, P]),
@@ -123,8 +124,8 @@ class LayerGradsStruct(ctypes.Structure):
                                          "dwqkv", "dbqkv", "dwo", "dbo", "dg1", "db1", "dw1", "dbi1", "dw2", "dbi2", "dg2",
                                          "db2", "dpk", "dpv", "ws_main")] + [("ws_main_bytes", c_size_t), ("ws_side", c_void_p),
                                                                             ("ws_side_bytes", c_size_t), ("klist", c_void_p),
-                                                                            ("kcnt", c_void_p), ("lnpart2", c_void_p),
-                                                                            ("lnpart1", c_void_p)])
+                                                                            ("kcnt", c_void_p), ("zero_tail", c_int),
+                                                                            ("lnpart2", c_void_p), ("lnpart1", c_void_p)])
 
 
 _lib = None
@@ -468,11 +469,12 @@ def prefix_attn_bf16_fwd(qkv16, pk16, pv16, addmask, ctx16, lse, B, S, Pn, NH, p
 
 
 def prefix_attn_bf16_bwd(dctx16, qkv16, pk16, pv16, addmask, ctx16, lse, dqkv16, dpk, dpv, partq, partkv, B, S, Pn, NH, p,
-                         seed, offset):
-    """partq [B*ceil(S/64), H], partkv [B*ceil((Pn+S)/64), 2H]: per-block column sums of dQ and dK|dV (QKV bias gradient)."""
-    _ck(lib().mtvaf_prefix_attn_bf16_bwd(_p(dctx16), _p(qkv16), _p(pk16), _p(pv16), _p(addmask), _p(ctx16), _p(lse),
-                                         _p(dqkv16), _p(dpk), _p(dpv), _p(partq), _p(partkv), B, S, Pn, NH, 64, float(p),
-                                         seed, offset, _st()), "mtvaf_prefix_attn_bf16_bwd")
+                         seed, offset, zero_tail=False):
+    """partq [B*ceil(S/64), H], partkv [B*ceil((Pn+S)/64), 2H]: per-block column sums of dQ and dK|dV (QKV bias gradient).
+    zero_tail: as prefix_attn_bwd."""
+    _ck(lib().mtvaf_prefix_attn_bf16_bwd_tail(_p(dctx16), _p(qkv16), _p(pk16), _p(pv16), _p(addmask), _p(ctx16), _p(lse),
+                                              _p(dqkv16), _p(dpk), _p(dpv), _p(partq), _p(partkv), B, S, Pn, NH, 64, float(p),
+                                              seed, offset, int(bool(zero_tail)), _st()), "mtvaf_prefix_attn_bf16_bwd_tail")
 
 
 def crf_workspace(B, S, C, device):

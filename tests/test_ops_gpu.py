@@ -299,6 +299,42 @@ def test_prefix_attention_backward_zero_tail_contract(hip, B, S, Pn, NH, p):
         assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("B,S,Pn,NH,p", [(4, 128, 36, 12, 0.0), (4, 128, 36, 3, 0.1), (3, 200, 16, 2, 0.1)])
+def test_prefix_attention_bf16_backward_zero_tail_contract(hip, B, S, Pn, NH, p):
+    """The bf16 attention backward under the zero-tail contract (mtvaf_prefix_attn_bf16_bwd_tail): with dctx exactly zero behind
+    each sentence's last unmasked position, the key side's shortened query loop gives the same bits as the full one."""
+    H, T = NH * 64, Pn + S
+    bf = lambda t: t.to(DEV).to(torch.bfloat16)
+    qkv, pk, pv = bf(rnd(B * S, 3 * H, seed=21)), bf(rnd(B, max(Pn, 1) * H, seed=22)), bf(rnd(B, max(Pn, 1) * H, seed=23))
+    lens = [S, 1, S // 2 + 3, max(2, S // 5)][:B]
+    mask = torch.zeros(B, T)
+    for b, Lb in enumerate(lens):
+        mask[b, : Pn + Lb] = 1
+    if B > 2:
+        mask[2, Pn + 4] = 0
+    addmask = ((1 - mask) * -10000.0).to(DEV)
+    dctx = rnd(B * S, H, seed=24).view(B, S, H)
+    for b, Lb in enumerate(lens):
+        dctx[b, Lb:] = 0.0
+    dctx = bf(dctx.view(B * S, H))
+    ctx, lse = torch.empty(B * S, H, device=DEV, dtype=torch.bfloat16), torch.empty(B, NH, S, device=DEV)
+    hip.prefix_attn_bf16_fwd(qkv, pk if Pn else None, pv if Pn else None, addmask, ctx, lse, B, S, Pn, NH, p, 5, 9)
+    nqt, nkt = (S + 63) // 64, (Pn + S + 63) // 64
+    outs = []
+    for tail in (False, True):
+        dqkv = torch.full((B * S, 3 * H), float("nan"), device=DEV, dtype=torch.bfloat16)
+        dpk = torch.full((B, max(Pn, 1) * H), float("nan"), device=DEV) if Pn else None
+        dpv = torch.full((B, max(Pn, 1) * H), float("nan"), device=DEV) if Pn else None
+        partq, partkv = torch.full((B * nqt, H), float("nan"), device=DEV), torch.full((B * nkt, 2 * H), float("nan"), device=DEV)
+        hip.prefix_attn_bf16_bwd(dctx, qkv, pk if Pn else None, pv if Pn else None, addmask, ctx, lse, dqkv, dpk, dpv, partq, partkv,
+                                 B, S, Pn, NH, p, 5, 9, zero_tail=tail)
+        assert bool(torch.isfinite(dqkv.float()).all()) and bool(torch.isfinite(partq).all()) and bool(torch.isfinite(partkv).all())
+        outs.append((dqkv, dpk, dpv, partq, partkv))
+    for x, y in zip(outs[0], outs[1]):
+        if x is not None:
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("B,S,Pn,NH", [(3, 16, 0, 2), (3, 16, 4, 2), (2, 128, 36, 12), (2, 100, 16, 3), (1, 200, 36, 2),
                                        (2, 64, 100, 1)])
 def test_prefix_attention_bf16(hip, B, S, Pn, NH):
