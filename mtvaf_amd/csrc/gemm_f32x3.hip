@@ -80,12 +80,19 @@ __device__ __forceinline__ int kc_row(int g) { return (g & ~7) | ((g & 1) << 2) 
 // (ds_write_b64: 4 k of one row) covers all 8 k quads of two adjacent row groups = 32 distinct banks (conflict-free; the
 // first form -- k PAIRS, 4-byte stores -- ran the weight-gradient kernel with 60 % of its LDS cycles in bank conflicts),
 // and the 64 lanes of a load instruction cover 8 k-rows x 128 contiguous bytes.
+// MTVAF_X3_KM_LANES (compile-time experiment switch): how many consecutive lanes load consecutive 16-byte pieces of one k-row.
+// 1 = the mapping above (every lane of a load instruction starts its own 16-byte piece: the texture addresser sees 64 of them
+// -- a KM request batch costs its wave 770 ticks where a KC batch costs 370, tools/x3_trace.py); 4 = four lanes cover 64
+// contiguous bytes (kq above them): a quarter of the pieces, at the price of 2-way bank conflicts in the plane stores.
+#ifndef MTVAF_X3_KM_LANES
+#define MTVAF_X3_KM_LANES 4
+#endif
 template <int BK>
 __device__ __forceinline__ void km_unit(int u, int& kq, int& c4) {
-  kq = u & (BK / 4 - 1);
-  c4 = (u / (BK / 4)) * 4;
+  constexpr int CL = MTVAF_X3_KM_LANES, NKQ = BK / 4;
+  kq = (u / CL) & (NKQ - 1);
+  c4 = ((u / (CL * NKQ)) * CL + (u & (CL - 1))) * 4;
 }
-
 // global -> registers (whole tiles only: the launcher checks alignment).  KC: float4 idx -> (row = idx / (BK/4), k = (idx %
 // (BK/4)) * 4).  KM: unit u -> (k quad kq, 4 rows c4; km_unit): four float4 (the same 4 rows at k .. k + 3).
 // rlim: the last row a load may start at (KC: rows - 1, KM: rows - 4; default: no limit) -- tiles that hang over the operand
@@ -551,14 +558,16 @@ __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
     if (kt < nk) pstep(kt, ra1, rb1);
     if constexpr (GROUP) {
       if (do_sum) {
+        int kq_, c4_;
+        km_unit<BK>(ptid, kq_, c4_);  // (the eight k quads of a column group: lanes MTVAF_X3_KM_LANES * {0 .. 7} apart)
 #pragma unroll
-        for (int d = 1; d < 8; d <<= 1) {
+        for (int d = MTVAF_X3_KM_LANES; d < 8 * MTVAF_X3_KM_LANES; d <<= 1) {
           csum.x += __shfl_xor(csum.x, d, 64);
           csum.y += __shfl_xor(csum.y, d, 64);
           csum.z += __shfl_xor(csum.z, d, 64);
           csum.w += __shfl_xor(csum.w, d, 64);
         }
-        if ((ptid & 7) == 0) *reinterpret_cast<f32x4*>(colsum + m0 + (ptid >> 3) * 4) = csum;
+        if (kq_ == 0) *reinterpret_cast<f32x4*>(colsum + m0 + c4_) = csum;
       }
     }
   }

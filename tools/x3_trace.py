@@ -2,7 +2,7 @@
 clock around every tile barrier).  Consumers (waves 0-3): [2] arrive at the barrier, [3] leave it.  Producers (4-7): [0] step
 start, [1] planes stored, [2] next loads requested = arrive, [3] leave.
 
-    python tools/x3_trace.py [M N K] [cfg]
+    python tools/x3_trace.py [M N K] [cfg] [la lb]     # la / lb: 0 = KC (reduction index contiguous), 1 = KM (k-major)
 """
 import os
 import sys
@@ -16,8 +16,11 @@ dev = "cuda"
 args = [int(a) for a in sys.argv[1:]]
 M, N, K = (args + [4096, 3072, 768])[:3] if len(args) >= 3 else (4096, 3072, 768)
 cfg = args[3] if len(args) > 3 else 5
-a, b, out = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev), torch.empty(M, N, device=dev)
-run = lambda: hip.gemm(a, 0, b, 0, out, M, N, K, compute="fp32x3", cfg=cfg)
+la, lb = (args[4], args[5]) if len(args) > 5 else (0, 0)
+a = torch.randn(*((K, M) if la else (M, K)), device=dev)
+b = torch.randn(*((K, N) if lb else (N, K)), device=dev)
+out = torch.empty(M, N, device=dev)
+run = lambda: hip.gemm(a, la, b, lb, out, M, N, K, compute="fp32x3", cfg=cfg)
 for _ in range(3):
     run()
 buf = torch.zeros(8 * 64 * 4 + 17, dtype=torch.int64, device=dev)
