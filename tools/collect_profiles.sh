@@ -29,6 +29,10 @@ python bench.py --steps 5 --warmup 4 --batch 128 --seq 512 --no-cpu-baseline --n
 python tools/f32x3_bench.py > $O/${T}_f32x3_microbench.txt 2>/dev/null
 python tools/x3_trace.py 4096 3072 768 5 > $O/${T}_x3_trace.txt 2>/dev/null
 python tools/x3_trace.py 4096 768 768 6 >> $O/${T}_x3_trace.txt 2>/dev/null
+echo "== weight gradient (KM x KM), 768 x 3072 x 2048 ==" >> $O/${T}_x3_trace.txt
+python tools/x3_trace.py 768 3072 2048 5 1 1 2>/dev/null | tail -4 >> $O/${T}_x3_trace.txt
+echo "== dX (KC x KM), 4096 x 3072 x 768 ==" >> $O/${T}_x3_trace.txt
+python tools/x3_trace.py 4096 3072 768 5 0 1 2>/dev/null | tail -4 >> $O/${T}_x3_trace.txt
 # sustained bf16 MFMA rate of the whole chip (hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form=1 tools/micro/mfma_bf16_rate.hip)
 [ -x tools/micro/mfma_bf16_rate ] && tools/micro/mfma_bf16_rate > $O/${T}_mfma_bf16_rate.txt 2>&1
 fi
