@@ -21,7 +21,10 @@ SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16x.hip", "gemm_bf16p.hip", "gem
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"] + os.environ.get("MTVAF_EXTRA_FLAGS", "").split()
 # The attention kernels read their MFMA results with VALU code every 16 products (softmax, dS): keeping the
 # accumulators in architectural VGPRs saves ~200 v_accvgpr moves per key tile (gfx950 has one unified file).
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               # the operand split writes its residuals as scalar subtractions: the SLP vectoriser would pair them into
+               # v_pk_add_f32, which issues slower beside MFMAs (csrc/gemm_f32x3.hip, resid2)
+               "gemm_f32x3.hip": ["-fno-slp-vectorize"]}
 
 
 def _headers_digest() -> bytes:

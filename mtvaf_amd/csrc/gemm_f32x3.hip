@@ -36,7 +36,10 @@ __device__ __forceinline__ unsigned cvt_pk(const f32x2 v) { return __builtin_bit
 __device__ __forceinline__ f32x2 widen(const unsigned pk) {
   return f32x2{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
 }
-// Residual x - bf16 pair by plain v_sub_f32 (beside MFMAs a v_pk_add_f32 costs several plain instructions' issue time).
+// Residual x - bf16 pair by two plain v_sub_f32 (beside MFMAs a v_pk_add_f32 costs several plain instructions' issue time):
+// scalar subtractions, and this file is compiled with -fno-slp-vectorize (mtvaf_amd/build.py) so that they stay scalar.  Until
+// round 4 they were inline assembly -- which kept them apart too, but made hipcc put an s_nop behind every one that feeds
+// the next conversion (31 per staged k-tile: it cannot see inside the asm) and use the 8-byte encoding.
 // Tried and dropped in round 4: v_dot2c_f32_bf16 with b = (-1, 0) / (0, -1) folds the widening into the subtraction (7
 // instead of 11 vector instructions per pair) but issues slower than the three instructions it replaces -- the producers'
 // staging went from 1840 to 2660 cycles per k-tile (tools/x3_trace.py) -- and hipcc 7.2 encodes the (-1, 0) operand as the
@@ -44,8 +47,8 @@ __device__ __forceinline__ f32x2 widen(const unsigned pk) {
 __device__ __forceinline__ f32x2 resid2(const f32x2 x, const unsigned hpk) {
   const f32x2 w = widen(hpk);
   f32x2 r;
-  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r.x) : "v"(x.x), "v"(w.x));
-  asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r.y) : "v"(x.y), "v"(w.y));
+  r.x = x.x - w.x;
+  r.y = x.y - w.y;
   return r;
 }
 __device__ __forceinline__ void split3_pair(const f32x2 x, unsigned& h, unsigned& m, unsigned& l) {
@@ -55,6 +58,8 @@ __device__ __forceinline__ void split3_pair(const f32x2 x, unsigned& h, unsigned
   l = cvt_pk(resid2(r, m));
 }
 __device__ __forceinline__ void split3(const f32x4 x, bf16x4& h, bf16x4& m, bf16x4& l) {
+  // (the stages of several pairs interleaved by hand -- every operand several instructions old -- measured no better: 1115 vs
+  // 1104 us over a layer's products; the vector instructions beside the matrix stream are bound by issue, not by latency)
   unsigned h0, m0, l0, h1, m1, l1;
   split3_pair(f32x2{x.x, x.y}, h0, m0, l0);
   split3_pair(f32x2{x.z, x.w}, h1, m1, l1);
