@@ -919,8 +919,9 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
            (!aux || ((ldaux % 4 == 0) && (((uintptr_t)aux & 15) == 0))) && (!bias || (((uintptr_t)bias & 15) == 0));
     const bool forced = (cfg == 5 && (can5 || rag5)) || (cfg == 6 && can6) || (cfg == 3 && can3);
     const bool plannable = can5 || rag5 || can3 || x3_tile96_ok(M, N, layout_a, layout_b);
+    // (leading dimensions < 2^23 elements: a tile's loads address it by 32-bit byte offsets from a scalar base)
     const bool ok = (K % 32 == 0) && (forced || plannable) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
-                    (((uintptr_t)B & 15) == 0) && !(layout_a == 1 && layout_b == 0);
+                    (((uintptr_t)B & 15) == 0) && !(layout_a == 1 && layout_b == 0) && lda < (1 << 23) && ldb < (1 << 23);
     // (few output tiles -- the 256-token products of BASELINE configs[0] -- leave most CUs without a block of the 128x128
     // kernel: the fp32 pipe's 64x64 tiles are faster there, measured 4.37 vs 4.53 ms per C1 step)
     const long tiles96 = can6 ? (long)(M / 128) * (N / 96) : 0;

@@ -103,25 +103,39 @@ __device__ __forceinline__ void km_unit(int u, int& kq, int& c4) {
 // rlim: the last row a load may start at (KC: rows - 1, KM: rows - 4; default: no limit) -- tiles that hang over the operand
 // (ragged results of the wave-specialised kernel) re-read its last rows, finite values whose products are never stored; the
 // clamp is loop-invariant (only k0 moves), so the k-loop does not see it.
+// Addresses are a UNIFORM tile base (moves with k0: scalar arithmetic) + a per-thread 32-bit element offset inside the tile
+// that does not depend on k0 (rows of the tile x leading dimension < 2^31: checked by the launcher) -- hipcc then forms
+// global_load_dwordx4 v, v_offset, s[base] and the k-loop carries no 64-bit vector address arithmetic (16 v_lshl_add_u64
+// per k-tile until round 4).
 template <int ROWS, int NT, bool KM, int BK>
 __device__ __forceinline__ void g_load(f32x4* reg, const float* base, int ld, int r0, int k0, int tid, int rlim = 0x7fffffff) {
   if constexpr (!KM) {
+    const float* tb = base + (long)r0 * ld + k0;  // (uniform)
 #pragma unroll
     for (int i = 0; i < Stage<ROWS, NT, KM, BK>::NKC; ++i) {
       const int idx = tid + i * NT;
       const int row = BK == 32 ? kc_row(idx >> 3) : idx / (BK / 4);
-      reg[i] = *reinterpret_cast<const f32x4*>(base + (long)min(r0 + row, rlim) * ld + k0 + (idx % (BK / 4)) * 4);
+      // BYTE offset in 32 bits (so that it can be the load's vector offset beside a scalar base), opaque here: otherwise hipcc
+      // hoists base + offset into a vector pair and adds k0 to each of them, one 64-bit vector add per load and k-tile
+      unsigned off = (unsigned)((min(r0 + row, rlim) - r0) * ld + (idx % (BK / 4)) * 4) * 4u;
+      asm("" : "+v"(off));
+      reg[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tb) + off);
     }
   } else {
+    const float* tb = base + (long)k0 * ld + r0;  // (uniform)
 #pragma unroll
     for (int i = 0; i < Stage<ROWS, NT, KM, BK>::NU; ++i) {
       const int u = tid + i * NT;
       if (Stage<ROWS, NT, KM, BK>::UNITS % NT != 0 && u >= Stage<ROWS, NT, KM, BK>::UNITS) continue;
       int kq, c4;
       km_unit<BK>(u, kq, c4);
-      const float* q = base + (long)(k0 + 4 * kq) * ld + min(r0 + c4, rlim);
+      const unsigned off = (unsigned)(4 * kq * ld + (min(r0 + c4, rlim) - r0));
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) reg[4 * i + kk] = *reinterpret_cast<const f32x4*>(q + (long)kk * ld);
+      for (int kk = 0; kk < 4; ++kk) {
+        unsigned o = (off + (unsigned)(kk * ld)) * 4u;
+        asm("" : "+v"(o));
+        reg[4 * i + kk] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(tb) + o);
+      }
     }
   }
 }
