@@ -1166,6 +1166,7 @@ static int dw_group_impl(int n, const float* const* A, const int* lda, const flo
   if (dw_group_on_split_kernel(n, M, N, K)) {
     for (int i = 0; i < n; ++i) {
       if (lda[i] % 4 || ldb[i] % 4 || ldc[i] % 4 || (((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C[i]) & 15)) return MTVAF_ERR_ALIGN;
+      if (lda[i] >= (1 << 23) || ldb[i] >= (1 << 23)) return MTVAF_ERR_SHAPE;  // (32-bit byte offsets inside a tile)
       a.grp_tile_begin[i] = (int)tiles;
       tiles += (long)(M[i] / 128) * (N[i] / 128);
       outs += (long)M[i] * N[i];
