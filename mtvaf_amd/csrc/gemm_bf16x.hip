@@ -68,18 +68,20 @@ __global__ __launch_bounds__((DW ? 2 : 1) * WM* WN * 64, (BM * BN > 256 * 128) ?
     kbeg = 0;
   }
 
-  // ---- per-lane DMA source addresses: LDS position (row, chunk position cp) receives source chunk cp ^ swizzle(row)
-  const unsigned char* pa[IA];
-  const unsigned char* pb[IB];
+  // ---- per-lane DMA source addresses: LDS position (row, chunk position cp) receives source chunk cp ^ swizzle(row).
+  // A request's address is a UNIFORM base (the operand's tile at the current k-tile: scalar arithmetic) + a per-lane 32-bit
+  // byte offset that never changes (round 4: global_load_lds ... v_offset, s[base]; until then every lane carried IA + IB
+  // 64-bit pointers and advanced each with a 64-bit vector add per request and k-tile).
+  unsigned oa[IA], ob[IB];
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
     const int f = (wave * IA + i) * 64 + lane;
     if (!A_KM) {
       const int r = f >> 3, cp = f & 7;
-      pa[i] = reinterpret_cast<const unsigned char*>(p.A + (long)(m0 + r) * p.lda + kbeg) + ((cp ^ ((r >> 1) & 7)) << 4);
+      oa[i] = (unsigned)r * (unsigned)p.lda * 2u + (unsigned)((cp ^ ((r >> 1) & 7)) << 4);
     } else {
       const int r = f >> 4, cp = f & 15;
-      pa[i] = reinterpret_cast<const unsigned char*>(p.A + (long)(kbeg + r) * p.lda + m0) + ((cp ^ km_swz(r)) << 4);
+      oa[i] = (unsigned)r * (unsigned)p.lda * 2u + (unsigned)((cp ^ km_swz(r)) << 4);
     }
   }
 #pragma unroll
@@ -87,41 +89,50 @@ __global__ __launch_bounds__((DW ? 2 : 1) * WM* WN * 64, (BM * BN > 256 * 128) ?
     const int f = (wave * IB + i) * 64 + lane;
     if (!B_KM) {
       const int r = f >> 3, cp = f & 7;
-      pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(n0 + r) * p.ldb + kbeg) + ((cp ^ ((r >> 1) & 7)) << 4);
+      ob[i] = (unsigned)r * (unsigned)p.ldb * 2u + (unsigned)((cp ^ ((r >> 1) & 7)) << 4);
     } else if (BN == 128) {
       const int r = f >> 4, cp = f & 15;
-      pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(kbeg + r) * p.ldb + n0) + ((cp ^ km_swz(r)) << 4);
+      ob[i] = (unsigned)r * (unsigned)p.ldb * 2u + (unsigned)((cp ^ km_swz(r)) << 4);
     } else {  // 192-byte rows: consecutive rows start 48 banks apart, the transposing reads are conflict-free unswizzled
       const int o = f << 4, half = o / KM96_HALF_B, oo = o % KM96_HALF_B, r = oo / 192, cb = oo % 192;
-      pb[i] = reinterpret_cast<const unsigned char*>(p.B + (long)(kbeg + r) * p.ldb + n0 + half * 96) + cb;
+      ob[i] = (unsigned)r * (unsigned)p.ldb * 2u + (unsigned)(half * 192 + cb);
     }
   }
+  const unsigned char* const baseA =
+      reinterpret_cast<const unsigned char*>(A_KM ? p.A + (long)kbeg * p.lda + m0 : p.A + (long)m0 * p.lda + kbeg);
+  const unsigned char* const baseB =
+      reinterpret_cast<const unsigned char*>(B_KM ? p.B + (long)kbeg * p.ldb + n0 : p.B + (long)n0 * p.ldb + kbeg);
   const long stepA = A_KM ? (long)BK * p.lda * 2 : BK * 2;
   const long stepB = B_KM ? (long)BK * p.ldb * 2 : BK * 2;
+  long posA = 0, posB = 0;  // (uniform) byte position of the next k-tile to request
   int issued = 0;
   int kt_next = (klist_mode && nk > 0) ? p.klist[lbeg] : 0;  // fetched one issue ahead (a uniform scalar load)
   auto issue = [&](int stage) {
     unsigned char* sa = smem_b + stage * STAGE_B + wave * IA * 1024;
     unsigned char* sb = smem_b + stage * STAGE_B + A_B + wave * IB * 1024;
     if constexpr (klist_mode) {
-      const long oa = (long)kt_next * stepA, ob = (long)kt_next * stepB;
+      posA = (long)kt_next * stepA;
+      posB = (long)kt_next * stepB;
       ++issued;
       kt_next = p.klist[lbeg + min(issued, nk - 1)];
-#pragma unroll
-      for (int i = 0; i < IA; ++i) glds16x(pa[i] + oa, sa + i * 1024);
-#pragma unroll
-      for (int i = 0; i < IB; ++i) glds16x(pb[i] + ob, sb + i * 1024);
-      return;
     }
+    const unsigned char* ca = baseA + posA;
+    const unsigned char* cb = baseB + posB;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      glds16x(pa[i], sa + i * 1024);
-      pa[i] += stepA;
+      unsigned o = oa[i];
+      asm("" : "+v"(o));  // (opaque: keeps base + offset from being hoisted into a 64-bit vector pointer per request)
+      glds16x(ca + o, sa + i * 1024);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      glds16x(pb[i], sb + i * 1024);
-      pb[i] += stepB;
+      unsigned o = ob[i];
+      asm("" : "+v"(o));
+      glds16x(cb + o, sb + i * 1024);
+    }
+    if constexpr (!klist_mode) {
+      posA += stepA;
+      posB += stepB;
     }
   };
 
