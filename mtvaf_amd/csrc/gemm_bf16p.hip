@@ -140,14 +140,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK
   auto stage_A = [&](int buf, int h, int kt) {
     const unsigned char* s = Abase + (long)kt * stepA + h * hstepA;
     unsigned char* d = dma_dst + buf * BUF + h * HALF;
-    glds16x(s + voffA[0], d);
-    glds16x(s + voffA[1], d + 1024);
+    unsigned o0 = voffA[0], o1 = voffA[1];
+    asm("" : "+v"(o0), "+v"(o1));  // (opaque: the requests stay scalar base + 32-bit lane offset instead of hoisted 64-bit pointers)
+    glds16x(s + o0, d);
+    glds16x(s + o1, d + 1024);
   };
   auto stage_B = [&](int buf, int h, int kt) {
     const unsigned char* s = Bbase + (long)kt * stepB + h * hstepB;
     unsigned char* d = dma_dst + buf * BUF + (2 + h) * HALF;
-    glds16x(s + voffB[0], d);
-    glds16x(s + voffB[1], d + 1024);
+    unsigned o0 = voffB[0], o1 = voffB[1];
+    asm("" : "+v"(o0), "+v"(o1));
+    glds16x(s + o0, d);
+    glds16x(s + o1, d + 1024);
   };
 
   // ---- fragment read offsets (bytes inside a half-tile image) ----
