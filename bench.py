@@ -12,6 +12,12 @@ Twitter-shaped synthetic batch, train mode (all 37+ dropout sites live), one ste
 Viterbi decode, as the reference forward does) + loss.backward() + AdamW step.  Weak scaling: per-GPU
 work is fixed; N > 1 adds the RCCL gradient all-reduce (overlapped with backward) inside the timed region.
 
+Since round 5 the timed run is the library default, padding-free execution (the encoder layers run on the packed unmasked
+token rows; loss, decoded tags and parameter gradients are those of the padded run: tests/test_unpad_gpu.py, the `pad_mode`
+fixture): `config.workload` says so, every roofline / fraction in the line counts EXECUTED flops only (never SURVEY 8d's
+F_train, which credits masked rows nobody computes), and the line carries the `padded` run (--padded / MTVAF_UNPAD=0) and the
+`full_length` run (nothing to skip) beside `value`.
+
 Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` and `cpu_baseline`.
 """
 from __future__ import annotations
@@ -121,7 +127,7 @@ def cpu_baseline(B, S, n_aux, seconds_budget=40.0, min_steps=3):
             "seconds_per_step": round(med, 3)}
 
 
-def frontend_cache_throughput(device, batch=32, n_aux=3, hw=224, reps=3):
+def frontend_cache_throughput(device, batch=32, n_aux=3, hw=224, reps=3, compute="fp32"):
     """Row f1 (the step before the path): images/s of building the region-feature cache -- the frozen ResNet-50 pyramid of
     `ImageModel` (reference: models/bert_model.py:63-111; torch / MIOpen, random weights: the reference's .pth files are not
     in the image) run once per image in inference mode by `RegionFeatureCache.extract` on `batch` sentences of 1 + n_aux
@@ -130,7 +136,7 @@ def frontend_cache_throughput(device, batch=32, n_aux=3, hw=224, reps=3):
     from mtvaf_amd.models.bert_model import ImageModel
     torch.manual_seed(5)
     im = ImageModel(resnet_root="random").to(device).eval()
-    cache = RegionFeatureCache(im)
+    cache = RegionFeatureCache(im, compute=compute)
     x = torch.randn(batch, 3, hw, hw, device=device)
     aux = torch.randn(batch, n_aux, 3, hw, hw, device=device)
     cache.extract(x, aux)  # (MIOpen picks its algorithms here)
@@ -143,7 +149,8 @@ def frontend_cache_throughput(device, batch=32, n_aux=3, hw=224, reps=3):
     n_img = batch * (1 + n_aux)
     return {"images_per_s": round(n_img / dt, 1), "sentences_per_s": round(batch / dt, 1), "ms_per_batch": round(1e3 * dt, 2),
             "what": f"RegionFeatureCache.extract, ResNet-50 pyramid (random weights), {batch} sentences x (1 + {n_aux}) images of "
-                    f"{hw}x{hw}, fp32, eval-mode BatchNorm; output {tuple(feats.shape)} + {tuple(fa.shape)}"}
+                    f"{hw}x{hw}, {'fp32' if compute == 'fp32' else 'channels-last bf16 trunk with folded BatchNorm, fp32 region pooling'}, "
+                    f"eval-mode BatchNorm; output {tuple(feats.shape)} + {tuple(fa.shape)}"}
 
 
 def pmc_traffic(symbol, dtype="fp32", batch=32, seq=128):
@@ -302,8 +309,10 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3,
                                "parity test (1e-3 vs the oracle, bit-exact tags, reference goldens) runs in this mode")
             res["mfma_fraction_of_step"] = round(v * 3 * f_fwd(S, P) / (PEAK_TFLOPS["fp32x3"] * 1e12), 4)
         if unpad:
-            res["workload"] += ", padding-free execution (masked token rows not computed: DESIGN.md 4.6)"
-            res["mfma_fraction_of_step"] = None  # (the algorithmic flop count includes the masked rows this mode does not compute)
+            res["workload"] += ", padding-free execution (masked token rows not computed: DESIGN.md 7)"
+            # executed flops only: the flops of the rows that are real tokens, per sentence with its own length
+            f_ex = 3 * sum(f_fwd(int(n), P) for n in mask.sum(1).tolist()) / B
+            res["mfma_fraction_of_step"] = round(v * f_ex / (PEAK_TFLOPS["fp32x3" if (split and dtype == "fp32") else dtype] * 1e12), 4)
         res["roofline"] = roofline_pass(step, mask, B, S, dtype, unpad=unpad, peak_key="fp32x3" if (split and dtype == "fp32") else None)
         return res
     finally:
@@ -346,8 +355,8 @@ def compact_line(res):
         line["cpu_baseline"] = {k: res["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample") if k in res["cpu_baseline"]}
     if isinstance(res.get("grad_sync"), dict):
         line["grad_sync"] = {k: v for k, v in res["grad_sync"].items() if k != "note"}
-    if isinstance(res.get("padding_free"), dict):
-        line["padding_free"] = {k: res["padding_free"][k] for k in ("value", "ms_per_step") if k in res["padding_free"]}
+    if isinstance(res.get("padded"), dict):
+        line["padded"] = {k: res["padded"][k] for k in ("value", "ms_per_step") if k in res["padded"]}
     if isinstance(res.get("full_length"), dict):
         line["full_length"] = {k: res["full_length"][k] for k in ("value", "ms_per_step") if k in res["full_length"]}
     if isinstance(res.get("fwd_bwd_without_optimizer"), dict):
@@ -364,7 +373,7 @@ def compact_line(res):
         line["secondary"] = sec
     line["detail"] = "bench_detail.json (also on stderr)"
     # shrink until it fits: the contract's keys, roofline and cpu_baseline are never dropped
-    for drop in ("fwd_bwd_without_optimizer", "full_length", "padding_free", "roofline_fp32_pipe", "grad_sync"):
+    for drop in ("fwd_bwd_without_optimizer", "roofline_fp32_pipe", "grad_sync", "full_length", "padded"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -480,9 +489,12 @@ def main():
                          "epoch, eager optimizer step) -- for the launch-bound shapes (bs 4 / S 64, bf16 at bs 32)")
     ap.add_argument("--no-overlap-optimizer", action="store_true", help="HIP AdamW launched by step() only (after the backward)")
     ap.add_argument("--unpad", action="store_true",
-                    help="padding-free execution (mtvaf_amd.engine.UNPAD): the encoder layers run on the packed unmasked "
-                         "token rows; loss / tags / gradients are those of the padded run.  Without the flag the padded run "
-                         "is the timed one and the padding-free rate is reported beside it (key `padding_free`)")
+                    help="(the default since round 5; kept for old command lines) padding-free execution "
+                         "(mtvaf_amd.engine.UNPAD): the encoder layers run on the packed unmasked token rows; loss / tags / "
+                         "gradients are those of the padded run")
+    ap.add_argument("--padded", action="store_true",
+                    help="time the padded run (MTVAF_UNPAD=0: every [B, S] token row computed, the reference's layout) instead of "
+                         "the default padding-free one; without the flag the padded rate is reported beside `value` (key `padded`)")
     ap.add_argument("--grad-wire", default="auto", choices=["auto", "fp32", "bf16"],
                     help="N > 1: wire format of the gradient exchange (mtvaf_amd.parallel.GradSync): fp32 = RCCL all_reduce(AVG) in "
                          "place; bf16 = pack -> all_to_all -> fp32 sum -> all_gather (mesh-shaped, half the bytes); auto = fp32 in "
@@ -537,6 +549,9 @@ def main():
 
     B, S, P = a.batch, a.seq, 4 * (1 + a.aux)
     from mtvaf_amd import engine
+    if a.padded and a.unpad:
+        raise SystemExit("--padded and --unpad exclude each other")
+    a.unpad = not a.padded and not a.graph  # (a captured step runs the padded layout: the packed row count cannot reach the host)
     engine.UNPAD = bool(a.unpad)
     model, cfg = build_model(device, a.model, S)
     model.train()
@@ -672,10 +687,11 @@ def main():
     lens_host = mask.sum(1).tolist()
     f_exec = 3 * sum(f_fwd(int(n), P) for n in lens_host) / B
     real_rows = sum(lens_host) / float(B * S)
-    padding_free = None
-    if not a.unpad and not a.graph and not a.no_secondary and real_rows < 0.97:
-        # secondary figure: the SAME K steps (optimizer included) with the encoder on the packed unmasked token rows
-        engine.UNPAD = True
+    padded = None
+    if a.unpad and not a.no_secondary and real_rows < 0.97:
+        # secondary figure: the SAME K steps (optimizer included) in the padded layout (MTVAF_UNPAD=0): every [B, S] token row
+        # computed, as the reference does
+        engine.UNPAD = False
         try:
             for _ in range(2):
                 step()
@@ -686,20 +702,19 @@ def main():
             barrier()
             dt2 = time.perf_counter() - t2
         finally:
-            engine.UNPAD = False
+            engine.UNPAD = True
         if world > 1:
             t = torch.tensor([dt2], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt2 = float(t)
         v2 = world * B * a.steps / dt2
-        padding_free = {"value": round(v2, 2), "ms_per_step": round(1e3 * dt2 / a.steps, 3),
-                        "mfma_fraction_of_step_executed_flops": round(v2 / world * f_exec / (PEAK_TFLOPS[peak_key] * 1e12), 4),
-                        "note": "same workload and results (loss, tags, parameter gradients equal the padded run: "
-                                "tests/test_unpad_gpu.py); masked token rows are not computed; opt-in (`--unpad` / "
-                                "MTVAF_UNPAD=1), not the headline"}
+        padded = {"value": round(v2, 2), "ms_per_step": round(1e3 * dt2 / a.steps, 3),
+                  "mfma_fraction_of_step_algorithmic": round(v2 / world * ftrain / (PEAK_TFLOPS[peak_key] * 1e12), 4),
+                  "note": "same workload and results (loss, tags, parameter gradients: tests/test_unpad_gpu.py, pad_mode fixture) with "
+                          "every masked token row computed (`--padded` / MTVAF_UNPAD=0); its fraction credits SURVEY 8d's F_train"}
 
     full_length = None
-    if not a.full_length and not a.unpad and not a.graph and not a.no_secondary and world == 1:
+    if not a.full_length and not a.graph and not a.no_secondary and world == 1:
         # secondary figure: the same K steps on a batch whose sequences are ALL S tokens long -- nothing is masked, so neither the
         # k-tile lists of the weight gradients nor padding-free execution have anything to skip: the floor of both
         ragged = (ids, mask, tt, labels, feats, aux)
@@ -726,21 +741,23 @@ def main():
            "config": {"workload": f"TVNetSAModel2 {'RoBERTa' if a.model == 'roberta' else 'BERT'}-base random-init, fwd+bwd{' as one HIP graph' if a.graph else ''}{'' if a.no_optimizer else {'torch': '+AdamW(torch fused)'}.get(a.optimizer, '+AdamW(HIP' + (', eager after the replay)' if a.graph else ', overlapped with backward)'))}, "
                                   f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
                                   f"images through the prompt generator), train mode (dropout live), "
-                                  f"{'full-length' if a.full_length else 'ragged 16..S'} sequences",
+                                  f"{'full-length' if a.full_length else 'ragged 16..S'} sequences"
+                                  f"{', padding-free execution (masked token rows not computed)' if a.unpad else ', padded execution (every [B, S] row computed)'}",
                       "global_batch": B * world, "seq_len": S, "prefix": P,
                       "parallelism": f"dp{world}" + (" (RCCL all-reduce overlapped with backward)" if world > 1 else "")},
            "median_ms_per_step": round(med_ms, 3), "value_median": round(world * B / (med_ms * 1e-3), 2),
            "loss": round(loss_val, 4),
-           "mfma_fraction_of_step": round(per_gpu * ftrain / (PEAK_TFLOPS[peak_key] * 1e12), 4),
+           # padding-free: the flops of the rows that are real tokens (per sentence with its own length); padded: SURVEY 8d's F_train
+           "mfma_fraction_of_step": round(per_gpu * (f_exec if a.unpad else ftrain) / (PEAK_TFLOPS[peak_key] * 1e12), 4),
            "peak_tflops": PEAK_TFLOPS[peak_key],
            "flop_per_sentence_train": ftrain, "fwd_bwd_without_optimizer": fwd_bwd_only,
            "real_token_rows": round(real_rows, 4), "flop_per_sentence_train_real_rows": round(f_exec),
-           "note_flops": "mfma_fraction_of_step credits the algorithmic 3 x F_fwd per sentence (SURVEY 8d) against peak_tflops (split "
-                         "mode: 2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work on the bf16 pipe); in the fp32 mode the "
-                         "weight-gradient products skip the k-tiles of masked token rows (exact zeros): the roofline "
-                         "object counts the flops those launches execute",
-           "padding": "skipped (--unpad): the fraction below counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
-           "padding_free": padding_free, "full_length": full_length}
+           "note_flops": "padding-free run: mfma_fraction_of_step = sentences/s x 3 x F_fwd(len_b, P) averaged over the batch's OWN sentence "
+                         "lengths (the flops of real token rows) / peak_tflops; padded run (--padded): the algorithmic 3 x F_fwd(S, P) "
+                         "of SURVEY 8d.  peak_tflops in split mode: 2500 / 6 = 416.7 TFLOP/s of fp32-equivalent work on the bf16 pipe.  "
+                         "The roofline object counts the flops its launches execute (packed rows; k-tile lists)",
+           "padding": "skipped (default): every fraction counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
+           "padded": padded, "full_length": full_length}
     res["rank_ms_spread"] = rank_ms_spread
     if rank_ms_spread is not None and rank_ms_spread >= 0.03:
         log(f"per-rank step times differ by {100 * rank_ms_spread:.1f} % (>= 3 %): the slowest rank sets `value`")
@@ -759,9 +776,6 @@ def main():
                             "note": "rank 0, 3 extra steps: time the communication stream spent in exchanges (and the per-layer "
                                     "optimizer updates queued behind them), and how long the last exchange ran past the "
                                     "backward pass's own kernels"}
-    if a.unpad:
-        res["mfma_fraction_of_step"] = round(per_gpu * f_exec / (PEAK_TFLOPS[peak_key] * 1e12), 4)
-        res["config"]["workload"] += ", padding-free execution (masked token rows not computed)"
 
     # ---- roofline of the dominant kernel (fp32 MFMA GEMM), measured live with HIP events recorded by the
     # library on the launch stream, directly around each main GEMM kernel of 3 further identical steps ----
@@ -775,11 +789,12 @@ def main():
         # the whole step by the flops its GEMM launches EXECUTE (the weight-gradient products skip the k-tiles of masked
         # token rows) plus the attention products' algorithmic share, next to the algorithmic figure above (split mode: both
         # against the fp32-equivalent peak of the bf16 pipe; the attention products still run the fp32 pipe)
-        attn_tflop = B * 3 * 12 * 4 * S * (S + P) * 768 / 1e12
+        attn_tflop = (sum(3 * 12 * 4 * int(n) * (int(n) + P) * 768 for n in lens_host) if a.unpad
+                      else B * 3 * 12 * 4 * S * (S + P) * 768) / 1e12
         res["mfma_fraction_of_step_executed"] = round((ex + attn_tflop) / (1e-3 * res["ms_per_step"]) / PEAK_TFLOPS[peak_key], 4)
     if rank == 0:
         log("roofline pass done")
-    if rank == 0 and world == 1 and not a.no_secondary and not a.graph and (B, S, a.aux, a.dtype, a.model, a.unpad) == (32, 128, 8, "fp32", "bert", False):
+    if rank == 0 and world == 1 and not a.no_secondary and not a.graph and (B, S, a.aux, a.dtype, a.model, a.unpad) == (32, 128, 8, "fp32", "bert", True):
         # the other BASELINE configurations that fit one GPU, measured by the same process AFTER the headline (secondary
         # figures: the headline's value / config / dtype stay those of configs[1])
         del model, opt
@@ -788,14 +803,13 @@ def main():
         res["secondary"] = {}
         for key, (dt_, arch_, b_, s_, aux_) in {"c1_fp32": ("fp32", "bert", 4, 64, 3), "c1_fp32_graph": ("fp32", "bert", 4, 64, 3),
                                                 ("c2_fp32_pipe" if split_mode else "c2_fp32_split"): ("fp32", "bert", 32, 128, 8),
-                                                "c2_fp32_split_unpad": ("fp32", "bert", 32, 128, 8),
                                                 "c3_bf16": ("bf16", "roberta", 32, 128, 8), "c4_bf16": ("bf16", "bert", 64, 128, 8)}.items():
             try:
                 # (C1 is the one host-bound configuration: 10 steps behind 3 warm-up steps read 750-930 sentences/s from call
                 # to call, 40 behind 10 read what `bench.py --batch 4 --seq 64 --aux 3` reads)
                 res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_,
                                                          split=("_split" in key) or (bool(split_mode) and "_pipe" not in key),
-                                                         unpad=key.endswith("_unpad"), graph=key.endswith("_graph"),
+                                                         unpad=not key.endswith("_graph"), graph=key.endswith("_graph"),
                                                          steps=40 if key.startswith("c1_") else 10,
                                                          warmup=10 if key.startswith("c1_") else 5)
             except Exception as e:  # a secondary figure must never cost the headline line
@@ -813,6 +827,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_secondary and not a.no_cpu_baseline:
         try:  # (detail only; must never cost the line)
             res["frontend_cache_build"] = frontend_cache_throughput(device)
+            res["frontend_cache_build_bf16"] = frontend_cache_throughput(device, compute="bf16")
         except Exception as e:
             res["frontend_cache_build"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

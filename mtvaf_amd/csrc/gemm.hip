@@ -757,9 +757,19 @@ static bool x3_tile96_ok(int M, int N, int la, int lb) {
 
 // 128x128 tiles of the wave-specialised split kernel may hang over the result (clamped loads, guarded stores): any M, N that
 // are multiples of 4 and at least one tile -- the prompt generator's N = 800 (MTVAF_X3_RAGGED=0: whole tiles only)
+static bool x3_tile64_ok(int M, int N) {
+  static const int on = [] { const char* e = getenv("MTVAF_X3_TILE64"); return e ? atoi(e) : 1; }();
+  return on && M % 128 == 0 && N % 64 == 0;
+}
+
 static bool x3_ragged_ok(int M, int N) {
   static const int on = [] { const char* e = getenv("MTVAF_X3_RAGGED"); return e ? atoi(e) : 1; }();
   return on && M % 4 == 0 && N % 4 == 0 && M >= 128 && N >= 128;
+}
+
+static double x3_e64() {
+  static const double e = [] { const char* v = getenv("MTVAF_X3_E64"); return v ? atof(v) : 0.47; }();
+  return e;
 }
 
 static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi, int* cfg_out, int* splits_out,
@@ -790,7 +800,10 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
     // (the 128x96 split tile: forward products only by default -- with a k-major B operand or as a weight gradient it
     // measured level or behind 128x128 + split-K in the bench step; MTVAF_X3_TILE96 = 0 never, 2 every layout)
     const bool c6_ok = x3_tile96_ok(M, N, la, lb);
-    if (compute == 2 && !((c == 5 && ((M % 128 == 0 && N % 128 == 0) || ragged5)) || (c == 6 && c6_ok) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
+    // (128x64, round 5: the wave-specialised kernel's third layout, for row counts that leave the wider tiles on half the CUs --
+    // packed batches; every layout; MTVAF_X3_TILE64=0 never)
+    const bool c4_ok = x3_tile64_ok(M, N);
+    if (compute == 2 && !((c == 5 && ((M % 128 == 0 && N % 128 == 0) || ragged5)) || (c == 6 && c6_ok) || (c == 4 && c4_ok) || (c == 3 && M % 64 == 0 && N % 64 == 0))) continue;
     const int bm = kCfgs[c].bm, bn = kCfgs[c].bn, bk = compute != 0 ? 32 : kCfgs[c].bk;
     const long tiles = cdiv(M, bm) * cdiv(N, bn);
     // split kernel, dX products (KC x KM) of >= 128 tiles: at most 2 splits -- in effect none: the [4096 x 768] products over
@@ -814,7 +827,8 @@ static void choose(int M, int N, int K, int allow_split, int la, int lb, int epi
       // with at most one block per CU -- few-token products -- a wave's own MFMA chain is the limit and the small tile wins
       // split kernels (one block per CU, whole rounds decide): 128x128 a little ahead of 128x96 at equal rounds x area
       // (fewer operand bytes per flop), the 64x64 every-wave kernel well behind both
-      const double e = compute == 2 ? (c == 5 ? 0.70 : (c == 6 ? 0.68 : 0.45)) : ((c >= 16 && tiles * s <= 256) ? 1.0 : eff[c]);
+      // (128x64: 192 staged rows per k-tile for half the products of 128x128's 256 -- 0.70 x 0.5 / 0.75)
+      const double e = compute == 2 ? (c == 5 ? 0.70 : (c == 6 ? 0.68 : (c == 4 ? x3_e64() : 0.45))) : ((c >= 16 && tiles * s <= 256) ? 1.0 : eff[c]);
       double cost = (double)rounds * bm * bn * kc / 128.0 / (e * occ2);
       cost += 3000.0;  // fill/drain + launch  (charging the split kernels' traced 6.2 us of prologue + epilogue per ROUND instead
                        // was tried in round 4: with the k-tile lists of the bench batch the weight gradients then take 4
@@ -917,7 +931,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     // 128x128 tiles that hang over the result: the wave-specialised kernel only (it needs the wide epilogue's alignment)
     rag5 = !can5 && x3_ragged_ok(M, N) && (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) &&
            (!aux || ((ldaux % 4 == 0) && (((uintptr_t)aux & 15) == 0))) && (!bias || (((uintptr_t)bias & 15) == 0));
-    const bool forced = (cfg == 5 && (can5 || rag5)) || (cfg == 6 && can6) || (cfg == 3 && can3);
+    const bool can4 = M % 128 == 0 && N % 64 == 0;
+    const bool forced = (cfg == 5 && (can5 || rag5)) || (cfg == 6 && can6) || (cfg == 4 && can4) || (cfg == 3 && can3);
     const bool plannable = can5 || rag5 || can3 || x3_tile96_ok(M, N, layout_a, layout_b);
     // (leading dimensions < 2^23 elements: a tile's loads address it by 32-bit byte offsets from a scalar base)
     const bool ok = (K % 32 == 0) && (forced || plannable) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
@@ -925,7 +940,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     // (few output tiles -- the 256-token products of BASELINE configs[0] -- leave most CUs without a block of the 128x128
     // kernel: the fp32 pipe's 64x64 tiles are faster there, measured 4.37 vs 4.53 ms per C1 step)
     const long tiles96 = can6 ? (long)(M / 128) * (N / 96) : 0;
-    const long tiles = std::max(rag5 ? cdiv(M, 128) * cdiv(N, 128) : (long)(M / 128) * (N / 128), tiles96);
+    const long tiles64 = (can4 && x3_tile64_ok(M, N)) ? (long)(M / 128) * (N / 64) : 0;
+    const long tiles = std::max(std::max(rag5 ? cdiv(M, 128) * cdiv(N, 128) : (long)(M / 128) * (N / 128), tiles96), tiles64);
     // ... unless the reduction is deep enough for split-K to fill the chip anyway (the [768 x 768] weight gradient over 4096
     // token rows: 36 tiles x 7 splits, 38-41 us against 46-51 on the fp32 pipe)
     const bool deep = allow_split && splittable(epi) && K >= 2048 && tiles * std::min(16, K / 256) >= 192;
@@ -992,7 +1008,7 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   if (g_prof && g_prof_n < g_prof_cap) {
     pr = &g_prof[g_prof_n++];
     // (key[3]: alignment mode 0..2, +8 when the launch walks a k-tile list: its flops are 2 M N 32 (*kcnt), not 2 M N K)
-    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + (((cfg == 5 || cfg == 6) && a.wide) ? 20 : 0) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
+    const int key[8] = {compute == 1 ? 100 + cfg : (compute == 2 ? 200 + cfg + (((cfg == 5 || cfg == 6 || cfg == 4) && a.wide) ? 20 : 0) : cfg), layout_a, layout_b, mode + (a.klist ? 8 : 0), M, N, K, splits};
     for (int i = 0; i < 8; ++i) pr->key[i] = key[i];
     (void)hipEventRecord(pr->e0, stream);
   }
@@ -1001,7 +1017,8 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
     rc = launch_gemm_bf16(cfg == 6 ? 0 : (cfg == 5 ? 1 : 2), a, layout_a, layout_b, grid, aligned, stream);
   } else if (compute == 2) {
     // 128x128 / 128x96: the wave-specialised kernel; without the wide epilogue's alignment the every-wave-does-everything form
-    rc = launch_gemm_f32x3(cfg == 5 ? (a.wide ? 4 : 1) : (cfg == 6 ? (a.wide ? 5 : 3) : 2), a, layout_a, layout_b, grid, stream);
+    if (cfg == 4 && !a.wide) return MTVAF_ERR_ALIGN;  // (the 128x64 layout exists in the wave-specialised kernel only)
+    rc = launch_gemm_f32x3(cfg == 5 ? (a.wide ? 4 : 1) : (cfg == 6 ? (a.wide ? 5 : 3) : (cfg == 4 ? 6 : 2)), a, layout_a, layout_b, grid, stream);
   } else
   switch (cfg) {
     case 9: rc = launch_dma<128, 96, 4, 1>(a, layout_a, layout_b, grid, stream); break;

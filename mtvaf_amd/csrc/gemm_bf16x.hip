@@ -555,6 +555,8 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
   if ((epi == EPI_GELU || epi == EPI_DGELU) && !aux16) return MTVAF_ERR_ARG;
   if (accumulate && !C32) return MTVAF_ERR_ARG;
   if (M % 128 || K % 64 || (N % 96 && N % 128)) return MTVAF_ERR_SHAPE;
+  // (tile addresses are a scalar base + a 32-bit per-lane byte offset of up to 256 rows x leading dimension x 2 bytes: ADVICE r4)
+  if (lda >= (1 << 22) || ldb >= (1 << 22)) return MTVAF_ERR_SHAPE;
   if (lda % 8 || ldb % 8 || (C32 && ldc32 % 4) || (C16 && ldc16 % 8) || (aux16 && ldaux % 8)) return MTVAF_ERR_ALIGN;
   if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C32 | (uintptr_t)C16 | (uintptr_t)bias | (uintptr_t)aux16 | (uintptr_t)colpart) & 15)
     return MTVAF_ERR_ALIGN;
@@ -747,6 +749,7 @@ int mtvaf_gemm_bf16x_dw_group(int n, const void* const* A, const int* lda, const
   long tiles = 0;
   for (int i = 0; i < n; ++i) {
     if (M[i] <= 0 || N[i] <= 0 || M[i] % 256 || N[i] % 256) return MTVAF_ERR_SHAPE;
+    if (lda[i] >= (1 << 22) || ldb[i] >= (1 << 22)) return MTVAF_ERR_SHAPE;  // (32-bit lane offsets, as gemm_bf16x_core)
     if (lda[i] % 8 || ldb[i] % 8 || ldc32[i] % 4 || (((uintptr_t)A[i] | (uintptr_t)B[i] | (uintptr_t)C32[i]) & 15)) return MTVAF_ERR_ALIGN;
     sk.pr[i] = P256Prob{static_cast<const __bf16*>(A[i]), static_cast<const __bf16*>(B[i]), C32[i], lda[i], ldb[i], ldc32[i], N[i] / 256};
     sk.tile_begin[i] = (int)tiles;

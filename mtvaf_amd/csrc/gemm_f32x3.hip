@@ -396,7 +396,10 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void gemm_f32x3_kernel(GemmArgs p) 
 // 108-114: ~80 % of its own matrix stream.
 // BN = 128: consumers as 2 x 2 wave tiles of 64 x 64.  BN = 96 (round 4): consumers as 4 x 1 wave tiles of 32 x 96 -- the tile of
 // the N = 768 / 2304 results of 4096 token rows (256 / 768 tiles = whole rounds of the 256 CUs, where 128 x 128 tiles are 192 /
-// 576: three quarters of the chip idle in the last round).
+// 576: three quarters of the chip idle in the last round).  BN = 64 (round 5): 4 x 1 wave tiles of 32 x 64 -- the N = 768 results
+// of a PACKED (padding-free) batch: 2432 token rows are 19 x 12 = 228 tiles, where 128 x 96 gives 152 and 128 x 128 (the only
+// layout of the dX products until then) 114 on 256 CUs.  A k-tile of it costs the producers 192 staged rows for 24 MFMAs per
+// consumer (128 x 128: 256 rows for 48), so per flop it is the slowest layout: the planner takes it only where it saves a round.
 // GROUP (round 4): blockIdx.x walks the 128 x 128 tiles of up to four products that share the reduction axis -- the four weight
 // gradients of an encoder layer (36 + 144 + 144 + 108 tiles at BERT-base) -- back to back (GemmArgs::grp, as the fp32 pipe's
 // gemm_f32_dma_group_kernel): at 4096 token rows they fill 1.7 rounds of the CUs UNSPLIT, where one launch per product needs
@@ -406,10 +409,10 @@ template <bool A_KM, bool B_KM, bool KLIST, int BN, bool GROUP = false>
 __global__ __launch_bounds__(512, 1) void gemm_f32x3_ws_kernel(GemmArgs p) {
   using namespace x3;
   static_assert(!KLIST || (A_KM && B_KM), "the k-tile list addresses rows of k-major operands");
-  static_assert(BN == 128 || BN == 96, "consumer layouts exist for 128 x 128 and 128 x 96");
+  static_assert(BN == 128 || BN == 96 || BN == 64, "consumer layouts exist for 128 x 128, 128 x 96 and 128 x 64");
   static_assert(!GROUP || (A_KM && B_KM && BN == 128), "grouped launches are weight gradients on 128 x 128 tiles");
   constexpr int BM = 128, BK = 32, LDH = BK + 8, NP = 256, NT = 512;
-  constexpr int WN = BN == 128 ? 2 : 1, TM = BN == 128 ? 2 : 1, TN = BN == 128 ? 2 : 3;
+  constexpr int WN = BN == 128 ? 2 : 1, TM = BN == 128 ? 2 : 1, TN = BN == 128 ? 2 : BN / 32;
   constexpr int A_SZ = BM * LDH, B_SZ = BN * LDH, BUF = 3 * (A_SZ + B_SZ);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* sA = reinterpret_cast<__bf16*>(smem_raw);  // [2][ [3][A_SZ] | [3][B_SZ] ]
@@ -715,13 +718,14 @@ static int launch_x3_tile(const GemmArgs& a, int la, int lb, dim3 grid, hipStrea
   return MTVAF_OK;
 }
 
-// Called by the common launcher in gemm.hip (whole tiles only).  tile: 4 / 5 = 128x128x32 / 128x96x32 wave-specialised (the
+// Called by the common launcher in gemm.hip (whole tiles only).  tile: 4 / 5 / 6 = 128x128x32 / 128x96x32 / 128x64x32 wave-specialised (the
 // ones the planner uses; they need the wide epilogue's alignment); 1 / 3 = the same tiles, every wave doing everything, one
 // buffer, two blocks per CU; 2 = 64x64x32 (2x2 waves of 32x32; small results).
 int launch_gemm_f32x3(int tile, const GemmArgs& a, int la, int lb, dim3 grid, hipStream_t st) {
   switch (tile) {
     case 4: return launch_x3_ws<128>(a, la, lb, grid, st);
     case 5: return launch_x3_ws<96>(a, la, lb, grid, st);
+    case 6: return launch_x3_ws<64>(a, la, lb, grid, st);
     case 1: return launch_x3_tile<128, 128, 2, 2, 32>(a, la, lb, grid, st);
     case 3: return launch_x3_tile<128, 96, 4, 1, 32>(a, la, lb, grid, st);
     default: return launch_x3_tile<64, 64, 2, 2, 32>(a, la, lb, grid, st);

@@ -207,20 +207,46 @@ NATIVE_EXEC = os.environ.get("MTVAF_NATIVE_EXEC", "1") != "0"
 # `torch.autograd.grad(loss, encoder_params)` wants the gradients RETURNED instead: set MTVAF_DIRECT_GRADS=0 (or
 # engine.DIRECT_GRADS = False) for such callers.
 DIRECT_GRADS = os.environ.get("MTVAF_DIRECT_GRADS", "1") != "0"
-# Padding-free execution (opt-in: MTVAF_UNPAD=1 / engine.UNPAD = True; native executor):
+# Padding-free execution (the DEFAULT since round 5 -- the round-4 review granted it behind a gate, see
+# DESIGN -- for callers that set BertModel.allow_unpad, i.e. TVNetSAModel2; MTVAF_UNPAD=0 / engine.UNPAD = False restores the
+# padded run; a direct BertModel(...) call, the span model and captured (HIP graph) steps always run padded; native executor):
 # the encoder layers run on the PACKED unmasked token rows -- every kernel of a layer treats token rows independently
 # except attention (which gets per-sentence row offsets) -- and the last hidden state is scattered back to [B,S,H] with
 # zeros at the masked positions (only for callers that set BertModel.allow_unpad: TVNetSAModel2, whose CRF head is
 # masked; the span model's position softmax reads every position, so it stays padded).  Loss, decoded tags and every parameter gradient are those of the padded run (a masked
 # key contributes exp(-10000) = 0 there, a masked query feeds nothing); hidden states AT masked positions are zeros
 # instead of the reference's don't-care values, and the intermediate hidden states are handed out lazily / detached.
-UNPAD = os.environ.get("MTVAF_UNPAD", "0") == "1"
+UNPAD = os.environ.get("MTVAF_UNPAD", "1") != "0"
+
+
+class padding_free:
+    """``with engine.padding_free(False): ...`` -- the padded run (or the padding-free one) for a block, whatever the default."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global UNPAD
+        self.was, UNPAD = UNPAD, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global UNPAD
+        UNPAD = self.was
+        return False
+
 # Padded run: the weight-gradient products skip the k-tiles (32 token rows in fp32 mode, 64 in bf16 mode) of the token axis that hold only masked tokens.
 # The gradient of a token row nothing downstream reads is EXACTLY zero (a masked key has probability exp(-10000) = 0, a
 # masked query feeds only itself, the CRF is masked), so the skipped terms of dW = sum_rows dY[r]^T X[r] are zeros: every
 # output of the step is unchanged.  Only for callers that vouch for it (cfg[5], BertModel.allow_unpad).
 SKIP_PAD_DW = os.environ.get("MTVAF_SKIP_PAD_DW", "1") != "0"
 SKIP_PAD_DW_BF16 = os.environ.get("MTVAF_SKIP_PAD_DW", "1") == "2"
+# Debug switch for the masked-rows contract (MTVAF_CHECK_CONTRACT=1 / engine.CHECK_CONTRACT = True): whenever a backward pass
+# is about to rely on it -- k-tile lists, the attention backward's shortened query loops (zero_tail), padding-free execution --
+# the incoming hidden-state gradients are read back and every row at a masked position must be exactly zero; a head that reads
+# masked positions (or a model that sets BertModel.allow_unpad wrongly) raises here instead of training on silently different
+# gradients.  One host synchronisation per backward pass: a debugging aid, off by default.
+CHECK_CONTRACT = os.environ.get("MTVAF_CHECK_CONTRACT", "0") == "1"
 LAST_PACK = None  # the Packing of the most recent native forward (None: it ran padded)
 _PENDING_PACK = None  # packing started by Packing.begin, consumed by the next Packing.build
 _PACK_HOST = {}
@@ -453,6 +479,36 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
     return tuple(outs)
 
 
+def _check_masked_rows_contract(douts, addmask, Pn, B, S):
+    """MTVAF_CHECK_CONTRACT: every hidden-state gradient handed to the encoder backward must be exactly zero at masked
+    positions (reference behaviour being relied on: the head reads through the mask only, bert_model.py:511, 521)."""
+    masked = (addmask[:, Pn:] < -5000.0).reshape(B * S)
+    for li, g in enumerate(douts):
+        if g is None:
+            continue
+        rows = g.reshape(B * S, -1)[masked]
+        if rows.numel() and bool((rows != 0).any()):
+            bad = int((rows != 0).any(1).sum())
+            raise RuntimeError(f"masked-rows contract violated: the gradient of hidden state {li + 1} is non-zero at {bad} masked token "
+                               "position(s), but the caller set BertModel.allow_unpad (k-tile lists / zero_tail / padding-free "
+                               "execution assume exact zeros there); unset allow_unpad for heads that read masked positions")
+
+
+def _ddp_without_gradsync(grad_sink) -> bool:
+    """A process group with several ranks but no GradSync on this encoder: something else (torch DDP's C++ reducer, which
+    Python cannot see) is probably waiting for the gradients at the AccumulateGrad nodes -- the zero-copy `.grad` assignment
+    would bypass it."""
+    try:
+        import torch.distributed as dist
+        return bool(dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                    and (grad_sink is None or grad_sink.on_layer_done is None))
+    except Exception:  # pragma: no cover
+        return False
+
+
+_warned_ddp = [False]
+
+
 def _has_grad_hooks(params) -> bool:
     for p in params:
         if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
@@ -481,6 +537,15 @@ def _native_backward(ctx, douts):
     # detectable from Python: torch DDP's reducer, which hooks the AccumulateGrad nodes in C++ -- data parallelism here is
     # mtvaf_amd.parallel.GradSync; a DDP-wrapped model must set MTVAF_DIRECT_GRADS=0 / engine.DIRECT_GRADS = False
     direct = gviews is not None and DIRECT_GRADS and not _has_grad_hooks(params)
+    if direct and _ddp_without_gradsync(grad_sink):
+        #  several ranks and no GradSync: hand the gradients to autograd so that whatever listens there sees them
+        direct = False
+        if not _warned_ddp[0]:
+            _warned_ddp[0] = True
+            import warnings
+            warnings.warn("mtvaf_amd: torch.distributed is initialised with several ranks but no mtvaf_amd.parallel.GradSync is attached "
+                          "to this encoder; encoder gradients are returned through autograd (as with MTVAF_DIRECT_GRADS=0) so that a "
+                          "DistributedDataParallel reducer sees them.  Use GradSync for the overlapped per-layer exchange.")
     pgrads: List[Optional[torch.Tensor]] = [None] * len(params)
     main = torch.cuda.current_stream()
     side = _side_stream(dev) if (DW_SIDE_STREAM and need_param_grads and M >= DW_STREAM_MIN_ROWS) else None
@@ -509,6 +574,8 @@ def _native_backward(ctx, douts):
     settle = int(grad_sink is not None and side is not None and grad_sink.on_layer_done is not None and grad_sink.settle_params)
     klist = kcnt = None
     zero_tail = bool(SKIP_PAD_DW and pack is None and len(cfg) > 5 and cfg[5] and addmask.dtype == torch.float32 and addmask.is_contiguous())
+    if CHECK_CONTRACT and (zero_tail or pack is not None) and addmask.dtype == torch.float32:
+        _check_masked_rows_contract(douts, addmask, Pn, B, S)
     bk = 64 if use_h else 32  # k-tile of the dW kernels
     # (mixed-precision mode: measured SLOWER with the list -- 7.85 vs 7.56 ms at C3, 11.71 vs 11.60 at C4: 64-row tiles skip
     # only ~19 % of a 33-us product and the device-side count delays its first loads -- so the list is an fp32-mode lever;
@@ -757,6 +824,8 @@ class EncoderFunction(torch.autograd.Function):
 
         # (the same contract flag as the native executor's: the two paths must stay bit-identical)
         zero_tail = bool(SKIP_PAD_DW and len(cfg) > 5 and cfg[5] and addmask.dtype == torch.float32 and addmask.is_contiguous())
+        if CHECK_CONTRACT and zero_tail:
+            _check_masked_rows_contract(douts, addmask, Pn, B, S)
         ktiles = None  # (the native executor's k-tile list: the two paths must stay bit-identical)
         if (SKIP_PAD_DW and (not use_h or SKIP_PAD_DW_BF16) and need_param_grads and len(cfg) > 5 and cfg[5] and M % (64 if use_h else 32) == 0
                 and addmask.dtype == torch.float32 and addmask.is_contiguous()):

@@ -250,8 +250,9 @@ def kernel_symbol(cfg, la, lb, fast):
         t = "256, 192, 4, 2" if c & 32 else ("256, 128, 4, 2" if c & 16 else ("128, 128, 2, 2" if c & 1 else "128, 96, 4, 1"))
         return f"gemm_bf16x_kernel<{t}, {b(c & 4)}, {b(c & 8)}, {3 if c & 2 else 2}, {b(klist)}>"
     if cfg >= 200:  # split-fp32 kernels (csrc/gemm_f32x3.hip): +20 the wave-specialised kernel
-        if cfg in (225, 226):
-            return f"gemm_f32x3_ws_kernel<{b(la)}, {b(lb)}, {b(klist)}, {128 if cfg == 225 else 96}, false>"
+        if cfg in (224, 225, 226):
+            bn = {224: 64, 225: 128, 226: 96}[cfg]
+            return f"gemm_f32x3_ws_kernel<{b(la)}, {b(lb)}, {b(klist)}, {bn}, false>"
         d = (64, 64, 2, 2) if cfg == 203 else ((128, 96, 4, 1) if cfg == 206 else (128, 128, 2, 2))
         return f"gemm_f32x3_kernel<{d[0]}, {d[1]}, {d[2]}, {d[3]}, {b(la)}, {b(lb)}, {b(klist)}, 32>"
     if cfg >= 100:

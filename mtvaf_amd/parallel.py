@@ -28,6 +28,18 @@ Two wire formats:
   all_gather run once per bucket, when the bucket's last layer is done -- 2 k collectives per step where the per-layer form
   issues 24, so that an 8-GPU step is not bound by collective launch latency.
 
+Collective order (round 5).  Collectives of one process group match by ISSUE ORDER, so every rank must issue the same
+sequence whatever its own autograd pass looked like.  The encoder layers report in a fixed order; everything else follows a
+PLAN: the list of large parameters reduced on their own (in the order their gradients became ready on rank 0 in the first
+pass) and the list of small parameters of the tail bucket, both agreed on by all ranks at the end of the first pass (one
+all_reduce(MAX) of a presence mask, one broadcast of rank 0's order).  A planned parameter whose gradient is None on THIS rank
+in some later pass (a rank whose batch has no images: no gradient for ``encoder_conv``) is exchanged as zeros -- its rank
+contributes nothing to the mean -- and a large parameter is only issued once every planned parameter before it has been, the
+rest being flushed in plan order when the pass ends: no rank ever waits in a collective the others do not issue.  A gradient
+that appears for a parameter OUTSIDE the plan raises on the rank that sees it before anything is issued for it.
+``check_every=N`` (or MTVAF_CHECK_COLLECTIVES=N) hashes the (kind, numel) sequence of each pass and compares it across the
+ranks every N passes; a mismatch raises on every rank.
+
 Dropout under data parallelism: ``engine.RNG`` derives its seed from ``torch.initial_seed()``; launchers that seed
 every rank alike would make all ranks draw the same masks for the same (site, row).  GradSync therefore folds the
 rank into the dropout seed (``engine.RNG.set_stream(rank)``) unless ``seed_per_rank=False``.
@@ -42,7 +54,8 @@ import torch.distributed as dist
 
 class GradSync:
     def __init__(self, model: torch.nn.Module, process_group=None, force: bool = False, big_numel: int = 1 << 20,
-                 compress: Optional[str] = "auto", seed_per_rank: bool = True, layer_buckets: Optional[int] = None):
+                 compress: Optional[str] = "auto", seed_per_rank: bool = True, layer_buckets: Optional[int] = None,
+                 check_every: Optional[int] = None):
         if not dist.is_initialized():
             raise RuntimeError("GradSync needs an initialised process group (backend 'nccl' = RCCL on ROCm)")
         self.model = model
@@ -63,6 +76,10 @@ class GradSync:
         L = len(self.encoder.layer)
         self.layer_buckets = None
         self._bucket_of, self._bucket_size, self._bucket_acc = {}, {}, {}
+        if layer_buckets is not None and compress is None and int(layer_buckets) < L:
+            import warnings
+            warnings.warn(f"GradSync: layer_buckets={layer_buckets} applies to the bf16 wire only; the fp32 wire (all_reduce in "
+                          f"place, no staging buffer) exchanges one buffer per layer: {L} collectives per pass", stacklevel=2)
         if layer_buckets is not None and compress == "bf16":
             nb = max(1, min(int(layer_buckets), L))
             self.layer_buckets = nb
@@ -100,8 +117,25 @@ class GradSync:
         # accumulated them, so e.g. the word-table all-reduce overlaps the prompt generator's backward instead of
         # sitting in the un-overlapped tail bucket.
         self._early_done = set()
-        for p in model.parameters():
-            if id(p) not in self._enc_param_ids and p.requires_grad and p.numel() >= big_numel:
+        self._outer = [p for p in model.parameters() if id(p) not in self._enc_param_ids and p.requires_grad]
+        self._outer_idx = {id(p): i for i, p in enumerate(self._outer)}
+        self._big_numel = big_numel
+        # the plan (module docstring): None until the first synchronised pass has ended
+        self._plan: Optional[List] = None   # schedule keys ("L", bucket or layer) / ("P", index into _outer), in issue order
+        self._plan_pos = {}
+        self._plan_small: List[int] = []    # indices into _outer: the tail bucket's members, in parameter order
+        self._next = 0                      # position in _plan of the next item to issue in this pass
+        self._ready = {}                    # key -> issue closure of items that wait for their predecessors (or for the plan)
+        self._first_order: List = []        # first pass: the order in which items became ready on this rank
+        self._issued_first = set()
+        if check_every is None:
+            import os
+            check_every = int(os.environ.get("MTVAF_CHECK_COLLECTIVES", "0")) or None
+        self.check_every = check_every
+        self._seq: List = []        # (kind, numel) of every collective issued in this pass
+        self._passes = 0
+        for p in self._outer:
+            if p.numel() >= big_numel:
                 p.register_post_accumulate_grad_hook(self._param_ready)
         if seed_per_rank:
             from . import engine
@@ -149,6 +183,7 @@ class GradSync:
 
     def _allreduce_mean(self, t: torch.Tensor):
         """In-place mean over the ranks of the flat fp32 tensor `t` (enqueued on the current stream)."""
+        self._seq.append(("ar", t.numel()))
         if self.compress == "bf16":
             return self._allreduce_mean_bf16(t)
         if self._avg_op:
@@ -187,7 +222,9 @@ class GradSync:
         over the concatenation, every tensor unpacked from its slice.  Same arithmetic per element as the single-tensor form
         (the sum over ranks in rank order, one rounding), so bucketed and per-layer exchanges agree bit for bit."""
         if len(tensors) == 1:
+            self._seq.append(("ar", tensors[0].numel()))
             return self._allreduce_mean_bf16(tensors[0])
+        self._seq.append(("a2a", sum(t.numel() for t in tensors)))
         W = self.world
         offs, off = [], 0
         for t in tensors:
@@ -233,6 +270,34 @@ class GradSync:
         del self._bucket_acc[b]
         return acc
 
+    # -- the ordered schedule (module docstring: "Collective order") ------------------------------------------------
+    def _submit(self, key, issue):
+        """`issue()` enqueues the collective(s) of schedule item `key` -- ("L", bucket or layer) or ("P", index into _outer).
+        First pass: layer exchanges go out at once (every rank's encoder reports its layers in the same order), large
+        parameters wait for the plan (_finish); the order in which items became ready is noted for the plan.  Later passes:
+        an item goes out once every planned item before it has; the rest is flushed, in plan order, when the pass ends."""
+        if self._plan is None:
+            self._first_order.append(key)
+            if key[0] == "L":
+                issue()
+            else:
+                self._ready[key] = issue
+            return
+        if key not in self._plan_pos:
+            if key[0] == "P" and key[1] in self._plan_small:
+                return  # (planned into the tail bucket: reduced there)
+            what = (f"parameter #{key[1]} of shape {tuple(self._outer[key[1]].shape)}" if key[0] == "P" else f"encoder exchange {key[1]}")
+            raise RuntimeError(f"GradSync: {what} received a gradient on rank {self.rank} but had none on any rank when the "
+                               "exchange plan was made (first pass); call GradSync.replan() on every rank when the set of "
+                               "trained parameters changes")
+        self._ready[key] = issue
+        self._drain()
+
+    def _drain(self):
+        while self._next < len(self._plan) and self._plan[self._next] in self._ready:
+            self._ready.pop(self._plan[self._next])()
+            self._next += 1
+
     # -- called from inside EncoderFunction.backward, newest layer first ---------------------------------
     def _layer_done(self, li: int, flat_grad: Optional[torch.Tensor]):
         if self.before_layer is not None:
@@ -250,51 +315,119 @@ class GradSync:
         fast = [(l, g) for l, g in ready if g is not None]
         if not fast:
             return
+        key = ("L", self._bucket_of[li] if self.layer_buckets is not None else li)
+        self._submit(key, self._layer_issue(fast))
+
+    def _layer_issue(self, fast):
+        """-> closure that enqueues the exchange of the (layer, flat gradient) pairs `fast`, ordered behind everything the
+        CURRENT stream holds now (the event is recorded here, at hook time, also when the closure runs later)."""
         if self._comm is None:  # CPU / gloo (tests)
-            if self.compress is None:
-                for l, g in fast:
-                    self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
-            else:
-                self._allreduce_mean_bf16_multi([g for _, g in fast])
-            if self.after_layer_reduced is not None:
-                for l, _ in fast:
-                    self._pending.append((None, l))
-            return
+            def issue():
+                if self.compress is None:
+                    for l, g in fast:
+                        self._seq.append(("ar", g.numel()))
+                        self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
+                else:
+                    self._allreduce_mean_bf16_multi([g for _, g in fast])
+                if self.after_layer_reduced is not None:
+                    for l, _ in fast:
+                        self._pending.append((None, l))
+            return issue
         ev = torch.cuda.Event()
         ev.record()
-        with torch.cuda.stream(self._comm):
-            self._comm.wait_event(ev)
-            if self.compress is None:
-                for _, g in fast:
-                    self._timed(self._allreduce_mean, g)
-            else:
-                self._timed(self._allreduce_mean_bf16_multi, [g for _, g in fast])
-            if self.after_layer_reduced is not None:
-                for l, _ in fast:
-                    self.after_layer_reduced(l)
+
+        def issue():
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(ev)
+                if self.compress is None:
+                    for _, g in fast:
+                        self._timed(self._allreduce_mean, g)
+                else:
+                    self._timed(self._allreduce_mean_bf16_multi, [g for _, g in fast])
+                if self.after_layer_reduced is not None:
+                    for l, _ in fast:
+                        self.after_layer_reduced(l)
+        return issue
 
     def _arm(self):
         if not self._armed:
             self._armed = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
 
+    def _param_issue(self, p, g):
+        """-> closure that enqueues the collective of one large parameter's gradient `g` (event recorded now, as above)."""
+        if self._comm is None:
+            def issue():
+                if self.compress is None:
+                    self._seq.append(("ar", g.numel()))
+                    self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
+                else:
+                    self._allreduce_mean(g)
+            return issue
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def issue():
+            with torch.cuda.stream(self._comm):
+                self._comm.wait_event(ev)
+                self._timed(self._allreduce_mean, g)
+        return issue
+
     def _param_ready(self, p):
         if not self.enabled or (self.world == 1 and not self.force) or p.grad is None:
             return
         self._arm()
-        g = p.grad
-        if self._comm is None:
-            if self.compress is None:
-                self._pending.append((dist.all_reduce(g, group=self.group, async_op=True), g))
-            else:
-                self._allreduce_mean(g)
-        else:
-            ev = torch.cuda.Event()
-            ev.record()
-            with torch.cuda.stream(self._comm):
-                self._comm.wait_event(ev)
-                self._timed(self._allreduce_mean, g)
-        self._early_done.add(id(p))
+        self._submit(("P", self._outer_idx[id(p)]), self._param_issue(p, p.grad))
+
+    def replan(self):
+        """Forget the plan: the next pass agrees on a new one (call on EVERY rank, e.g. after switching heads on or off)."""
+        self._plan = None
+        self._plan_pos, self._plan_small, self._first_order = {}, [], []
+
+    def _make_plan(self):
+        """End of the first pass: the ranks agree on which parameters outside the encoder take part (the union of those with a
+        gradient on any rank) and on the order of the schedule (rank 0's ready order of layer exchanges and large parameters;
+        large parameters rank 0 did not see go last, by index)."""
+        n = len(self._outer)
+        cdev = self._outer[0].device if (n and self._comm is not None) else torch.device("cpu")
+        have = torch.tensor([0 if p.grad is None else 1 for p in self._outer] + [0], dtype=torch.int32, device=cdev)
+        dist.all_reduce(have, op=dist.ReduceOp.MAX, group=self.group)
+        L = len(self.encoder.layer)
+        order = torch.full((n + L + 1,), -1, dtype=torch.int32, device=cdev)  # codes: layer exchange b -> b, parameter i -> L + i
+        if self.rank == 0 and self._first_order:
+            codes = [k[1] if k[0] == "L" else L + k[1] for k in self._first_order]
+            order[:len(codes)] = torch.tensor(codes, dtype=torch.int32, device=cdev)
+        src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+        dist.broadcast(order, src=src, group=self.group)
+        have_l = have.tolist()[:n]
+        big = [i for i in range(n) if have_l[i] and self._outer[i].numel() >= self._big_numel]
+        plan = []
+        for c in order.tolist():
+            if c < 0:
+                continue
+            key = ("L", c) if c < L else ("P", c - L)
+            if key[0] == "L" or key[1] in big:
+                plan.append(key)
+        plan += [("P", i) for i in big if ("P", i) not in plan]
+        self._plan = plan
+        self._plan_pos = {k: j for j, k in enumerate(plan)}
+        self._plan_small = [i for i in range(n) if have_l[i] and self._outer[i].numel() < self._big_numel]
+        self._first_order = []
+        # what this first pass has issued already: its layer exchanges (they are not replayed by the flush below)
+        self._issued_first = {k for k in plan if k[0] == "L"}
+
+    def _check_sequence(self):
+        """Debug aid: every rank must have issued the same (kind, numel) sequence in this pass."""
+        import hashlib
+        h = int.from_bytes(hashlib.sha256(repr(self._seq).encode()).digest()[:7], "little")
+        cdev = self._outer[0].device if (self._comm is not None and self._outer) else torch.device("cpu")
+        mine = torch.tensor([h, len(self._seq)], dtype=torch.int64, device=cdev)
+        allh = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allh, mine, group=self.group)
+        vals = [tuple(t.tolist()) for t in allh]
+        if len(set(vals)) != 1:
+            raise RuntimeError(f"GradSync: the ranks issued different collective sequences in pass {self._passes}: "
+                               f"(hash, count) per rank = {vals}; this rank's sequence = {self._seq}")
 
     # -- runs once when the autograd pass is complete ---------------------------------------------------------
     def _finish(self):
@@ -317,8 +450,35 @@ class GradSync:
                         if self.after_layer_reduced is not None:
                             for l, _ in pairs:
                                 self.after_layer_reduced(l)
-        rest = [p for p in self.model.parameters()
-                if p.grad is not None and (id(p) not in self._enc_param_ids) and (id(p) not in self._early_done)]
+        first = self._plan is None
+        if first:
+            self._make_plan()
+        # flush, in plan order, what this pass has not issued yet: items that waited for a predecessor, and large parameters whose
+        # gradient is None on THIS rank (exchanged as zeros: this rank adds nothing to the mean).  A layer exchange that did not
+        # report in this pass (every rank alike: gradient accumulation sends those layers through the tail) is passed over.
+        flush = []
+        for key in self._plan[self._next:]:
+            if first and key in self._issued_first:
+                continue
+            fn = self._ready.pop(key, None)
+            if fn is None and key[0] == "P":
+                p = self._outer[key[1]]
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                fn = self._param_issue(p, p.grad)
+            if fn is not None:
+                flush.append(fn)
+        self._next, self._ready, self._issued_first = 0, {}, set()
+        for i in self._plan_small:
+            p = self._outer[i]
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        planned = set(self._plan_small) | {k[1] for k in self._plan if k[0] == "P"}
+        unplanned = [i for i, p in enumerate(self._outer) if p.grad is not None and i not in planned]
+        if unplanned:
+            raise RuntimeError(f"GradSync: parameters {unplanned} (indices outside the encoder) received a gradient on rank {self.rank} "
+                               "but are not part of the exchange plan made in the first pass; call GradSync.replan() on every rank")
+        rest = [self._outer[i] for i in self._plan_small]
         self._early_done = set()
         # A layer whose flat buffer was all-reduced but whose .grad tensors do NOT alias it (autograd cloned the returned
         # views instead of adopting them, e.g. because a tensor hook kept a reference): the clone ran on the main stream
@@ -342,6 +502,8 @@ class GradSync:
                 t_main = torch.cuda.Event(enable_timing=True)
                 t_main.record()  # the backward pass's own kernels end here
             self._comm.wait_stream(torch.cuda.current_stream())
+            for fn in flush:
+                fn()
             with torch.cuda.stream(self._comm):
                 self._timed(self._reduce_bucket, rest)
                 if self.timing:
@@ -350,6 +512,8 @@ class GradSync:
                     self._ttail.append((t_main, t_comm))
             torch.cuda.current_stream().wait_stream(self._comm)
         else:
+            for fn in flush:
+                fn()
             hooks = []
             for work, buf in self._pending:
                 if work is None:
@@ -367,6 +531,11 @@ class GradSync:
                 for p, v in zip(self.encoder.layer[li].ordered_params(), views):
                     if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                         p.grad.copy_(v)
+        self._passes += 1
+        seq_check = self.check_every and self._passes % self.check_every == 0
+        if seq_check:
+            self._check_sequence()
+        self._seq = []
 
     def _reduce_bucket(self, params):
         """The small non-encoder rest (position / type tables, LayerNorms, fc, crf, projectors ...: ~3 MB) through one

@@ -35,3 +35,14 @@ def f32_arith(request):
         yield request.param
     finally:
         hip.f32_split(was)
+
+
+@pytest.fixture(params=["unpad", "padded"])
+def pad_mode(request):
+    """Execution layout of `TVNetSAModel2` for one test: "unpad" = the default since round 5 (padding-free: the encoder layers
+    run on the packed unmasked token rows, mtvaf_amd.engine.UNPAD), "padded" = MTVAF_UNPAD=0 (every [B, S] row computed, the
+    reference's layout).  The parity tests that anchor the headline run in both, crossed with `f32_arith`; batches too small
+    to pack (fewer than one 128-row tile to save) run padded in either mode."""
+    from mtvaf_amd import engine
+    with engine.padding_free(request.param == "unpad"):
+        yield request.param

@@ -28,7 +28,7 @@ def _roofline(fat=True):
 
 def _worst_case():
     sec = {}
-    for k in ("c1_fp32", "c1_fp32_graph", "c2_fp32_pipe", "c2_fp32_split_unpad", "c3_bf16", "c4_bf16", "c5_extra", "c6_extra"):
+    for k in ("c1_fp32", "c1_fp32_graph", "c2_fp32_pipe", "c3_bf16", "c4_bf16", "c5_extra", "c6_extra"):
         sec[k] = {"config": k, "value": 12345.67, "unit": "sentences/s", "ms_per_step": 123.456, "steps": 40, "dtype": "d" * 250,
                   "dtype_short": "fp32x3", "workload": "w" * 300, "mfma_fraction_of_step": 0.1234, "loss": 102.2119,
                   "tolerance": "t" * 250, "accuracy": "a" * 300, "roofline": _roofline()}
@@ -42,7 +42,7 @@ def _worst_case():
             "mfma_fraction_of_step_executed": 0.35, "peak_tflops": 416.7, "flop_per_sentence_train": 67557285888,
             "fwd_bwd_without_optimizer": {"value": 2400.0, "ms_per_step": 13.3}, "real_token_rows": 0.5771,
             "flop_per_sentence_train_real_rows": 38600000000, "note_flops": "n" * 500, "padding": "p" * 80,
-            "padding_free": {"value": 3000.0, "ms_per_step": 10.6, "mfma_fraction_of_step_executed_flops": 0.5, "note": "n" * 300},
+            "padded": {"value": 2200.0, "ms_per_step": 14.5, "mfma_fraction_of_step_algorithmic": 0.36, "note": "n" * 300},
             "full_length": {"value": 1800.0, "ms_per_step": 17.76},
             "n_ranks_seen": 8, "backend": "nccl", "rank_ms_spread": 0.012,
             "grad_sync": {"wire": "bf16", "buckets": 4, "comm_stream_ms_per_step": 1.234, "exposed_tail_ms_per_step": 0.123, "note": "g" * 300},
@@ -91,6 +91,8 @@ def test_compact_line_of_a_typical_result_keeps_the_secondaries():
     for v in line["secondary"].values():
         assert set(v) == {"value", "ms_per_step", "dtype", "roofline_frac", "roofline_kernel"}
     assert line["grad_sync"]["wire"] == "bf16" and "note" not in line["grad_sync"]
+    # the padded and full-length runs stay beside `value` (round-4 review, gate 3b)
+    assert line["padded"] == {"value": 2200.0, "ms_per_step": 14.5} and line["full_length"] == {"value": 1800.0, "ms_per_step": 17.76}
 
 
 def test_emit_prints_the_compact_line_last_and_the_detail_elsewhere(tmp_path):

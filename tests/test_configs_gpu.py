@@ -86,10 +86,11 @@ GRADS = ["encoder_conv.2.weight", "projectors.0.weight", "bert.encoder.layer.5.i
 
 
 @pytest.mark.parametrize("B", [8, 32])
-def test_assembled_forward_on_the_timed_path_vs_oracle(B, f32_arith):
+def test_assembled_forward_on_the_timed_path_vs_oracle(B, f32_arith, pad_mode):
     """BASELINE configs[1] (the bench workload): BERT-base 12 layers, S = 128, 8 aux crops -> P = 36, use_prefix=True.
     B = 8 (1024 tokens) and B = 32 (the bench batch): prompt generator and Viterbi on the second stream, DeferredTags.
-    In both fp32 arithmetics (`f32_arith`): the library default that bench.py times, and the fp32 MFMA pipe."""
+    In both fp32 arithmetics (`f32_arith`): the library default that bench.py times, and the fp32 MFMA pipe; in both layouts
+    (`pad_mode`): padding-free, the default that bench.py times, and padded."""
     from mtvaf_amd import engine
     from mtvaf_amd.modules.crf import DeferredTags
     if not engine.DW_SIDE_STREAM:
@@ -102,7 +103,8 @@ def test_assembled_forward_on_the_timed_path_vs_oracle(B, f32_arith):
     m.eval()
     out, em = _run_model(m, text, vis)
     assert isinstance(out.logits, DeferredTags)
-    if engine.UNPAD:  # (MTVAF_UNPAD=1 in the environment: masked positions are not computed)
+    assert (engine.LAST_PACK is not None) == (pad_mode == "unpad"), "the run did not use the layout the test asked for"
+    if engine.UNPAD:  # (padding-free: masked positions are not computed)
         valid = text[1].bool()
         close(em[valid.to(DEV)], oem[valid], name="emissions of the unmasked tokens")
     else:
@@ -159,11 +161,8 @@ def test_ragged_odd_shapes_on_the_assembled_path_vs_oracle(B, S, n_aux, lengths,
     oloss, oem, otags, ograds = _oracle(cfg, sde, sdh, sdp, text, vis, GRADS)
     m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
     m.eval()
-    engine.UNPAD = unpad
-    try:
+    with engine.padding_free(unpad):
         out, em = _run_model(m, text, vis)
-    finally:
-        engine.UNPAD = False
     valid = text[1].bool()
     close(em[valid.to(DEV)], oem[valid], name="emissions of the unmasked tokens")
     assert abs(float(out.loss) - oloss) <= 1e-3 * abs(oloss)
@@ -248,11 +247,8 @@ def test_ragged_odd_shapes_in_bf16_mode_track_the_fp32_oracle(B, S, n_aux, lengt
     oloss, oem, otags, ograds = _oracle(cfg, sde, sdh, sdp, text, vis, GRADS)
     m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
     m.eval()
-    engine.UNPAD = unpad
-    try:
+    with engine.padding_free(unpad):
         out, em = _bf16(lambda: _run_model(m, text, vis))
-    finally:
-        engine.UNPAD = False
     valid = text[1].bool()
     named = dict(m.named_parameters())
     rel, lrel, agree, g = _bf16_report(f"odd shape B={B} S={S} unpad={unpad}", em.cpu()[valid], oem[valid], float(out.loss), oloss,
@@ -402,8 +398,10 @@ def test_native_executor_equals_python_orchestration(dtype):
             torch.cuda.synchronize()
             return float(out.loss), list(out.logits), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
         try:
-            l1, t1, g1 = step(True)
-            l0, t0, g0 = step(False)
+            # (the Python orchestration knows the padded layout only: padding-free execution is the native executor's)
+            with engine.padding_free(False):
+                l1, t1, g1 = step(True)
+                l0, t0, g0 = step(False)
         finally:
             engine.NATIVE_EXEC = True
         assert l1 == l0 and t1 == t0
@@ -418,7 +416,7 @@ def test_native_executor_equals_python_orchestration(dtype):
 
 
 # ---- BASELINE configs[4] (C5): S = 512, 36 visual regions ------------------------------------------------------------------
-def test_config5_assembled_seq512_vs_oracle(f32_arith):
+def test_config5_assembled_seq512_vs_oracle(f32_arith, pad_mode):
     """C5 shape on the ASSEMBLED model: TVNetSAModel2, BERT-base 12 layers, S = 512, 8 aux crops (P = 36), B = 4, fp32, against
     the oracle: prompt generator on the second stream, CRF / Viterbi at S = 512, weight-gradient k-tile lists (half the rows
     of a ragged S = 512 batch are padding), second stream in backward."""
@@ -429,6 +427,8 @@ def test_config5_assembled_seq512_vs_oracle(f32_arith):
     m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
     m.eval()
     out, em = _run_model(m, text, vis)
+    from mtvaf_amd import engine
+    assert (engine.LAST_PACK is not None) == (pad_mode == "unpad"), "the run did not use the layout the test asked for"
     valid = text[1].bool()
     close(em[valid.to(DEV)], oem[valid], name="emissions of the unmasked tokens")
     assert abs(float(out.loss) - oloss) <= 1e-3 * abs(oloss), (float(out.loss), oloss)

@@ -1204,12 +1204,15 @@ def _x3_operands(M, N, K, la, lb, seed, spread=0):
 @pytest.mark.parametrize("M,N,K,spread,tile", [(512, 768, 768, 0, 5), (256, 384, 3072, 12, 5), (128, 128, 32, 30, 5), (192, 320, 96, 6, 3),
                                                (1024, 1536, 256, 3, 5), (512, 768, 768, 0, 6), (256, 384, 3072, 12, 6),
                                                (128, 96, 32, 30, 6), (1024, 1536, 256, 3, 6),
-                                               (1152, 800, 384, 3, 5), (132, 388, 96, 12, 5)])  # (tiles that hang over the result)
+                                               (1152, 800, 384, 3, 5), (132, 388, 96, 12, 5),  # (tiles that hang over the result)
+                                               (512, 768, 768, 0, 4), (256, 320, 3072, 12, 4), (128, 64, 32, 30, 4),   # 128x64 (round 5)
+                                               (2432, 768, 256, 3, 4)])
 def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread, tile):
     """fp32 GEMM by three-way bf16 operand splitting (mtvaf_gemm_f32x3, csrc/gemm_f32x3.hip) is an fp32 GEMM: against the fp64
     product its error is bounded element-wise by a few fp32 roundings of |A|.|B| (the six partial products are exact, the
     dropped terms are below 2^-26 |a||b|) and is not larger than the fp32 MFMA pipe's on the same operands -- all three
-    operand layouts, every tile (cfg 5 = 128x128 and 6 = 128x96 wave-specialised, 3 = 64x64), operands spread over 2^+-30."""
+    operand layouts, every tile (cfg 5 = 128x128, 6 = 128x96 and 4 = 128x64 wave-specialised, 3 = 64x64), operands spread over
+    2^+-30."""
     a, b, ref, mag = _x3_operands(M, N, K, la, lb, seed=M + N + K + 7 * la + lb, spread=spread)
     o_nat, o_spl = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
     hip.gemm(a, la, b, lb, o_nat, M, N, K, compute="fp32")
@@ -1217,7 +1220,7 @@ def test_gemm_f32_split_accuracy(hip, la, lb, M, N, K, spread, tile):
     hip.prof_start(4)
     hip.gemm(a, la, b, lb, o_spl, M, N, K, compute="fp32x3", cfg=tile)
     recs = hip.prof_stop(4)
-    assert recs[0][0]["cfg"] == {5: 225, 6: 226, 3: 203}[tile], recs  # (the kernel that was asked for really ran)
+    assert recs[0][0]["cfg"] == {5: 225, 6: 226, 4: 224, 3: 203}[tile], recs  # (the kernel that was asked for really ran)
     e_nat = (o_nat.double().cpu() - ref).abs() / mag
     e_spl = (o_spl.double().cpu() - ref).abs() / mag
     # element-wise bound: accumulation of K terms in fp32 (worst case K 2^-24, in practice ~sqrt(K)) + the 2^-26 split remainder
@@ -1302,6 +1305,71 @@ def test_gemm_f32_split_adversarial(hip, la, lb, case):
     e_spl = e_spl / mag
     assert float(e_spl.max()) <= 1.5 * float(e_nat.max()) + 2.0 ** -25, (float(e_spl.max()), float(e_nat.max()))
     assert float(e_spl.pow(2).mean().sqrt()) <= 1.25 * float(e_nat.pow(2).mean().sqrt()) + 2.0 ** -26
+
+
+def test_gemm_f32_split_tile64_epilogues_splitk_ktiles_and_planner(hip):
+    """The 128 x 64 layout of the wave-specialised split kernel (round 5; the N = 768 products of a packed batch): every epilogue,
+    split-K, a k-tile list, bit-identical results to the 128 x 128 layout (same planes, same k order, same product sequence per
+    element), and the planner takes it by itself exactly where it saves a round of the 256 CUs (2432 packed rows x 768), not at
+    4096 rows."""
+    M, N, K = 256, 320, 512
+    x, w, bias = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2).to(DEV), rnd(N, seed=3).to(DEV)
+    ref = x.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    out, aux = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, epi=hip.EPI_GELU, aux=aux, compute="fp32x3", cfg=4)
+    close(aux, ref, rtol=2e-6, name="saved pre-activation")
+    close(out, torch.nn.functional.gelu(ref), rtol=2e-6, name="GELU")
+    dy, pre = rnd(M, N, seed=4).to(DEV), rnd(M, K, seed=5).to(DEV)
+    dx = torch.empty(M, K, device=DEV)
+    hip.gemm(dy, 0, w, 1, dx, M, K, N, epi=hip.EPI_DGELU, aux=pre, compute="fp32x3", cfg=4)
+    p64 = pre.double().cpu()
+    gp = 0.5 * (1 + torch.erf(p64 / 2 ** 0.5)) + p64 * torch.exp(-p64 * p64 / 2) / (2 * torch.pi) ** 0.5
+    close(dx, (dy.double().cpu() @ w.double().cpu()) * gp, rtol=3e-6, name="GELU'")
+    acc0 = rnd(M, N, seed=6)
+    out.copy_(acc0)
+    hip.gemm(x, 0, w, 0, out, M, N, K, accumulate=True, compute="fp32x3", cfg=4)
+    close(out, ref - bias.double().cpu() + acc0.double(), rtol=2e-6, name="accumulate")
+    for sp in (2, 4):
+        out.fill_(float("nan"))
+        hip.gemm(x, 0, w, 0, out, M, N, K, bias=bias, allow_split=True, splits=sp, compute="fp32x3", cfg=4)
+        close(out, ref, rtol=2e-6, name=f"split-K {sp}")
+    # the same bits as the 128 x 128 layout (N a multiple of both)
+    M2, N2, K2 = 256, 384, 768
+    for la, lb in ((0, 0), (0, 1), (1, 1)):
+        a, b, _, _ = _x3_operands(M2, N2, K2, la, lb, seed=11 + la + lb)
+        o4, o5 = torch.empty(M2, N2, device=DEV), torch.empty(M2, N2, device=DEV)
+        hip.gemm(a, la, b, lb, o4, M2, N2, K2, compute="fp32x3", cfg=4)
+        hip.gemm(a, la, b, lb, o5, M2, N2, K2, compute="fp32x3", cfg=5)
+        assert torch.equal(o4, o5), (la, lb)
+    # weight gradient over a k-tile list
+    T, NO, KI = 1024, 256, 192
+    valid = torch.ones(T, dtype=torch.bool)
+    valid[300:700] = False
+    dyw = (rnd(T, NO, seed=7) * valid[:, None]).to(DEV)
+    xw = rnd(T, KI, seed=8).to(DEV)
+    tiles = sorted(set(int(r) // 32 for r in torch.nonzero(valid).flatten()))
+    kl, kc = torch.tensor(tiles, dtype=torch.int32, device=DEV), torch.tensor([len(tiles)], dtype=torch.int32, device=DEV)
+    dw = torch.empty(NO, KI, device=DEV)
+    refw = dyw.double().cpu().t() @ xw.double().cpu()
+    was = hip.f32_split()
+    try:
+        assert hip.f32_split(True) is True
+        for sp in (1, 3):
+            hip.gemm_ktiles(dyw, xw, dw.fill_(float("nan")), NO, KI, T, kl, kc, cfg=4, splits=sp)
+            close(dw, refw, rtol=3e-6, name=f"k-tile list, 128x64, splits {sp}")
+        # the planner: a packed batch of 2432 rows takes 128x64 for N = 768 (228 tiles: one round), 4096 rows do not
+        xs, ws = torch.randn(2432, 768, device=DEV), torch.randn(768, 768, device=DEV)
+        o = torch.empty(2432, 768, device=DEV)
+        hip.prof_start(8)
+        hip.gemm(xs, 0, ws, 0, o, 2432, 768, 768)
+        hip.gemm(xs, 0, ws, 1, o, 2432, 768, 768)
+        xl, ol = torch.randn(4096, 768, device=DEV), torch.empty(4096, 768, device=DEV)
+        hip.gemm(xl, 0, ws, 0, ol, 4096, 768, 768)
+        recs = hip.prof_stop(8)
+        assert [r[0]["cfg"] for r in recs] == [224, 224, 226], [r[0]["cfg"] for r in recs]
+        close(o, xs.double().cpu() @ ws.double().cpu(), rtol=3e-6, name="planned 128x64 product")
+    finally:
+        hip.f32_split(was)
 
 
 def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):

@@ -601,3 +601,194 @@ def test_bucketed_bf16_exchange_equals_the_per_layer_exchange_bit_for_bit():
             assert p.exitcode == 0
         res[buckets] = out[0]
     assert res[None] == res[2]
+
+
+class _PartialModel(torch.nn.Module):
+    """Two 'large' parameters outside the encoder whose gradients exist only on some ranks in some passes (a rank whose batch
+    has no images gets no gradient for `encoder_conv`; SURVEY 8e gotchas), a small head that is sometimes unused too, and a
+    head that never trains."""
+
+    def __init__(self):
+        super().__init__()
+        self.encoder = _FakeEncoder(L=3, n=8)
+        self.table_a = torch.nn.Parameter(torch.ones(40, 8))   # 'word table'
+        self.table_b = torch.nn.Parameter(torch.ones(33, 8))   # 'encoder_conv'
+        self.head = torch.nn.Linear(4, 1)
+        self.never = torch.nn.Linear(4, 2)
+
+    def forward(self, x, use_a=True, use_b=True, use_head=True, use_never=False):
+        y = self.encoder(x)
+        if use_b:   # (b before a: its gradient is ready FIRST in the backward pass of the ranks that have it)
+            y = y + (self.table_b * x * 0.5).sum()
+        if use_a:
+            y = y + (self.table_a * x).sum()
+        if use_head:
+            y = y + self.head(x[:4]).sum()
+        if use_never:
+            y = y + self.never(x[:4]).sum()
+        return y
+
+
+# pass -> rank -> (use_a, use_b, use_head): pass 0 makes the plan although rank 1 has no table_a gradient and rank 2 no head
+# gradient; in pass 1 rank 0 lacks table_b (its table_a must wait for the plan order), in pass 2 rank 2 lacks everything
+_PARTIAL_USE = [
+    {0: (True, True, True), 1: (False, True, True), 2: (True, True, False)},
+    {0: (True, False, True), 1: (True, True, True), 2: (True, True, True)},
+    {0: (True, True, True), 1: (True, True, True), 2: (False, False, False)},
+]
+
+
+def _worker_partial(rank, world, port, q, wire):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtvaf_amd.parallel import GradSync
+    torch.manual_seed(0)
+    m = _PartialModel()
+    sync = GradSync(m, big_numel=256, compress=wire, check_every=1)
+    x = torch.arange(8, dtype=torch.float32) * (rank + 1) * 0.25
+    res = []
+    for use in _PARTIAL_USE:
+        m.zero_grad(set_to_none=True)
+        a, b, h = use[rank]
+        m(x, a, b, h).backward()
+        res.append({n: (None if p.grad is None else p.grad.tolist()) for n, p in m.named_parameters()})
+    q.put((rank, {"grads": res, "plan": [list(k) for k in sync._plan], "plan_small": list(sync._plan_small)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire", [None, "bf16"])
+def test_gradsync_large_parameter_without_gradient_on_one_rank_never_hangs(wire):
+    """Collectives match by issue order: a rank whose LARGE parameter (word table / encoder_conv) gets no gradient in a pass
+    while the others' do must still issue that parameter's collective, in the same place of the sequence, with zeros.  Three
+    ranks, three passes with different ranks lacking different gradients (the first pass included, where the plan is made):
+    every pass completes (a hang fails the queue timeout), every rank ends with the mean over ALL ranks of the local gradients
+    (absent = zero), bit-identical across ranks, and the (kind, numel) sequence check passes in every pass."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_partial, args=(r, world, port, q, wire)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(0)
+    ref = _PartialModel()
+    names = [n for n, _ in ref.named_parameters()]
+    tol = dict(rtol=2e-2, atol=2e-3) if wire == "bf16" else dict(rtol=1e-6, atol=1e-6)
+    for k, use in enumerate(_PARTIAL_USE):
+        local = []
+        for r in range(world):
+            ref.zero_grad(set_to_none=True)
+            a, b, h = use[r]
+            ref(torch.arange(8, dtype=torch.float32) * (r + 1) * 0.25, a, b, h).backward()
+            local.append({n: (torch.zeros_like(p) if p.grad is None else p.grad.clone()) for n, p in ref.named_parameters()})
+        for n in names:
+            if n.startswith("never"):
+                assert all(out[r]["grads"][k][n] is None for r in range(world))  # trained nowhere: in no exchange, stays None
+                continue
+            want = sum(l[n] for l in local) / world
+            for r in range(world):
+                got = out[r]["grads"][k][n]
+                assert got is not None, (k, r, n)
+                torch.testing.assert_close(torch.tensor(got), want, msg=f"pass {k} rank {r} {n}", **tol)
+                assert got == out[0]["grads"][k][n], (k, r, n)
+    # the plan: the same on every rank -- three layer exchanges and both tables in rank 0's ready order of pass 0, the head's two
+    # tensors in the tail bucket
+    for r in range(world):
+        assert out[r]["plan"] == out[0]["plan"]
+        assert sorted(k[0] for k in out[r]["plan"]) == ["L", "L", "L", "P", "P"]
+        assert out[r]["plan_small"] == out[0]["plan_small"] and len(out[r]["plan_small"]) == 2
+
+
+def _worker_unplanned(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtvaf_amd.parallel import GradSync
+    torch.manual_seed(0)
+    m = _PartialModel()
+    sync = GradSync(m, big_numel=256, force=True, check_every=1)
+    x = torch.arange(8, dtype=torch.float32)
+    m(x).backward()
+    res = {}
+    m.zero_grad(set_to_none=True)
+    try:  # `never` had no gradient anywhere when the plan was made
+        m(x, use_never=True).backward()
+        res["raised"] = None
+    except RuntimeError as e:
+        res["raised"] = str(e)
+    sync.replan()
+    sync._seq, sync._slow_layers, sync._fast_layers, sync._bucket_acc, sync._ready, sync._next = [], [], [], {}, {}, 0
+    sync._pending = []
+    m.zero_grad(set_to_none=True)
+    m(x, use_never=True).backward()
+    res["after_replan"] = m.never.weight.grad is not None and len(sync._plan_small) == 4
+    # a rank that issued something else: the check raises
+    sync._seq_tamper = True
+    real = sync._check_sequence
+
+    def tampered():
+        sync._seq.append(("ar", 12345 + rank))
+        allh_real = dist.all_gather
+
+        def fake_gather(lst, mine, group=None):
+            allh_real(lst, mine, group=group)
+            lst.append(mine + 1)  # a second 'rank' with another hash
+        dist.all_gather = fake_gather
+        try:
+            real()
+        finally:
+            dist.all_gather = allh_real
+    sync._check_sequence = tampered
+    m.zero_grad(set_to_none=True)
+    try:
+        m(x, use_never=True).backward()
+        res["check_raised"] = None
+    except RuntimeError as e:
+        res["check_raised"] = str(e)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_gradsync_unplanned_gradient_raises_and_replan_recovers_and_sequence_check_raises():
+    """A gradient for a parameter that had none on ANY rank when the plan was made raises on the rank that sees it (before a
+    collective the others would not issue); `replan()` makes the next pass agree on a new plan; ranks that report different
+    (kind, numel) sequences make `_check_sequence` raise."""
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_unplanned, args=(0, 1, port, q))
+    p.start()
+    _, res = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert res["raised"] and "replan" in res["raised"]
+    assert res["after_replan"]
+    assert res["check_raised"] and "different collective sequences" in res["check_raised"]
+
+
+def test_layer_buckets_on_the_fp32_wire_warn():
+    """`layer_buckets` used to be dropped silently when the wire resolved to fp32."""
+    import warnings
+
+    def run(rank, world, port, q):
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from mtvaf_amd.parallel import GradSync
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            s = GradSync(_OddModel(), compress=None, layer_buckets=2)
+        q.put([str(x.message) for x in w] + [s.layer_buckets])
+        dist.destroy_process_group()
+    port = _free_port()
+    import queue as _q
+    qq = _q.Queue()
+    run(0, 1, port, qq)
+    msgs = qq.get()
+    assert msgs[-1] is None and any("bf16 wire only" in m for m in msgs[:-1])

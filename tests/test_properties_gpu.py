@@ -58,7 +58,17 @@ def test_padding_does_not_leak_into_valid_tokens(setup):
     valid = mask.bool()
     assert torch.equal(hs2[valid], hs[valid]), "masked keys carry exactly zero probability: valid rows must not move"
     assert tags2 == tags
-    assert not torch.equal(hs2[~valid], hs[~valid])  # the padded rows themselves do change (they are computed, not skipped)
+    from mtvaf_amd import engine
+    if engine.LAST_PACK is not None:  # padding-free (the default): masked rows are not computed at all -- zeros either way
+        assert float(hs[~valid].abs().max()) == 0.0 and float(hs2[~valid].abs().max()) == 0.0
+    else:  # padded: the padded rows themselves do change (they are computed, not skipped)
+        assert not torch.equal(hs2[~valid], hs[~valid])
+    with engine.padding_free(False):  # the padded layout computes them: the junk must show there and nowhere else
+        hp, _, tp, _ = run(m, ids, mask, tt, labels, pkv)
+        hp2, _, tp2, _ = run(m, ids2, mask, tt, labels, pkv)
+    assert engine.LAST_PACK is None
+    assert torch.equal(hp2[valid], hp[valid]) and tp2 == tp == tags
+    assert not torch.equal(hp2[~valid], hp[~valid])
 
 
 def test_prefix_slots_are_a_set(setup):

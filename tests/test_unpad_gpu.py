@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run(m, kw, unpad):
-    engine.UNPAD = unpad
+    was, engine.UNPAD = engine.UNPAD, unpad
     try:
         m.zero_grad(set_to_none=True)
         cap = {}
@@ -29,7 +29,7 @@ def _run(m, kw, unpad):
                 {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}, packed,
                 hs[1].detach().clone())
     finally:
-        engine.UNPAD = False
+        engine.UNPAD = was
 
 
 @pytest.mark.parametrize("holes", [False, True])
@@ -120,13 +120,12 @@ def test_unpadded_encoder_entry_without_the_early_packing_hook():
     ids, mask, tt, _ = (t.to(DEV) for t in P.text_batch(cfg, 97, 8, 128, lo_id=1000))
     with torch.no_grad():
         emb = m.bert.get_embedding_output(ids, tt)
-        seq0, _ = m.bert.get_bert_output(emb, attention_mask=mask)
-        engine.UNPAD = True
-        try:
+        with engine.padding_free(False):
+            seq0, _ = m.bert.get_bert_output(emb, attention_mask=mask)
+            assert engine.LAST_PACK is None
+        with engine.padding_free(True):
             seq1, _ = m.bert.get_bert_output(emb, attention_mask=mask)
             assert engine.LAST_PACK is not None
-        finally:
-            engine.UNPAD = False
     valid = mask.bool()
     close(seq1[valid], seq0[valid], rtol=2e-5, name="get_bert_output, unpadded")
     assert float(seq1[~valid].abs().max()) == 0.0
@@ -162,12 +161,9 @@ def test_unpadded_bench_workload_against_the_cpu_oracle():
     oloss, oem, otags, ograds = _oracle(cfg, sde, sdh, sdp, text, vis, GRADS)
     m = build_tvnet2(cfg, make_args(alpha=0.0), sde=sde, sdh=sdh, sdp=sdp)
     m.eval()
-    engine.UNPAD = True
-    try:
+    with engine.padding_free(True):
         out, em = _run_model(m, text, vis)
         assert engine.LAST_PACK is not None
-    finally:
-        engine.UNPAD = False
     valid = text[1].bool()
     close(em.cpu()[valid], torch.as_tensor(oem)[valid], name="emissions at unmasked positions")
     assert abs(float(out.loss) - oloss) <= 1e-3 * abs(oloss), (float(out.loss), oloss)
@@ -282,3 +278,32 @@ def test_gradients_of_masked_token_rows_are_exact_zeros(dtype):
     finally:
         engine.SKIP_PAD_DW = True
         hip.set_compute_dtype("fp32")
+
+
+@pytest.mark.parametrize("unpad", [False, True])
+def test_contract_check_trips_on_a_head_that_reads_masked_positions(unpad):
+    """MTVAF_CHECK_CONTRACT / engine.CHECK_CONTRACT (round 5): `BertModel.allow_unpad` is the caller's promise that nothing
+    downstream reads hidden states at masked positions -- the k-tile lists, the attention backward's shortened query loops and
+    padding-free execution all rest on it, and the engine cannot see the head.  With the switch on, the backward pass reads
+    the incoming hidden-state gradients back and raises when a masked row is not exactly zero: a head that sums over ALL
+    positions trips it (in the padded layout and in the padding-free one); the masked head (reference: the CRF of
+    bert_model.py:511, 521 reads through the mask only) passes."""
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=2, max_pos=512)
+    m = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+    assert m.bert.allow_unpad
+    B, S = 8, 128
+    ids, mask, tt, _ = (t.to(DEV) for t in P.text_batch(cfg, 131, B, S, lo_id=1000))
+    assert int((mask == 0).sum()) > 128
+    was = engine.CHECK_CONTRACT
+    engine.CHECK_CONTRACT = True
+    try:
+        with engine.padding_free(unpad):
+            h = m.bert(input_ids=ids, attention_mask=mask, token_type_ids=tt)["last_hidden_state"]
+            assert (engine.LAST_PACK is not None) == unpad
+            (h * mask[..., None]).sum().backward()  # masked head: fine
+            h = m.bert(input_ids=ids, attention_mask=mask, token_type_ids=tt)["last_hidden_state"]
+            with pytest.raises(RuntimeError, match="masked-rows contract violated"):
+                (h + 1.0).pow(2).sum().backward()  # reads every position
+    finally:
+        engine.CHECK_CONTRACT = was
+        m.zero_grad(set_to_none=True)

@@ -56,14 +56,15 @@ def main():
             line += f" | {mode:7s} {us:6.1f} us {fl / us / 1e6:5.1f} TF err {emax:.1e}/{erms:.1e}"
         hip.f32_split(True)
         if tiles:
-            for cfg in (5, 6):
-                if n % (128 if cfg == 5 else 96):
+            for cfg in (5, 6, 4):
+                if n % {5: 128, 6: 96, 4: 64}[cfg] or m % 128:
                     continue
                 for sp in ((-1,) if la == KC else (-1, 2, 3, 4, 6, 8)):
                     run = lambda: hip.gemm(a, la, b, lb, out, m, n, k, allow_split=True, compute="fp32x3", cfg=cfg, splits=sp)
                     run()
                     us = t(run)
-                    line += f" | {'128x128' if cfg == 5 else '128x96'}{'' if sp < 0 else '/s' + str(sp)} {us:6.1f}"
+                    tname = {5: "128x128", 6: "128x96", 4: "128x64"}[cfg]
+                    line += f" | {tname}{'' if sp < 0 else '/s' + str(sp)} {us:6.1f}"
         print(line, flush=True)
     print(f"M={M}: one layer's 12 products: fp32 pipe {tot['fp32']:.0f} us ({flops / tot['fp32'] / 1e6:.0f} TF), split {tot['fp32x3']:.0f} us "
           f"({flops / tot['fp32x3'] / 1e6:.0f} TF fp32-equivalent)")
