@@ -317,8 +317,8 @@ def test_cached_features_reproduce_raw_image_prefix():
 @pytest.mark.gpu
 def test_folded_bf16_cache_build_on_the_gpu_per_level():
     """The reduced-precision cache build on MIOpen (channels-last bf16, BatchNorm folded, fp32 pooling) against the exact
-    eval-mode pyramid of the same seeded ResNet-50 trunk on the GPU, per pyramid level (bound 2e-2 in norm; measured on the CPU
-    1.5e-3 .. 5.3e-3), main image and aux crops."""
+    eval-mode pyramid of the same seeded ResNet-50 trunk on the GPU, per pyramid level (bound 3e-2 in norm; measured on the
+    MI355X 1.0e-2 .. 1.2e-2 -- MIOpen's bf16 convolutions; on the CPU 1.5e-3 .. 5.3e-3), main image and aux crops."""
     from mtvaf_amd.features import RegionFeatureCache
     from mtvaf_amd.models.bert_model import ImageModel
     torch.manual_seed(0)
@@ -334,5 +334,5 @@ def test_folded_bf16_cache_build_on_the_gpu_per_level():
         d = float((feats[:, off:off + c] - ref[:, off:off + c]).norm() / ref[:, off:off + c].norm())
         da = float((fa[:, :, off:off + c] - refa[:, :, off:off + c]).norm() / refa[:, :, off:off + c].norm())
         print(f"[bf16 cache build] level of {c} channels: {d:.3e} (aux {da:.3e})", flush=True)
-        assert d <= 2e-2 and da <= 2e-2, (c, d, da)
+        assert d <= 3e-2 and da <= 3e-2, (c, d, da)
         off += c
