@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmtvaf_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16x.hip", "gemm_bf16p.hip", "gemm_f32x3.hip", "attention.hip", "attention_bf16.hip", "rowops.hip", "crf.hip", "prompt.hip", "span.hip", "optim.hip", "executor.hip", "runtime.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16x.hip", "gemm_bf16p.hip", "gemm_f32x3.hip", "gemm_f32p.hip", "attention.hip", "attention_bf16.hip", "rowops.hip", "crf.hip", "prompt.hip", "span.hip", "optim.hip", "executor.hip", "runtime.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"] + os.environ.get("MTVAF_EXTRA_FLAGS", "").split()
 # The attention kernels read their MFMA results with VALU code every 16 products (softmax, dS): keeping the
 # accumulators in architectural VGPRs saves ~200 v_accvgpr moves per key tile (gfx950 has one unified file).

@@ -1,0 +1,411 @@
+// fp32 GEMM on the bf16 matrix pipe from PRE-SPLIT operands (round 5; research kernel behind mtvaf_gemm_f32p): both operands
+// arrive as plane images -- the three bf16 planes x = x1 + x2 + x3 of gemm_f32x3.hip's split, written once per tensor by
+// mtvaf_f32_split_planes (or, one day, by the kernel that produces the tensor) -- and a product a.b is the same six MFMA
+// products a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1 (fp32 accumulation, smallest first), here on
+// v_mfma_f32_16x16x32_bf16.
+//
+// Why this form.  The wave-specialised kernel of gemm_f32x3.hip is bound by INSTRUCTION ISSUE on its SIMDs: per 32-deep k-tile a
+// SIMD issues the consumer's 48 MFMAs and 24 fragment reads AND the producer's ~200 vector instructions (the split: 11 per pair
+// of values), 24 plane stores and 16 loads -- 2200 - 2460 cycles per k-tile where the MFMAs need 1536.  With the
+// split hoisted out of the k-loop nothing but MFMAs and fragment reads is left beside the requests, so the matrix pipe is the
+// limit -- and then the MFMA SHAPE decides the rate, because a chip full of MFMAs runs at its power limit: a pure 32x32x16
+// stream holds 1.51 GHz = 1545 TFLOP/s, a 16x16x32 stream 1.82 GHz = 1812 (profiles/r04_mfma_bf16_rate.txt).  In the
+// wave-specialised kernel the 16x16 shape lost (twice the MFMA issues beside the producers); without producers it does not.
+//
+// Shape: 128 x 128 x 32 tile, 512 threads: waves 0-3 multiply (2 x 2 grid of 64 x 64 wave tiles = 4 x 4 blocks of 16 x 16; 96
+// MFMAs and 24 ds_read_b128 per k-tile), waves 4-7 only issue LDS-DMA requests (global_load_lds_dwordx4: a request costs its wave
+// 60 - 95 issue cycles, so they get waves of their own).  Three stages of 48 KiB (3 planes x (128 + 128) rows x 64 B), two
+// k-tiles in flight behind a counted vmcnt, ONE raw s_barrier per k-tile placed so that the fragments of the next tile are read
+// under the last 24 MFMAs of this one.
+//
+// LDS image of a k-contiguous (KC) operand plane: 128 rows x 64 B, unpadded; the 16-byte chunk c of row r sits at position
+// c ^ G[(r >> 2) & 3] with G = {0, 2, 3, 1}: the ds_read_b128 of a 16x16x32 fragment (lane l: row l & 15, chunk l >> 4) is then
+// conflict-free in every one of its four 16-lane groups.  LDS-DMA writes lane-linear, so the swizzle sits on the per-lane SOURCE
+// address.  Plane images in memory are addressed by three byte strides (plane, row, k-tile): the natural form ([3][rows][ld], the
+// fp32 tensor's own layout) and the tile-blocked form ([k-tile][plane][rows][32]: every 1-KiB request reads 1 KiB of contiguous
+// memory) are both served.
+#include "gemm_bf16x.h"
+
+namespace mtvaf {
+
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4p __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+typedef unsigned fragp_t __attribute__((ext_vector_type(4)));
+
+struct GemmArgsP {
+  const unsigned char* Ap;  // plane 0 of A (bf16), byte addressed
+  const unsigned char* Bp;
+  long a_plane, a_row, a_kt;  // byte strides: plane -> plane, row -> row, k-tile (32 k) -> k-tile
+  long b_plane, b_row, b_kt;
+  float* C;
+  const float* bias;
+  float* aux;
+  int M, N, K;
+  int ldc, ldaux;
+  int k_chunk;
+  long slab_stride;
+  int epi, accumulate, tiles_n;
+  int ablate;        // research switches: 1 = no MFMAs, 2 = no DMA requests, 4 = no fragment reads
+  long long* trace;  // [8 waves][64 k-tiles][2] shader-clock stamps of block 0 (arrive at / leave the tile barrier) + 17, or NULL
+};
+
+namespace f32p {
+
+// the RNE three-way split of gemm_f32x3.hip (same planes bit for bit)
+__device__ __forceinline__ unsigned cvt_pk(const f32x2p v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2p)); }
+__device__ __forceinline__ f32x2p widen(const unsigned pk) {
+  return f32x2p{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+}
+__device__ __forceinline__ void split3_pair(const f32x2p x, unsigned& h, unsigned& m, unsigned& l) {
+  h = cvt_pk(x);
+  const f32x2p r = x - widen(h);
+  m = cvt_pk(r);
+  l = cvt_pk(r - widen(m));
+}
+
+__device__ __forceinline__ int swz(int row) {  // G[(row >> 2) & 3], G = {0, 2, 3, 1}
+  const int q = (row >> 2) & 3;
+  return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
+}
+
+}  // namespace f32p
+
+// fp32 [rows][cols] (leading dimension ld) -> plane image at dst with the byte strides (plane, row, k-tile); a thread takes 8
+// consecutive columns (one 16-byte chunk of each plane)
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, int rows,
+                                                           int cols, int ld, long s_plane, long s_row, long s_kt) {
+  const long n8 = (long)rows * (cols / 8);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (cols / 8)), c8 = (int)(i % (cols / 8));
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + (long)r * ld + 8 * c8);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + (long)r * ld + 8 * c8 + 4);
+    unsigned h[4], m[4], l[4];
+    f32p::split3_pair(f32x2p{v0.x, v0.y}, h[0], m[0], l[0]);
+    f32p::split3_pair(f32x2p{v0.z, v0.w}, h[1], m[1], l[1]);
+    f32p::split3_pair(f32x2p{v1.x, v1.y}, h[2], m[2], l[2]);
+    f32p::split3_pair(f32x2p{v1.z, v1.w}, h[3], m[3], l[3]);
+    unsigned char* d = dst + (long)(c8 >> 2) * s_kt + (long)r * s_row + (c8 & 3) * 16;
+    *reinterpret_cast<uint4*>(d) = uint4{h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<uint4*>(d + s_plane) = uint4{m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<uint4*>(d + 2 * s_plane) = uint4{l[0], l[1], l[2], l[3]};
+  }
+}
+
+// ABL: timing-only research switches, compile-time so that the product instantiation (0) carries no branch in its k-loop (as
+// run-time tests every MFMA group sat in a block of its own behind an s_waitcnt lgkmcnt(0): the fragment reads issued just
+// before it were waited for at once): 1 = no MFMAs, 2 = no DMA requests, 4 = no fragment reads.  TRACE: shader-clock stamps.
+template <int ABL, bool TRACE>
+__global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
+  constexpr int BM = 128, BN = 128, NS = 3;
+  constexpr int PL_B = 128 * 64;       // bytes of one plane tile
+  constexpr int OP_B = 3 * PL_B;       // one operand's stage: 24 KiB
+  constexpr int STAGE_B = 2 * OP_B;    // 48 KiB
+  constexpr int NPIECE = OP_B / 1024;  // 24 requests per operand and k-tile
+  constexpr int IW = NPIECE / 4;       // 6 per DMA wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_p[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool dma_wave = wave >= 4;
+  const int w4 = wave & 3;
+  const int wm = w4 >> 1, wn = w4 & 1;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (bid / p.tiles_n) * BM;
+  const int n0 = (bid % p.tiles_n) * BN;
+  const int kbeg = blockIdx.z * p.k_chunk;
+  const int kend = min(p.K, kbeg + p.k_chunk);
+  const int nk = (kend - kbeg) / 32;
+  long long* const tr = (TRACE && p.trace && blockIdx.x == 0 && blockIdx.z == 0) ? p.trace : nullptr;
+  if (TRACE && tr && tid == 0) tr[8 * 64 * 2] = __builtin_amdgcn_s_memtime();
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (dma_wave) {
+    // ---- request issue: piece I of an operand = plane I / 8, 16 rows (I % 8) * 16 ..; lane -> row + lane / 4, LDS chunk position
+    // lane % 4, source chunk = position ^ swz(row)
+    const unsigned char* pa[IW];
+    const unsigned char* pb[IW];
+#pragma unroll
+    for (int i = 0; i < IW; ++i) {
+      const int I = w4 * IW + i, plane = I >> 3, row = (I & 7) * 16 + (lane >> 2), cp = lane & 3;
+      const int sc = cp ^ f32p::swz(row);
+      pa[i] = p.Ap + plane * p.a_plane + (long)(m0 + row) * p.a_row + (long)(kbeg / 32) * p.a_kt + sc * 16;
+      pb[i] = p.Bp + plane * p.b_plane + (long)(n0 + row) * p.b_row + (long)(kbeg / 32) * p.b_kt + sc * 16;
+    }
+    auto issue = [&](int stage) __attribute__((always_inline)) {
+      unsigned char* sa = smem_p + stage * STAGE_B + w4 * IW * 1024;
+      unsigned char* sb = sa + OP_B;
+#pragma unroll
+      for (int i = 0; i < IW; ++i) {
+        glds16x(pa[i], sa + i * 1024);
+        pa[i] += p.a_kt;
+      }
+#pragma unroll
+      for (int i = 0; i < IW; ++i) {
+        glds16x(pb[i], sb + i * 1024);
+        pb[i] += p.b_kt;
+      }
+    };
+    constexpr bool go = !(ABL & 2);
+    // prologue: tiles 0 and 1 are requested, tile 0 is waited for and published (barrier -1), THEN tile 2 is requested -- with all
+    // three stages requested first the consumers started 12 requests (~1000 cycles of issue) later
+    if (go) {
+      if (nk > 0) issue(0);
+      if (nk > 1) issue(1);
+    }
+    if (nk > 1) wait_vm<2 * IW>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (go && nk > 2) issue(2);
+    int st = 0;
+    for (int t = 0; t < nk; ++t) {
+      // barrier t: tile t + 1 has landed (tile t + 2 may still be in flight), every fragment of tile t is in registers
+      if (TRACE && tr && t < 64 && lane == 0) tr[(wave * 64 + t) * 2 + 0] = __builtin_amdgcn_s_memtime();
+      if (t + 2 < nk) wait_vm<2 * IW>();
+      else wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (TRACE && tr && t < 64 && lane == 0) tr[(wave * 64 + t) * 2 + 1] = __builtin_amdgcn_s_memtime();
+      if (go && t + NS < nk) issue(st);  // tile t + 3 into the stage tile t has left
+      st = st + 1 == NS ? 0 : st + 1;
+    }
+  } else {
+    // ---- fragment read offsets inside a plane tile: row-block i of this wave's 64 rows, lane -> row l & 15, chunk l >> 4
+    const int r15 = lane & 15, ch = lane >> 4;
+    const int offA = (wm * 64 + r15) * 64 + ((ch ^ f32p::swz(r15)) << 4);
+    const int offB = (wn * 64 + r15) * 64 + ((ch ^ f32p::swz(r15)) << 4);
+    fragp_t fb[2][3][4], fa[2][3];
+    constexpr bool do_rd = !(ABL & 4), do_mm = !(ABL & 1);
+    auto rd_b = [&](const unsigned char* s, fragp_t (&f)[3][4]) __attribute__((always_inline)) {
+      if constexpr (!do_rd) return;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[q][j] = *reinterpret_cast<const fragp_t*>(s + OP_B + q * PL_B + offB + j * 1024);
+    };
+    auto rd_a = [&](const unsigned char* s, int i, fragp_t (&f)[3]) __attribute__((always_inline)) {
+      if constexpr (!do_rd) return;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const fragp_t*>(s + q * PL_B + offA + i * 1024);
+    };
+    auto mm = [&](int i, const fragp_t (&a)[3], const fragp_t (&b)[3][4]) __attribute__((always_inline)) {
+      if constexpr (!do_mm) return;
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first (as gemm_f32x3.hip)
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[PA[t]]), __builtin_bit_cast(bf16x8, b[PB[t]][j]),
+                                                              acc[i][j], 0, 0, 0);
+    };
+    if constexpr ((ABL & 4) != 0) {  // (defined operands for the timing-only ablation)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          fa[u][q] = fragp_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) fb[u][q][j] = fragp_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        }
+    }
+    __builtin_amdgcn_s_setprio(2);
+    __builtin_amdgcn_s_barrier();  // barrier -1: tile 0 is in stage 0
+    asm volatile("" ::: "memory");
+    if (nk > 0) {
+      rd_b(smem_p, fb[0]);
+      rd_a(smem_p, 0, fa[0]);
+    }
+    int st = 0;
+    // (two k-tiles per trip so that the fragment buffers are indexed by constants)
+    // A wave issues in order: a burst of fragment reads between two MFMA groups leaves the matrix pipe idle for the burst's issue
+    // time (measured: + 22 % on the MFMA stream alone).  sched_group_barrier puts ONE read behind each of a group's first MFMAs
+    // instead: the three fragments of the next row-block ride behind MFMAs 1-3 of a group of 24 (21 MFMAs = 340 cycles to land),
+    // the fifteen of the next tile behind MFMAs 1-15 of the group behind the barrier.
+    auto spread = [&](int nreads) __attribute__((always_inline)) {
+      if constexpr (do_rd && do_mm) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (i < nreads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tile = [&](int t, const int cur) __attribute__((always_inline)) {
+      const unsigned char* s = smem_p + st * STAGE_B;
+      rd_a(s, 1, fa[1]);
+      mm(0, fa[0], fb[cur]);
+      spread(3);
+      rd_a(s, 2, fa[0]);
+      mm(1, fa[1], fb[cur]);
+      spread(3);
+      rd_a(s, 3, fa[1]);
+      mm(2, fa[0], fb[cur]);
+      spread(3);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last fragments of tile t are in registers: its stage may be refilled
+      if (TRACE && tr && t < 64 && lane == 0) tr[(wave * 64 + t) * 2 + 0] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_barrier();  // barrier t
+      asm volatile("" ::: "memory");
+      if (TRACE && tr && t < 64 && lane == 0) tr[(wave * 64 + t) * 2 + 1] = __builtin_amdgcn_s_memtime();
+      st = st + 1 == NS ? 0 : st + 1;
+      {  // (UNCONDITIONAL -- past the end a harmless read of the next stage: behind a conditional block of reads hipcc cannot
+         // count on them and puts s_waitcnt lgkmcnt(0) in front of the next MFMA group, i.e. waits for reads issued just before it)
+        const unsigned char* sn = smem_p + st * STAGE_B;
+        rd_b(sn, fb[cur ^ 1]);
+        rd_a(sn, 0, fa[0]);
+      }
+      mm(3, fa[1], fb[cur]);
+      spread(15);
+    };
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      tile(t, 0);
+      tile(t + 1, 1);
+    }
+    if (t < nk) tile(t, 0);
+  }
+
+  if (TRACE && tr && lane == 0) tr[8 * 64 * 2 + 1 + wave] = __builtin_amdgcn_s_memtime();  // this wave's k-loop is over
+  // ---- epilogue: the 128 x 128 image through the LDS (every request has landed: the last barrier waited for vmcnt(0)), wide stores
+  {
+    constexpr int LDE = BN + 4, C4 = BN / 4;
+    float* smem = reinterpret_cast<float*>(smem_p);
+    float* C = p.C + (long)blockIdx.z * p.slab_stride;
+    const bool split = gridDim.z > 1;
+    __syncthreads();
+    if (!dma_wave) {
+      const int c15 = lane & 15, rq = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) smem[(wm * 64 + i * 16 + rq * 4 + r) * LDE + wn * 64 + j * 16 + c15] = acc[i][j][r];
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int idx = tid; idx < BM * C4; idx += 512) {
+      const int r = idx / C4, c = (idx % C4) * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * LDE + c);
+      const long row = m0 + r;
+      const int col = n0 + c;
+      if (!split) {
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+        if (p.epi == EPI_GELU) {
+          *reinterpret_cast<f32x4*>(p.aux + row * p.ldaux + col) = v;
+          v = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+        } else if (p.epi == EPI_TANH) {
+          v = f32x4{tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w)};
+        } else if (p.epi == EPI_DGELU) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+          v = f32x4{v.x * gelu_erf_grad(a.x), v.y * gelu_erf_grad(a.y), v.z * gelu_erf_grad(a.z), v.w * gelu_erf_grad(a.w)};
+        } else if (p.epi == EPI_DTANH) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+          v = v * (1.f - t * t);
+        }
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * p.ldc + col);
+      }
+      *reinterpret_cast<f32x4*>(C + row * p.ldc + col) = v;
+    }
+  }
+  if (TRACE && tr && lane == 0) tr[8 * 64 * 2 + 9 + wave] = __builtin_amdgcn_s_memtime();
+}
+
+int launch_split_planes(const float* src, void* dst, int rows, int cols, int ld, long s_plane, long s_row, long s_kt, hipStream_t st) {
+  const long n8 = (long)rows * (cols / 8);
+  const int blocks = (int)std::min<long>((n8 + 255) / 256, 4096);
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, st, src, static_cast<unsigned char*>(dst), rows, cols, ld, s_plane,
+                     s_row, s_kt);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+template <int ABL, bool TRACE>
+static int launch_p16_t(const GemmArgsP& a, dim3 grid, hipStream_t st) {
+  constexpr size_t smem = (size_t)3 * 2 * 3 * 128 * 64;  // 147456
+  auto kern = gemm_f32p16_kernel<ABL, TRACE>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+int launch_gemm_f32p16(const GemmArgsP& a, dim3 grid, hipStream_t st) {
+  if (a.trace) return launch_p16_t<0, true>(a, grid, st);
+  switch (a.ablate) {
+    case 0: return launch_p16_t<0, false>(a, grid, st);
+    case 1: return launch_p16_t<1, false>(a, grid, st);
+    case 2: return launch_p16_t<2, false>(a, grid, st);
+    case 4: return launch_p16_t<4, false>(a, grid, st);
+    case 5: return launch_p16_t<5, false>(a, grid, st);
+    case 6: return launch_p16_t<6, false>(a, grid, st);
+    default: return MTVAF_ERR_ARG;
+  }
+}
+
+}  // namespace mtvaf
+
+using namespace mtvaf;
+
+extern "C" {
+
+// fp32 [rows][cols] (ld) -> its three bf16 planes (the RNE split of gemm_f32x3.hip) as a plane image with the given byte strides
+// (plane -> plane, row -> row, 32-column k-tile -> k-tile); cols % 32 == 0, 16-byte aligned.
+int mtvaf_f32_split_planes(const float* src, void* dst, int rows, int cols, int ld, long s_plane, long s_row, long s_kt, hipStream_t stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || cols % 32 || ld % 4) return MTVAF_ERR_SHAPE;
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) || (s_plane % 16) || (s_row % 16) || (s_kt % 16)) return MTVAF_ERR_ALIGN;
+  return launch_split_planes(src, dst, rows, cols, ld, s_plane, s_row, s_kt, stream);
+}
+
+static long long* g_f32p_trace = nullptr;
+int mtvaf_f32p_trace(void* buf) {
+  g_f32p_trace = static_cast<long long*>(buf);
+  return MTVAF_OK;
+}
+
+// C[M,N] = A[M,K] . B[N,K]^T (+ bias, epilogue) from plane images of both operands (both k-contiguous: the layout of every
+// nn.Linear forward, modeling_bert.py:266, 283-284, 353, 420-421, 433).  M, N % 128 == 0, K % 32 == 0.  splits > 1: split-K slabs
+// in `workspace` (deterministic ordered reduction, as mtvaf_gemm_f32).
+int mtvaf_gemm_f32p(const void* Aplanes, long a_plane, long a_row, long a_kt, const void* Bplanes, long b_plane, long b_row, long b_kt,
+                    float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
+                    int splits, void* workspace, size_t workspace_bytes, int ablate, hipStream_t stream) {
+  if (!Aplanes || !Bplanes || !C || M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_ARG;
+  if (M % 128 || N % 128 || K % 32) return MTVAF_ERR_SHAPE;
+  if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
+  if ((ldc % 4) || (aux && ldaux % 4) || (((uintptr_t)Aplanes | (uintptr_t)Bplanes | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15))
+    return MTVAF_ERR_ALIGN;
+  if ((a_plane | a_row | a_kt | b_plane | b_row | b_kt) & 15) return MTVAF_ERR_ALIGN;
+  if (splits < 1) splits = 1;
+  if (splits > 1 && ((size_t)splits * M * N * sizeof(float) > workspace_bytes || !workspace)) return MTVAF_ERR_WORKSPACE;
+  GemmArgsP a = {};
+  a.Ap = static_cast<const unsigned char*>(Aplanes); a.Bp = static_cast<const unsigned char*>(Bplanes);
+  a.a_plane = a_plane; a.a_row = a_row; a.a_kt = a_kt; a.b_plane = b_plane; a.b_row = b_row; a.b_kt = b_kt;
+  a.bias = bias; a.aux = aux; a.M = M; a.N = N; a.K = K; a.ldaux = ldaux; a.epi = epi; a.accumulate = accumulate;
+  int kc = ((K + splits - 1) / splits + 31) / 32 * 32;
+  splits = (K + kc - 1) / kc;
+  a.k_chunk = kc;
+  if (splits > 1) { a.C = (float*)workspace; a.ldc = N; a.slab_stride = (long)M * N; }
+  else { a.C = C; a.ldc = ldc; a.slab_stride = 0; }
+  a.tiles_n = N / 128;
+  a.ablate = ablate;
+  a.trace = g_f32p_trace;
+  dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
+  const int rc = launch_gemm_f32p16(a, grid, stream);
+  if (rc != MTVAF_OK) return rc;
+  if (splits > 1) return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
+  return MTVAF_OK;
+}
+
+}  // extern "C"

@@ -35,6 +35,9 @@ _SIGS = {
     "mtvaf_gemm_f32x3": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_f32_split": (c_int, [I]),
     "mtvaf_f32x3_trace": (c_int, [P]),
+    "mtvaf_f32_split_planes": (c_int, [P, P, I, I, I, L, L, L, P]),
+    "mtvaf_gemm_f32p": (c_int, [P, L, L, L, P, L, L, L, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, P]),
+    "mtvaf_f32p_trace": (c_int, [P]),
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -289,6 +292,39 @@ def f32_split(on=None) -> bool:
     mtvaf_gemm_f32 / _ktiles call of the process (Python orchestration and native executor alike); None queries.
     Default: ON (MTVAF_F32_SPLIT=0 in the environment keeps the fp32 MFMA pipe)."""
     return bool(lib().mtvaf_f32_split(-1 if on is None else int(bool(on))))
+
+
+class Planes:
+    """Plane image of an fp32 matrix [rows, cols] (csrc/gemm_f32p.hip): the three bf16 planes of the split, `blocked` =
+    [k-tile][plane][rows][32] (every 1-KiB request of the kernel reads contiguous memory) or natural [3][rows][cols]."""
+    __slots__ = ("img", "s_plane", "s_row", "s_kt", "rows", "cols")
+
+    def __init__(self, x: torch.Tensor, blocked: bool = True):
+        rows, cols = x.shape
+        self.rows, self.cols = rows, cols
+        self.img = torch.empty(3 * rows * cols, dtype=torch.bfloat16, device=x.device)
+        if blocked:
+            self.s_plane, self.s_row, self.s_kt = rows * 64, 64, 3 * rows * 64
+        else:
+            self.s_plane, self.s_row, self.s_kt = rows * cols * 2, cols * 2, 64
+        self.refresh(x)
+
+    def refresh(self, x: torch.Tensor):
+        _ck(lib().mtvaf_f32_split_planes(_p(x), _p(self.img), self.rows, self.cols, x.stride(0), self.s_plane, self.s_row, self.s_kt,
+                                         _st()), "mtvaf_f32_split_planes")
+
+
+def gemm_planes(a: Planes, b: Planes, out, bias=None, epi=EPI_NONE, aux=None, accumulate=False, splits=1, ablate=0):
+    """out[M,N] = A[M,K] . B[N,K]^T from the plane images of both operands (mtvaf_gemm_f32p)."""
+    M, N, K = a.rows, b.rows, a.cols
+    ws, wsb = None, 0
+    if splits > 1:
+        wsb = splits * M * N * 4
+        ws = workspace(wsb, out.device)
+    _ck(lib().mtvaf_gemm_f32p(_p(a.img), a.s_plane, a.s_row, a.s_kt, _p(b.img), b.s_plane, b.s_row, b.s_kt, _p(out), out.stride(0), M, N, K,
+                              _p(bias), epi, _p(aux), aux.stride(0) if aux is not None else 0, int(accumulate), splits, _p(ws), wsb,
+                              ablate, _st()), "mtvaf_gemm_f32p")
+    return out
 
 
 def set_compute_dtype(dtype: str):

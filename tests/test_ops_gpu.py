@@ -1372,6 +1372,52 @@ def test_gemm_f32_split_tile64_epilogues_splitk_ktiles_and_planner(hip):
         hip.f32_split(was)
 
 
+@pytest.mark.parametrize("M,N,K,spread", [(256, 384, 768, 0), (128, 128, 32, 12), (128, 256, 64, 20), (384, 128, 96, 3), (512, 768, 3072, 6)])
+def test_gemm_f32_presplit_planes_accuracy_and_epilogues(hip, M, N, K, spread):
+    """mtvaf_f32_split_planes + mtvaf_gemm_f32p (csrc/gemm_f32p.hip, round 5: both operands as pre-split bf16 plane images,
+    v_mfma_f32_16x16x32_bf16, nothing split inside the k-loop): the planes are those of the in-kernel split (x = p1 + p2 + p3 to
+    2^-24 |x|, every plane a bf16), the product is an fp32 GEMM under the bound of `test_gemm_f32_split_accuracy` -- against the
+    fp64 product and not worse than the fp32 MFMA pipe -- in both plane layouts (tile-blocked, natural), with 1, 2, 3 k-tiles
+    (prologue / drain of the three-stage ring) and many, bias + GELU with the saved pre-activation, accumulate, and a
+    deterministic 2-way split-K."""
+    a, b, ref, mag = _x3_operands(M, N, K, 0, 0, seed=M + N + K, spread=spread)
+    o_nat = torch.empty(M, N, device=DEV)
+    hip.gemm(a, 0, b, 0, o_nat, M, N, K, compute="fp32")
+    e_nat = (o_nat.double().cpu() - ref).abs() / mag
+    for blocked in (True, False):
+        pa, pb = hip.Planes(a, blocked), hip.Planes(b, blocked)
+        # the image holds the three planes of every element: their sum is the element to 2^-24
+        if blocked:
+            img = pa.img.view(K // 32, 3, M, 32).float()
+            back = img.sum(1).permute(1, 0, 2).reshape(M, K)
+        else:
+            back = pa.img.view(3, M, K).float().sum(0)
+        assert float(((back.double() - a.double()).abs() / a.double().abs().clamp_min(1e-30)).max()) <= 2.0 ** -23
+        out = torch.full((M, N), float("nan"), device=DEV)
+        hip.gemm_planes(pa, pb, out)
+        e = (out.double().cpu() - ref).abs() / mag
+        assert float(e.max()) <= 2.0 ** -24 * (4 + K ** 0.5), (blocked, float(e.max()), float(e_nat.max()))
+        assert float(e.max()) <= 1.25 * float(e_nat.max()) + 2.0 ** -25, (blocked, float(e.max()), float(e_nat.max()))
+        assert float(e.pow(2).mean().sqrt()) <= 1.1 * float(e_nat.pow(2).mean().sqrt()) + 2.0 ** -27
+    bias = rnd(N, seed=5).to(DEV)
+    aux = torch.full((M, N), float("nan"), device=DEV)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm_planes(pa, pb, out, bias=bias, epi=hip.EPI_GELU, aux=aux)
+    scale = float(mag.max())
+    close(aux, ref + bias.double().cpu(), rtol=3e-6, atol=3e-6 * scale, name="saved pre-activation")
+    close(out, torch.nn.functional.gelu(ref + bias.double().cpu()), rtol=3e-6, atol=3e-6 * scale, name="GELU")
+    acc0 = rnd(M, N, seed=6).to(DEV)
+    out.copy_(acc0)
+    hip.gemm_planes(pa, pb, out, accumulate=True)
+    close(out, ref + acc0.double().cpu(), rtol=3e-6, atol=3e-6 * scale, name="accumulate")
+    if K >= 64:
+        o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        hip.gemm_planes(pa, pb, o1, bias=bias, splits=2)
+        hip.gemm_planes(pa, pb, o2, bias=bias, splits=2)
+        close(o1, ref + bias.double().cpu(), rtol=3e-6, atol=3e-6 * scale, name="split-K 2")
+        assert torch.equal(o1, o2), "split-K must be deterministic"
+
+
 def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
     """The split kernel behind the fp32 entry points: every epilogue of the path (bias, bias + GELU with the saved
     pre-activation, GELU', tanh, accumulate), forced split-K, a k-tile list (weight gradient: dY exactly zero outside the listed
