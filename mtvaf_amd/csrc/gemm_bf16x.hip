@@ -202,6 +202,31 @@ __global__ __launch_bounds__((DW ? 2 : 1) * WM* WN * 64, (BM * BN > 256 * 128) ?
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
   };
+  // one MFMA, then its share of the slice's fragment reads (a k-major fragment is two transposing reads).
+  // MTVAF_BF16X_SPREAD=0 (compile-time A/B switch): the reads as a burst in front of the MFMA group, as until round 4.
+#ifndef MTVAF_BF16X_SPREAD
+#define MTVAF_BF16X_SPREAD 1
+#endif
+  auto burst = [&]() __attribute__((always_inline)) {
+    if constexpr (!MTVAF_BF16X_SPREAD) __builtin_amdgcn_sched_barrier(0);
+  };
+  auto spread = [&]() __attribute__((always_inline)) {
+    if constexpr (!MTVAF_BF16X_SPREAD) {
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
+    constexpr int NMF = TM * TN, NRD = TM * (A_KM ? 2 : 1) + TN * (B_KM ? 2 : 1), PER = (NRD + NMF - 1) / NMF;
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, PER, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa1[i] = bf16x8{};
+#pragma unroll
+  for (int j = 0; j < TN; ++j) fb1[j] = bf16x8{};
   if (!DW || dma_wave) {
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
@@ -249,25 +274,27 @@ __global__ __launch_bounds__((DW ? 2 : 1) * WM* WN * 64, (BM * BN > 256 * 128) ?
     // Fragment reads run ONE k-slice ahead of the MFMAs that consume them, across the tile barrier too (slice 3 of tile kt-1
     // is multiplied behind the barrier of tile kt, while slice 0 of tile kt is in flight): a slice is only TM x TN MFMAs
     // (128-512 cycles), and an in-order wave that reads and then multiplies pays the LDS latency per slice.
-    if (kt > 0) {
-      rdf(a, b, 0, fa0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      mm(fa1, fb1);
-    } else {
-      rdf(a, b, 0, fa0, fb0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    // Round 5 (found on the pre-split fp32 kernel, csrc/gemm_f32p.hip): (1) the reads of a slice are SPREAD behind the MFMAs
+    // of the slice before it (sched_group_barrier: one MFMA, then its share of the reads) -- issued as a burst between two MFMA
+    // groups they kept the matrix pipe idle for the burst's issue time, which at 3-4 MFMAs per slice is half the loop;
+    // (2) no conditional block: the first tile multiplies zero fragments instead of skipping the group (behind a branch hipcc
+    // cannot count on the reads in flight and waits lgkmcnt(0) for the ones issued just before).
+    rdf(a, b, 0, fa0, fb0);
+    burst();
+    mm(fa1, fb1);  // slice 3 of tile kt - 1 (kt == 0: zero fragments)
+    spread();
     rdf(a, b, 1, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
+    burst();
     mm(fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
+    spread();
     rdf(a, b, 2, fa0, fb0);
-    __builtin_amdgcn_sched_barrier(0);
+    burst();
     mm(fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
+    spread();
     rdf(a, b, 3, fa1, fb1);
-    __builtin_amdgcn_sched_barrier(0);
+    burst();
     mm(fa0, fb0);
+    spread();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragment reads of tile kt done before its stage can be refilled
     __builtin_amdgcn_sched_barrier(0);
     st = st + 1 == NSTAGE ? 0 : st + 1;

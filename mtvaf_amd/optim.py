@@ -21,6 +21,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional
 
+import os
+
 import torch
 
 from . import hip
@@ -140,8 +142,8 @@ class AdamW(torch.optim.Optimizer):
     # an update enqueued from inside the backward pass runs beside MFMA-bound products: on 128 blocks it trickles under
     # them (csrc/optim.hip); below this many token rows a layer's backward is shorter than such an update and it would
     # only pile up behind the pass
-    BACKGROUND_MIN_ROWS = 2048
-    BACKGROUND_BLOCKS = 128
+    BACKGROUND_MIN_ROWS = int(os.environ.get("MTVAF_ADAMW_BG_MIN_ROWS", "2048"))
+    BACKGROUND_BLOCKS = int(os.environ.get("MTVAF_ADAMW_BG_BLOCKS", "128"))
 
     def _update_layer_flat(self, li: int, group: dict, store, background: bool = False):
         st = self._layer_state(li, store)
