@@ -124,23 +124,44 @@ __device__ __forceinline__ void kv_store(float* dst, const f32x4 (&reg)[N]) {
     *reinterpret_cast<f32x4*>(dst + ((threadIdx.x >> 4) + 16 * i) * LD + (threadIdx.x & 15) * 4) = reg[i];
 }
 
+// XCD-aware block order (round 5).  Workgroups are dealt round-robin over the 8 XCDs by their linear id, x fastest: the nx blocks
+// of one (sentence, head) -- 2 query tiles forward; 2 query + 3 key tiles backward, which all read the same q / k / v / dO / O
+// slices (3.5x the unique bytes: 165 - 205 MB per backward launch by the PMC counters against ~50 MB) -- landed on nx different
+// XCDs, each with a private L2.  This bijective remap gives the k-th group of nx consecutive slots of ONE XCD to one
+// (sentence, head), so the re-reads hit that XCD's L2.  Placement is a speed hint only: results never depend on it.
+// Identity when the number of (sentence, head) pairs is not a multiple of 8.  nz = the sentences (the zero-fill slice z == B of a
+// packed launch is dispatched behind them and keeps its index).
+#ifndef MTVAF_ATTN_XCD_GROUP
+#define MTVAF_ATTN_XCD_GROUP 1
+#endif
+__device__ __forceinline__ void xcd_group(int nx, int ny, int nz, int& x, int& y, int& z) {
+  if (!MTVAF_ATTN_XCD_GROUP || ((ny * nz) & 7) || z >= nz) return;
+  const int L = x + nx * (y + ny * z);
+  const int xcd = L & 7, slot = L >> 3;
+  const int gi = (slot / nx) * 8 + xcd;
+  x = slot % nx;
+  y = gi % ny;
+  z = gi / ny;
+}
+
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[KT * LDK];
   __shared__ __attribute__((aligned(16))) float Vs[KT * LDT];
   __shared__ __attribute__((aligned(16))) float Ms[KT];  // additive mask * log2(e) of the tile's keys (-1e30 beyond T)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 64 + wave * 16 + lq;
+  int bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  xcd_group(gridDim.x, gridDim.y, a.B, bx, h, b);
+  const int q = bx * 64 + wave * 16 + lq;
   if (a.cu && b == a.B) {  // (block-uniform) the rows that pad the packed image: zeros (0 x NaN of an unwritten row would poison dW)
     const int r0 = a.cu[a.B];
-    for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < a.pad_rows; r += gridDim.x * 16)
+    for (int r = bx * 16 + (threadIdx.x >> 4); r < a.pad_rows; r += gridDim.x * 16)
       *reinterpret_cast<f32x4*>(a.ctx + (long)(r0 + r) * a.H + h * D + (threadIdx.x & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     return;
   }
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
-  if ((int)blockIdx.x * 64 >= Sb) return;  // (block-uniform; packed rows: a query tile beyond the sentence)
+  if (bx * 64 >= Sb) return;  // (block-uniform; packed rows: a query tile beyond the sentence)
   const int Tf = a.P + a.S;  // row length of the additive mask
   __shared__ int t_eff_slot;
   const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
@@ -254,10 +275,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 // backward, query side: dQ (and delta = rowsum(dO.O)); same decomposition as the forward.
 // ---------------------------------------------------------------------------------------------
 // Ks [KT*LDT]: read as row fragments AND as columns; Vs [KT*LDK]: row fragments only; Ms [KT]
-__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, float* Ks, float* Vs, float* Ms, int* t_eff_slot) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, int b, int h, float* Ks, float* Vs, float* Ms, int* t_eff_slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
   const int q = qtile * 64 + wave * 16 + lq;
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
@@ -404,11 +424,10 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, f
 // Qs, dOs [KT*LDT]; lse_s [KT] = lse * log2(e) (+1e30 for rows beyond S); del_s [KT] = rowsum(dO.O), computed here
 // from the staged dO tile and the matching O rows so that this side does not depend on the query side (both run in
 // one launch); rh_s [KT] = dropout row hashes of the tile's queries.
-__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, float* Qs, float* dOs, float* lse_s,
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, int b, int h, float* Qs, float* dOs, float* lse_s,
                                                   float* del_s, uint32_t* rh_s, int* t_eff_slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lk = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
   const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * (a.P + a.S), a.P, a.S, t_eff_slot);  // keys >= T: trailing padding, dK = dV = 0
@@ -597,10 +616,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(AttnArgs a, int nq) { 
         *reinterpret_cast<f32x4*>(a.dqkv + (long)(r0 + r) * 3 * a.H + c * a.H + h * D + (threadIdx.x & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
     return;
   }
-  if ((int)blockIdx.x < nq) {
-    attn_bwd_dq_body(a, blockIdx.x, tile0, tile1, small, &t_eff_slot);
+  int bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  xcd_group(gridDim.x, gridDim.y, a.B, bx, h, b);
+  if (bx < nq) {
+    attn_bwd_dq_body(a, bx, b, h, tile0, tile1, small, &t_eff_slot);
   } else {
-    attn_bwd_dkv_body(a, blockIdx.x - nq, tile0, tile1, small, small + KT, reinterpret_cast<uint32_t*>(small + 2 * KT), &t_eff_slot);
+    attn_bwd_dkv_body(a, bx - nq, b, h, tile0, tile1, small, small + KT, reinterpret_cast<uint32_t*>(small + 2 * KT), &t_eff_slot);
   }
 }
 
