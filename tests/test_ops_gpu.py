@@ -1410,6 +1410,14 @@ def test_gemm_f32_presplit_planes_accuracy_and_epilogues(hip, M, N, K, spread):
     out.copy_(acc0)
     hip.gemm_planes(pa, pb, out, accumulate=True)
     close(out, ref + acc0.double().cpu(), rtol=3e-6, atol=3e-6 * scale, name="accumulate")
+    # the dX form: B [K, N] with the reduction index as its ROW (k-major: transposing fragment reads), natural plane image
+    a2, b2, ref2, mag2 = _x3_operands(M, N, K, 0, 1, seed=M + N + K + 1, spread=spread)
+    if N % 128 == 0:
+        pa2, pb2 = hip.Planes(a2, True), hip.Planes(b2, False)
+        o_km = torch.full((M, N), float("nan"), device=DEV)
+        hip.gemm_planes(pa2, pb2, o_km, layout_b=hip.KM)
+        e = (o_km.double().cpu() - ref2).abs() / mag2
+        assert float(e.max()) <= 2.0 ** -24 * (4 + K ** 0.5), ("k-major B", float(e.max()))
     if K >= 64:
         o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
         hip.gemm_planes(pa, pb, o1, bias=bias, splits=2)

@@ -82,6 +82,36 @@ def main():
             print(line, flush=True)
             tot_ws += us_ws
         print(f"M={M}: four forward products: ws {tot_ws:.0f} us, P16 (blocked planes, best split) {tot_p:.0f} us", flush=True)
+        # the dX products: A = dY [M, N_w] (k-contiguous), B = W [N_w, K_w] with the reduction index as its row (natural planes)
+        dy, dy3, dyq = rn(M, H), rn(M, I), rn(M, 3 * H)
+        tot_ws = tot_p = 0.0
+        for name, a, w in (("ffn2 dX", dy, w2), ("ffn1 dX", dy3, w1), ("wo dX", dy, wo), ("qkv dX", dyq, wq)):
+            m, k = a.shape
+            n = w.shape[1]
+            out = torch.empty(m, n, device=dev)
+            ref = a.double() @ w.double()
+            fl = 2.0 * m * n * k
+            run_ws = lambda: hip.gemm(a, hip.KC, w, hip.KM, out, m, n, k, allow_split=True)
+            run_ws()
+            e_ws = float((out.double() - ref).abs().max() / ref.abs().max())
+            us_ws = t(run_ws)
+            pa, pb = hip.Planes(a, True), hip.Planes(w, False)
+            line = f"M={M} {name:9s} [{m:5d}x{n:5d}x{k:5d}] | ws {us_ws:6.1f} us {fl / us_ws / 1e6:5.1f} TF err {e_ws:.1e}"
+            best = None
+            for sp in (1, 2):
+                if sp == 2 and (m // 128) * (n // 128) > 200:
+                    continue
+                run_p = lambda: hip.gemm_planes(pa, pb, out, splits=sp, layout_b=hip.KM)
+                out.zero_(); run_p()
+                e_p = float((out.double() - ref).abs().max() / ref.abs().max())
+                us_p = t(run_p)
+                line += f" | P16{'/s2' if sp == 2 else ''} {us_p:6.1f} us {fl / us_p / 1e6:5.1f} TF err {e_p:.1e}"
+                best = us_p if best is None else min(best, us_p)
+            print(line, flush=True)
+            print("      trace: " + trace(lambda: hip.gemm_planes(pa, pb, out, layout_b=hip.KM), k // 32), flush=True)
+            tot_ws += us_ws
+            tot_p += best
+        print(f"M={M}: four dX products: ws {tot_ws:.0f} us, P16 (k-major B from natural planes, best split) {tot_p:.0f} us", flush=True)
 
 
 if __name__ == "__main__":
