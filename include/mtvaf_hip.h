@@ -310,14 +310,16 @@ int mtvaf_f32x3_trace(void* buf);
  * k-tile -> k-tile (natural form: cols * 2 * rows / ld * 2 / 64; tile-blocked form [k-tile][plane][rows][32]: rows * 64 / 64 /
  * 3 * rows * 64).  mtvaf_gemm_f32p: C[M,N] = A[M,K] . op(B) (+ bias, epilogue, accumulate) from the plane images of both
  * operands on v_mfma_f32_16x16x32_bf16, nothing split inside the k-loop; layout_b 0: B [N][K] (forward), 1: B [K][N] (the dX
- * products: natural plane image, b_row = N * 2, b_kt = 32 * N * 2, b_col = 256); M, N % 128 == 0, K % 32 == 0; splits > 1 = deterministic
+ * products: natural plane image, b_row = N * 2, b_kt = 32 * N * 2, b_col = 256); layout_a 1 (with layout_b 1): A [K][M] too, the
+ * weight-gradient products; M, N % 128 == 0, K % 32 == 0; splits > 1 = deterministic
  * split-K through `workspace`; ablate = 0 (research switches: 1 no MFMAs, 2 no requests, 4 no fragment reads: timing only).
  * mtvaf_f32p_trace: shader-clock stamps of block 0 ([8 waves][64 k-tiles][2] + 17 int64), NULL = off. */
 int mtvaf_f32_split_planes(const float* src, void* dst, int rows, int cols, int ld, long s_plane, long s_row, long s_kt,
                            mtvaf_stream_t stream);
-int mtvaf_gemm_f32p(const void* Aplanes, long a_plane, long a_row, long a_kt, int layout_b, const void* Bplanes, long b_plane, long b_row,
-                    long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
-                    int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate, mtvaf_stream_t stream);
+int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                    long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias, int epi,
+                    float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
+                    mtvaf_stream_t stream);
 int mtvaf_f32p_trace(void* buf);
 
 /* The (up to four) weight-gradient products of one encoder layer in fp32, dW_i[M_i,N_i] = A_i^T . B_i with A_i [K,M_i], B_i [K,N_i]

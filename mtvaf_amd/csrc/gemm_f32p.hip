@@ -37,6 +37,7 @@ struct GemmArgsP {
   const unsigned char* Ap;  // plane 0 of A (bf16), byte addressed
   const unsigned char* Bp;
   long a_plane, a_row, a_kt;  // byte strides: plane -> plane, row -> row, k-tile (32 k) -> k-tile
+  long a_col;                 // k-major A only: byte stride from one 128-column block of A to the next (natural image: 256)
   long b_plane, b_row, b_kt;
   long b_col;  // k-major B only: byte stride from one 128-column block of B to the next (natural image: 256)
   float* C;
@@ -100,8 +101,11 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // the LDS image is 32 k-rows x 256 B (128 output columns), 16-byte chunk c of row r at c ^ km_swz(r) (gemm_bf16x.h), and a
 // 16x16x32 B fragment (lane l: column l & 15, k = 8 (l >> 4) .. + 7) is two ds_read_b64_tr_b16 on the 4 x 16 blocks of rows
 // 8 (l >> 4) .. + 3 and .. + 4 .. + 7 -- the two blocks a 32-lane half reads are 8 rows apart in the same columns: conflict-free.
-template <int ABL, bool TRACE, bool B_KM>
+// A_KM (with B_KM: the weight-gradient products dW = dY^T . X, both operands [tokens][features] with the token as the reduction
+// index): the same image and the same transposing reads for A.
+template <int ABL, bool TRACE, bool B_KM, bool A_KM = false>
 __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
+  static_assert(!A_KM || B_KM, "k-major A comes with k-major B (weight gradients)");
   constexpr int BM = 128, BN = 128, NS = 3;
   constexpr int PL_B = 128 * 64;       // bytes of one plane tile
   constexpr int OP_B = 3 * PL_B;       // one operand's stage: 24 KiB
@@ -140,7 +144,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
     for (int i = 0; i < IW; ++i) {
       const int I = w4 * IW + i, plane = I >> 3, row = (I & 7) * 16 + (lane >> 2), cp = lane & 3;
       const int sc = cp ^ f32p::swz(row);
-      pa[i] = p.Ap + plane * p.a_plane + (long)(m0 + row) * p.a_row + (long)(kbeg / 32) * p.a_kt + sc * 16;
+      if constexpr (!A_KM) {
+        pa[i] = p.Ap + plane * p.a_plane + (long)(m0 + row) * p.a_row + (long)(kbeg / 32) * p.a_kt + sc * 16;
+      } else {
+        const int kr = (I & 7) * 4 + (lane >> 4), cpa = lane & 15;
+        pa[i] = p.Ap + plane * p.a_plane + (long)kr * p.a_row + (long)(kbeg / 32) * p.a_kt + (long)(m0 / 128) * p.a_col +
+                ((cpa ^ km_swz(kr)) << 4);
+      }
       if constexpr (!B_KM) {
         pb[i] = p.Bp + plane * p.b_plane + (long)(n0 + row) * p.b_row + (long)(kbeg / 32) * p.b_kt + sc * 16;
       } else {  // piece I = plane I / 8, 4 k-rows (I % 8) * 4 ..; lane -> k-row + lane / 16, chunk position lane % 16
@@ -193,6 +203,17 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
     const int offA = (wm * 64 + r15) * 64 + ((ch ^ f32p::swz(r15)) << 4);
     const int offB = (wn * 64 + r15) * 64 + ((ch ^ f32p::swz(r15)) << 4);
     // k-major B: lane (g, q, pp) of a 16-lane group g addresses row 8 g + q (+ 4), columns 16 j + 4 pp .. + 3 of the wave's 64
+    int offA0[4], offA1[4];
+    if constexpr (A_KM) {
+      const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+      const int r0 = 8 * g + q, r1 = r0 + 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 8 * wm + 2 * i + (pp >> 1);
+        offA0[i] = r0 * 256 + ((c ^ km_swz(r0)) << 4) + 8 * (pp & 1);
+        offA1[i] = r1 * 256 + ((c ^ km_swz(r1)) << 4) + 8 * (pp & 1);
+      }
+    }
     int offB0[4], offB1[4];
     if constexpr (B_KM) {
       const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
@@ -219,7 +240,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
     auto rd_a = [&](const unsigned char* s, int i, fragp_t (&f)[3]) __attribute__((always_inline)) {
       if constexpr (!do_rd) return;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) f[q] = *reinterpret_cast<const fragp_t*>(s + q * PL_B + offA + i * 1024);
+      for (int q = 0; q < 3; ++q) {
+        if constexpr (!A_KM) f[q] = *reinterpret_cast<const fragp_t*>(s + q * PL_B + offA + i * 1024);
+        else f[q] = __builtin_bit_cast(fragp_t, tr_read8(s + q * PL_B + offA0[i], s + q * PL_B + offA1[i]));
+      }
     };
     auto mm = [&](int i, const fragp_t (&a)[3], const fragp_t (&b)[3][4]) __attribute__((always_inline)) {
       if constexpr (!do_mm) return;
@@ -269,13 +293,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
       const unsigned char* s = smem_p + st * STAGE_B;
       rd_a(s, 1, fa[1]);
       mm(0, fa[0], fb[cur]);
-      spread(3);
+      spread(A_KM ? 6 : 3);
       rd_a(s, 2, fa[0]);
       mm(1, fa[1], fb[cur]);
-      spread(3);
+      spread(A_KM ? 6 : 3);
       rd_a(s, 3, fa[1]);
       mm(2, fa[0], fb[cur]);
-      spread(3);
+      spread(A_KM ? 6 : 3);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last fragments of tile t are in registers: its stage may be refilled
       if (TRACE && tr && t < 64 && lane == 0) tr[(wave * 64 + t) * 2 + 0] = __builtin_amdgcn_s_memtime();
       __builtin_amdgcn_s_barrier();  // barrier t
@@ -289,7 +313,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
         rd_a(sn, 0, fa[0]);
       }
       mm(3, fa[1], fb[cur]);
-      spread(B_KM ? 27 : 15);
+      spread((B_KM ? 24 : 12) + (A_KM ? 6 : 3));
     };
     int t = 0;
     for (; t + 1 < nk; t += 2) {
@@ -354,10 +378,10 @@ int launch_split_planes(const float* src, void* dst, int rows, int cols, int ld,
   return MTVAF_OK;
 }
 
-template <int ABL, bool TRACE, bool B_KM = false>
+template <int ABL, bool TRACE, bool B_KM = false, bool A_KM = false>
 static int launch_p16_t(const GemmArgsP& a, dim3 grid, hipStream_t st) {
   constexpr size_t smem = (size_t)3 * 2 * 3 * 128 * 64;  // 147456
-  auto kern = gemm_f32p16_kernel<ABL, TRACE, B_KM>;
+  auto kern = gemm_f32p16_kernel<ABL, TRACE, B_KM, A_KM>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -369,7 +393,9 @@ static int launch_p16_t(const GemmArgsP& a, dim3 grid, hipStream_t st) {
   return MTVAF_OK;
 }
 
-int launch_gemm_f32p16(const GemmArgsP& a, int b_km, dim3 grid, hipStream_t st) {
+int launch_gemm_f32p16(const GemmArgsP& a, int a_km, int b_km, dim3 grid, hipStream_t st) {
+  if (a_km && !b_km) return MTVAF_ERR_ARG;
+  if (a_km) return a.trace ? launch_p16_t<0, true, true, true>(a, grid, st) : (a.ablate ? MTVAF_ERR_ARG : launch_p16_t<0, false, true, true>(a, grid, st));
   if (b_km) return a.trace ? launch_p16_t<0, true, true>(a, grid, st) : (a.ablate ? MTVAF_ERR_ARG : launch_p16_t<0, false, true>(a, grid, st));
   if (a.trace) return launch_p16_t<0, true>(a, grid, st);
   switch (a.ablate) {
@@ -405,24 +431,26 @@ int mtvaf_f32p_trace(void* buf) {
 
 // C[M,N] = A[M,K] . op(B) (+ bias, epilogue) from plane images of both operands.  layout_b 0: B [N][K], k contiguous (every
 // nn.Linear forward, modeling_bert.py:266, 283-284, 353, 420-421, 433); layout_b 1: B [K][N], the reduction index is the row (their
-// dX products: dY . W), b_row / b_kt = byte strides of a k-row / of 32 k-rows, b_col = of a 128-column block.  M, N % 128 == 0,
+// dX products: dY . W), b_row / b_kt = byte strides of a k-row / of 32 k-rows, b_col = of a 128-column block.  layout_a 1 (with
+// layout_b 1): A [K][M] as well -- their weight-gradient products dW = dY^T . X, reduction over the token rows.  M, N % 128 == 0,
 // K % 32 == 0.  splits > 1: split-K slabs
 // in `workspace` (deterministic ordered reduction, as mtvaf_gemm_f32).
-int mtvaf_gemm_f32p(const void* Aplanes, long a_plane, long a_row, long a_kt, int layout_b, const void* Bplanes, long b_plane, long b_row,
-                    long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
-                    int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate, hipStream_t stream) {
+int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                    long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias, int epi,
+                    float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
+                    hipStream_t stream) {
   if (!Aplanes || !Bplanes || !C || M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_ARG;
   if (M % 128 || N % 128 || K % 32) return MTVAF_ERR_SHAPE;
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
   if ((ldc % 4) || (aux && ldaux % 4) || (((uintptr_t)Aplanes | (uintptr_t)Bplanes | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15))
     return MTVAF_ERR_ALIGN;
-  if ((a_plane | a_row | a_kt | b_plane | b_row | b_kt | b_col) & 15) return MTVAF_ERR_ALIGN;
-  if (layout_b < 0 || layout_b > 1) return MTVAF_ERR_ARG;
+  if ((a_plane | a_row | a_kt | a_col | b_plane | b_row | b_kt | b_col) & 15) return MTVAF_ERR_ALIGN;
+  if (layout_a < 0 || layout_a > 1 || layout_b < 0 || layout_b > 1 || (layout_a == 1 && layout_b == 0)) return MTVAF_ERR_ARG;
   if (splits < 1) splits = 1;
   if (splits > 1 && ((size_t)splits * M * N * sizeof(float) > workspace_bytes || !workspace)) return MTVAF_ERR_WORKSPACE;
   GemmArgsP a = {};
   a.Ap = static_cast<const unsigned char*>(Aplanes); a.Bp = static_cast<const unsigned char*>(Bplanes);
-  a.a_plane = a_plane; a.a_row = a_row; a.a_kt = a_kt; a.b_plane = b_plane; a.b_row = b_row; a.b_kt = b_kt; a.b_col = b_col;
+  a.a_plane = a_plane; a.a_row = a_row; a.a_kt = a_kt; a.a_col = a_col; a.b_plane = b_plane; a.b_row = b_row; a.b_kt = b_kt; a.b_col = b_col;
   a.bias = bias; a.aux = aux; a.M = M; a.N = N; a.K = K; a.ldaux = ldaux; a.epi = epi; a.accumulate = accumulate;
   int kc = ((K + splits - 1) / splits + 31) / 32 * 32;
   splits = (K + kc - 1) / kc;
@@ -433,7 +461,7 @@ int mtvaf_gemm_f32p(const void* Aplanes, long a_plane, long a_row, long a_kt, in
   a.ablate = ablate;
   a.trace = g_f32p_trace;
   dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
-  const int rc = launch_gemm_f32p16(a, layout_b, grid, stream);
+  const int rc = launch_gemm_f32p16(a, layout_a, layout_b, grid, stream);
   if (rc != MTVAF_OK) return rc;
   if (splits > 1) return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
   return MTVAF_OK;

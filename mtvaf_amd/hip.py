@@ -36,7 +36,7 @@ _SIGS = {
     "mtvaf_f32_split": (c_int, [I]),
     "mtvaf_f32x3_trace": (c_int, [P]),
     "mtvaf_f32_split_planes": (c_int, [P, P, I, I, I, L, L, L, P]),
-    "mtvaf_gemm_f32p": (c_int, [P, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, P]),
+    "mtvaf_gemm_f32p": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, P]),
     "mtvaf_f32p_trace": (c_int, [P]),
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -314,21 +314,30 @@ class Planes:
                                          _st()), "mtvaf_f32_split_planes")
 
 
-def gemm_planes(a: Planes, b: Planes, out, bias=None, epi=EPI_NONE, aux=None, accumulate=False, splits=1, ablate=0, layout_b=KC):
+def gemm_planes(a: Planes, b: Planes, out, bias=None, epi=EPI_NONE, aux=None, accumulate=False, splits=1, ablate=0, layout_b=KC,
+                layout_a=KC):
     """out[M,N] = A[M,K] . B[N,K]^T (layout_b = KC) or A[M,K] . B[K,N] (layout_b = KM: `b` must be a NATURAL plane image of the
     [K, N] matrix) from the plane images of both operands (mtvaf_gemm_f32p)."""
-    if layout_b == KM:
+    if layout_a == KM:  # weight gradients: out[M,N] = A[K,M]^T . B[K,N], both natural plane images
+        assert layout_b == KM and a.s_row == a.cols * 2 and b.s_row == b.cols * 2 and a.rows == b.rows
+        M, N, K = a.cols, b.cols, a.rows
+        as_ = (a.s_plane, a.s_row, 32 * a.s_row, 256)
+        bs = (b.s_plane, b.s_row, 32 * b.s_row, 256)
+    elif layout_b == KM:
         M, N, K = a.rows, b.cols, a.cols
         assert b.rows == K and b.s_row == b.cols * 2, "k-major B: natural plane image of the [K, N] matrix"
+        as_ = (a.s_plane, a.s_row, a.s_kt, 0)
         bs = (b.s_plane, b.s_row, 32 * b.s_row, 256)
     else:
         M, N, K = a.rows, b.rows, a.cols
+        as_ = (a.s_plane, a.s_row, a.s_kt, 0)
         bs = (b.s_plane, b.s_row, b.s_kt, 0)
     ws, wsb = None, 0
     if splits > 1:
         wsb = splits * M * N * 4
         ws = workspace(wsb, out.device)
-    _ck(lib().mtvaf_gemm_f32p(_p(a.img), a.s_plane, a.s_row, a.s_kt, layout_b, _p(b.img), bs[0], bs[1], bs[2], bs[3], _p(out), out.stride(0), M, N, K,
+    _ck(lib().mtvaf_gemm_f32p(layout_a, _p(a.img), as_[0], as_[1], as_[2], as_[3], layout_b, _p(b.img), bs[0], bs[1], bs[2], bs[3], _p(out),
+                              out.stride(0), M, N, K,
                               _p(bias), epi, _p(aux), aux.stride(0) if aux is not None else 0, int(accumulate), splits, _p(ws), wsb,
                               ablate, _st()), "mtvaf_gemm_f32p")
     return out

@@ -1418,6 +1418,14 @@ def test_gemm_f32_presplit_planes_accuracy_and_epilogues(hip, M, N, K, spread):
         hip.gemm_planes(pa2, pb2, o_km, layout_b=hip.KM)
         e = (o_km.double().cpu() - ref2).abs() / mag2
         assert float(e.max()) <= 2.0 ** -24 * (4 + K ** 0.5), ("k-major B", float(e.max()))
+    # the dW form: out[M, N] = A[K, M]^T . B[K, N], the reduction index is the ROW of both operands (natural plane images)
+    a3, b3, ref3, mag3 = _x3_operands(M, N, K, 1, 1, seed=M + N + K + 2, spread=spread)
+    if N % 128 == 0:
+        pa3, pb3 = hip.Planes(a3, False), hip.Planes(b3, False)
+        o_dw = torch.full((M, N), float("nan"), device=DEV)
+        hip.gemm_planes(pa3, pb3, o_dw, layout_a=hip.KM, layout_b=hip.KM)
+        e = (o_dw.double().cpu() - ref3).abs() / mag3
+        assert float(e.max()) <= 2.0 ** -24 * (4 + K ** 0.5), ("k-major A and B", float(e.max()))
     if K >= 64:
         o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
         hip.gemm_planes(pa, pb, o1, bias=bias, splits=2)
