@@ -302,6 +302,22 @@ int mtvaf_gemm_f32x3(int layout_a, int layout_b, const float* A, int lda, const 
 int mtvaf_f32_split(int on);
 /* profiling hook (tools/x3_trace.py): block 0 of every following wave-specialised split launch stores per wave and k-tile the
  * shader clock around the tile barrier into buf ([8 waves][64 k-tiles][4] + 17 int64 on the device); NULL switches it off */
+/* Round 5: a dense product in front of a LayerNorm may leave its split-K slabs unreduced -- the LayerNorm adds them itself, in
+ * the order the reduction launch would (modeling_bert.py:353-355, 433-435 and their autograd backward).  mtvaf_gemm_f32_slabs =
+ * mtvaf_gemm_f32 with a plain epilogue: *splits_out == 1: C holds the result (+ bias, accumulate); s > 1: `workspace` holds s slabs
+ * [M][N] (slab stride M * N floats), neither bias nor accumulate applied, C untouched.  mtvaf_dropout_res_ln_fwd_slabs: x = slab 0
+ * + ... + bias is stored to x_out (the backward pass reads it), then as mtvaf_dropout_res_ln_fwd.  mtvaf_dropout_res_ln_bwd_rows_slabs:
+ * dout = (slab 0 + ...) + dout_base, then as mtvaf_dropout_res_ln_bwd_rows. */
+int mtvaf_gemm_f32_slabs(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                         int K, const float* bias, int accumulate, void* workspace, size_t workspace_bytes, int* splits_out,
+                         mtvaf_stream_t stream);
+int mtvaf_dropout_res_ln_fwd_slabs(const float* slabs, int nslab, const float* bias, float* x_out, const float* res, const float* gamma,
+                                   const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop,
+                                   uint64_t seed, uint64_t offset, void* out_bf16, mtvaf_stream_t st);
+int mtvaf_dropout_res_ln_bwd_rows_slabs(const float* dout_base, const float* slabs, int nslab, const float* x, const float* res,
+                                        const float* gamma, const float* mean, const float* rstd, float* dx, float* dres,
+                                        int dres_accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset, float* part,
+                                        void* dx_bf16, mtvaf_stream_t st);
 int mtvaf_f32x3_trace(void* buf);
 
 /* Pre-split operands (csrc/gemm_f32p.hip, round 5; the same nn.Linear products, modeling_bert.py:266, 283-284, 353, 420-421,

@@ -86,6 +86,16 @@ int mtvaf_dropout_res_ln_bwd_rows(const float* dout, const float* x, const float
                                   uint64_t seed, uint64_t offset, float* part, void* dx_bf16, hipStream_t st);
 int mtvaf_dropout_res_ln_bwd_finish(const float* part, int M, int H, float* dgamma, float* dbeta, float* dbias_x, int accumulate,
                                     hipStream_t st);
+int mtvaf_gemm_f32_slabs(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                         int K, const float* bias, int accumulate, void* workspace, size_t workspace_bytes, int* splits_out,
+                         hipStream_t stream);
+int mtvaf_dropout_res_ln_fwd_slabs(const float* slabs, int nslab, const float* bias, float* x_out, const float* res, const float* gamma,
+                                   const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop,
+                                   uint64_t seed, uint64_t offset, void* out_bf16, hipStream_t st);
+int mtvaf_dropout_res_ln_bwd_rows_slabs(const float* dout_base, const float* slabs, int nslab, const float* x, const float* res,
+                                        const float* gamma, const float* mean, const float* rstd, float* dx, float* dres,
+                                        int dres_accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset, float* part,
+                                        void* dx_bf16, hipStream_t st);
 int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma, const float* mean,
                              const float* rstd, float* dx, float* dres, int dres_accumulate, float* dgamma, float* dbeta,
                              float* dbias_x, int accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset,
@@ -116,6 +126,33 @@ static int fork_to(hipStream_t from, hipStream_t to) {
 }  // namespace mtvaf
 
 using namespace mtvaf;
+
+// Round 5: where a dense product in front of a LayerNorm runs as split-K slabs (the N = 768 products of a packed batch: 114
+// tiles x 2 splits), the LayerNorm adds the slabs itself -- forward Wo / FFN-2 (+ bias), backward the accumulating FFN-1 dX -- instead
+// of a reduction launch in between: 36 launches and as many passes over [M, H] less per step; same bits (the sum runs in the
+// reduction launch's order).  MTVAF_LN_SLABS=0: the reduction launches, as before.
+static bool ln_slabs_on() {
+  static const int on = [] { const char* e = getenv("MTVAF_LN_SLABS"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
+// dense product (+ bias) -> dropout + residual + LayerNorm, with the split-K slabs of the product handed to the LayerNorm
+static int dense_ln_fwd(const float* A, int K, const float* W, const float* bias, float* x_out, const float* res, const float* gamma,
+                        const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
+                        uint64_t offset, void* ws, size_t ws_bytes, hipStream_t st) {
+  if (ln_slabs_on() && ws) {
+    int ns = 1;
+    const int rc = mtvaf_gemm_f32_slabs(0, 0, A, K, W, K, x_out, H, M, H, K, bias, 0, ws, ws_bytes, &ns, st);
+    if (rc != MTVAF_OK) return rc;
+    if (ns > 1)
+      return mtvaf_dropout_res_ln_fwd_slabs(static_cast<const float*>(ws), ns, bias, x_out, res, gamma, beta, out, mean, rstd, M, H, eps,
+                                            p_drop, seed, offset, nullptr, st);
+  } else {
+    const int rc = mtvaf_gemm_f32(0, 0, A, K, W, K, x_out, H, M, H, K, bias, 0, nullptr, 0, 0, 1, ws, ws_bytes, -1, -1, st);
+    if (rc != MTVAF_OK) return rc;
+  }
+  return mtvaf_dropout_res_ln_fwd(x_out, res, gamma, beta, out, mean, rstd, M, H, eps, p_drop, seed, offset, nullptr, st);
+}
 
 #define MTVAF_TRY(call)            \
   do {                             \
@@ -215,13 +252,11 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
     MTVAF_TRY(mtvaf_prefix_attn_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->addmask, cx, L->lse,
                                     L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
   }
-  MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, cx, H, L->wo, H, L->a, H, M, H, H, L->bo, X_EPI_NONE, nullptr, 0, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
-  MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden, L->seed,
-                                     L->offset + 1, nullptr, st));
+  MTVAF_TRY(dense_ln_fwd(cx, H, L->wo, L->bo, L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden, L->seed,
+                         L->offset + 1, L->ws, L->ws_bytes, st));
   MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, L->h1, H, L->w1, H, act, I, M, I, H, L->bi1, X_EPI_GELU, pre, I, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
-  MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, act, I, L->w2, I, L->f, H, M, H, I, L->bi2, X_EPI_NONE, nullptr, 0, 0, 1, L->ws, L->ws_bytes, -1, -1, st));
-  MTVAF_TRY(mtvaf_dropout_res_ln_fwd(L->f, L->h1, L->g2, L->b2, L->h2, L->mean2, L->rstd2, M, H, L->eps, L->p_hidden, L->seed,
-                                     L->offset + 2, nullptr, st));
+  MTVAF_TRY(dense_ln_fwd(act, I, L->w2, L->bi2, L->f, L->h1, L->g2, L->b2, L->h2, L->mean2, L->rstd2, M, H, L->eps, L->p_hidden, L->seed,
+                         L->offset + 2, L->ws, L->ws_bytes, st));
   return MTVAF_OK;
 }
 
@@ -348,10 +383,24 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     if (!grp) MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
     if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, dpre, I, L->h1, H, g->dw1, H, I, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
-    MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dpre, I, L->w1, H, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, 1, g->ws_main,
-                             g->ws_main_bytes, -1, -1, mainS));
-    MTVAF_TRY(ln_bwd_forked(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, g->dg1, g->db1, g->dbo, M, H, L->p_hidden, L->seed,
-                            L->offset + 1, g->lnpart1, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
+    // (the LayerNorm backward behind this accumulating product adds its split-K slabs itself when its column sums have their
+    // own partial buffer -- otherwise its scratch would be the workspace that holds the slabs)
+    int ns1 = 1;
+    if (ln_slabs_on() && g->lnpart1 && side != mainS && g->ws_main) {
+      MTVAF_TRY(mtvaf_gemm_f32_slabs(X_KC, X_KM, dpre, I, L->w1, H, g->dh1, H, M, H, I, nullptr, 1, g->ws_main, g->ws_main_bytes, &ns1, mainS));
+    } else {
+      MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, dpre, I, L->w1, H, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, 1, g->ws_main,
+                               g->ws_main_bytes, -1, -1, mainS));
+    }
+    if (ns1 > 1) {
+      MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_slabs(g->dh1, static_cast<const float*>(g->ws_main), ns1, L->a, L->x, L->g1, L->mean1, L->rstd1,
+                                                    da, g->dh, 0, M, H, L->p_hidden, L->seed, L->offset + 1, g->lnpart1, nullptr, mainS));
+      MTVAF_TRY(fork_to(mainS, side));
+      MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart1, M, H, g->dg1, g->db1, g->dbo, 0, side));
+    } else {
+      MTVAF_TRY(ln_bwd_forked(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, g->dg1, g->db1, g->dbo, M, H, L->p_hidden, L->seed,
+                              L->offset + 1, g->lnpart1, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
+    }
     if (!grp) MTVAF_TRY(mtvaf_gemm_f32_ktiles(X_KM, X_KM, da, H, cx, H, g->dwo, H, H, H, M, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_side,
                              g->ws_side_bytes, -1, -1, g->klist, g->kcnt, side));
     MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KM, da, H, L->wo, H, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, 1, g->ws_main,

@@ -913,8 +913,9 @@ static int g_x3_tile_walk = [] { const char* e = getenv("MTVAF_X3_TILE_WALK"); r
 static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb,
                          float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux, int ldaux,
                          int accumulate, int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits,
-                         hipStream_t stream, const int* klist = nullptr, const int* kcnt = nullptr) {
+                         hipStream_t stream, const int* klist = nullptr, const int* kcnt = nullptr, int* keep_slabs = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_SHAPE;
+  if (keep_slabs) *keep_slabs = 1;
   if (compute == 1) {
     // the bf16 kernels need k-aligned, vector-loadable operands; anything else runs the fp32 kernels
     const bool ok = (K % 32 == 0) && (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A & 15) == 0) &&
@@ -1042,8 +1043,13 @@ static int gemm_dispatch(int compute, int layout_a, int layout_b, const float* A
   }
   if (pr) (void)hipEventRecord(pr->e1, stream);
   if (rc != MTVAF_OK) return rc;
-  if (splits > 1)
+  if (splits > 1) {
+    if (keep_slabs) {  // (mtvaf_gemm_f32_slabs: the caller's next kernel adds the slabs itself)
+      *keep_slabs = splits;
+      return MTVAF_OK;
+    }
     return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
+  }
   return MTVAF_OK;
 }
 
@@ -1084,6 +1090,19 @@ int mtvaf_gemm_f32(int layout_a, int layout_b, const float* A, int lda, const fl
                    hipStream_t stream) {
   return gemm_dispatch(mtvaf_f32_split(-1) ? 2 : 0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate,
                        allow_split, workspace, workspace_bytes, cfg, splits, stream);
+}
+
+// mtvaf_gemm_f32 (plain epilogue) that leaves a split-K plan's slabs UNREDUCED (round 5): *splits_out = 1 -> C holds the result
+// (+ bias, accumulate) as usual; *splits_out = s > 1 -> `workspace` holds s slabs [M][N] (leading dimension N, slab stride M * N
+// floats), neither bias nor accumulate applied, C untouched: the consumer adds them in the order the reduction launch would
+// (slab 0 + slab 1 + ... + bias [+ C]) -- mtvaf_dropout_res_ln_fwd_slabs / mtvaf_dropout_res_ln_bwd_rows_slabs -- and must run
+// before anything else uses the workspace.  Saves the reduction launch and one pass over the result per product.
+int mtvaf_gemm_f32_slabs(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                         int K, const float* bias, int accumulate, void* workspace, size_t workspace_bytes, int* splits_out,
+                         hipStream_t stream) {
+  if (!splits_out) return MTVAF_ERR_ARG;
+  return gemm_dispatch(mtvaf_f32_split(-1) ? 2 : 0, layout_a, layout_b, A, lda, B, ldb, C, ldc, M, N, K, bias, EPI_NONE, nullptr, 0, accumulate,
+                       1, workspace, workspace_bytes, -1, -1, stream, nullptr, nullptr, splits_out);
 }
 
 // mtvaf_gemm_f32 for a weight-gradient product (layouts KM x KM: C[M,N] = A[K,M]^T . B[K,N], the reduction index is the

@@ -23,6 +23,9 @@ struct RowCtx {
 // ------------------------------------------------------------------------------------------
 // MODE 0: z = dropout(x) + res ; y = LN(z)
 // MODE 1: z = word[id] + type[tt] + pos[p] ; y = dropout(LN(z))
+// MODE 2 (round 5): MODE 0 with x = slab 0 + slab 1 + ... + bias, the unreduced split-K slabs of the dense product in front of
+//   it (mtvaf_gemm_f32_slabs): `x` = slab 0, `wword` = the bias, `wpos` = where the reduced x is stored (the backward pass reads
+//   it), S = the slab count, `wtype` unused; slab stride = M * H.  The sum runs in the order of the reduction launch it replaces.
 template <int MODE>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                     const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
@@ -53,8 +56,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
       const int c = lane + 64 * i;
       z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c < nch) {
-        if (MODE == 0) {
+        if (MODE == 0 || MODE == 2) {
           f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)row * H + c * 4);
+          if (MODE == 2) {
+            for (int zs = 1; zs < S; ++zs) xv += *reinterpret_cast<const f32x4*>(x + (long)zs * M * H + (long)row * H + c * 4);
+            if (wword) xv += *reinterpret_cast<const f32x4*>(wword + c * 4);
+            *reinterpret_cast<f32x4*>(const_cast<float*>(wpos) + (long)row * H + c * 4) = xv;
+          }
           f32x4 rv = *reinterpret_cast<const f32x4*>(res + (long)row * H + c * 4);
           if (p_drop > 0.f) {
             const uint32_t k = dropout_keep4(seed, offset, (uint64_t)row * nch + c, p_drop);
@@ -164,6 +172,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         }
         xh[i] = (z - mu) * rstd;
         f32x4 dy = *reinterpret_cast<const f32x4*>(dout + (long)row * H + c * 4);
+        if (MODE == 0 && wword) {  // dout = (slab 0 + slab 1 + ...) + dout: the unreduced dX product in front (mtvaf_gemm_f32_slabs, accumulate)
+          f32x4 sl = *reinterpret_cast<const f32x4*>(wword + (long)row * H + c * 4);
+          for (int zs = 1; zs < S; ++zs) sl += *reinterpret_cast<const f32x4*>(wword + (long)zs * M * H + (long)row * H + c * 4);
+          dy = sl + dy;
+        }
         if (MODE == 1 && p_drop > 0.f) {
           dy.x = (keep[i] & 1) ? dy.x * scale : 0.f; dy.y = (keep[i] & 2) ? dy.y * scale : 0.f;
           dy.z = (keep[i] & 4) ? dy.z * scale : 0.f; dy.w = (keep[i] & 8) ? dy.w * scale : 0.f;
@@ -575,6 +588,18 @@ int mtvaf_embed_ln_fwd(const int64_t* ids, const int64_t* type_ids, const int32_
   return MTVAF_OK;
 }
 
+int mtvaf_dropout_res_ln_fwd_slabs(const float* slabs, int nslab, const float* bias, float* x_out, const float* res, const float* gamma,
+                                   const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop,
+                                   uint64_t seed, uint64_t offset, void* out_bf16, hipStream_t st) {
+  if (H % 4 || H > MAXC * 256 || M <= 0 || nslab < 1) return MTVAF_ERR_SHAPE;
+  if (!slabs || !x_out) return MTVAF_ERR_ARG;
+  hipLaunchKernelGGL((ln_fwd_kernel<2>), dim3(row_grid(M)), dim3(256), 0, st, slabs, res, nullptr, nullptr, nullptr, bias, x_out,
+                     nullptr, gamma, beta, out, mean, rstd, M, nslab, H, eps, p_drop, seed, offset, static_cast<__bf16*>(out_bf16),
+                     rng_epoch_ptr());
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
 int mtvaf_dropout_res_ln_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* out,
                              float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
                              uint64_t offset, void* out_bf16, hipStream_t st) {
@@ -602,6 +627,21 @@ int mtvaf_dropout_res_ln_bwd_rows(const float* dout, const float* x, const float
   hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
                      nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
                      offset, static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+// _rows with dout = (slab 0 + ... + slab nslab-1) + dout_base: the split-K slabs of the accumulating dX product that feeds this
+// LayerNorm (mtvaf_gemm_f32_slabs), added in the order of the reduction launch it replaces.
+int mtvaf_dropout_res_ln_bwd_rows_slabs(const float* dout_base, const float* slabs, int nslab, const float* x, const float* res,
+                                        const float* gamma, const float* mean, const float* rstd, float* dx, float* dres,
+                                        int dres_accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset, float* part,
+                                        void* dx_bf16, hipStream_t st) {
+  if (H % 4 || H > MAXC * 256 || M <= 0 || nslab < 1) return MTVAF_ERR_SHAPE;
+  if ((!dx && !dx_bf16) || !part || !slabs || !dout_base) return MTVAF_ERR_ARG;
+  const int g = row_grid_bwd(M);
+  hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout_base, x, res, nullptr, nullptr, nullptr, slabs, nullptr,
+                     nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, nslab, H, p_drop, seed, offset,
+                     static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

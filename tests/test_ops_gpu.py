@@ -1434,6 +1434,65 @@ def test_gemm_f32_presplit_planes_accuracy_and_epilogues(hip, M, N, K, spread):
         assert torch.equal(o1, o2), "split-K must be deterministic"
 
 
+def test_layernorm_adds_the_split_k_slabs_itself_bit_for_bit(hip):
+    """Round 5: mtvaf_gemm_f32_slabs leaves a split-K plan's slabs unreduced and the LayerNorm behind the product adds them in the
+    reduction launch's order (slab 0 + slab 1 + ... + bias; backward: (slab 0 + ...) + dout) -- forward Wo / FFN-2, backward the
+    accumulating FFN-1 dX of a packed batch (modeling_bert.py:353-355, 433-435).  Same bits as product + reduction + LayerNorm:
+    outputs, statistics, the stored dense output the backward pass reads, dx / dres and the column-sum partials."""
+    import ctypes
+    L_ = hip.lib()
+    M, H, K = 2432, 768, 3072   # 19 x 6 tiles: the planner splits
+    x = rnd(M, K, seed=1).to(DEV)
+    w = (rnd(H, K, seed=2) * 0.05).to(DEV)
+    bias, res = rnd(H, seed=3).to(DEV), rnd(M, H, seed=4).to(DEV)
+    gamma, beta = (rnd(H, seed=5) * 0.1 + 1).to(DEV), rnd(H, seed=6).to(DEV)
+    wsb = L_.mtvaf_gemm_f32_workspace_bytes(M, H, K, 1)
+    ws = hip.workspace(wsb, x.device)
+    E = lambda *s_: torch.empty(*s_, device=DEV)
+    # reference: product (+ its own reduction) then LayerNorm
+    a0, o0, mu0, rs0 = E(M, H), E(M, H), E(M), E(M)
+    hip.gemm(x, 0, w, 0, a0, M, H, K, bias=bias, allow_split=True)
+    hip._ck(L_.mtvaf_dropout_res_ln_fwd(hip._p(a0), hip._p(res), hip._p(gamma), hip._p(beta), hip._p(o0), hip._p(mu0), hip._p(rs0), M, H,
+                                        1e-12, 0.1, 77, 5, None, hip._st()), "ln")
+    # fused: slabs kept, LayerNorm adds them
+    a1, o1, mu1, rs1 = torch.full((M, H), float("nan"), device=DEV), E(M, H), E(M), E(M)
+    ns = ctypes.c_int(0)
+    hip._ck(L_.mtvaf_gemm_f32_slabs(0, 0, hip._p(x), K, hip._p(w), K, hip._p(a1), H, M, H, K, hip._p(bias), 0, hip._p(ws), wsb, ctypes.byref(ns),
+                                    hip._st()), "slabs")
+    assert ns.value > 1, "the planner was expected to split this product"
+    assert bool(torch.isnan(a1).all())  # (C untouched)
+    hip._ck(L_.mtvaf_dropout_res_ln_fwd_slabs(hip._p(ws), ns.value, hip._p(bias), hip._p(a1), hip._p(res), hip._p(gamma), hip._p(beta),
+                                              hip._p(o1), hip._p(mu1), hip._p(rs1), M, H, 1e-12, 0.1, 77, 5, None, hip._st()), "ln slabs")
+    assert torch.equal(a1, a0) and torch.equal(o1, o0) and torch.equal(mu1, mu0) and torch.equal(rs1, rs0)
+    # backward: dX = dpre . W (accumulating into dh1) then LayerNorm backward, against the slab-adding form
+    dpre, w1 = rnd(M, K, seed=7).to(DEV), (rnd(K, H, seed=8) * 0.05).to(DEV)
+    base = rnd(M, H, seed=9).to(DEV)
+    nb = L_.mtvaf_ln_bwd_workspace_bytes(M, H)
+    part0, part1 = torch.empty(nb // 4, device=DEV), torch.empty(nb // 4, device=DEV)
+    d0 = base.clone()
+    hip.gemm(dpre, 0, w1, 1, d0, M, H, K, accumulate=True, allow_split=True)
+    dx0, dr0 = E(M, H), E(M, H)
+    hip._ck(L_.mtvaf_dropout_res_ln_bwd_rows(hip._p(d0), hip._p(a0), hip._p(res), hip._p(gamma), hip._p(mu0), hip._p(rs0), hip._p(dx0),
+                                             hip._p(dr0), 0, M, H, 0.1, 77, 5, hip._p(part0), None, hip._st()), "bwd rows")
+    d1 = base.clone()
+    hip._ck(L_.mtvaf_gemm_f32_slabs(0, 1, hip._p(dpre), K, hip._p(w1), H, hip._p(d1), H, M, H, K, None, 1, hip._p(ws), wsb, ctypes.byref(ns),
+                                    hip._st()), "slabs bwd")
+    assert ns.value > 1 and torch.equal(d1, base)
+    dx1, dr1 = E(M, H), E(M, H)
+    hip._ck(L_.mtvaf_dropout_res_ln_bwd_rows_slabs(hip._p(d1), hip._p(ws), ns.value, hip._p(a0), hip._p(res), hip._p(gamma), hip._p(mu0),
+                                                   hip._p(rs0), hip._p(dx1), hip._p(dr1), 0, M, H, 0.1, 77, 5, hip._p(part1), None,
+                                                   hip._st()), "bwd rows slabs")
+    assert torch.equal(dx1, dx0) and torch.equal(dr1, dr0) and torch.equal(part1, part0)
+    # an unsplit plan: the entry point behaves as mtvaf_gemm_f32
+    xs = rnd(4096, 768, seed=10).to(DEV)
+    ws_ = (rnd(3072, 768, seed=11) * 0.05).to(DEV)
+    c0, c1 = E(4096, 3072), E(4096, 3072)
+    hip.gemm(xs, 0, ws_, 0, c0, 4096, 3072, 768, allow_split=True)
+    hip._ck(L_.mtvaf_gemm_f32_slabs(0, 0, hip._p(xs), 768, hip._p(ws_), 768, hip._p(c1), 3072, 4096, 3072, 768, None, 0, hip._p(ws), wsb,
+                                    ctypes.byref(ns), hip._st()), "unsplit")
+    assert ns.value == 1 and torch.equal(c1, c0)
+
+
 def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
     """The split kernel behind the fp32 entry points: every epilogue of the path (bias, bias + GELU with the saved
     pre-activation, GELU', tanh, accumulate), forced split-K, a k-tile list (weight gradient: dY exactly zero outside the listed
