@@ -1468,7 +1468,7 @@ def test_layernorm_adds_the_split_k_slabs_itself_bit_for_bit(hip):
     dpre, w1 = rnd(M, K, seed=7).to(DEV), (rnd(K, H, seed=8) * 0.05).to(DEV)
     base = rnd(M, H, seed=9).to(DEV)
     nb = L_.mtvaf_ln_bwd_workspace_bytes(M, H)
-    part0, part1 = torch.empty(nb // 4, device=DEV), torch.empty(nb // 4, device=DEV)
+    part0, part1 = torch.zeros(nb // 4, device=DEV), torch.zeros(nb // 4, device=DEV)  # (the kernel writes a prefix of the workspace)
     d0 = base.clone()
     hip.gemm(dpre, 0, w1, 1, d0, M, H, K, accumulate=True, allow_split=True)
     dx0, dr0 = E(M, H), E(M, H)
