@@ -564,8 +564,9 @@ def main():
     sync = None
     if world > 1:
         from mtvaf_amd.parallel import GradSync
-        sync = GradSync(model, compress={"auto": "auto", "fp32": None, "bf16": "bf16"}[a.grad_wire],
-                        layer_buckets=a.grad_buckets if a.grad_buckets > 0 else None)
+        wire = {"auto": ("bf16" if a.dtype == "bf16" else None), "fp32": None, "bf16": "bf16"}[a.grad_wire]
+        # (the bucket count belongs to the bf16 wire; the fp32 wire exchanges one flat buffer per layer in place)
+        sync = GradSync(model, compress=wire, layer_buckets=(a.grad_buckets if (a.grad_buckets > 0 and wire == "bf16") else None))
     sched = None
     if a.no_optimizer:
         opt = None

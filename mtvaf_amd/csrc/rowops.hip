@@ -553,7 +553,12 @@ static inline void zero_f32(float* p, long n, hipStream_t st) {
 
 static inline int row_grid(int M) { return std::max(1, std::min((M + 3) / 4, 1024)); }
 // LN backward keeps per-block column partials: fewer, fatter blocks (2 per CU) keep the partial slab small
-static inline int row_grid_bwd(int M) { return std::max(1, std::min((M + 3) / 4, 512)); }
+// blocks of the LayerNorm backward (4 rows per block and pass; each block leaves one row of column partials).
+// MTVAF_LN_BWD_BLOCKS overrides the cap (experiment switch; read once: the partial-buffer size follows it).
+static inline int row_grid_bwd(int M) {
+  static const int cap = [] { const char* e = getenv("MTVAF_LN_BWD_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 512; }();
+  return std::max(1, std::min((M + 3) / 4, cap));
+}
 
 }  // namespace mtvaf
 

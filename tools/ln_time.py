@@ -2,7 +2,7 @@ import os, sys, torch
 sys.path.insert(0, os.getcwd())
 from mtvaf_amd import hip
 dev = "cuda"
-for M in (2048, 4096, 8192):
+for M in (2432, 4096):
     H = 768
     g = torch.Generator(device=dev).manual_seed(1)
     r = lambda *s: torch.randn(*s, device=dev, generator=g)
