@@ -601,6 +601,10 @@ static int gemm_bf16x_core(int layout_a, int layout_b, const void* A, int lda, c
     if (!can96) bn = 128;
     else if (!can128) bn = 96;
     else bn = (epi == EPI_GELU || epi == EPI_DGELU || t128 >= 512) ? 128 : 96;  // 96: more tiles for the 768-wide outputs
+    // ... unless the 96-wide tiles spill into a second round of the CUs that the 128-wide ones avoid (round 5: the 768-wide
+    // products of a packed bs-64 batch, 4864 rows: 304 tiles against 228 -- measured 36.3 -> 28.3 / 35.8 -> 27.4 / 28.3 -> 22.6 us
+    // on FFN-2 forward / FFN-1 dX / QKV dX, tools/bf16x_bench.py 4864: one round of the 3-deep ring instead of two of the 2-deep)
+    if (bn == 96 && can128 && (long)(M / 128) * (N / 96) > 256 && t128 <= 256) bn = 128;
     // big problems: the 256-row tile once it still gives every CU several tiles
     // (measured, tools/bf16x_bench.py at M = 65536: +6..10 % on the KC x KC products with the 3-deep ring; no gain with a
     // k-major B operand)

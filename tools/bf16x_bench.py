@@ -1,7 +1,7 @@
 """bf16-operand GEMM (mtvaf_gemm_bf16x): rate of every product shape of the path in its real operand layout
 (forward KCxKC, dX KCxKM, dW KMxKM + split-K), per tile / ring depth, at one or more token counts.
 
-    python tools/bf16x_bench.py [M ...]         # default 4096 8192 65536
+    python tools/bf16x_bench.py [M ...] [--splits]   # default 4096 8192 65536; --splits: also split-K 2 / 3 / 4 of the fp32-output products
 """
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,7 +23,7 @@ def bf(*shape):
 
 
 def main():
-    Ms = [int(a) for a in sys.argv[1:]] or [4096, 8192, 65536]
+    Ms = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [4096, 8192, 65536]
     for M in Ms:
         x, x3, w_qkv, w_o, w_1, w_2 = bf(M, H), bf(M, I), bf(3 * H, H), bf(H, H), bf(I, H), bf(H, I)
         dy, dy3, dyq = bf(M, H), bf(M, I), bf(M, 3 * H)
@@ -61,11 +61,24 @@ def main():
                     print(f"M={M:6d} {name:14s} [{m:5d}x{n:5d}x{k:5d}] tile {['', '128x96 ', '128x128', '256x128', '256x192'][tile]} stages {stages}: {us:8.1f} us {tf:7.1f} TF", flush=True)
                     if best is None or us < best[0]:
                         best = (us, tile, stages)
+            if "--splits" in sys.argv and la == 0 and not (kw.get("gelu") or kw.get("dgelu")):
+                # fp32-output forward / dX products: the deterministic split-K (slabs + ordered reduction) per tile
+                for tile in (1, 2):
+                    if tile == 1 and n % 96:
+                        continue
+                    for stages in (2, 3):
+                        for sp in (2, 3, 4):
+                            run = lambda: hip.gemm_bf16x(a, la, b, lb, m, n, k, out32=out32, bias=bias, allow_split=True, tile=tile, stages=stages, splits=sp)
+                            us = t(run)
+                            print(f"M={M:6d} {name:14s} [{m:5d}x{n:5d}x{k:5d}] tile {['', '128x96 ', '128x128'][tile]} stages {stages} splits {sp}: {us:8.1f} us "
+                                  f"{2.0 * m * n * k / us / 1e6:7.1f} TF", flush=True)
+                            if us < best[0]:
+                                best = (us, tile, stages, sp)
             us_auto = t(lambda: (hip.gemm_bf16x(a, la, b, lb, m, n, k, out32=out32, allow_split=bool(kw.get("split")))
                                  if not (kw.get("gelu") or kw.get("dgelu")) else
                                  hip.gemm_bf16x(a, la, b, lb, m, n, k, out16=out16, bias=bias if kw.get("gelu") else None,
                                                 epi=hip.EPI_GELU if kw.get("gelu") else hip.EPI_DGELU, aux16=aux)))
-            print(f"    -> best {best[0]:.1f} us (tile {best[1]}, stages {best[2]}); auto {us_auto:.1f} us", flush=True)
+            print(f"    -> best {best[0]:.1f} us (tile {best[1]}, stages {best[2]}{', splits ' + str(best[3]) if len(best) > 3 else ''}); auto {us_auto:.1f} us", flush=True)
             tot_us += us_auto
             tot_fl += 2.0 * m * n * k
         print(f"M={M}: one layer's 12 products {tot_us:.0f} us, {tot_fl / tot_us / 1e6:.0f} TF average (auto plan)\n", flush=True)
