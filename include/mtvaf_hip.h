@@ -337,6 +337,26 @@ int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row,
                     float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
                     mtvaf_stream_t stream);
 int mtvaf_f32p_trace(void* buf);
+/* research entry: up to four weight-gradient products C_i [M_i][N_i] = A_i^T . B_i from plane images (A_i [K][M_i], B_i [K][N_i], the
+ * token rows K shared) in ONE unsplit launch over the 128 x 128 tiles of all of them -- what the grouped launch of
+ * mtvaf_gemm_f32_dw_group becomes with pre-split operands (no bias sums, no k-tile list).  strides: eight byte strides per product
+ * (a_plane, a_row, a_kt, a_col, b_plane, b_row, b_kt, b_col; natural image of [K][C]: C*K*2, C*2, 64*C, 256; tile-blocked image
+ * [C/32][3][K][32]: K*64, 64, 2048, 12*K*64).  M_i, N_i % 128 == 0, K % 32 == 0. */
+int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
+                             const int* M, const int* N, int K, mtvaf_stream_t stream);
+/* mtvaf_gemm_f32p with a plain epilogue that leaves a split-K plan's slabs unreduced (as mtvaf_gemm_f32_slabs: *splits_out = 1 -> C
+ * holds the result; s > 1 -> `workspace` holds s slabs [M][N], bias / accumulate not applied): the LayerNorm kernels behind the Wo /
+ * FFN-2 / FFN-1 dX products add them (modeling_bert.py:353-355, 433-435 and their backward). */
+int mtvaf_gemm_f32p_slabs(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                          long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias,
+                          int accumulate, int splits, void* workspace, size_t workspace_bytes, int* splits_out, mtvaf_stream_t stream);
+/* mtvaf_gemm_f32p, unsplit, whose result is written as a tile-blocked plane image c_planes [N / 32][3][M][32] -- beside the fp32
+ * result (C != NULL) or instead of it (C == NULL: a tensor that only GEMMs read: the GELU output between the two FFN products, the
+ * GELU' output between their dX products) -- and, optionally, its per-tile column sums colpart [M / 128][N] (finished by
+ * mtvaf_colsum_small: the FFN-1 bias gradient). */
+int mtvaf_gemm_f32p_ep(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                       long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, void* c_planes, float* colpart, int M, int N, int K,
+                       const float* bias, int epi, float* aux, int ldaux, int accumulate, mtvaf_stream_t stream);
 
 /* The (up to four) weight-gradient products of one encoder layer in fp32, dW_i[M_i,N_i] = A_i^T . B_i with A_i [K,M_i], B_i [K,N_i]
  * row-major, as ONE launch of the 128x96 LDS-DMA kernel (autograd backward of modeling_bert.py:266, 283-284, 353, 420-421, 433);
@@ -444,6 +464,13 @@ typedef struct {
    * pad the image to whole 128-row tiles; lse / delta keep [B,NH,S].  cu == NULL: the padded [B*S] layout. */
   const int* cu;
   int Mv, Mp;
+  /* fp32 mode, optional (round 5; all of them, with the weights' plane images in w*_h, packed rows, H and I % 128 == 0): PRE-SPLIT
+   * operands -- tile-blocked plane images ([cols / 32][3][Mp][32] bf16: mtvaf_f32_split_planes with strides Mp * 64 / 64 / 3 * Mp * 64) of
+   * the layer input x_p (given), and of the attention context, the attention-block output, the GELU output and the layer output
+   * (written here: cx_p, h1_p, act_p, h2_p = the next layer's x_p, or NULL).  The eight forward / dX products and the grouped weight
+   * gradients then run on the pre-split kernels of csrc/gemm_f32p.hip (nothing split inside their k-loops). */
+  const void* x_p;
+  void *cx_p, *h1_p, *act_p, *h2_p;
 } mtvaf_layer_t;
 
 typedef struct {
@@ -466,6 +493,9 @@ typedef struct {
   /* optional (both or neither): the layer's own LayerNorm-backward partials of the FFN / attention block,
    * mtvaf_ln_bwd_workspace_bytes(M, H) each -- their column sums then run on `side` instead of the main chain */
   float *lnpart2, *lnpart1;
+  /* fp32 mode with pre-split operands (see mtvaf_layer_t::x_p): scratch plane images of the four upstream gradients that are GEMM
+   * operands -- [Mp, H], [Mp, I], [Mp, H], [Mp, 3H] -- alive until the second stream has finished the layer's weight gradients */
+  void *df_p, *dpre_p, *da_p, *dqkv_p;
 } mtvaf_layer_grads_t;
 
 int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* layer, mtvaf_stream_t stream);

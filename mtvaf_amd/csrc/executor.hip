@@ -67,6 +67,19 @@ int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const floa
                                  const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
 int mtvaf_zero_f32(float* p, long n, hipStream_t st);
+int mtvaf_f32_split_planes(const float* src, void* dst, int rows, int cols, int ld, long s_plane, long s_row, long s_kt, hipStream_t stream);
+int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                    long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias, int epi,
+                    float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
+                    hipStream_t stream);
+int mtvaf_gemm_f32p_slabs(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                          long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias,
+                          int accumulate, int splits, void* workspace, size_t workspace_bytes, int* splits_out, hipStream_t stream);
+int mtvaf_gemm_f32p_ep(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                       long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, void* c_planes, float* colpart, int M, int N, int K,
+                       const float* bias, int epi, float* aux, int ldaux, int accumulate, hipStream_t stream);
+int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
+                             const int* M, const int* N, int K, hipStream_t stream);
 int mtvaf_gemm_f32_ktiles(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                           int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
                           int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits, const int* klist,
@@ -154,6 +167,29 @@ static int dense_ln_fwd(const float* A, int K, const float* W, const float* bias
   return mtvaf_dropout_res_ln_fwd(x_out, res, gamma, beta, out, mean, rstd, M, H, eps, p_drop, seed, offset, nullptr, st);
 }
 
+// ---- pre-split operands (round 5; csrc/gemm_f32p.hip): tile-blocked plane images [cols / 32][3][rows][32] ----
+static int planes_of(const float* src, void* dst, int rows, int cols, hipStream_t st) {
+  return mtvaf_f32_split_planes(src, dst, rows, cols, cols, (long)rows * 64, 64, (long)3 * rows * 64, st);
+}
+// the split-K plan of a forward / dX product on the pre-split kernel: two slabs where the 128 x 128 tiles alone leave half the
+// CUs idle (the 768-wide results of a packed batch: 114 tiles), measured best in tools/f32p_bench.py at 2432 and 4096 rows
+static int p16_splits(int M, int N, int K) {
+  const long tiles = (long)(M / 128) * (N / 128);
+  return (tiles <= 128 && K / 32 >= 8) ? 2 : 1;
+}
+// C[M,N] = A . W^T (lb = 0: W [N][K], every forward product) or A . W (lb = 1: W [K][N], the dX products) from the blocked images of
+// A [M][K] and of the whole weight; keep != NULL: a split plan's slabs stay in ws (mtvaf_gemm_f32p_slabs)
+static int p16(int lb, const void* Ap, const void* Wp, float* C, int ldc, int M, int N, int K, const float* bias, int epi, float* aux,
+               int ldaux, int accumulate, void* ws, size_t wsb, int* keep, hipStream_t st) {
+  const long ap = (long)M * 64, akt = (long)3 * M * 64;
+  const long bp = (long)(lb == 0 ? N : K) * 64, bkt = lb == 0 ? (long)3 * N * 64 : 2048, bc = lb == 0 ? 0 : (long)12 * K * 64;
+  int splits = p16_splits(M, N, K);
+  if (splits > 1 && (!ws || (size_t)splits * M * N * sizeof(float) > wsb)) splits = 1;
+  if (keep)
+    return mtvaf_gemm_f32p_slabs(0, Ap, ap, 64, akt, 0, lb, Wp, bp, 64, bkt, bc, C, ldc, M, N, K, bias, accumulate, splits, ws, wsb, keep, st);
+  return mtvaf_gemm_f32p(0, Ap, ap, 64, akt, 0, lb, Wp, bp, 64, bkt, bc, C, ldc, M, N, K, bias, epi, aux, ldaux, accumulate, splits, ws, wsb, 0, st);
+}
+
 #define MTVAF_TRY(call)            \
   do {                             \
     const int rc_ = (call);        \
@@ -188,6 +224,8 @@ struct mtvaf_layer_t {
   void* ws; size_t ws_bytes;                   // main-stream scratch of the forward pass (split-K slabs of small-M products)
   const int* cu;                               // padding-free execution: [B+1] row offsets of the PACKED token tensors, or NULL
   int Mv, Mp;                                  // valid rows, rows of the packed image (Mv rounded up to whole 128-row tiles)
+  const void* x_p;                             // fp32 mode, pre-split operands (round 5): tile-blocked plane image of x, or NULL
+  void *cx_p, *h1_p, *act_p, *h2_p;            // ... and of cx / h1 / act / h2 (written by the forward; h2_p may be NULL)
 };
 
 struct mtvaf_layer_grads_t {
@@ -206,7 +244,40 @@ struct mtvaf_layer_grads_t {
                                                // gradients (what a k-tile list implies): attention backward stops its query loops there
   float *lnpart2, *lnpart1;                    // optional (both or neither): per-layer LayerNorm-backward partials of the FFN / attention
                                                // block (mtvaf_ln_bwd_workspace_bytes each) -- their column sums then run on `side`
+  void *df_p, *dpre_p, *da_p, *dqkv_p;         // pre-split operands: scratch plane images of df / dpre / da / dqkv, or NULL
 };
+
+// fp32 mode with pre-split operands: every plane image present, packed rows (whole 128-row tiles), whole 128-column tiles
+// p16 whose result leaves as a plane image (and per-tile column sums), no fp32 copy (mtvaf_gemm_f32p_ep)
+static int p16_ep(int lb, const void* Ap, const void* Wp, void* Cp, float* colpart, int M, int N, int K, const float* bias, int epi, float* aux,
+                  int ldaux, hipStream_t st) {
+  const long ap = (long)M * 64, akt = (long)3 * M * 64;
+  const long bp = (long)(lb == 0 ? N : K) * 64, bkt = lb == 0 ? (long)3 * N * 64 : 2048, bc = lb == 0 ? 0 : (long)12 * K * 64;
+  return mtvaf_gemm_f32p_ep(0, Ap, ap, 64, akt, 0, lb, Wp, bp, 64, bkt, bc, nullptr, 0, Cp, colpart, M, N, K, bias, epi, aux, ldaux, 0, st);
+}
+// MTVAF_P16_EP=0: the GELU / GELU' results as fp32 tensors + a split pass each (the first form of the pre-split path)
+static bool p16_ep_on() {
+  static const int on = [] { const char* e = getenv("MTVAF_P16_EP"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
+static bool planes_mode(const mtvaf_layer_t* L) {
+  return !L->bf16 && L->cu && L->x_p && L->cx_p && L->h1_p && L->act_p && L->wqkv_h && L->wo_h && L->w1_h && L->w2_h && L->Mp % 128 == 0 &&
+         L->H % 128 == 0 && L->I % 128 == 0 && L->ws;
+}
+
+// dense product on the pre-split kernel (+ bias) -> dropout + residual + LayerNorm, the product's split-K slabs handed to the LayerNorm
+static int dense_ln_fwd_p(const void* Ap, int K, const void* Wp, const float* bias, float* x_out, const float* res, const float* gamma,
+                          const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
+                          uint64_t offset, void* ws, size_t ws_bytes, hipStream_t st) {
+  int ns = 1;
+  int rc = p16(0, Ap, Wp, x_out, H, M, H, K, bias, X_EPI_NONE, nullptr, 0, 0, ws, ws_bytes, ln_slabs_on() ? &ns : nullptr, st);
+  if (rc != MTVAF_OK) return rc;
+  if (ns > 1)
+    return mtvaf_dropout_res_ln_fwd_slabs(static_cast<const float*>(ws), ns, bias, x_out, res, gamma, beta, out, mean, rstd, M, H, eps, p_drop,
+                                          seed, offset, nullptr, st);
+  return mtvaf_dropout_res_ln_fwd(x_out, res, gamma, beta, out, mean, rstd, M, H, eps, p_drop, seed, offset, nullptr, st);
+}
 
 int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
   if (!L) return MTVAF_ERR_ARG;
@@ -240,6 +311,27 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
   float* cx = static_cast<float*>(L->cx);
   float* pre = static_cast<float*>(L->pre);
   float* act = static_cast<float*>(L->act);
+  if (planes_mode(L)) {
+    // pre-split operands (round 5): the same layer on the kernels of csrc/gemm_f32p.hip; every GEMM operand is read as a plane
+    // image -- weights written once per optimizer step, activations by one pass behind the kernel that produces them
+    MTVAF_TRY(p16(0, L->x_p, L->wqkv_h, qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE, nullptr, 0, 0, L->ws, L->ws_bytes, nullptr, st));
+    MTVAF_TRY(mtvaf_prefix_attn_varlen_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
+                                           L->Mp - L->Mv, cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
+    MTVAF_TRY(planes_of(cx, L->cx_p, M, H, st));
+    MTVAF_TRY(dense_ln_fwd_p(L->cx_p, H, L->wo_h, L->bo, L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden,
+                             L->seed, L->offset + 1, L->ws, L->ws_bytes, st));
+    MTVAF_TRY(planes_of(L->h1, L->h1_p, M, H, st));
+    if (p16_ep_on()) {  // (the GELU output is read by GEMMs only: it leaves the FFN-1 epilogue as a plane image, no fp32 copy)
+      MTVAF_TRY(p16_ep(0, L->h1_p, L->w1_h, L->act_p, nullptr, M, I, H, L->bi1, X_EPI_GELU, pre, I, st));
+    } else {
+      MTVAF_TRY(p16(0, L->h1_p, L->w1_h, act, I, M, I, H, L->bi1, X_EPI_GELU, pre, I, 0, L->ws, L->ws_bytes, nullptr, st));
+      MTVAF_TRY(planes_of(act, L->act_p, M, I, st));
+    }
+    MTVAF_TRY(dense_ln_fwd_p(L->act_p, I, L->w2_h, L->bi2, L->f, L->h1, L->g2, L->b2, L->h2, L->mean2, L->rstd2, M, H, L->eps, L->p_hidden,
+                             L->seed, L->offset + 2, L->ws, L->ws_bytes, st));
+    if (L->h2_p) MTVAF_TRY(planes_of(L->h2, L->h2_p, M, H, st));
+    return MTVAF_OK;
+  }
   // (plain-bias products may use the deterministic split-K: the planner only splits when the tile grid underfills the chip)
   MTVAF_TRY(mtvaf_gemm_f32(X_KC, X_KC, L->x, H, L->wqkv, H, qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE, nullptr, 0, 0, 1, L->ws,
                            L->ws_bytes, -1, -1, st));
@@ -371,6 +463,58 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     const float* cx = static_cast<const float*>(L->cx);
     float* pre = static_cast<float*>(L->pre);
     const float* act = static_cast<const float*>(L->act);
+    if (planes_mode(L) && g->df_p && g->dpre_p && g->da_p && g->dqkv_p && g->ws_main) {
+      // pre-split operands (round 5): the dX chain and the grouped weight gradients on the kernels of csrc/gemm_f32p.hip
+      MTVAF_TRY(ln_bwd_forked(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, g->dg2, g->db2, g->dbi2, M, H, L->p_hidden, L->seed,
+                              L->offset + 2, g->lnpart2, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
+      MTVAF_TRY(planes_of(df, g->df_p, M, H, mainS));
+      const bool ep = p16_ep_on() && g->part != nullptr;
+      if (ep) {  // (dpre is read by GEMMs only -- and summed over its rows for the FFN-1 bias gradient: per-tile sums from the epilogue)
+        MTVAF_TRY(p16_ep(1, g->df_p, L->w2_h, g->dpre_p, g->part, M, I, H, nullptr, X_EPI_DGELU, pre, I, mainS));
+      } else {
+        MTVAF_TRY(p16(1, g->df_p, L->w2_h, dpre, I, M, I, H, nullptr, X_EPI_DGELU, pre, I, 0, g->ws_main, g->ws_main_bytes, nullptr, mainS));
+        MTVAF_TRY(planes_of(dpre, g->dpre_p, M, I, mainS));
+      }
+      int ns1 = 1;
+      const bool slabs1 = ln_slabs_on() && g->lnpart1 && side != mainS;
+      MTVAF_TRY(p16(1, g->dpre_p, L->w1_h, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, g->ws_main, g->ws_main_bytes,
+                    slabs1 ? &ns1 : nullptr, mainS));
+      if (ns1 > 1) {
+        MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_slabs(g->dh1, static_cast<const float*>(g->ws_main), ns1, L->a, L->x, L->g1, L->mean1, L->rstd1,
+                                                      da, g->dh, 0, M, H, L->p_hidden, L->seed, L->offset + 1, g->lnpart1, nullptr, mainS));
+        MTVAF_TRY(fork_to(mainS, side));
+        MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart1, M, H, g->dg1, g->db1, g->dbo, 0, side));
+      } else {
+        MTVAF_TRY(ln_bwd_forked(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, g->dg1, g->db1, g->dbo, M, H, L->p_hidden, L->seed,
+                                L->offset + 1, g->lnpart1, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
+      }
+      MTVAF_TRY(planes_of(da, g->da_p, M, H, mainS));
+      MTVAF_TRY(p16(1, g->da_p, L->wo_h, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, g->ws_main, g->ws_main_bytes, nullptr, mainS));
+      MTVAF_TRY(mtvaf_prefix_attn_varlen_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
+                                             L->Mp - L->Mv, cx, L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn,
+                                             L->seed, L->offset, mainS));
+      MTVAF_TRY(planes_of(dqkv, g->dqkv_p, M, 3 * H, mainS));
+      MTVAF_TRY(fork_to(mainS, side));
+      // second stream: the two bias gradients that are column sums of dY, then the four weight gradients as ONE launch
+      if (ep) MTVAF_TRY(mtvaf_colsum_small(g->part, M / 128, I, g->dbi1, 0, side));
+      else MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
+      MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
+      {
+        const void* const As[4] = {g->df_p, g->dpre_p, g->da_p, g->dqkv_p};
+        const void* const Bs[4] = {L->act_p, L->h1_p, L->cx_p, L->x_p};
+        float* const Cs[4] = {g->dw2, g->dw1, g->dwo, g->dwqkv};
+        const int ldc[4] = {I, H, H, H}, Ms[4] = {H, I, H, 3 * H}, Ns[4] = {I, H, H, H};
+        long strides[32];
+        for (int i = 0; i < 8; ++i) {  // (every image has M rows: plane M * 64, k-row 64, k-tile 2048, 128-column block 12 * M * 64)
+          strides[4 * i] = (long)M * 64; strides[4 * i + 1] = 64; strides[4 * i + 2] = 2048; strides[4 * i + 3] = (long)12 * M * 64;
+        }
+        MTVAF_TRY(mtvaf_gemm_f32p_dw_group(4, As, Bs, strides, Cs, ldc, Ms, Ns, M, side));
+      }
+      MTVAF_TRY(p16(1, g->dqkv_p, L->wqkv_h, g->dh, H, M, H, 3 * H, nullptr, X_EPI_NONE, nullptr, 0, 1, g->ws_main, g->ws_main_bytes, nullptr,
+                    mainS));
+      if (settle) MTVAF_TRY(fork_to(mainS, side));
+      return MTVAF_OK;
+    }
     const bool grp = mtvaf_dw_group_wanted(M, H, I) != 0;
     MTVAF_TRY(ln_bwd_forked(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, g->dg2, g->db2, g->dbi2, M, H, L->p_hidden, L->seed,
                             L->offset + 2, g->lnpart2, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));

@@ -48,8 +48,24 @@ struct GemmArgsP {
   int k_chunk;
   long slab_stride;
   int epi, accumulate, tiles_n;
+  // the result ALSO (C != NULL) or ONLY (C == NULL) as a tile-blocked plane image [N / 32][3][M][32] -- the operand form of the
+  // product that reads it next (FFN-1 forward -> FFN-2 forward, FFN-2 dX -> FFN-1 dX and both weight gradients) -- written by the
+  // epilogue of an UNSPLIT launch; colpart [M / 128][N]: per-tile column sums of the result (the bias gradient behind a dX product)
+  unsigned char* Cpl;
+  float* colpart;
   int ablate;        // research switches: 1 = no MFMAs, 2 = no DMA requests, 4 = no fragment reads
   long long* trace;  // [8 waves][64 k-tiles][2] shader-clock stamps of block 0 (arrive at / leave the tile barrier) + 17, or NULL
+  // GROUP (weight gradients): blockIdx.x walks the 128 x 128 tiles of up to four products that share the reduction axis back to
+  // back; product q owns tiles grp_tile_begin[q] .. grp_tile_begin[q + 1] - 1 (as GemmArgs::grp of the wave-specialised kernel)
+  int ngrp;
+  int grp_tile_begin[5];
+  struct Prob {
+    const unsigned char* Ap;
+    const unsigned char* Bp;
+    long a_plane, a_row, a_kt, a_col, b_plane, b_row, b_kt, b_col;
+    float* C;
+    int ldc, tiles_n;
+  } grp[4];
 };
 
 namespace f32p {
@@ -103,9 +119,15 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // 8 (l >> 4) .. + 3 and .. + 4 .. + 7 -- the two blocks a 32-lane half reads are 8 rows apart in the same columns: conflict-free.
 // A_KM (with B_KM: the weight-gradient products dW = dY^T . X, both operands [tokens][features] with the token as the reduction
 // index): the same image and the same transposing reads for A.
-template <int ABL, bool TRACE, bool B_KM, bool A_KM = false>
+// k-major images are addressed through FOUR byte strides: plane, k-row, k-tile (32 k-rows) and a_col / b_col = the stride of a
+// 128-column block, a quarter of which is the stride of a 32-column block: the natural image ([3][rows][cols]: 256) and the
+// tile-blocked image ([cols / 32][3][rows][32]: a_row = 64, a_kt = 2048, a_col = 4 x 3 x rows x 64) are both served -- the blocked
+// image of an activation then feeds its forward / dX product (k-contiguous A) AND its weight-gradient product (k-major).
+// GROUP: see GemmArgsP::grp.
+template <int ABL, bool TRACE, bool B_KM, bool A_KM = false, bool GROUP = false>
 __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
   static_assert(!A_KM || B_KM, "k-major A comes with k-major B (weight gradients)");
+  static_assert(!GROUP || A_KM, "grouped launches are weight gradients");
   constexpr int BM = 128, BN = 128, NS = 3;
   constexpr int PL_B = 128 * 64;       // bytes of one plane tile
   constexpr int OP_B = 3 * PL_B;       // one operand's stage: 24 KiB
@@ -120,9 +142,22 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
   const bool dma_wave = wave >= 4;
   const int w4 = wave & 3;
   const int wm = w4 >> 1, wn = w4 & 1;
-  const int bid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (bid / p.tiles_n) * BM;
-  const int n0 = (bid % p.tiles_n) * BN;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned char* Apl = p.Ap;
+  const unsigned char* Bpl = p.Bp;
+  long a_plane = p.a_plane, a_row = p.a_row, a_kt = p.a_kt, a_col = p.a_col, b_plane = p.b_plane, b_row = p.b_row, b_kt = p.b_kt, b_col = p.b_col;
+  float* Cp = p.C;
+  int ldc = p.ldc, tiles_n = p.tiles_n;
+  if constexpr (GROUP) {
+    const int q = (bid >= p.grp_tile_begin[1]) + (bid >= p.grp_tile_begin[2]) + (bid >= p.grp_tile_begin[3]);
+    const GemmArgsP::Prob& pb = p.grp[q];
+    bid -= p.grp_tile_begin[q];
+    Apl = pb.Ap; Bpl = pb.Bp; Cp = pb.C; ldc = pb.ldc; tiles_n = pb.tiles_n;
+    a_plane = pb.a_plane; a_row = pb.a_row; a_kt = pb.a_kt; a_col = pb.a_col;
+    b_plane = pb.b_plane; b_row = pb.b_row; b_kt = pb.b_kt; b_col = pb.b_col;
+  }
+  const int m0 = (bid / tiles_n) * BM;
+  const int n0 = (bid % tiles_n) * BN;
   const int kbeg = blockIdx.z * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
   const int nk = (kend - kbeg) / 32;
@@ -145,18 +180,18 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
       const int I = w4 * IW + i, plane = I >> 3, row = (I & 7) * 16 + (lane >> 2), cp = lane & 3;
       const int sc = cp ^ f32p::swz(row);
       if constexpr (!A_KM) {
-        pa[i] = p.Ap + plane * p.a_plane + (long)(m0 + row) * p.a_row + (long)(kbeg / 32) * p.a_kt + sc * 16;
+        pa[i] = Apl + plane * a_plane + (long)(m0 + row) * a_row + (long)(kbeg / 32) * a_kt + sc * 16;
       } else {
-        const int kr = (I & 7) * 4 + (lane >> 4), cpa = lane & 15;
-        pa[i] = p.Ap + plane * p.a_plane + (long)kr * p.a_row + (long)(kbeg / 32) * p.a_kt + (long)(m0 / 128) * p.a_col +
-                ((cpa ^ km_swz(kr)) << 4);
+        const int kr = (I & 7) * 4 + (lane >> 4), sca = (lane & 15) ^ km_swz(kr);  // source chunk: 8 columns, 4 chunks per 32-column block
+        pa[i] = Apl + plane * a_plane + (long)kr * a_row + (long)(kbeg / 32) * a_kt + (long)(m0 / 128) * a_col + (long)(sca >> 2) * (a_col >> 2) +
+                ((sca & 3) << 4);
       }
       if constexpr (!B_KM) {
-        pb[i] = p.Bp + plane * p.b_plane + (long)(n0 + row) * p.b_row + (long)(kbeg / 32) * p.b_kt + sc * 16;
+        pb[i] = Bpl + plane * b_plane + (long)(n0 + row) * b_row + (long)(kbeg / 32) * b_kt + sc * 16;
       } else {  // piece I = plane I / 8, 4 k-rows (I % 8) * 4 ..; lane -> k-row + lane / 16, chunk position lane % 16
-        const int kr = (I & 7) * 4 + (lane >> 4), cpb = lane & 15;
-        pb[i] = p.Bp + plane * p.b_plane + (long)kr * p.b_row + (long)(kbeg / 32) * p.b_kt + (long)(n0 / 128) * p.b_col +
-                ((cpb ^ km_swz(kr)) << 4);
+        const int kr = (I & 7) * 4 + (lane >> 4), scb = (lane & 15) ^ km_swz(kr);
+        pb[i] = Bpl + plane * b_plane + (long)kr * b_row + (long)(kbeg / 32) * b_kt + (long)(n0 / 128) * b_col + (long)(scb >> 2) * (b_col >> 2) +
+                ((scb & 3) << 4);
       }
     }
     auto issue = [&](int stage) __attribute__((always_inline)) {
@@ -165,12 +200,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
 #pragma unroll
       for (int i = 0; i < IW; ++i) {
         glds16x(pa[i], sa + i * 1024);
-        pa[i] += p.a_kt;
+        pa[i] += a_kt;
       }
 #pragma unroll
       for (int i = 0; i < IW; ++i) {
         glds16x(pb[i], sb + i * 1024);
-        pb[i] += p.b_kt;
+        pb[i] += b_kt;
       }
     };
     constexpr bool go = !(ABL & 2);
@@ -328,7 +363,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
   {
     constexpr int LDE = BN + 4, C4 = BN / 4;
     float* smem = reinterpret_cast<float*>(smem_p);
-    float* C = p.C + (long)blockIdx.z * p.slab_stride;
+    float* C = Cp + (long)blockIdx.z * p.slab_stride;
     const bool split = gridDim.z > 1;
     __syncthreads();
     if (!dma_wave) {
@@ -341,6 +376,68 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
           for (int r = 0; r < 4; ++r) smem[(wm * 64 + i * 16 + rq * 4 + r) * LDE + wn * 64 + j * 16 + c15] = acc[i][j][r];
     }
     __syncthreads();
+    if (p.Cpl && !split) {
+      // plane-image output: a thread takes 8 consecutive columns (one 16-byte chunk of each plane) of 4 rows; the 16 threads of a
+      // row cover its 128 columns, so a wave writes 4 rows x 64 contiguous bytes in each of the four 32-column blocks of the tile
+      const int c8 = tid & 15, rr = tid >> 4;  // (the same 8 columns for all four rows of a thread)
+      const int col = n0 + 8 * c8;
+      const long pl_b = (long)p.M * 64;
+      unsigned char* dstc = p.Cpl + (long)(col >> 5) * 3 * pl_b + (col & 31) * 2;
+      f32x4 cs0 = {0.f, 0.f, 0.f, 0.f}, cs1 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) { b0 = *reinterpret_cast<const f32x4*>(p.bias + col); b1 = *reinterpret_cast<const f32x4*>(p.bias + col + 4); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = rr + 32 * i;
+        const long row = m0 + r;
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(smem + r * LDE + 8 * c8) + b0;
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(smem + r * LDE + 8 * c8 + 4) + b1;
+        if (p.epi == EPI_GELU) {
+          *reinterpret_cast<f32x4*>(p.aux + row * p.ldaux + col) = v0;
+          *reinterpret_cast<f32x4*>(p.aux + row * p.ldaux + col + 4) = v1;
+          v0 = f32x4{gelu_erf(v0.x), gelu_erf(v0.y), gelu_erf(v0.z), gelu_erf(v0.w)};
+          v1 = f32x4{gelu_erf(v1.x), gelu_erf(v1.y), gelu_erf(v1.z), gelu_erf(v1.w)};
+        } else if (p.epi == EPI_DGELU) {
+          const f32x4 a0 = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
+          const f32x4 a1 = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col + 4);
+          v0 = f32x4{v0.x * gelu_erf_grad(a0.x), v0.y * gelu_erf_grad(a0.y), v0.z * gelu_erf_grad(a0.z), v0.w * gelu_erf_grad(a0.w)};
+          v1 = f32x4{v1.x * gelu_erf_grad(a1.x), v1.y * gelu_erf_grad(a1.y), v1.z * gelu_erf_grad(a1.z), v1.w * gelu_erf_grad(a1.w)};
+        }
+        if (Cp) {
+          if (p.accumulate) {
+            v0 += *reinterpret_cast<const f32x4*>(Cp + row * ldc + col);
+            v1 += *reinterpret_cast<const f32x4*>(Cp + row * ldc + col + 4);
+          }
+          *reinterpret_cast<f32x4*>(Cp + row * ldc + col) = v0;
+          *reinterpret_cast<f32x4*>(Cp + row * ldc + col + 4) = v1;
+        }
+        cs0 += v0;
+        cs1 += v1;
+        unsigned h[4], m[4], l[4];
+        f32p::split3_pair(f32x2p{v0.x, v0.y}, h[0], m[0], l[0]);
+        f32p::split3_pair(f32x2p{v0.z, v0.w}, h[1], m[1], l[1]);
+        f32p::split3_pair(f32x2p{v1.x, v1.y}, h[2], m[2], l[2]);
+        f32p::split3_pair(f32x2p{v1.z, v1.w}, h[3], m[3], l[3]);
+        unsigned char* d = dstc + row * 64;
+        *reinterpret_cast<uint4*>(d) = uint4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<uint4*>(d + pl_b) = uint4{m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<uint4*>(d + 2 * pl_b) = uint4{l[0], l[1], l[2], l[3]};
+      }
+      if (p.colpart) {  // column sums of the tile: 32 row groups through the LDS, summed in a fixed order
+        __syncthreads();  // (every thread has read its part of the image)
+        *reinterpret_cast<f32x4*>(smem + rr * 128 + 8 * c8) = cs0;
+        *reinterpret_cast<f32x4*>(smem + rr * 128 + 8 * c8 + 4) = cs1;
+        __syncthreads();
+        if (tid < 128) {
+          float t = 0.f;
+#pragma unroll 8
+          for (int g = 0; g < 32; ++g) t += smem[g * 128 + tid];
+          p.colpart[(long)(m0 / 128) * p.N + n0 + tid] = t;
+        }
+      }
+      if (TRACE && tr && lane == 0) tr[8 * 64 * 2 + 9 + wave] = __builtin_amdgcn_s_memtime();
+      return;
+    }
 #pragma unroll 2
     for (int idx = tid; idx < BM * C4; idx += 512) {
       const int r = idx / C4, c = (idx % C4) * 4;
@@ -361,9 +458,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
           const f32x4 t = *reinterpret_cast<const f32x4*>(p.aux + row * p.ldaux + col);
           v = v * (1.f - t * t);
         }
-        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * p.ldc + col);
+        if (p.accumulate) v += *reinterpret_cast<const f32x4*>(C + row * ldc + col);
       }
-      *reinterpret_cast<f32x4*>(C + row * p.ldc + col) = v;
+      *reinterpret_cast<f32x4*>(C + row * ldc + col) = v;
     }
   }
   if (TRACE && tr && lane == 0) tr[8 * 64 * 2 + 9 + wave] = __builtin_amdgcn_s_memtime();
@@ -392,6 +489,22 @@ static int launch_p16_t(const GemmArgsP& a, dim3 grid, hipStream_t st) {
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
+
+template <int ABL, bool TRACE, bool B_KM, bool A_KM, bool GROUP>
+static int launch_p16_g(const GemmArgsP& a, dim3 grid, hipStream_t st) {
+  constexpr size_t smem = (size_t)3 * 2 * 3 * 128 * 64;
+  auto kern = gemm_f32p16_kernel<ABL, TRACE, B_KM, A_KM, GROUP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, a);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+int launch_gemm_f32p16_group(const GemmArgsP& a, dim3 grid, hipStream_t st) { return launch_p16_g<0, false, true, true, true>(a, grid, st); }
 
 int launch_gemm_f32p16(const GemmArgsP& a, int a_km, int b_km, dim3 grid, hipStream_t st) {
   if (a_km && !b_km) return MTVAF_ERR_ARG;
@@ -435,11 +548,14 @@ int mtvaf_f32p_trace(void* buf) {
 // layout_b 1): A [K][M] as well -- their weight-gradient products dW = dY^T . X, reduction over the token rows.  M, N % 128 == 0,
 // K % 32 == 0.  splits > 1: split-K slabs
 // in `workspace` (deterministic ordered reduction, as mtvaf_gemm_f32).
-int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
-                    long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias, int epi,
-                    float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
-                    hipStream_t stream) {
-  if (!Aplanes || !Bplanes || !C || M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_ARG;
+static int gemm_f32p_run(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                         long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias, int epi,
+                         float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
+                         hipStream_t stream, int* keep_slabs, void* c_planes = nullptr, float* colpart = nullptr) {
+  if (!Aplanes || !Bplanes || (!C && !c_planes) || M <= 0 || N <= 0 || K <= 0) return MTVAF_ERR_ARG;
+  if (c_planes && (((uintptr_t)c_planes & 15) || (long)M * N * 6 >= (1L << 40))) return MTVAF_ERR_ALIGN;
+  if (colpart && !c_planes) return MTVAF_ERR_ARG;
+  if (c_planes) splits = 1;  // (the plane image is written by the epilogue of an unsplit launch)
   if (M % 128 || N % 128 || K % 32) return MTVAF_ERR_SHAPE;
   if ((epi == EPI_GELU || epi == EPI_DGELU || epi == EPI_DTANH) && !aux) return MTVAF_ERR_ARG;
   if ((ldc % 4) || (aux && ldaux % 4) || (((uintptr_t)Aplanes | (uintptr_t)Bplanes | (uintptr_t)C | (uintptr_t)aux | (uintptr_t)bias) & 15))
@@ -458,13 +574,77 @@ int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row,
   if (splits > 1) { a.C = (float*)workspace; a.ldc = N; a.slab_stride = (long)M * N; }
   else { a.C = C; a.ldc = ldc; a.slab_stride = 0; }
   a.tiles_n = N / 128;
+  a.Cpl = static_cast<unsigned char*>(c_planes);
+  a.colpart = colpart;
   a.ablate = ablate;
   a.trace = g_f32p_trace;
   dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
   const int rc = launch_gemm_f32p16(a, layout_a, layout_b, grid, stream);
   if (rc != MTVAF_OK) return rc;
+  if (keep_slabs) {  // (the caller's next kernel adds the slabs itself, in the reduction's order)
+    *keep_slabs = splits;
+    return MTVAF_OK;
+  }
   if (splits > 1) return launch_splitk_reduce((const float*)workspace, splits, C, M, N, ldc, bias, accumulate, epi, aux, ldaux, stream);
   return MTVAF_OK;
+}
+
+int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                    long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias, int epi,
+                    float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
+                    hipStream_t stream) {
+  return gemm_f32p_run(layout_a, Aplanes, a_plane, a_row, a_kt, a_col, layout_b, Bplanes, b_plane, b_row, b_kt, b_col, C, ldc, M, N, K, bias, epi,
+                       aux, ldaux, accumulate, splits, workspace, workspace_bytes, ablate, stream, nullptr);
+}
+
+// mtvaf_gemm_f32p (unsplit) whose result is written as a tile-blocked PLANE IMAGE c_planes [N / 32][3][M][32] -- beside the fp32
+// result (C != NULL) or instead of it (C == NULL: a tensor that only GEMMs read) -- and, optionally, its per-tile column sums
+// colpart [M / 128][N] (finished by mtvaf_colsum_small: the bias gradient behind a dX product).
+int mtvaf_gemm_f32p_ep(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                       long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, void* c_planes, float* colpart, int M, int N, int K,
+                       const float* bias, int epi, float* aux, int ldaux, int accumulate, hipStream_t stream) {
+  if (!c_planes) return MTVAF_ERR_ARG;
+  return gemm_f32p_run(layout_a, Aplanes, a_plane, a_row, a_kt, a_col, layout_b, Bplanes, b_plane, b_row, b_kt, b_col, C, ldc, M, N, K, bias, epi,
+                       aux, ldaux, C ? accumulate : 0, 1, nullptr, 0, 0, stream, nullptr, c_planes, colpart);
+}
+
+// mtvaf_gemm_f32p with a plain epilogue that leaves a split-K plan's slabs UNREDUCED (as mtvaf_gemm_f32_slabs): *splits_out = 1 -> C
+// holds the result (+ bias, accumulate); s > 1 -> `workspace` holds s slabs [M][N], neither bias nor accumulate applied, C untouched.
+int mtvaf_gemm_f32p_slabs(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
+                          long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, int M, int N, int K, const float* bias,
+                          int accumulate, int splits, void* workspace, size_t workspace_bytes, int* splits_out, hipStream_t stream) {
+  if (!splits_out) return MTVAF_ERR_ARG;
+  return gemm_f32p_run(layout_a, Aplanes, a_plane, a_row, a_kt, a_col, layout_b, Bplanes, b_plane, b_row, b_kt, b_col, C, ldc, M, N, K, bias,
+                       EPI_NONE, nullptr, 0, accumulate, splits, workspace, workspace_bytes, 0, stream, splits_out);
+}
+
+// Up to four weight-gradient products C_i [M_i][N_i] = A_i^T . B_i from plane images, A_i [K][M_i] and B_i [K][N_i] k-major (the
+// reduction index K -- the token rows -- is shared), in ONE launch that walks the 128 x 128 tiles of all of them back to back,
+// unsplit (research entry: what mtvaf_gemm_f32_dw_group's launch of the wave-specialised kernel would become with pre-split
+// operands; no bias sums, no k-tile list).  strides: per product eight byte strides a_plane, a_row, a_kt, a_col, b_plane, b_row,
+// b_kt, b_col (see mtvaf_gemm_f32p; tile-blocked images: row 64, k-tile 2048, col 12 x K x 64).  M_i, N_i % 128 == 0, K % 32 == 0.
+int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
+                             const int* M, const int* N, int K, hipStream_t stream) {
+  if (n < 1 || n > 4 || !Aplanes || !Bplanes || !strides || !C || !ldc || !M || !N || K <= 0 || K % 32) return MTVAF_ERR_ARG;
+  GemmArgsP a = {};
+  a.K = K; a.k_chunk = K; a.slab_stride = 0; a.epi = EPI_NONE; a.ngrp = n;
+  long tiles = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!Aplanes[i] || !Bplanes[i] || !C[i] || M[i] <= 0 || N[i] <= 0 || M[i] % 128 || N[i] % 128 || ldc[i] % 4) return MTVAF_ERR_SHAPE;
+    if ((((uintptr_t)Aplanes[i] | (uintptr_t)Bplanes[i] | (uintptr_t)C[i]) & 15)) return MTVAF_ERR_ALIGN;
+    for (int j = 0; j < 8; ++j)
+      if (strides[8 * i + j] & 15) return MTVAF_ERR_ALIGN;
+    GemmArgsP::Prob& q = a.grp[i];
+    q.Ap = static_cast<const unsigned char*>(Aplanes[i]); q.Bp = static_cast<const unsigned char*>(Bplanes[i]);
+    q.a_plane = strides[8 * i]; q.a_row = strides[8 * i + 1]; q.a_kt = strides[8 * i + 2]; q.a_col = strides[8 * i + 3];
+    q.b_plane = strides[8 * i + 4]; q.b_row = strides[8 * i + 5]; q.b_kt = strides[8 * i + 6]; q.b_col = strides[8 * i + 7];
+    q.C = C[i]; q.ldc = ldc[i]; q.tiles_n = N[i] / 128;
+    a.grp_tile_begin[i] = (int)tiles;
+    tiles += (long)(M[i] / 128) * (N[i] / 128);
+  }
+  for (int i = n; i < 5; ++i) a.grp_tile_begin[i] = (int)tiles;  // (absent products own no tiles)
+  a.M = M[0]; a.N = N[0]; a.tiles_n = N[0] / 128;
+  return launch_gemm_f32p16_group(a, dim3((unsigned)tiles, 1, 1), stream);
 }
 
 }  // extern "C"

@@ -100,7 +100,7 @@ class EmbeddingsFunction(torch.autograd.Function):
 class LayerWeights:
     """Device pointers of one encoder layer in kernel-ready (QKV-packed) form."""
     __slots__ = ("wqkv", "bqkv", "wo", "bo", "g1", "b1", "w1", "bi1", "w2", "bi2", "g2", "b2", "wparams", "_h", "flat", "_st",
-                 "_gst")
+                 "_gst", "_pl")
 
 
 def _bf16(*shape, like: torch.Tensor):
@@ -163,6 +163,47 @@ try:  # every optimizer step invalidates the bf16 weight shadows
 except Exception:  # pragma: no cover - very old torch: never cache
     _HAVE_OPT_HOOK = False
 BF16_WCACHE = os.environ.get("MTVAF_BF16_WCACHE", "1") != "0" and _HAVE_OPT_HOOK
+# fp32 mode, PRE-SPLIT OPERANDS (round 5; csrc/gemm_f32p.hip): on packed rows every GEMM operand of an encoder layer is read as a
+# tile-blocked plane image (the three bf16 planes of the split arithmetic, written once per tensor) by kernels that split nothing
+# inside their k-loops -- the eight forward / dX products and the layer's four weight gradients as one grouped launch.  Weights:
+# one image per layer, rewritten behind the optimizer's update of the layer (same stream) or rebuilt when the masters may have
+# changed, exactly as the bf16 shadows above.  MTVAF_F32_PLANES=0: the wave-specialised in-kernel-split path for everything.
+F32_PLANES = os.environ.get("MTVAF_F32_PLANES", "1") != "0" and _HAVE_OPT_HOOK
+
+
+def _f32_planes_on(use_h, pack, H, I) -> bool:
+    return bool(F32_PLANES and not use_h and pack is not None and H % 128 == 0 and I % 128 == 0 and hip.f32_split())
+
+
+def _wplane_fill(w: "LayerWeights", views):
+    for t, v in zip((w.wqkv, w.wo, w.w1, w.w2), views):
+        hip.split_planes_blocked(t, v)
+
+
+def _weights_planes(w: "LayerWeights"):
+    """-> the plane images of the layer's four weight matrices (uint8 views of one buffer), rebuilt when stale."""
+    ver = shadow_version(w) if not FORCE_SHADOW_REFRESH else None
+    c = w._pl
+    if ver is None or c is None or c[0] != ver:
+        if c is None:
+            mats = (w.wqkv, w.wo, w.w1, w.w2)
+            img = torch.empty(6 * sum(t.numel() for t in mats), dtype=torch.uint8, device=w.flat.device)
+            off, views = 0, []
+            for t in mats:
+                views.append(img[off:off + 6 * t.numel()])
+                off += 6 * t.numel()
+            c = w._pl = [None, img, tuple(views)]
+        _wplane_fill(w, c[2])
+        c[0] = ver
+    return c[2]
+
+
+def planes_rewrite(w: "LayerWeights"):
+    """Called from inside ``optimizer.step()`` (or the backward pass preceding it) on the stream of the layer's update: the plane
+    images are rebuilt from the updated masters and match them as they will be once this step's post-step hook has run."""
+    if w._pl is not None and F32_PLANES and hip.COMPUTE == "fp32":
+        _wplane_fill(w, w._pl[2])
+        w._pl[0] = shadow_version(w, 1)
 FORCE_SHADOW_REFRESH = False  # set while a whole-step graph is captured (mtvaf_amd.graph): the cast becomes a graph node
 BF16_OPERANDS = os.environ.get("MTVAF_BF16_OPERANDS", "1") != "0"  # 0: fp32-operand bf16 kernels only (gemm_bf16.hip)
 
@@ -349,32 +390,37 @@ def _layout(fields):
     return out, max(off, 256)
 
 
-def _fwd_layout(M, H, I, B, NH, S, use_h):
-    """Offsets of one layer's activation buffers inside its arena (one allocation per layer, saved for backward)."""
-    key = ("f", M, H, I, B, NH, S, use_h)
+def _fwd_layout(M, H, I, B, NH, S, use_h, planes=False):
+    """Offsets of one layer's activation buffers inside its arena (one allocation per layer, saved for backward).  planes: the
+    plane images of the GEMM operands the layer writes (pre-split operands, fp32 mode) -- 6 bytes per element."""
+    key = ("f", M, H, I, B, NH, S, use_h, planes)
     lay = _layouts.get(key)
     if lay is None:
         e = 2 if use_h else 4
+        pl = 6 if planes else 0
         lay = _layouts[key] = _layout([("qkv", M * 3 * H * e), ("cx", M * H * e), ("lse", B * NH * S * 4), ("a", M * H * 4),
                                        ("h1", M * H * 4), ("h1_h", M * H * 2 if use_h else 0), ("mean1", M * 4), ("rstd1", M * 4),
                                        ("pre", M * I * e), ("act", M * I * e), ("f", M * H * 4), ("h2", M * H * 4),
-                                       ("h2_h", M * H * 2 if use_h else 0), ("mean2", M * 4), ("rstd2", M * 4)])
+                                       ("h2_h", M * H * 2 if use_h else 0), ("mean2", M * 4), ("rstd2", M * 4),
+                                       ("cx_p", M * H * pl), ("h1_p", M * H * pl), ("act_p", M * I * pl), ("h2_p", M * H * pl)])
     return lay
 
 
-def _bwd_layout(M, H, I, B, NH, S, Pn, use_h):
-    key = ("b", M, H, I, B, NH, S, Pn, use_h)
+def _bwd_layout(M, H, I, B, NH, S, Pn, use_h, planes=False):
+    key = ("b", M, H, I, B, NH, S, Pn, use_h, planes)
     lay = _layouts.get(key)
     if lay is None:
         e = 2 if use_h else 4
         nqt, nkt = (S + 63) // 64, (Pn + S + 63) // 64
         lay = _layouts[key] = _layout([("dh1", M * H * 4), ("df", M * H * e), ("dpre", M * I * e), ("da", M * H * e),
                                        ("dctx", M * H * e), ("dqkv", M * 3 * H * e),
-                                       ("part", (M // 128) * I * 4 if use_h else 0), ("partq", B * nqt * H * 4 if use_h else 0),
+                                       ("part", (M // 128) * I * 4 if (use_h or planes) else 0), ("partq", B * nqt * H * 4 if use_h else 0),
                                        ("partkv", B * nkt * 2 * H * 4 if use_h else 0), ("delta", 0 if use_h else B * NH * S * 4),
                                        # (the layer's own LayerNorm-backward partials: their column sums run on the second stream)
                                        ("lnpart2", int(hip.lib().mtvaf_ln_bwd_workspace_bytes(M, H)) if LN_SUMS_ON_SIDE else 0),
-                                       ("lnpart1", int(hip.lib().mtvaf_ln_bwd_workspace_bytes(M, H)) if LN_SUMS_ON_SIDE else 0)])
+                                       ("lnpart1", int(hip.lib().mtvaf_ln_bwd_workspace_bytes(M, H)) if LN_SUMS_ON_SIDE else 0),
+                                       ("df_p", M * H * 6 if planes else 0), ("dpre_p", M * I * 6 if planes else 0),
+                                       ("da_p", M * H * 6 if planes else 0), ("dqkv_p", M * 3 * H * 6 if planes else 0)])
     return lay
 
 
@@ -393,7 +439,7 @@ def _exec_workspace_bytes(M, H, I, use_h):
     return max((8 if use_h else 16) * big * 4, 512 * 4 * H * 4, 64 * max(3 * H, I) * 4, 64 << 20)
 
 
-def _layer_struct(w: LayerWeights, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed):
+def _layer_struct(w: LayerWeights, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed, planes=False):
     c = w._st
     key = (B, S, Pn, NH, H, I, use_h, w.flat.data_ptr())
     if c is None or c[0] != key:  # shapes and parameter pointers: refilled only when they change
@@ -410,6 +456,14 @@ def _layer_struct(w: LayerWeights, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_a
         if c[2] is not wh:
             st.wqkv_h, st.wo_h, st.w1_h, st.w2_h = (t.data_ptr() for t in wh)
             c[2] = wh
+    elif planes:
+        wp = _weights_planes(w)  # (fp32 mode: the same four fields carry the weights' plane images)
+        if c[2] is not wp:
+            st.wqkv_h, st.wo_h, st.w1_h, st.w2_h = (t.data_ptr() for t in wp)
+            c[2] = wp
+    elif c[2] is not None:
+        st.wqkv_h = st.wo_h = st.w1_h = st.w2_h = None
+        c[2] = None
     return st
 
 
@@ -438,9 +492,16 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
         if use_h:
             pkv_k = _bf16(*pkv.shape, like=x)  # one cast of all layers' prefix slabs per step
             hip.cast_bf16(pkv.view(-1, pkv.shape[3]), out=pkv_k.view(-1, pkv.shape[3]))
-    (lay, total) = _fwd_layout(M, H, I, B, NH, S, use_h)
+    planes = _f32_planes_on(use_h, pack, H, I)
+    (lay, total) = _fwd_layout(M, H, I, B, NH, S, use_h, planes)
     o_h2 = dict(lay)["h2"]
     o_h2h = dict(lay)["h2_h"]
+    o_h2p = dict(lay)["h2_p"]
+    x0_p = None
+    if planes:  # the first layer's input as a plane image (every later layer's is written by the layer before it)
+        x0_p = torch.empty(M * H * 6, dtype=torch.uint8, device=dev)
+        hip.split_planes_blocked(x, x0_p)
+    xp_ptr = x0_p.data_ptr() if planes else None
     ws = None if use_h else hip.workspace(_exec_workspace_bytes(M, H, I, use_h), dev)
     fn, stream = hip.lib().mtvaf_encoder_layer_fwd, hip._st()
     pk_ptr = pkv_k.data_ptr() if Pn else 0
@@ -453,7 +514,7 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
         off = RNG.next(3)
         arena = torch.empty(total, dtype=torch.uint8, device=dev)
         base = arena.data_ptr()
-        st = _layer_struct(w, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed)
+        st = _layer_struct(w, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed, planes)
         st.offset = off
         st.cu, st.Mv, st.Mp = (pack.cu.data_ptr(), pack.Mv, pack.Mp) if pack is not None else (None, 0, 0)
         st.x, st.x_h, st.addmask = x_ptr, xh_ptr, am_ptr
@@ -461,6 +522,11 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
         st.pv = (pk_ptr + li * pk_layer + pk_step) if Pn else None
         for name, o in lay:
             setattr(st, name, base + o if o >= 0 else None)
+        st.x_p = xp_ptr
+        if planes:
+            xp_ptr = base + o_h2p
+            if li == L - 1:
+                st.h2_p = None  # (nobody multiplies the last layer's output)
         st.ws, st.ws_bytes = (ws.data_ptr(), ws.numel()) if ws is not None else (None, 0)
         hip._ck(fn(ctypes.byref(st), stream), "mtvaf_encoder_layer_fwd")
         h2 = arena[o_h2:o_h2 + M * H * 4].view(torch.float32)
@@ -473,8 +539,9 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
         arenas.append(arena)
         offs.append(off)
         x_ptr, xh_ptr = base + o_h2, (base + o_h2h if use_h else 0)
-    saved = [x] + ([x0_h] if use_h else []) + arenas
+    saved = [x] + ([x0_h] if use_h else []) + ([x0_p] if planes else []) + arenas
     ctx.save_for_backward(*saved)
+    ctx.planes = planes
     ctx.stash = (offs, weights, pkv, addmask, cfg, seed, (B, S, H, Pn), grad_sink, params)
     ctx.native = (use_h, pkv_k if (use_h and Pn) else None)
     ctx.pack = pack
@@ -531,7 +598,9 @@ def _native_backward(ctx, douts):
     saved = ctx.saved_tensors
     x0 = saved[0]
     x0_h = saved[1] if use_h else None
-    arenas = saved[2:] if use_h else saved[1:]
+    planes = bool(getattr(ctx, "planes", False))
+    x0_p = saved[1] if planes else None
+    arenas = saved[2:] if (use_h or planes) else saved[1:]
     NH, eps, p_hidden, p_attn = cfg[:4]
     pack = ctx.pack
     L, M = len(weights), (pack.Mp if pack is not None else B * S)
@@ -570,8 +639,8 @@ def _native_backward(ctx, douts):
         ws_side = ws_main
     if use_h and need_param_grads:
         _streamk_on(side, dev)  # the executor groups the layer's weight-gradient products when its dW stream has a scratch
-    (flay, _), (blay, btotal) = _fwd_layout(M, H, I, B, NH, S, use_h), _bwd_layout(M, H, I, B, NH, S, Pn, use_h)
-    o_h2, o_h2h = dict(flay)["h2"], dict(flay)["h2_h"]
+    (flay, _), (blay, btotal) = _fwd_layout(M, H, I, B, NH, S, use_h, planes), _bwd_layout(M, H, I, B, NH, S, Pn, use_h, planes)
+    o_h2, o_h2h, o_h2p = dict(flay)["h2"], dict(flay)["h2_h"], dict(flay)["h2_p"]
     fn = hip.lib().mtvaf_encoder_layer_bwd
     pk_src = pkv16 if use_h else pkv
     pk_ptr = pk_src.data_ptr() if Pn else 0
@@ -623,7 +692,7 @@ def _native_backward(ctx, douts):
         else:
             G = [torch.empty_like(p) for p in params[base_i:base_i + N_LAYER_PARAMS]]
             dwqkv, dbqkv = _empty(3 * H, H, like=x0), _empty(3 * H, like=x0)
-        st = _layer_struct(w, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed)
+        st = _layer_struct(w, B, S, Pn, NH, H, I, use_h, eps, p_hidden, p_attn, seed, planes)
         st.offset = offs[li]
         st.cu, st.Mv, st.Mp = (pack.cu.data_ptr(), pack.Mv, pack.Mp) if pack is not None else (None, 0, 0)
         base = arenas[li].data_ptr()
@@ -631,9 +700,11 @@ def _native_backward(ctx, douts):
             setattr(st, name, base + o if o >= 0 else None)
         if li == 0:
             st.x, st.x_h = x0.data_ptr(), (x0_h.data_ptr() if use_h else None)
+            st.x_p = x0_p.data_ptr() if planes else None
         else:
             pb = arenas[li - 1].data_ptr()
             st.x, st.x_h = pb + o_h2, (pb + o_h2h if use_h else None)
+            st.x_p = (pb + o_h2p) if planes else None
         st.addmask = am_ptr
         st.pk = (pk_ptr + li * pk_layer) if Pn else None
         st.pv = (pk_ptr + li * pk_layer + pk_step) if Pn else None

@@ -41,6 +41,9 @@ _SIGS = {
     "mtvaf_f32_split_planes": (c_int, [P, P, I, I, I, L, L, L, P]),
     "mtvaf_gemm_f32p": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, P]),
     "mtvaf_f32p_trace": (c_int, [P]),
+    "mtvaf_gemm_f32p_dw_group": (c_int, [I, P, P, P, P, P, P, P, I, P]),
+    "mtvaf_gemm_f32p_slabs": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, I, P, SZ, P, P]),
+    "mtvaf_gemm_f32p_ep": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, P, P, I, I, I, P, I, P, I, I, P]),
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
     "mtvaf_prefix_attn_fwd": (c_int, [P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
@@ -121,7 +124,8 @@ class LayerStruct(ctypes.Structure):
                 [(n, c_void_p) for n in ("wqkv", "wo", "w1", "w2", "wqkv_h", "wo_h", "w1_h", "w2_h", "bqkv", "bo", "g1", "b1",
                                          "bi1", "bi2", "g2", "b2", "x", "x_h", "pk", "pv", "addmask", "qkv", "cx", "lse", "a",
                                          "h1", "h1_h", "mean1", "rstd1", "pre", "act", "f", "h2", "h2_h", "mean2", "rstd2",
-                                         "ws")] + [("ws_bytes", c_size_t), ("cu", c_void_p), ("Mv", c_int), ("Mp", c_int)])
+                                         "ws")] + [("ws_bytes", c_size_t), ("cu", c_void_p), ("Mv", c_int), ("Mp", c_int)] +
+                [(n, c_void_p) for n in ("x_p", "cx_p", "h1_p", "act_p", "h2_p")])
 
 
 class LayerGradsStruct(ctypes.Structure):
@@ -131,7 +135,8 @@ class LayerGradsStruct(ctypes.Structure):
                                          "db2", "dpk", "dpv", "ws_main")] + [("ws_main_bytes", c_size_t), ("ws_side", c_void_p),
                                                                             ("ws_side_bytes", c_size_t), ("klist", c_void_p),
                                                                             ("kcnt", c_void_p), ("zero_tail", c_int),
-                                                                            ("lnpart2", c_void_p), ("lnpart1", c_void_p)])
+                                                                            ("lnpart2", c_void_p), ("lnpart1", c_void_p)] +
+                [(n, c_void_p) for n in ("df_p", "dpre_p", "da_p", "dqkv_p")])
 
 
 _lib = None
@@ -302,7 +307,7 @@ class Planes:
     [k-tile][plane][rows][32] (every 1-KiB request of the kernel reads contiguous memory) or natural [3][rows][cols]."""
     __slots__ = ("img", "s_plane", "s_row", "s_kt", "rows", "cols")
 
-    def __init__(self, x: torch.Tensor, blocked: bool = True):
+    def __init__(self, x: torch.Tensor, blocked: bool = True, fill: bool = True):
         rows, cols = x.shape
         self.rows, self.cols = rows, cols
         self.img = torch.empty(3 * rows * cols, dtype=torch.bfloat16, device=x.device)
@@ -310,27 +315,43 @@ class Planes:
             self.s_plane, self.s_row, self.s_kt = rows * 64, 64, 3 * rows * 64
         else:
             self.s_plane, self.s_row, self.s_kt = rows * cols * 2, cols * 2, 64
-        self.refresh(x)
+        if fill:  # (False: an image some kernel is about to write; x only gives the shape)
+            self.refresh(x)
 
     def refresh(self, x: torch.Tensor):
         _ck(lib().mtvaf_f32_split_planes(_p(x), _p(self.img), self.rows, self.cols, x.stride(0), self.s_plane, self.s_row, self.s_kt,
                                          _st()), "mtvaf_f32_split_planes")
 
 
+def gemm_planes_ep(a: "Planes", b: "Planes", out_planes: "Planes", out=None, bias=None, epi=EPI_NONE, aux=None, colpart=None, layout_b=KC):
+    """mtvaf_gemm_f32p_ep: the product of two plane images written as the (tile-blocked) plane image `out_planes` -- and as fp32 `out`
+    too unless None; colpart [M / 128, N]: per-tile column sums."""
+    if layout_b == KM:
+        M, N, K = a.rows, b.cols, a.cols
+        bs = _km_strides(b)
+    else:
+        M, N, K = a.rows, b.rows, a.cols
+        bs = (b.s_plane, b.s_row, b.s_kt, 0)
+    assert (out_planes.rows, out_planes.cols) == (M, N) and out_planes.s_row == 64, "the result image is tile-blocked"
+    _ck(lib().mtvaf_gemm_f32p_ep(KC, _p(a.img), a.s_plane, a.s_row, a.s_kt, 0, layout_b, _p(b.img), bs[0], bs[1], bs[2], bs[3], _p(out),
+                                 out.stride(0) if out is not None else 0, _p(out_planes.img), _p(colpart), M, N, K, _p(bias), epi, _p(aux),
+                                 aux.stride(0) if aux is not None else 0, 0, _st()), "mtvaf_gemm_f32p_ep")
+    return out_planes
+
+
 def gemm_planes(a: Planes, b: Planes, out, bias=None, epi=EPI_NONE, aux=None, accumulate=False, splits=1, ablate=0, layout_b=KC,
                 layout_a=KC):
-    """out[M,N] = A[M,K] . B[N,K]^T (layout_b = KC) or A[M,K] . B[K,N] (layout_b = KM: `b` must be a NATURAL plane image of the
-    [K, N] matrix) from the plane images of both operands (mtvaf_gemm_f32p)."""
-    if layout_a == KM:  # weight gradients: out[M,N] = A[K,M]^T . B[K,N], both natural plane images
-        assert layout_b == KM and a.s_row == a.cols * 2 and b.s_row == b.cols * 2 and a.rows == b.rows
+    """out[M,N] = A[M,K] . B[N,K]^T (layout_b = KC) or A[M,K] . B[K,N] (layout_b = KM: `b` is the plane image of the [K, N]
+    matrix, natural or tile-blocked) from the plane images of both operands (mtvaf_gemm_f32p)."""
+    if layout_a == KM:  # weight gradients: out[M,N] = A[K,M]^T . B[K,N] (natural or tile-blocked images)
+        assert layout_b == KM and a.rows == b.rows
         M, N, K = a.cols, b.cols, a.rows
-        as_ = (a.s_plane, a.s_row, 32 * a.s_row, 256)
-        bs = (b.s_plane, b.s_row, 32 * b.s_row, 256)
+        as_, bs = _km_strides(a), _km_strides(b)
     elif layout_b == KM:
         M, N, K = a.rows, b.cols, a.cols
-        assert b.rows == K and b.s_row == b.cols * 2, "k-major B: natural plane image of the [K, N] matrix"
+        assert b.rows == K, "k-major B: the plane image of the [K, N] matrix"
         as_ = (a.s_plane, a.s_row, a.s_kt, 0)
-        bs = (b.s_plane, b.s_row, 32 * b.s_row, 256)
+        bs = _km_strides(b)
     else:
         M, N, K = a.rows, b.rows, a.cols
         as_ = (a.s_plane, a.s_row, a.s_kt, 0)
@@ -344,6 +365,36 @@ def gemm_planes(a: Planes, b: Planes, out, bias=None, epi=EPI_NONE, aux=None, ac
                               _p(bias), epi, _p(aux), aux.stride(0) if aux is not None else 0, int(accumulate), splits, _p(ws), wsb,
                               ablate, _st()), "mtvaf_gemm_f32p")
     return out
+
+
+def split_planes_blocked(x: torch.Tensor, out: torch.Tensor):
+    """fp32 [rows, cols] (contiguous) -> its tile-blocked plane image [cols / 32][3][rows][32] bf16 in `out` (6 rows cols bytes)."""
+    rows, cols = x.shape
+    _ck(lib().mtvaf_f32_split_planes(_p(x), _p(out), rows, cols, x.stride(0), rows * 64, 64, 3 * rows * 64, _st()), "mtvaf_f32_split_planes")
+    return out
+
+
+def _km_strides(pl: "Planes"):
+    """(plane, k-row, k-tile, 128-column block) byte strides of a plane image read K-MAJOR (its rows are the reduction index)."""
+    if pl.s_row == pl.cols * 2:  # natural [3][rows][cols]
+        return (pl.s_plane, pl.s_row, 32 * pl.s_row, 256)
+    return (pl.s_plane, 64, 32 * 64, 4 * pl.s_kt)  # tile-blocked [cols / 32][3][rows][32]: a 32-column block is pl.s_kt apart
+
+
+def gemm_planes_dw_group(items):
+    """items: up to four (a: Planes of dY [K, M], b: Planes of X [K, N], out [M, N] fp32): out = dY^T . X for each, one unsplit launch
+    (mtvaf_gemm_f32p_dw_group; natural or tile-blocked images)."""
+    n = len(items)
+    K = items[0][0].rows
+    assert all(a.rows == K and b.rows == K for a, b, _ in items)
+    vp = lambda ts: (ctypes.c_void_p * n)(*[_p(t) for t in ts])
+    ia = lambda xs: (ctypes.c_int * n)(*xs)
+    st = []
+    for a, b, _ in items:
+        st += list(_km_strides(a)) + list(_km_strides(b))
+    _ck(lib().mtvaf_gemm_f32p_dw_group(n, vp([a.img for a, _, _ in items]), vp([b.img for _, b, _ in items]), (ctypes.c_long * (8 * n))(*st),
+                                       vp([o for _, _, o in items]), ia([o.stride(0) for _, _, o in items]), ia([a.cols for a, _, _ in items]),
+                                       ia([b.cols for _, b, _ in items]), K, _st()), "mtvaf_gemm_f32p_dw_group")
 
 
 def set_compute_dtype(dtype: str):

@@ -170,6 +170,7 @@ class _LayerStore:
         (w.wo, w.bo, w.g1, w.b1, w.w1, w.bi1, w.w2, w.bi2, w.g2, w.b2) = [p.data for p in ps[6:]]
         w.wparams = (ps[0], ps[2], ps[4], ps[6], ps[10], ps[12])  # the weight matrices' Parameters (version counters)
         w._h = None
+        w._pl = None
         w._st = None
         w._gst = None
         w.flat = self.flat

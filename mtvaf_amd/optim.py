@@ -156,6 +156,7 @@ class AdamW(torch.optim.Optimizer):
                   st["step"], p_bf16=shadow, max_blocks=self.BACKGROUND_BLOCKS if background else 0)
         if shadow is not None:
             engine.shadow_written(store.weights)
+        engine.planes_rewrite(store.weights)  # fp32 mode: the weights' plane images, rebuilt behind the update on its stream
 
     def _early_layer_update(self, li: int):
         """Called from inside the backward pass (current stream: the one the layer's gradients are final on)."""

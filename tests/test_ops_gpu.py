@@ -1426,12 +1426,74 @@ def test_gemm_f32_presplit_planes_accuracy_and_epilogues(hip, M, N, K, spread):
         hip.gemm_planes(pa3, pb3, o_dw, layout_a=hip.KM, layout_b=hip.KM)
         e = (o_dw.double().cpu() - ref3).abs() / mag3
         assert float(e.max()) <= 2.0 ** -24 * (4 + K ** 0.5), ("k-major A and B", float(e.max()))
+        # the TILE-BLOCKED images serve the k-major reads too (same planes at other addresses: the same bits), also for the dX form
+        o_b = torch.full((M, N), float("nan"), device=DEV)
+        hip.gemm_planes(hip.Planes(a3, True), hip.Planes(b3, True), o_b, layout_a=hip.KM, layout_b=hip.KM)
+        assert torch.equal(o_b, o_dw), "k-major reads of tile-blocked images"
+        o_b.fill_(float("nan"))
+        hip.gemm_planes(pa2, hip.Planes(b2, True), o_b, layout_b=hip.KM)
+        assert torch.equal(o_b, o_km), "k-major B from a tile-blocked image"
     if K >= 64:
         o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
         hip.gemm_planes(pa, pb, o1, bias=bias, splits=2)
         hip.gemm_planes(pa, pb, o2, bias=bias, splits=2)
         close(o1, ref + bias.double().cpu(), rtol=3e-6, atol=3e-6 * scale, name="split-K 2")
         assert torch.equal(o1, o2), "split-K must be deterministic"
+
+
+def test_gemm_f32_presplit_result_as_plane_image_and_column_partials(hip):
+    """mtvaf_gemm_f32p_ep (round 5): the product leaves its epilogue as a tile-blocked plane image -- exactly the planes a split
+    pass over the fp32 result would write (GELU forward with the saved pre-activation; GELU' backward with per-tile column sums: the
+    FFN-1 bias gradient), with and without the fp32 copy."""
+    M, N, K = 256, 384, 256
+    x, w, bias = rnd(M, K, seed=51).to(DEV), rnd(N, K, seed=52).to(DEV), rnd(N, seed=53).to(DEV)
+    pa, pb = hip.Planes(x, True), hip.Planes(w, True)
+    out, pre = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    hip.gemm_planes(pa, pb, out, bias=bias, epi=hip.EPI_GELU, aux=pre)
+    want = hip.Planes(out, True)
+    for with_c in (True, False):
+        o2, pre2 = torch.full((M, N), float("nan"), device=DEV), torch.full((M, N), float("nan"), device=DEV)
+        got = hip.Planes(out, True, fill=False)
+        got.img.fill_(float("nan"))
+        hip.gemm_planes_ep(pa, pb, got, out=o2 if with_c else None, bias=bias, epi=hip.EPI_GELU, aux=pre2)
+        assert torch.equal(got.img.view(torch.int16), want.img.view(torch.int16)), with_c
+        assert torch.equal(pre2, pre)
+        if with_c:
+            assert torch.equal(o2, out)
+    # the dX form with GELU' and the column partials
+    dy, w2 = rnd(M, K, seed=54).to(DEV), rnd(K, N, seed=55).to(DEV)   # dX [M, N] = dy [M, K] . w2 [K, N]
+    pd, pw = hip.Planes(dy, True), hip.Planes(w2, True)
+    dx = torch.empty(M, N, device=DEV)
+    hip.gemm_planes(pd, pw, dx, epi=hip.EPI_DGELU, aux=pre, layout_b=hip.KM)
+    want = hip.Planes(dx, True)
+    got = hip.Planes(dx, True, fill=False)
+    part = torch.full((M // 128, N), float("nan"), device=DEV)
+    hip.gemm_planes_ep(pd, pw, got, epi=hip.EPI_DGELU, aux=pre, colpart=part, layout_b=hip.KM)
+    assert torch.equal(got.img.view(torch.int16), want.img.view(torch.int16))
+    close(part.sum(0), dx.double().sum(0), rtol=1e-5, atol=1e-5 * float(dx.double().sum(0).abs().max()), name="column sums")
+    close(part[1], dx[128:].double().sum(0), rtol=1e-5, atol=1e-5 * float(dx.double().sum(0).abs().max()), name="second tile row")
+
+
+def test_gemm_f32_presplit_planes_grouped_weight_gradients(hip):
+    """mtvaf_gemm_f32p_dw_group (research entry, round 5): the four weight-gradient products of a layer from plane images in ONE
+    unsplit launch -- the same bits as one launch per product, from natural and from tile-blocked images, with fewer than four
+    products too."""
+    K, Hh, Ii = 384, 128, 256
+    dys = [rnd(K, w, seed=30 + i).to(DEV) for i, w in enumerate((Hh, Ii, Hh, 3 * Hh))]
+    xs = [rnd(K, w, seed=40 + i).to(DEV) for i, w in enumerate((Ii, Hh, Hh, Hh))]
+    for blocked in (False, True):
+        pas, pbs = [hip.Planes(t, blocked) for t in dys], [hip.Planes(t, blocked) for t in xs]
+        singles = []
+        for pa, pb in zip(pas, pbs):
+            o = torch.empty(pa.cols, pb.cols, device=DEV)
+            hip.gemm_planes(pa, pb, o, layout_a=hip.KM, layout_b=hip.KM)
+            singles.append(o)
+        close(singles[0], dys[0].double().cpu().t() @ xs[0].double().cpu(), rtol=3e-6, name="one product")
+        for n in (4, 2, 1):
+            outs = [torch.full_like(o, float("nan")) for o in singles[:n]]
+            hip.gemm_planes_dw_group(list(zip(pas[:n], pbs[:n], outs)))
+            for i in range(n):
+                assert torch.equal(outs[i], singles[i]), (blocked, n, i)
 
 
 def test_layernorm_adds_the_split_k_slabs_itself_bit_for_bit(hip):

@@ -317,3 +317,72 @@ def test_contract_check_trips_on_a_head_that_reads_masked_positions(unpad):
     finally:
         engine.CHECK_CONTRACT = was
         m.zero_grad(set_to_none=True)
+
+
+def test_presplit_operand_path_against_the_in_kernel_split_path():
+    """Round 5 (engine.F32_PLANES): on packed rows the encoder's GEMM operands are plane images read by the pre-split kernels
+    (csrc/gemm_f32p.hip: forward, dX and the grouped weight gradients) instead of fp32 tensors split tile by tile.  The same
+    products of the same planes in a different accumulation grouping: three optimizer steps (AdamW updates issued from inside
+    backward, the weights' images rewritten behind them) track the in-kernel-split run to rounding -- loss, tags, every gradient,
+    the weights after the steps; and after the masters change behind the optimizer's back (load_state_dict, an in-place update
+    through a Parameter) the next forward has rebuilt the images."""
+    import copy
+    from mtvaf_amd import hip
+    from mtvaf_amd.optim import AdamW
+    if not hip.f32_split():
+        pytest.skip("plane images belong to the split arithmetic")
+    cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=2, max_pos=512)
+    B, S = 16, 128
+    ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 95, B, S, lo_id=1000))
+    feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(96, B, 8))
+    kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+    state = copy.deepcopy(_props_model(cfg, "bert-base-uncased", dropout=0.1).state_dict())
+
+    def run(planes):
+        was_p, was_u = engine.F32_PLANES, engine.UNPAD
+        engine.F32_PLANES, engine.UNPAD = planes, True
+        try:
+            m = _props_model(cfg, "bert-base-uncased", dropout=0.1).train()
+            m.load_state_dict(state)
+            opt = AdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-2, model=m, overlap=True)
+            out = []
+            for step in range(3):
+                engine.RNG.offset = 1000 * step  # (both runs draw the same dropout masks)
+                torch.manual_seed(7 + step)
+                o = m(**kw)
+                o.loss.backward()
+                grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+                out.append((float(o.loss.detach()), list(o.logits), grads))
+            torch.cuda.synchronize()
+            used = m.bert.encoder._stores[0].weights._pl is not None
+            after = {n: p.detach().clone() for n, p in m.named_parameters() if "encoder.layer" in n}
+            with torch.no_grad():
+                m.bert.encoder.layer[1].intermediate.dense.weight.mul_(0.5)
+            sd = {k: (v * 1.25 if k.endswith("layer.0.attention.output.dense.weight") else v) for k, v in m.state_dict().items()}
+            m.load_state_dict(sd)
+            m.eval()
+            o = m(**kw)
+            torch.cuda.synchronize()
+            return out, float(o.loss.detach()), list(o.logits), used, after
+        finally:
+            engine.F32_PLANES, engine.UNPAD = was_p, was_u
+
+    r1, l1, t1, used1, w1 = run(True)
+    r0, l0, t0, used0, w0 = run(False)
+    assert used1 and not used0, "the plane images were not built / were built with the switch off"
+    for step, ((la, ta, ga), (lb, tb, gb)) in enumerate(zip(r1, r0)):
+        assert abs(la - lb) <= (3e-6 if step == 0 else 2e-5) * abs(lb), (step, la, lb)
+        assert ta == tb, step
+        assert set(ga) == set(gb)
+        for n in ga:
+            # (step 0: the same weights, rounding of the products only; later steps: two trajectories one rounding apart)
+            tol = (1e-4 if "word_embeddings" in n else 3e-5) * (1 if step == 0 else 10)
+            close(ga[n], gb[n], rtol=tol, atol=(6e-6 if step == 0 else 6e-5) * float(gb[n].abs().max()) + 1e-9, name=f"step {step} {n}")
+    assert abs(l1 - l0) <= 2e-5 * abs(l0) and t1 == t0
+    for n in w0:
+        # (AdamW normalises the gradient: where it is tiny, one rounding of it moves the update by a visible fraction of lr = 1e-4)
+        # -- so: no element further apart than the three steps can carry a sign flip (3 lr), all but a handful within 0.3 lr
+        err = (w1[n] - w0[n]).abs()
+        assert float(err.max()) <= 3e-4 and float((err > 3e-5).float().mean()) <= 1e-5, (n, float(err.max()), int((err > 3e-5).sum()))

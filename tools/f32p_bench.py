@@ -141,6 +141,21 @@ def main():
             tot_ws += us_ws
             tot_p += best
         print(f"M={M}: four weight-gradient products, one launch each: ws {tot_ws:.0f} us, P16 (best split) {tot_p:.0f} us", flush=True)
+        # ... and the four in ONE unsplit launch: the wave-specialised kernel's grouped launch (the product path; here without its bias
+        # sums) against the P16 kernel's (mtvaf_gemm_f32p_dw_group), natural and tile-blocked images
+        prods = [(dy, x3), (dy3, x), (dy, x), (dyq, x)]
+        outs = [torch.empty(a.shape[1], b.shape[1], device=dev) for a, b in prods]
+        us_ws = t(lambda: hip.gemm_f32_dw_group([(a, b, o) for (a, b), o in zip(prods, outs)], M))
+        fl = sum(2.0 * a.shape[1] * b.shape[1] * M for a, b in prods)
+        line = f"M={M} grouped dW (432 tiles) | ws {us_ws:6.1f} us {fl / us_ws / 1e6:5.1f} TF"
+        for blocked in (False, True):
+            items = [(hip.Planes(a, blocked), hip.Planes(b, blocked), o) for (a, b), o in zip(prods, outs)]
+            run_p = lambda: hip.gemm_planes_dw_group(items)
+            run_p()
+            err = max(float((o.double() - a.double().t() @ b.double()).abs().max() / (a.double().t() @ b.double()).abs().max()) for (a, b), o in zip(prods, outs))
+            us_p = t(run_p)
+            line += f" | P16 {'blocked' if blocked else 'natural'} images {us_p:6.1f} us {fl / us_p / 1e6:5.1f} TF err {err:.1e}"
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
