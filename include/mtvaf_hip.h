@@ -318,6 +318,18 @@ int mtvaf_dropout_res_ln_bwd_rows_slabs(const float* dout_base, const float* sla
                                         const float* gamma, const float* mean, const float* rstd, float* dx, float* dres,
                                         int dres_accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset, float* part,
                                         void* dx_bf16, mtvaf_stream_t st);
+/* Round 5, pre-split operands: the two LayerNorm kernels that ALSO write the tile-blocked plane image [H / 32][3][M][32] of their
+ * output (H % 32 == 0), bit for bit what mtvaf_f32_split_planes would write behind them.  _fwd_planes: nslab == 0 -> x is the dense
+ * output (as mtvaf_dropout_res_ln_fwd), nslab >= 1 -> x = the product's unreduced slabs (as mtvaf_dropout_res_ln_fwd_slabs).
+ * _bwd_rows_planes: nslab == 0 -> dout = dout_base (as mtvaf_dropout_res_ln_bwd_rows), nslab >= 1 -> dout = slabs + dout_base; dx may
+ * be NULL (a gradient only GEMMs read). */
+int mtvaf_dropout_res_ln_fwd_planes(const float* x, int nslab, const float* bias, float* x_out, const float* res, const float* gamma,
+                                    const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop,
+                                    uint64_t seed, uint64_t offset, void* out_planes, mtvaf_stream_t st);
+int mtvaf_dropout_res_ln_bwd_rows_planes(const float* dout_base, const float* slabs, int nslab, const float* x, const float* res,
+                                         const float* gamma, const float* mean, const float* rstd, float* dx, float* dres,
+                                         int dres_accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset, float* part,
+                                         void* dx_planes, mtvaf_stream_t st);
 int mtvaf_f32x3_trace(void* buf);
 
 /* Pre-split operands (csrc/gemm_f32p.hip, round 5; the same nn.Linear products, modeling_bert.py:266, 283-284, 353, 420-421,

@@ -109,6 +109,13 @@ int mtvaf_dropout_res_ln_bwd_rows_slabs(const float* dout_base, const float* sla
                                         const float* gamma, const float* mean, const float* rstd, float* dx, float* dres,
                                         int dres_accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset, float* part,
                                         void* dx_bf16, hipStream_t st);
+int mtvaf_dropout_res_ln_fwd_planes(const float* x, int nslab, const float* bias, float* x_out, const float* res, const float* gamma,
+                                    const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop,
+                                    uint64_t seed, uint64_t offset, void* out_planes, hipStream_t st);
+int mtvaf_dropout_res_ln_bwd_rows_planes(const float* dout_base, const float* slabs, int nslab, const float* x, const float* res,
+                                         const float* gamma, const float* mean, const float* rstd, float* dx, float* dres,
+                                         int dres_accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset, float* part,
+                                         void* dx_planes, hipStream_t st);
 int mtvaf_dropout_res_ln_bwd(const float* dout, const float* x, const float* res, const float* gamma, const float* mean,
                              const float* rstd, float* dx, float* dres, int dres_accumulate, float* dgamma, float* dbeta,
                              float* dbias_x, int accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset,
@@ -267,12 +274,27 @@ static bool planes_mode(const mtvaf_layer_t* L) {
 }
 
 // dense product on the pre-split kernel (+ bias) -> dropout + residual + LayerNorm, the product's split-K slabs handed to the LayerNorm
+// MTVAF_LN_PLANES=0: the LayerNorm kernels write fp32 only and a split pass follows (the first form of the pre-split path)
+static bool ln_planes_on() {
+  static const int on = [] { const char* e = getenv("MTVAF_LN_PLANES"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
 static int dense_ln_fwd_p(const void* Ap, int K, const void* Wp, const float* bias, float* x_out, const float* res, const float* gamma,
                           const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop, uint64_t seed,
-                          uint64_t offset, void* ws, size_t ws_bytes, hipStream_t st) {
+                          uint64_t offset, void* ws, size_t ws_bytes, void* out_planes, hipStream_t st) {
   int ns = 1;
   int rc = p16(0, Ap, Wp, x_out, H, M, H, K, bias, X_EPI_NONE, nullptr, 0, 0, ws, ws_bytes, ln_slabs_on() ? &ns : nullptr, st);
   if (rc != MTVAF_OK) return rc;
+  if (out_planes && ln_planes_on())  // (the LayerNorm writes the plane image of its output itself)
+    return mtvaf_dropout_res_ln_fwd_planes(ns > 1 ? static_cast<const float*>(ws) : x_out, ns > 1 ? ns : 0, bias, x_out, res, gamma, beta, out,
+                                           mean, rstd, M, H, eps, p_drop, seed, offset, out_planes, st);
+  if (out_planes) {
+    rc = ns > 1 ? mtvaf_dropout_res_ln_fwd_slabs(static_cast<const float*>(ws), ns, bias, x_out, res, gamma, beta, out, mean, rstd, M, H, eps,
+                                                 p_drop, seed, offset, nullptr, st)
+                : mtvaf_dropout_res_ln_fwd(x_out, res, gamma, beta, out, mean, rstd, M, H, eps, p_drop, seed, offset, nullptr, st);
+    if (rc != MTVAF_OK) return rc;
+    return planes_of(out, out_planes, M, H, st);
+  }
   if (ns > 1)
     return mtvaf_dropout_res_ln_fwd_slabs(static_cast<const float*>(ws), ns, bias, x_out, res, gamma, beta, out, mean, rstd, M, H, eps, p_drop,
                                           seed, offset, nullptr, st);
@@ -319,8 +341,7 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
                                            L->Mp - L->Mv, cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
     MTVAF_TRY(planes_of(cx, L->cx_p, M, H, st));
     MTVAF_TRY(dense_ln_fwd_p(L->cx_p, H, L->wo_h, L->bo, L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden,
-                             L->seed, L->offset + 1, L->ws, L->ws_bytes, st));
-    MTVAF_TRY(planes_of(L->h1, L->h1_p, M, H, st));
+                             L->seed, L->offset + 1, L->ws, L->ws_bytes, L->h1_p, st));
     if (p16_ep_on()) {  // (the GELU output is read by GEMMs only: it leaves the FFN-1 epilogue as a plane image, no fp32 copy)
       MTVAF_TRY(p16_ep(0, L->h1_p, L->w1_h, L->act_p, nullptr, M, I, H, L->bi1, X_EPI_GELU, pre, I, st));
     } else {
@@ -328,8 +349,7 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
       MTVAF_TRY(planes_of(act, L->act_p, M, I, st));
     }
     MTVAF_TRY(dense_ln_fwd_p(L->act_p, I, L->w2_h, L->bi2, L->f, L->h1, L->g2, L->b2, L->h2, L->mean2, L->rstd2, M, H, L->eps, L->p_hidden,
-                             L->seed, L->offset + 2, L->ws, L->ws_bytes, st));
-    if (L->h2_p) MTVAF_TRY(planes_of(L->h2, L->h2_p, M, H, st));
+                             L->seed, L->offset + 2, L->ws, L->ws_bytes, L->h2_p, st));
     return MTVAF_OK;
   }
   // (plain-bias products may use the deterministic split-K: the planner only splits when the tile grid underfills the chip)
@@ -465,9 +485,19 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
     const float* act = static_cast<const float*>(L->act);
     if (planes_mode(L) && g->df_p && g->dpre_p && g->da_p && g->dqkv_p && g->ws_main) {
       // pre-split operands (round 5): the dX chain and the grouped weight gradients on the kernels of csrc/gemm_f32p.hip
-      MTVAF_TRY(ln_bwd_forked(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, g->dg2, g->db2, g->dbi2, M, H, L->p_hidden, L->seed,
-                              L->offset + 2, g->lnpart2, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
-      MTVAF_TRY(planes_of(df, g->df_p, M, H, mainS));
+      // (df and da are read by GEMMs only: with per-layer partial buffers and a second stream the LayerNorm backward kernels write
+      // their plane images themselves and no fp32 copy)
+      const bool lnp = ln_planes_on() && g->lnpart2 && g->lnpart1 && side != mainS;
+      if (lnp) {
+        MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_planes(g->dh, nullptr, 0, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, M, H,
+                                                       L->p_hidden, L->seed, L->offset + 2, g->lnpart2, g->df_p, mainS));
+        MTVAF_TRY(fork_to(mainS, side));
+        MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart2, M, H, g->dg2, g->db2, g->dbi2, 0, side));
+      } else {
+        MTVAF_TRY(ln_bwd_forked(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, g->dg2, g->db2, g->dbi2, M, H, L->p_hidden, L->seed,
+                                L->offset + 2, g->lnpart2, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
+        MTVAF_TRY(planes_of(df, g->df_p, M, H, mainS));
+      }
       const bool ep = p16_ep_on() && g->part != nullptr;
       if (ep) {  // (dpre is read by GEMMs only -- and summed over its rows for the FFN-1 bias gradient: per-tile sums from the epilogue)
         MTVAF_TRY(p16_ep(1, g->df_p, L->w2_h, g->dpre_p, g->part, M, I, H, nullptr, X_EPI_DGELU, pre, I, mainS));
@@ -479,16 +509,25 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
       const bool slabs1 = ln_slabs_on() && g->lnpart1 && side != mainS;
       MTVAF_TRY(p16(1, g->dpre_p, L->w1_h, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, g->ws_main, g->ws_main_bytes,
                     slabs1 ? &ns1 : nullptr, mainS));
-      if (ns1 > 1) {
-        MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_slabs(g->dh1, static_cast<const float*>(g->ws_main), ns1, L->a, L->x, L->g1, L->mean1, L->rstd1,
-                                                      da, g->dh, 0, M, H, L->p_hidden, L->seed, L->offset + 1, g->lnpart1, nullptr, mainS));
+      if (lnp) {
+        MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_planes(g->dh1, static_cast<const float*>(g->ws_main), ns1 > 1 ? ns1 : 0, L->a, L->x, L->g1,
+                                                       L->mean1, L->rstd1, nullptr, g->dh, 0, M, H, L->p_hidden, L->seed, L->offset + 1,
+                                                       g->lnpart1, g->da_p, mainS));
         MTVAF_TRY(fork_to(mainS, side));
         MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart1, M, H, g->dg1, g->db1, g->dbo, 0, side));
       } else {
-        MTVAF_TRY(ln_bwd_forked(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, g->dg1, g->db1, g->dbo, M, H, L->p_hidden, L->seed,
-                                L->offset + 1, g->lnpart1, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
+        if (ns1 > 1) {
+          MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_slabs(g->dh1, static_cast<const float*>(g->ws_main), ns1, L->a, L->x, L->g1, L->mean1,
+                                                        L->rstd1, da, g->dh, 0, M, H, L->p_hidden, L->seed, L->offset + 1, g->lnpart1, nullptr,
+                                                        mainS));
+          MTVAF_TRY(fork_to(mainS, side));
+          MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart1, M, H, g->dg1, g->db1, g->dbo, 0, side));
+        } else {
+          MTVAF_TRY(ln_bwd_forked(g->dh1, L->a, L->x, L->g1, L->mean1, L->rstd1, da, g->dh, g->dg1, g->db1, g->dbo, M, H, L->p_hidden, L->seed,
+                                  L->offset + 1, g->lnpart1, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
+        }
+        MTVAF_TRY(planes_of(da, g->da_p, M, H, mainS));
       }
-      MTVAF_TRY(planes_of(da, g->da_p, M, H, mainS));
       MTVAF_TRY(p16(1, g->da_p, L->wo_h, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, g->ws_main, g->ws_main_bytes, nullptr, mainS));
       MTVAF_TRY(mtvaf_prefix_attn_varlen_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
                                              L->Mp - L->Mv, cx, L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn,

@@ -26,7 +26,33 @@ struct RowCtx {
 // MODE 2 (round 5): MODE 0 with x = slab 0 + slab 1 + ... + bias, the unreduced split-K slabs of the dense product in front of
 //   it (mtvaf_gemm_f32_slabs): `x` = slab 0, `wword` = the bias, `wpos` = where the reduced x is stored (the backward pass reads
 //   it), S = the slab count, `wtype` unused; slab stride = M * H.  The sum runs in the order of the reduction launch it replaces.
-template <int MODE>
+// A row's 4 consecutive values (columns col .. col + 3) as 8 bytes of each plane of the tile-blocked image [H / 32][3][M][32] --
+// the three-way RNE split of csrc/gemm_f32x3.hip, bit for bit what mtvaf_f32_split_planes writes (round 5: the LayerNorm kernels
+// emit the plane images the pre-split GEMMs of csrc/gemm_f32p.hip read, instead of a split pass behind them)
+typedef float f32x2r __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2r __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pl_cvt(const f32x2r v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2r)); }
+__device__ __forceinline__ f32x2r pl_widen(const unsigned pk) {
+  return f32x2r{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+}
+__device__ __forceinline__ void pl_split(const f32x2r x, unsigned& h, unsigned& m, unsigned& l) {
+  h = pl_cvt(x);
+  const f32x2r r = x - pl_widen(h);
+  m = pl_cvt(r);
+  l = pl_cvt(r - pl_widen(m));
+}
+__device__ __forceinline__ void planes_store4(unsigned char* img, long M, long row, int col, const f32x4 v) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  pl_split(f32x2r{v.x, v.y}, h0, m0, l0);
+  pl_split(f32x2r{v.z, v.w}, h1, m1, l1);
+  unsigned char* d = img + (long)(col >> 5) * 3 * M * 64 + row * 64 + (col & 31) * 2;
+  *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
+  *reinterpret_cast<uint2*>(d + M * 64) = uint2{m0, m1};
+  *reinterpret_cast<uint2*>(d + 2 * M * 64) = uint2{l0, l1};
+}
+
+// PL: `out16` is not a bf16 copy but the tile-blocked PLANE IMAGE of the output (planes_store4)
+template <int MODE, bool PL = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
                                                     const int64_t* __restrict__ ids, const int64_t* __restrict__ tts,
                                                     const int32_t* __restrict__ pos_ids, const float* __restrict__ wword,
@@ -102,8 +128,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
           y.z = (k & 4) ? y.z * scale : 0.f; y.w = (k & 8) ? y.w * scale : 0.f;
         }
         *reinterpret_cast<f32x4*>(out + (long)row * H + c * 4) = y;
-        if (out16)  // bf16 copy: the next projection's operand in the mixed-precision mode (no separate cast pass)
+        if constexpr (PL) {
+          planes_store4(reinterpret_cast<unsigned char*>(out16), M, row, c * 4, y);
+        } else if (out16) {  // bf16 copy: the next projection's operand in the mixed-precision mode (no separate cast pass)
           *reinterpret_cast<bf16x4*>(out16 + (long)row * H + c * 4) = bf16x4{(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
+        }
       }
     }
   }
@@ -114,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // = the bias gradient of the dense layer that produced x) and NP = 4 in MODE 1 (dgamma, dbeta, 2 token-type rows).  MODE 0 writes dx (grad wrt the dropout input) and dres (grad wrt the residual);
 // MODE 1 writes dz (grad wrt the summed embeddings) to dx.
 // ------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool PL = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                     const float* __restrict__ res, const int64_t* __restrict__ ids,
                                                     const int64_t* __restrict__ tts, const int32_t* __restrict__ pos_ids,
@@ -205,8 +234,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
             d.z = (keep[i] & 4) ? d.z * scale : 0.f; d.w = (keep[i] & 8) ? d.w * scale : 0.f;
           }
           if (dx) *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = d;
-          if (dx16)  // the gradient is only a GEMM operand downstream (dX and dW products of the dense layer)
+          if constexpr (PL) {  // the gradient is only a GEMM operand downstream: its plane image, no fp32 copy needed
+            planes_store4(reinterpret_cast<unsigned char*>(dx16), M, row, c * 4, d);
+          } else if (dx16) {  // the gradient is only a GEMM operand downstream (dX and dW products of the dense layer)
             *reinterpret_cast<bf16x4*>(dx16 + (long)row * H + c * 4) = bf16x4{(__bf16)d.x, (__bf16)d.y, (__bf16)d.z, (__bf16)d.w};
+          }
           at0[i] += d;
         } else {
           *reinterpret_cast<f32x4*>(dx + (long)row * H + c * 4) = dz;
@@ -647,6 +679,40 @@ int mtvaf_dropout_res_ln_bwd_rows_slabs(const float* dout_base, const float* sla
   hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout_base, x, res, nullptr, nullptr, nullptr, slabs, nullptr,
                      nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, nslab, H, p_drop, seed, offset,
                      static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+// Round 5, pre-split operands (csrc/gemm_f32p.hip): the two LayerNorm kernels that ALSO write the tile-blocked plane image
+// [H / 32][3][M][32] of their output -- the operand form of the products that read it next -- instead of a split pass behind them.
+// _fwd_planes: nslab == 0 -> x is the dense output (as mtvaf_dropout_res_ln_fwd), nslab >= 1 -> x = the product's unreduced slabs
+// (as mtvaf_dropout_res_ln_fwd_slabs: bias added, the sum stored to x_out).  _bwd_rows_planes: nslab == 0 -> dout = dout_base (as
+// mtvaf_dropout_res_ln_bwd_rows), nslab >= 1 -> dout = slabs + dout_base; dx may be NULL (a gradient only GEMMs read).
+int mtvaf_dropout_res_ln_fwd_planes(const float* x, int nslab, const float* bias, float* x_out, const float* res, const float* gamma,
+                                    const float* beta, float* out, float* mean, float* rstd, int M, int H, float eps, float p_drop,
+                                    uint64_t seed, uint64_t offset, void* out_planes, hipStream_t st) {
+  if (H % 32 || H > MAXC * 256 || M <= 0 || nslab < 0) return MTVAF_ERR_SHAPE;
+  if (!x || !out_planes || (nslab >= 1 && !x_out) || (((uintptr_t)out_planes) & 15)) return MTVAF_ERR_ARG;
+  if (nslab >= 1)
+    hipLaunchKernelGGL((ln_fwd_kernel<2, true>), dim3(row_grid(M)), dim3(256), 0, st, x, res, nullptr, nullptr, nullptr, bias, x_out,
+                       nullptr, gamma, beta, out, mean, rstd, M, nslab, H, eps, p_drop, seed, offset, static_cast<__bf16*>(out_planes),
+                       rng_epoch_ptr());
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<0, true>), dim3(row_grid(M)), dim3(256), 0, st, x, res, nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, gamma, beta, out, mean, rstd, M, 1, H, eps, p_drop, seed, offset, static_cast<__bf16*>(out_planes),
+                       rng_epoch_ptr());
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+int mtvaf_dropout_res_ln_bwd_rows_planes(const float* dout_base, const float* slabs, int nslab, const float* x, const float* res,
+                                         const float* gamma, const float* mean, const float* rstd, float* dx, float* dres,
+                                         int dres_accumulate, int M, int H, float p_drop, uint64_t seed, uint64_t offset, float* part,
+                                         void* dx_planes, hipStream_t st) {
+  if (H % 32 || H > MAXC * 256 || M <= 0 || nslab < 0) return MTVAF_ERR_SHAPE;
+  if (!dx_planes || !part || !dout_base || (nslab >= 1 && !slabs) || (((uintptr_t)dx_planes) & 15)) return MTVAF_ERR_ARG;
+  const int g = row_grid_bwd(M);
+  hipLaunchKernelGGL((ln_bwd_kernel<0, true>), dim3(g), dim3(256), 0, st, dout_base, x, res, nullptr, nullptr, nullptr,
+                     nslab >= 1 ? slabs : nullptr, nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M,
+                     nslab >= 1 ? nslab : 1, H, p_drop, seed, offset, static_cast<__bf16*>(dx_planes), rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

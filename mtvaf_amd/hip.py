@@ -38,6 +38,8 @@ _SIGS = {
     "mtvaf_gemm_f32_slabs": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, SZ, P, P]),
     "mtvaf_dropout_res_ln_fwd_slabs": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, F, U64, U64, P, P]),
     "mtvaf_dropout_res_ln_bwd_rows_slabs": (c_int, [P, P, I, P, P, P, P, P, P, P, I, I, I, F, U64, U64, P, P, P]),
+    "mtvaf_dropout_res_ln_fwd_planes": (c_int, [P, I, P, P, P, P, P, P, P, P, I, I, F, F, U64, U64, P, P]),
+    "mtvaf_dropout_res_ln_bwd_rows_planes": (c_int, [P, P, I, P, P, P, P, P, P, P, I, I, I, F, U64, U64, P, P, P]),
     "mtvaf_f32_split_planes": (c_int, [P, P, I, I, I, L, L, L, P]),
     "mtvaf_gemm_f32p": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, P]),
     "mtvaf_f32p_trace": (c_int, [P]),

@@ -1474,6 +1474,54 @@ def test_gemm_f32_presplit_result_as_plane_image_and_column_partials(hip):
     close(part[1], dx[128:].double().sum(0), rtol=1e-5, atol=1e-5 * float(dx.double().sum(0).abs().max()), name="second tile row")
 
 
+def test_layernorm_kernels_write_the_plane_images_of_their_outputs(hip):
+    """Round 5: mtvaf_dropout_res_ln_fwd_planes / _bwd_rows_planes also write the tile-blocked plane image of their output -- the
+    bits a split pass over the fp32 output would write -- and leave every fp32 result of the plain kernels unchanged (with and
+    without the split-K slabs of the product in front; backward: no fp32 dx at all)."""
+    L_ = hip.lib()
+    M, H, ns = 384, 256, 2
+    x, res = rnd(M, H, seed=61).to(DEV), rnd(M, H, seed=62).to(DEV)
+    gamma, beta, bias = rnd(H, seed=63).to(DEV), rnd(H, seed=64).to(DEV), rnd(H, seed=65).to(DEV)
+    slabs = rnd(ns, M, H, seed=66).to(DEV)
+    for nslab in (0, ns):
+        o0, mu0, rs0, xo0 = (torch.empty(M, H, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV), torch.empty(M, H, device=DEV))
+        o1, mu1, rs1, xo1 = (torch.empty(M, H, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV), torch.empty(M, H, device=DEV))
+        img = hip.Planes(o0, True, fill=False)
+        img.img.fill_(float("nan"))
+        if nslab:
+            hip._ck(L_.mtvaf_dropout_res_ln_fwd_slabs(hip._p(slabs), nslab, hip._p(bias), hip._p(xo0), hip._p(res), hip._p(gamma), hip._p(beta),
+                                                      hip._p(o0), hip._p(mu0), hip._p(rs0), M, H, 1e-12, 0.1, 77, 5, None, hip._st()), "ln")
+        else:
+            hip._ck(L_.mtvaf_dropout_res_ln_fwd(hip._p(x), hip._p(res), hip._p(gamma), hip._p(beta), hip._p(o0), hip._p(mu0), hip._p(rs0), M, H,
+                                                1e-12, 0.1, 77, 5, None, hip._st()), "ln")
+        hip._ck(L_.mtvaf_dropout_res_ln_fwd_planes(hip._p(slabs if nslab else x), nslab, hip._p(bias), hip._p(xo1), hip._p(res), hip._p(gamma),
+                                                   hip._p(beta), hip._p(o1), hip._p(mu1), hip._p(rs1), M, H, 1e-12, 0.1, 77, 5, hip._p(img.img),
+                                                   hip._st()), "ln planes")
+        assert torch.equal(o0, o1) and torch.equal(mu0, mu1) and torch.equal(rs0, rs1)
+        if nslab:
+            assert torch.equal(xo0, xo1)
+        assert torch.equal(img.img.view(torch.int16), hip.Planes(o0, True).img.view(torch.int16)), nslab
+        # backward rows
+        dout = rnd(M, H, seed=67).to(DEV)
+        xin = xo0 if nslab else x
+        nb = int(L_.mtvaf_ln_bwd_workspace_bytes(M, H))
+        p0, p1 = torch.zeros(nb // 4, device=DEV), torch.zeros(nb // 4, device=DEV)
+        dx0, dr0, dr1 = torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV), torch.empty(M, H, device=DEV)
+        if nslab:
+            hip._ck(L_.mtvaf_dropout_res_ln_bwd_rows_slabs(hip._p(dout), hip._p(slabs), nslab, hip._p(xin), hip._p(res), hip._p(gamma), hip._p(mu0),
+                                                           hip._p(rs0), hip._p(dx0), hip._p(dr0), 0, M, H, 0.1, 77, 5, hip._p(p0), None, hip._st()), "b")
+        else:
+            hip._ck(L_.mtvaf_dropout_res_ln_bwd_rows(hip._p(dout), hip._p(xin), hip._p(res), hip._p(gamma), hip._p(mu0), hip._p(rs0), hip._p(dx0),
+                                                     hip._p(dr0), 0, M, H, 0.1, 77, 5, hip._p(p0), None, hip._st()), "b")
+        dimg = hip.Planes(dx0, True, fill=False)
+        dimg.img.fill_(float("nan"))
+        hip._ck(L_.mtvaf_dropout_res_ln_bwd_rows_planes(hip._p(dout), hip._p(slabs) if nslab else None, nslab, hip._p(xin), hip._p(res),
+                                                        hip._p(gamma), hip._p(mu0), hip._p(rs0), None, hip._p(dr1), 0, M, H, 0.1, 77, 5, hip._p(p1),
+                                                        hip._p(dimg.img), hip._st()), "b planes")
+        assert torch.equal(dr0, dr1) and torch.equal(p0, p1)
+        assert torch.equal(dimg.img.view(torch.int16), hip.Planes(dx0, True).img.view(torch.int16)), nslab
+
+
 def test_gemm_f32_presplit_planes_grouped_weight_gradients(hip):
     """mtvaf_gemm_f32p_dw_group (research entry, round 5): the four weight-gradient products of a layer from plane images in ONE
     unsplit launch -- the same bits as one launch per product, from natural and from tile-blocked images, with fewer than four
