@@ -112,6 +112,18 @@ int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float*
 int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows,
                                  const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, mtvaf_stream_t stream);
+
+/* Round 5, pre-split operands: the packed-row attention that ALSO writes the tile-blocked plane image of its GEMM-operand result --
+ * the context as [H / 32][3][rows][32] (read by the Wo product, modeling_bert.py:353, and its weight gradient) / dQ | dK | dV as
+ * [3H / 32][3][rows][32] (read by the QKV dX product and its weight gradient); rows = the packed image's row count.  Bit for bit what
+ * mtvaf_f32_split_planes writes over the fp32 result, which is written as before. */
+int mtvaf_prefix_attn_varlen_fwd_planes(const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows, float* ctx,
+                                        float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                        uint64_t offset, void* ctx_planes, int rows, mtvaf_stream_t st);
+int mtvaf_prefix_attn_varlen_bwd_planes(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows,
+                                        const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B,
+                                        int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                        void* dqkv_planes, int rows, mtvaf_stream_t st);
 /* dst[r][:] = map[r] >= 0 ? src[map[r]][:] : 0  (rows_dst rows of H floats): packs / unpacks token rows. */
 int mtvaf_gather_rows(const float* src, const int* map, float* dst, int rows_dst, int H, mtvaf_stream_t stream);
 /* Token packing of a batch from its additive mask [B, T = P + S] (text keys at columns P..; kept: > -5000): cu [B+1] row

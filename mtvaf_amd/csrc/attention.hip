@@ -54,7 +54,48 @@ struct AttnArgs {
   // of a sentence (trailing padding: nothing downstream reads those rows -- the contract of the k-tile lists of the weight
   // gradients).  Their dQ is exactly zero and they add exactly nothing to dK / dV: the key side stops its query loop there.
   int zero_tail;
+  // pre-split operands (round 5; packed rows only): ALSO write the tile-blocked plane image of the context ([H / 32][3][Mrows][32])
+  // / of dQ | dK | dV ([3H / 32][3][Mrows][32]) -- what the Wo / QKV-dX products and the weight gradients read -- or NULL
+  unsigned char* ctx_p;
+  unsigned char* dqkv_p;
+  long Mrows;
 };
+
+// 4 consecutive values of row `row` (columns col .. col + 3) as 8 bytes of each plane of a tile-blocked image with Mrows rows: the
+// three-way RNE split of csrc/gemm_f32x3.hip, bit for bit what mtvaf_f32_split_planes writes
+typedef float f32x2a __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2a __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pla_cvt(const f32x2a v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2a)); }
+__device__ __forceinline__ f32x2a pla_widen(const unsigned pk) {
+  return f32x2a{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+}
+__device__ __forceinline__ void pla_split(const f32x2a x, unsigned& h, unsigned& m, unsigned& l) {
+  h = pla_cvt(x);
+  const f32x2a r = x - pla_widen(h);
+  m = pla_cvt(r);
+  l = pla_cvt(r - pla_widen(m));
+}
+__device__ __forceinline__ void planes_store4(unsigned char* img, long M, long row, int col, f32x4 v) {
+  // (the values as they were ROUNDED for the fp32 store: under -ffp-contract=fast the residual x - bf16(x) would otherwise fuse
+  // with the multiplication that produced x and split the unrounded product -- planes that differ from a split pass in the last bits)
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+  unsigned h0, m0, l0, h1, m1, l1;
+  pla_split(f32x2a{v.x, v.y}, h0, m0, l0);
+  pla_split(f32x2a{v.z, v.w}, h1, m1, l1);
+  unsigned char* d = img + (long)(col >> 5) * 3 * M * 64 + row * 64 + (col & 31) * 2;
+  *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
+  *reinterpret_cast<uint2*>(d + M * 64) = uint2{m0, m1};
+  *reinterpret_cast<uint2*>(d + 2 * M * 64) = uint2{l0, l1};
+}
+// the stores of the two results that are GEMM operands downstream: fp32, and the plane image when the caller asked for it
+__device__ __forceinline__ void store_ctx(const AttnArgs& a, long row, int col, const f32x4 v) {
+  *reinterpret_cast<f32x4*>(a.ctx + row * a.H + col) = v;
+  if (a.ctx_p) planes_store4(a.ctx_p, a.Mrows, row, col, v);
+}
+__device__ __forceinline__ void store_dqkv(const AttnArgs& a, long row, int col, const f32x4 v) {
+  *reinterpret_cast<f32x4*>(a.dqkv + row * 3 * a.H + col) = v;
+  if (a.dqkv_p) planes_store4(a.dqkv_p, a.Mrows, row, col, v);
+}
 
 struct Sent {
   long tok0;  // first token row of the sentence
@@ -156,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   if (a.cu && b == a.B) {  // (block-uniform) the rows that pad the packed image: zeros (0 x NaN of an unwritten row would poison dW)
     const int r0 = a.cu[a.B];
     for (int r = bx * 16 + (threadIdx.x >> 4); r < a.pad_rows; r += gridDim.x * 16)
-      *reinterpret_cast<f32x4*>(a.ctx + (long)(r0 + r) * a.H + h * D + (threadIdx.x & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      store_ctx(a, (long)(r0 + r), h * D + (threadIdx.x & 15) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
     return;
   }
   const Sent sn = sentence(a, b);
@@ -266,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const float inv_l = 1.f / l_run;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<f32x4*>(a.ctx + (sn.tok0 + q) * a.H + h * D + 16 * dt + 4 * g) = oacc[dt] * inv_l;
+      store_ctx(a, sn.tok0 + q, h * D + 16 * dt + 4 * g, oacc[dt] * inv_l);
     if (g == 0) a.lse[((long)b * a.NH + h) * a.S + q] = (m_run + log2f(l_run)) * LN2;
   }
 }
@@ -289,7 +330,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, i
     if (qok) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(a.dqkv + (sn.tok0 + q) * 3 * a.H + h * D + 16 * dt + 4 * g) = z;
+      for (int dt = 0; dt < 4; ++dt) store_dqkv(a, sn.tok0 + q, h * D + 16 * dt + 4 * g, z);
       if (g == 0) a.delta[((long)b * a.NH + h) * a.S + q] = 0.f;
     }
     return;
@@ -350,7 +391,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, i
       if (qok) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          *reinterpret_cast<f32x4*>(a.dqkv + (sn.tok0 + q) * 3 * a.H + h * D + 16 * dt + 4 * g) = dq[dt];
+          store_dqkv(a, sn.tok0 + q, h * D + 16 * dt + 4 * g, dq[dt]);
       }
       return;
     }
@@ -412,7 +453,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, i
   if (qok) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
-      *reinterpret_cast<f32x4*>(a.dqkv + (sn.tok0 + q) * 3 * a.H + h * D + 16 * dt + 4 * g) = dq[dt];
+      store_dqkv(a, sn.tok0 + q, h * D + 16 * dt + 4 * g, dq[dt]);
   }
 }
 
@@ -435,12 +476,11 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
   const int key = ktile * 64 + wave * 16 + lk;
   if (ktile * 64 >= T) {  // (block-uniform) a key tile of trailing padding only: exact zeros, no query loop
     if (key < Tf) {
-      float* dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        *reinterpret_cast<f32x4*>(dkrow + 16 * dt) = z;
-        *reinterpret_cast<f32x4*>(dkrow + a.H + 16 * dt) = z;
+        store_dqkv(a, sn.tok0 + (key - a.P), a.H + h * D + 16 * dt + 4 * g, z);
+        store_dqkv(a, sn.tok0 + (key - a.P), 2 * a.H + h * D + 16 * dt + 4 * g, z);
       }
     }
     return;
@@ -573,28 +613,28 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& a, int ktile, 
     }
   }
   if (!kok && key < Tf) {  // trailing padding inside a partially valid tile
-    float* dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D + 4 * g;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      *reinterpret_cast<f32x4*>(dkrow + 16 * dt) = z;
-      *reinterpret_cast<f32x4*>(dkrow + a.H + 16 * dt) = z;
+      store_dqkv(a, sn.tok0 + (key - a.P), a.H + h * D + 16 * dt + 4 * g, z);
+      store_dqkv(a, sn.tok0 + (key - a.P), 2 * a.H + h * D + 16 * dt + 4 * g, z);
     }
   }
   if (kok) {
-    float* dkrow;
-    float* dvrow;
     if (key < a.P) {
-      dkrow = a.dpk + ((long)b * a.P * a.NH + (long)h * a.P + key) * D;
-      dvrow = a.dpv + ((long)b * a.P * a.NH + (long)h * a.P + key) * D;
-    } else {
-      dkrow = a.dqkv + (sn.tok0 + (key - a.P)) * 3 * a.H + a.H + h * D;
-      dvrow = dkrow + a.H;
-    }
+      float* dkrow = a.dpk + ((long)b * a.P * a.NH + (long)h * a.P + key) * D;
+      float* dvrow = a.dpv + ((long)b * a.P * a.NH + (long)h * a.P + key) * D;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      *reinterpret_cast<f32x4*>(dkrow + 16 * dt + 4 * g) = dk[dt];
-      *reinterpret_cast<f32x4*>(dvrow + 16 * dt + 4 * g) = dv[dt];
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<f32x4*>(dkrow + 16 * dt + 4 * g) = dk[dt];
+        *reinterpret_cast<f32x4*>(dvrow + 16 * dt + 4 * g) = dv[dt];
+      }
+    } else {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        store_dqkv(a, sn.tok0 + (key - a.P), a.H + h * D + 16 * dt + 4 * g, dk[dt]);
+        store_dqkv(a, sn.tok0 + (key - a.P), 2 * a.H + h * D + 16 * dt + 4 * g, dv[dt]);
+      }
     }
   }
 }
@@ -613,7 +653,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(AttnArgs a, int nq) { 
     for (int r = blockIdx.x * 16 + (threadIdx.x >> 4); r < a.pad_rows; r += gridDim.x * 16)
 #pragma unroll
       for (int c = 0; c < 3; ++c)
-        *reinterpret_cast<f32x4*>(a.dqkv + (long)(r0 + r) * 3 * a.H + c * a.H + h * D + (threadIdx.x & 15) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        store_dqkv(a, (long)(r0 + r), c * a.H + h * D + (threadIdx.x & 15) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
     return;
   }
   int bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -651,11 +691,13 @@ static void fill_common(AttnArgs& a, int B, int S, int P, int NH, float p_drop, 
 
 static int attn_fwd_launch(const float* qkv, const float* pk, const float* pv, const float* addmask, const int* cu, int pad_rows,
                            float* ctx, float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
-                           uint64_t offset, hipStream_t st) {
+                           uint64_t offset, hipStream_t st, void* ctx_planes = nullptr, long rows = 0) {
   if (head_dim != D) return MTVAF_ERR_SHAPE;
   if (!cu && !addmask) return MTVAF_ERR_ARG;
   AttnArgs a{};
   a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.pad_rows = pad_rows; a.ctx = ctx; a.lse = lse;
+  a.ctx_p = static_cast<unsigned char*>(ctx_planes); a.Mrows = rows;
+  if (ctx_planes && (!cu || rows <= 0 || (((uintptr_t)ctx_planes) & 15))) return MTVAF_ERR_ARG;
   fill_common(a, B, S, P, NH, p_drop, seed, offset);
   int rc = check(a);
   if (rc) return rc;
@@ -668,13 +710,15 @@ static int attn_fwd_launch(const float* qkv, const float* pk, const float* pv, c
 static int attn_bwd_launch(const float* dctx, const float* qkv, const float* pk, const float* pv, const float* addmask,
                            const int* cu, int pad_rows, const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv,
                            int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st,
-                           int zero_tail = 0) {
+                           int zero_tail = 0, void* dqkv_planes = nullptr, long rows = 0) {
   if (head_dim != D) return MTVAF_ERR_SHAPE;
   if (!cu && !addmask) return MTVAF_ERR_ARG;
   AttnArgs a{};
   a.qkv = qkv; a.pk = pk; a.pv = pv; a.addmask = addmask; a.cu = cu; a.pad_rows = pad_rows; a.ctx = const_cast<float*>(ctx);
   a.lse = const_cast<float*>(lse); a.dctx = dctx; a.delta = delta; a.dqkv = dqkv; a.dpk = dpk; a.dpv = dpv;
   a.zero_tail = zero_tail;
+  a.dqkv_p = static_cast<unsigned char*>(dqkv_planes); a.Mrows = rows;
+  if (dqkv_planes && (!cu || rows <= 0 || (((uintptr_t)dqkv_planes) & 15))) return MTVAF_ERR_ARG;
   fill_common(a, B, S, P, NH, p_drop, seed, offset);
   int rc = check(a);
   if (rc) return rc;
@@ -729,6 +773,25 @@ int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const floa
   if (!cu) return MTVAF_ERR_ARG;
   return attn_bwd_launch(dctx, qkv, pk, pv, nullptr, cu, pad_rows, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed,
                          offset, st);
+}
+
+// The packed-row attention that ALSO writes the tile-blocked plane image of its GEMM-operand result (round 5, pre-split operands:
+// csrc/gemm_f32p.hip): the context as [H / 32][3][rows][32] -- the operand of the Wo product and of its weight gradient -- / dQ | dK |
+// dV as [3H / 32][3][rows][32] -- the operand of the QKV dX product and of its weight gradient; rows = the packed image's row count
+// (whole 128-row tiles).  Bit for bit what mtvaf_f32_split_planes writes over the fp32 result, which is written too.
+int mtvaf_prefix_attn_varlen_fwd_planes(const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows, float* ctx,
+                                        float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                        uint64_t offset, void* ctx_planes, int rows, hipStream_t st) {
+  if (!cu || !ctx_planes) return MTVAF_ERR_ARG;
+  return attn_fwd_launch(qkv, pk, pv, nullptr, cu, pad_rows, ctx, lse, B, S, P, NH, head_dim, p_drop, seed, offset, st, ctx_planes, rows);
+}
+int mtvaf_prefix_attn_varlen_bwd_planes(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows,
+                                        const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B,
+                                        int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                        void* dqkv_planes, int rows, hipStream_t st) {
+  if (!cu || !dqkv_planes) return MTVAF_ERR_ARG;
+  return attn_bwd_launch(dctx, qkv, pk, pv, nullptr, cu, pad_rows, ctx, lse, delta, dqkv, dpk, dpv, B, S, P, NH, head_dim, p_drop, seed,
+                         offset, st, 0, dqkv_planes, rows);
 }
 
 }  // extern "C"

@@ -66,6 +66,13 @@ int mtvaf_prefix_attn_varlen_fwd(const float* qkv, const float* pk, const float*
 int mtvaf_prefix_attn_varlen_bwd(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows,
                                  const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B, int S,
                                  int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset, hipStream_t st);
+int mtvaf_prefix_attn_varlen_fwd_planes(const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows, float* ctx,
+                                        float* lse, int B, int S, int P, int NH, int head_dim, float p_drop, uint64_t seed,
+                                        uint64_t offset, void* ctx_planes, int rows, hipStream_t st);
+int mtvaf_prefix_attn_varlen_bwd_planes(const float* dctx, const float* qkv, const float* pk, const float* pv, const int* cu, int pad_rows,
+                                        const float* ctx, const float* lse, float* delta, float* dqkv, float* dpk, float* dpv, int B,
+                                        int S, int P, int NH, int head_dim, float p_drop, uint64_t seed, uint64_t offset,
+                                        void* dqkv_planes, int rows, hipStream_t st);
 int mtvaf_zero_f32(float* p, long n, hipStream_t st);
 int mtvaf_f32_split_planes(const float* src, void* dst, int rows, int cols, int ld, long s_plane, long s_row, long s_kt, hipStream_t stream);
 int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
@@ -268,6 +275,12 @@ static bool p16_ep_on() {
   return on != 0;
 }
 
+// MTVAF_ATTN_PLANES=0: the attention kernels write fp32 only and a split pass follows
+static bool attn_planes_on() {
+  static const int on = [] { const char* e = getenv("MTVAF_ATTN_PLANES"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
+
 static bool planes_mode(const mtvaf_layer_t* L) {
   return !L->bf16 && L->cu && L->x_p && L->cx_p && L->h1_p && L->act_p && L->wqkv_h && L->wo_h && L->w1_h && L->w2_h && L->Mp % 128 == 0 &&
          L->H % 128 == 0 && L->I % 128 == 0 && L->ws;
@@ -337,9 +350,15 @@ int mtvaf_encoder_layer_fwd(const mtvaf_layer_t* L, hipStream_t st) {
     // pre-split operands (round 5): the same layer on the kernels of csrc/gemm_f32p.hip; every GEMM operand is read as a plane
     // image -- weights written once per optimizer step, activations by one pass behind the kernel that produces them
     MTVAF_TRY(p16(0, L->x_p, L->wqkv_h, qkv, 3 * H, M, 3 * H, H, L->bqkv, X_EPI_NONE, nullptr, 0, 0, L->ws, L->ws_bytes, nullptr, st));
-    MTVAF_TRY(mtvaf_prefix_attn_varlen_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
-                                           L->Mp - L->Mv, cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
-    MTVAF_TRY(planes_of(cx, L->cx_p, M, H, st));
+    if (attn_planes_on()) {  // (the attention kernel writes the context's plane image itself)
+      MTVAF_TRY(mtvaf_prefix_attn_varlen_fwd_planes(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
+                                                    L->Mp - L->Mv, cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset,
+                                                    L->cx_p, M, st));
+    } else {
+      MTVAF_TRY(mtvaf_prefix_attn_varlen_fwd(qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
+                                             L->Mp - L->Mv, cx, L->lse, L->B, L->S, L->P, L->NH, 64, L->p_attn, L->seed, L->offset, st));
+      MTVAF_TRY(planes_of(cx, L->cx_p, M, H, st));
+    }
     MTVAF_TRY(dense_ln_fwd_p(L->cx_p, H, L->wo_h, L->bo, L->a, L->x, L->g1, L->b1, L->h1, L->mean1, L->rstd1, M, H, L->eps, L->p_hidden,
                              L->seed, L->offset + 1, L->ws, L->ws_bytes, L->h1_p, st));
     if (p16_ep_on()) {  // (the GELU output is read by GEMMs only: it leaves the FFN-1 epilogue as a plane image, no fp32 copy)
@@ -529,10 +548,16 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
         MTVAF_TRY(planes_of(da, g->da_p, M, H, mainS));
       }
       MTVAF_TRY(p16(1, g->da_p, L->wo_h, dctx, H, M, H, H, nullptr, X_EPI_NONE, nullptr, 0, 0, g->ws_main, g->ws_main_bytes, nullptr, mainS));
-      MTVAF_TRY(mtvaf_prefix_attn_varlen_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
-                                             L->Mp - L->Mv, cx, L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn,
-                                             L->seed, L->offset, mainS));
-      MTVAF_TRY(planes_of(dqkv, g->dqkv_p, M, 3 * H, mainS));
+      if (attn_planes_on()) {
+        MTVAF_TRY(mtvaf_prefix_attn_varlen_bwd_planes(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
+                                                      L->Mp - L->Mv, cx, L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn,
+                                                      L->seed, L->offset, g->dqkv_p, M, mainS));
+      } else {
+        MTVAF_TRY(mtvaf_prefix_attn_varlen_bwd(dctx, qkv, static_cast<const float*>(L->pk), static_cast<const float*>(L->pv), L->cu,
+                                               L->Mp - L->Mv, cx, L->lse, g->delta, dqkv, g->dpk, g->dpv, B, S, P, NH, 64, L->p_attn,
+                                               L->seed, L->offset, mainS));
+        MTVAF_TRY(planes_of(dqkv, g->dqkv_p, M, 3 * H, mainS));
+      }
       MTVAF_TRY(fork_to(mainS, side));
       // second stream: the two bias gradients that are column sums of dY, then the four weight gradients as ONE launch
       if (ep) MTVAF_TRY(mtvaf_colsum_small(g->part, M / 128, I, g->dbi1, 0, side));

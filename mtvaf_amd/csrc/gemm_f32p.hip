@@ -413,6 +413,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
         }
         cs0 += v0;
         cs1 += v1;
+        // (split the values as ROUNDED for the fp32 result: under -ffp-contract=fast the residual x - bf16(x) would otherwise fuse
+        // with the multiplication that produced x)
+        asm volatile("" : "+v"(v0.x), "+v"(v0.y), "+v"(v0.z), "+v"(v0.w), "+v"(v1.x), "+v"(v1.y), "+v"(v1.z), "+v"(v1.w));
         unsigned h[4], m[4], l[4];
         f32p::split3_pair(f32x2p{v0.x, v0.y}, h[0], m[0], l[0]);
         f32p::split3_pair(f32x2p{v0.z, v0.w}, h[1], m[1], l[1]);

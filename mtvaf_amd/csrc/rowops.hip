@@ -41,7 +41,10 @@ __device__ __forceinline__ void pl_split(const f32x2r x, unsigned& h, unsigned& 
   m = pl_cvt(r);
   l = pl_cvt(r - pl_widen(m));
 }
-__device__ __forceinline__ void planes_store4(unsigned char* img, long M, long row, int col, const f32x4 v) {
+__device__ __forceinline__ void planes_store4(unsigned char* img, long M, long row, int col, f32x4 v) {
+  // (the values as they were ROUNDED for the fp32 store: under -ffp-contract=fast the residual x - bf16(x) would otherwise fuse
+  // with the multiplication that produced x and split the unrounded product -- planes that differ from a split pass in the last bits)
+  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
   unsigned h0, m0, l0, h1, m1, l1;
   pl_split(f32x2r{v.x, v.y}, h0, m0, l0);
   pl_split(f32x2r{v.z, v.w}, h1, m1, l1);

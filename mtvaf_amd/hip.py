@@ -52,6 +52,8 @@ _SIGS = {
     "mtvaf_prefix_attn_bwd_tail": (c_int, [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, I, P]),
     "mtvaf_prefix_attn_varlen_fwd": (c_int, [P, P, P, P, I, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_varlen_bwd": (c_int, [P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
+    "mtvaf_prefix_attn_varlen_fwd_planes": (c_int, [P, P, P, P, I, P, P, I, I, I, I, I, F, U64, U64, P, I, P]),
+    "mtvaf_prefix_attn_varlen_bwd_planes": (c_int, [P, P, P, P, P, I, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P, I, P]),
     "mtvaf_prefix_attn_bf16_varlen_fwd": (c_int, [P, P, P, P, I, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_prefix_attn_bf16_varlen_bwd": (c_int, [P, P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_gather_rows": (c_int, [P, P, P, I, I, P]),

@@ -1474,6 +1474,43 @@ def test_gemm_f32_presplit_result_as_plane_image_and_column_partials(hip):
     close(part[1], dx[128:].double().sum(0), rtol=1e-5, atol=1e-5 * float(dx.double().sum(0).abs().max()), name="second tile row")
 
 
+def test_packed_attention_writes_the_plane_images_of_its_results(hip):
+    """Round 5: mtvaf_prefix_attn_varlen_fwd_planes / _bwd_planes also write the tile-blocked plane images of the context / of
+    dQ | dK | dV (the bits of a split pass over the fp32 results, padding rows included) and leave the fp32 results unchanged."""
+    L_ = hip.lib()
+    B, S, Pn, NH, p = 5, 100, 36, 4, 0.1
+    H = NH * 64
+    lens = [S, 1, 53, 20, 77]
+    Mv = sum(lens)
+    Mp = (Mv + 127) // 128 * 128 + 128
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    qkv = torch.zeros(Mp, 3 * H, device=DEV)
+    qkv[:Mv] = rnd(Mv, 3 * H, seed=71).to(DEV)
+    pk, pv = rnd(B, Pn * H, seed=72).to(DEV), rnd(B, Pn * H, seed=73).to(DEV)
+    dctx = torch.zeros(Mp, H, device=DEV)
+    dctx[:Mv] = rnd(Mv, H, seed=74).to(DEV)
+    c0, c1 = torch.full((Mp, H), float("nan"), device=DEV), torch.full((Mp, H), float("nan"), device=DEV)
+    l0, l1 = torch.zeros(B, NH, S, device=DEV), torch.zeros(B, NH, S, device=DEV)
+    hip.prefix_attn_varlen_fwd(qkv, pk, pv, cu, Mp - Mv, c0, l0, B, S, Pn, NH, p, 11, 5)
+    img = hip.Planes(c0, True, fill=False)
+    img.img.fill_(float("nan"))
+    hip._ck(L_.mtvaf_prefix_attn_varlen_fwd_planes(hip._p(qkv), hip._p(pk), hip._p(pv), hip._p(cu), Mp - Mv, hip._p(c1), hip._p(l1), B, S, Pn, NH,
+                                                   64, p, 11, 5, hip._p(img.img), Mp, hip._st()), "fwd planes")
+    assert torch.equal(c0, c1) and torch.equal(l0, l1)
+    assert torch.equal(img.img.view(torch.int16), hip.Planes(c0, True).img.view(torch.int16))
+    d0, d1 = torch.full((Mp, 3 * H), float("nan"), device=DEV), torch.full((Mp, 3 * H), float("nan"), device=DEV)
+    k0, v0, k1, v1 = (torch.zeros(B, Pn * H, device=DEV) for _ in range(4))
+    de = torch.zeros(B, NH, S, device=DEV)
+    hip.prefix_attn_varlen_bwd(dctx, qkv, pk, pv, cu, Mp - Mv, c0, l0, de, d0, k0, v0, B, S, Pn, NH, p, 11, 5)
+    dimg = hip.Planes(d0, True, fill=False)
+    dimg.img.fill_(float("nan"))
+    hip._ck(L_.mtvaf_prefix_attn_varlen_bwd_planes(hip._p(dctx), hip._p(qkv), hip._p(pk), hip._p(pv), hip._p(cu), Mp - Mv, hip._p(c0), hip._p(l0),
+                                                   hip._p(de), hip._p(d1), hip._p(k1), hip._p(v1), B, S, Pn, NH, 64, p, 11, 5, hip._p(dimg.img), Mp,
+                                                   hip._st()), "bwd planes")
+    assert torch.equal(d0, d1) and torch.equal(k0, k1) and torch.equal(v0, v1)
+    assert torch.equal(dimg.img.view(torch.int16), hip.Planes(d0, True).img.view(torch.int16))
+
+
 def test_layernorm_kernels_write_the_plane_images_of_their_outputs(hip):
     """Round 5: mtvaf_dropout_res_ln_fwd_planes / _bwd_rows_planes also write the tile-blocked plane image of their output -- the
     bits a split pass over the fp32 output would write -- and leave every fp32 result of the plain kernels unchanged (with and
