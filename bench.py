@@ -183,6 +183,11 @@ def pmc_traffic(symbol, dtype="fp32", batch=32, seq=128, unpad=True):
 
 
 
+def _planes_on():
+    from mtvaf_amd import engine as _engine
+    return bool(_engine.F32_PLANES)
+
+
 def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3, peak_key=None):
     """Roofline object of the dominant GEMM kernel of `eager_step`, measured live: HIP events that the library records on the
     launch stream directly around each main GEMM kernel (mtvaf_prof_start/stop) in `nprof` further steps, with the
@@ -217,7 +222,7 @@ def roofline_pass(eager_step, mask, B, S, dtype, unpad=False, nprof=3, peak_key=
         e[0] += ms
         e[1] += 1
     def peak_of(sym_):  # the matrix pipe a kernel symbol runs on (the split mode leaves few-tile products on the fp32 pipe)
-        if sym_.startswith("gemm_f32x3"):
+        if sym_.startswith("gemm_f32x3") or sym_.startswith("gemm_f32p16"):  # (six bf16 products per fp32 product either way)
             return PEAK_TFLOPS["fp32x3"]
         return PEAK_TFLOPS["bf16"] if sym_.startswith("gemm_bf16") else PEAK_TFLOPS["fp32"]
     tot_ms = sum(v[0] for v in by_sym.values()) / nprof
@@ -749,7 +754,8 @@ def main():
                                   f"bs={B}/GPU, seq_len={S}, {P} visual prefix slots (1+{a.aux} region-feature "
                                   f"images through the prompt generator), train mode (dropout live), "
                                   f"{'full-length' if a.full_length else 'ragged 16..S'} sequences"
-                                  f"{', padding-free execution (masked token rows not computed)' if a.unpad else ', padded execution (every [B, S] row computed)'}",
+                                  f"{', padding-free execution (masked token rows not computed)' if a.unpad else ', padded execution (every [B, S] row computed)'}"
+                                  f"{', encoder GEMM operands as pre-split plane images' if (a.unpad and split_mode and _planes_on()) else ''}",
                       "global_batch": B * world, "seq_len": S, "prefix": P,
                       "parallelism": f"dp{world}" + (" (RCCL all-reduce overlapped with backward)" if world > 1 else "")},
            "median_ms_per_step": round(med_ms, 3), "value_median": round(world * B / (med_ms * 1e-3), 2),

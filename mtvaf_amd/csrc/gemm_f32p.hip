@@ -582,7 +582,11 @@ static int gemm_f32p_run(int layout_a, const void* Aplanes, long a_plane, long a
   a.ablate = ablate;
   a.trace = g_f32p_trace;
   dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
+  // (launch profiler of gemm.hip: key 400 + 4 [k-major A] + 8 [k-major B]; hip.kernel_symbol names the instantiation)
+  const int key[8] = {400 + 4 * layout_a + 8 * layout_b, layout_a, layout_b, 2, M, N, K, splits};
+  const int rec = prof_begin(key, stream);
   const int rc = launch_gemm_f32p16(a, layout_a, layout_b, grid, stream);
+  prof_end(rec, stream);
   if (rc != MTVAF_OK) return rc;
   if (keep_slabs) {  // (the caller's next kernel adds the slabs itself, in the reduction's order)
     *keep_slabs = splits;
@@ -647,7 +651,11 @@ int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* cons
   }
   for (int i = n; i < 5; ++i) a.grp_tile_begin[i] = (int)tiles;  // (absent products own no tiles)
   a.M = M[0]; a.N = N[0]; a.tiles_n = N[0] / 128;
-  return launch_gemm_f32p16_group(a, dim3((unsigned)tiles, 1, 1), stream);
+  const int key[8] = {400 + 4 + 8 + 16, 1, 1, 2, (int)(tiles * 128 * 128 / 768), 768, K, 1};  // (+16: the GROUP instantiation; M x 768 = all outputs)
+  const int rec = prof_begin(key, stream);
+  const int rc = launch_gemm_f32p16_group(a, dim3((unsigned)tiles, 1, 1), stream);
+  prof_end(rec, stream);
+  return rc;
 }
 
 }  // extern "C"

@@ -258,6 +258,9 @@ def kernel_symbol(cfg, la, lb, fast):
         return f"gemm_f32x3_ws_kernel<true, true, {b(klist)}, 128, true>"
     if cfg >= 1000:  # the grouped weight-gradient launch of the fp32 LDS-DMA kernel (mtvaf_gemm_f32_dw_group)
         return f"gemm_f32_dma_group_kernel<128, 96, 4, 1, 2, {b(klist)}>"
+    if 400 <= cfg < 500:  # pre-split operands (csrc/gemm_f32p.hip): gemm_f32p16_kernel<ABL, TRACE, B_KM, A_KM, GROUP>
+        c = cfg - 400
+        return f"gemm_f32p16_kernel<0, false, {b(c & 8)}, {b(c & 4)}, {b(c & 16)}>"
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>
         c = cfg - 300
         if c & 64:  # gemm_bf16_p256_kernel<A_KM, B_KM, SK> (+128: the in-launch-combine form, +256: a grouped launch)

@@ -19,6 +19,10 @@ def test_kernel_symbols_of_every_gemm_family():
     assert hip.kernel_symbol(206, 0, 0, 2) == "gemm_f32x3_kernel<128, 96, 4, 1, false, false, false, 32>"
     assert hip.kernel_symbol(205, 0, 1, 2) == "gemm_f32x3_kernel<128, 128, 2, 2, false, true, false, 32>"
     assert hip.kernel_symbol(203, 1, 1, 2) == "gemm_f32x3_kernel<64, 64, 2, 2, true, true, false, 32>"
+    # pre-split operands (csrc/gemm_f32p.hip): forward, dX, the grouped weight gradients
+    assert hip.kernel_symbol(400, 0, 0, 2) == "gemm_f32p16_kernel<0, false, false, false, false>"
+    assert hip.kernel_symbol(408, 0, 1, 2) == "gemm_f32p16_kernel<0, false, true, false, false>"
+    assert hip.kernel_symbol(428, 1, 1, 2) == "gemm_f32p16_kernel<0, false, true, true, true>"
     # bf16-operand kernels: the 256 x 256 eight-phase kernel and the rings
     assert hip.kernel_symbol(300 + 64 + 4 + 8 + 128, 1, 1, 2) == "gemm_bf16_p256_kernel<true, true, true>"
     assert hip.kernel_symbol(300 + 1 + 8, 0, 1, 2) == "gemm_bf16x_kernel<128, 128, 2, 2, false, true, 2, false>"
