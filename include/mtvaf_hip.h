@@ -541,6 +541,13 @@ size_t mtvaf_layer_struct_bytes(int which /* 0: mtvaf_layer_t, 1: mtvaf_layer_gr
 int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, double beta1, double beta2, float eps,
                 float weight_decay, float bc1, float bc2_sqrt, float grad_scale, void* p_bf16, int max_blocks,
                 mtvaf_stream_t stream);
+/* mtvaf_adamw over a flat buffer (n % 4 == 0, 16-byte aligned) that ALSO rewrites the plane images (the pre-split operand form of
+ * csrc/gemm_f32p.hip, round 5) of nseg <= 4 row-major fp32 matrices inside it -- an encoder layer's wqkv / wo / w1 / w2: matrix s starts
+ * at element seg_begin[s] (% 4 == 0), is [seg_rows[s]][seg_cols[s]] (cols % 32 == 0) and has its tile-blocked image
+ * [cols / 32][3][rows][32] bf16 at seg_img[s].  The same update as mtvaf_adamw, bit for bit; the images match the updated weights. */
+int mtvaf_adamw_planes(float* p, const float* g, float* m, float* v, long n, float lr, double beta1, double beta2, float eps,
+                       float weight_decay, float bc1, float bc2_sqrt, float grad_scale, int nseg, const long* seg_begin,
+                       const int* seg_rows, const int* seg_cols, void* const* seg_img, int max_blocks, mtvaf_stream_t stream);
 int mtvaf_adamw_multi(int count, float* const* p, const float* const* g, float* const* m, float* const* v,
                       const long* n, float lr, double beta1, double beta2, float eps, float weight_decay, float bc1,
                       float bc2_sqrt, float grad_scale, mtvaf_stream_t stream);

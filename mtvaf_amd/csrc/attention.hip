@@ -18,6 +18,7 @@
 // the B operand of the P.V product (O^T[d][q] = V^T.P^T) -- no LDS round trip for P.  The k index of
 // every product is permuted (step t, lane group g <-> k = 4g + t) identically on both operands.
 #include "common.h"
+#include "planes.h"
 
 namespace mtvaf {
 
@@ -61,32 +62,6 @@ struct AttnArgs {
   long Mrows;
 };
 
-// 4 consecutive values of row `row` (columns col .. col + 3) as 8 bytes of each plane of a tile-blocked image with Mrows rows: the
-// three-way RNE split of csrc/gemm_f32x3.hip, bit for bit what mtvaf_f32_split_planes writes
-typedef float f32x2a __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2a __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pla_cvt(const f32x2a v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2a)); }
-__device__ __forceinline__ f32x2a pla_widen(const unsigned pk) {
-  return f32x2a{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
-}
-__device__ __forceinline__ void pla_split(const f32x2a x, unsigned& h, unsigned& m, unsigned& l) {
-  h = pla_cvt(x);
-  const f32x2a r = x - pla_widen(h);
-  m = pla_cvt(r);
-  l = pla_cvt(r - pla_widen(m));
-}
-__device__ __forceinline__ void planes_store4(unsigned char* img, long M, long row, int col, f32x4 v) {
-  // (the values as they were ROUNDED for the fp32 store: under -ffp-contract=fast the residual x - bf16(x) would otherwise fuse
-  // with the multiplication that produced x and split the unrounded product -- planes that differ from a split pass in the last bits)
-  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-  unsigned h0, m0, l0, h1, m1, l1;
-  pla_split(f32x2a{v.x, v.y}, h0, m0, l0);
-  pla_split(f32x2a{v.z, v.w}, h1, m1, l1);
-  unsigned char* d = img + (long)(col >> 5) * 3 * M * 64 + row * 64 + (col & 31) * 2;
-  *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
-  *reinterpret_cast<uint2*>(d + M * 64) = uint2{m0, m1};
-  *reinterpret_cast<uint2*>(d + 2 * M * 64) = uint2{l0, l1};
-}
 // the stores of the two results that are GEMM operands downstream: fp32, and the plane image when the caller asked for it
 __device__ __forceinline__ void store_ctx(const AttnArgs& a, long row, int col, const f32x4 v) {
   *reinterpret_cast<f32x4*>(a.ctx + row * a.H + col) = v;

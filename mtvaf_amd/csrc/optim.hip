@@ -10,6 +10,7 @@
 //   7 fp32 streams per parameter (read p, g, m, v; write p, m, v) = 28 B; an optional bf16 copy of the new
 //   parameter (the GEMM operand shadow of the bf16 compute mode) adds 2 B.
 #include "common.h"
+#include "planes.h"
 
 namespace mtvaf {
 
@@ -71,6 +72,43 @@ __device__ __forceinline__ void adamw_span(float* __restrict__ p, const float* _
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, __bf16* ph, long n,
                                                     AdamHyper h) {
   adamw_span(p, g, m, v, ph, n, (long)blockIdx.x * 256 + threadIdx.x, (long)gridDim.x * 256, h);
+}
+
+// The update of a flat parameter buffer that ALSO rewrites the plane images (planes.h) of up to four row-major matrices inside it
+// (round 5, pre-split operands: an encoder layer's wqkv / wo / w1 / w2): a float4 of matrix s, at element e of it, is row e / cols,
+// columns e % cols .. + 3 of its image -- 6 more bytes written per weight instead of a split pass that reads the 4 again.
+struct AdamSegs {
+  long b4[4], e4[4];  // the matrix's float4 range in the flat buffer
+  int rows[4], cols[4];
+  unsigned char* img[4];
+  int n;
+};
+__global__ __launch_bounds__(256) void adamw_planes_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, long n4, AdamHyper h, AdamSegs sg) {
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 P = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + i);
+    const f32x4 G = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g) + i);
+    f32x4 M = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m) + i);
+    f32x4 V = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v) + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float pj = P[j], mj = M[j], vj = V[j];
+      adamw1(pj, G[j], mj, vj, h);
+      P[j] = pj; M[j] = mj; V[j] = vj;
+    }
+    reinterpret_cast<f32x4*>(p)[i] = P;
+    __builtin_nontemporal_store(M, reinterpret_cast<f32x4*>(m) + i);
+    __builtin_nontemporal_store(V, reinterpret_cast<f32x4*>(v) + i);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < sg.n && i >= sg.b4[s] && i < sg.e4[s]) {
+        const long e = (i - sg.b4[s]) * 4;
+        const long row = e / sg.cols[s];
+        planes_store4(sg.img[s], sg.rows[s], row, (int)(e - row * sg.cols[s]), P);
+      }
+    }
+  }
 }
 
 // several tensors of one parameter group in one launch: blockIdx.x -> (tensor, block within tensor) through a prefix table
@@ -175,6 +213,33 @@ int mtvaf_adamw(float* p, const float* g, float* m, float* v, long n, float lr, 
   if (max_blocks > 0 && max_blocks < grid) grid = max_blocks;
   hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v,
                      static_cast<__bf16*>(p_bf16), n, h);
+  MTVAF_LAUNCH_CHECK();
+  return MTVAF_OK;
+}
+
+// mtvaf_adamw over a flat buffer (n % 4 == 0, 16-byte aligned) that also rewrites the plane images of nseg <= 4 row-major fp32
+// matrices inside it: matrix s starts at element seg_begin[s] (% 4 == 0) of the buffer, is [seg_rows[s]][seg_cols[s]] (cols % 32 == 0)
+// and has its tile-blocked image (6 bytes per element) at seg_img[s].  Same update as mtvaf_adamw, bit for bit.
+int mtvaf_adamw_planes(float* p, const float* g, float* m, float* v, long n, float lr, double beta1, double beta2, float eps,
+                       float weight_decay, float bc1, float bc2_sqrt, float grad_scale, int nseg, const long* seg_begin,
+                       const int* seg_rows, const int* seg_cols, void* const* seg_img, int max_blocks, hipStream_t stream) {
+  if (!p || !g || !m || !v || n <= 0 || nseg < 0 || nseg > 4 || (nseg && (!seg_begin || !seg_rows || !seg_cols || !seg_img))) return MTVAF_ERR_ARG;
+  if ((n & 3) || (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15)) return MTVAF_ERR_ALIGN;
+  AdamSegs sg = {};
+  sg.n = nseg;
+  for (int s = 0; s < nseg; ++s) {
+    const long cnt = (long)seg_rows[s] * seg_cols[s];
+    if (seg_rows[s] <= 0 || seg_cols[s] <= 0 || seg_cols[s] % 32 || seg_begin[s] < 0 || (seg_begin[s] & 3) || seg_begin[s] + cnt > n || !seg_img[s] ||
+        (((uintptr_t)seg_img[s]) & 15))
+      return MTVAF_ERR_SHAPE;
+    sg.b4[s] = seg_begin[s] / 4; sg.e4[s] = (seg_begin[s] + cnt) / 4;
+    sg.rows[s] = seg_rows[s]; sg.cols[s] = seg_cols[s];
+    sg.img[s] = static_cast<unsigned char*>(seg_img[s]);
+  }
+  const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+  int grid = stream_grid(n / 4);
+  if (max_blocks > 0 && max_blocks < grid) grid = max_blocks;
+  hipLaunchKernelGGL(adamw_planes_kernel, dim3(grid), dim3(256), 0, stream, p, g, m, v, n / 4, h, sg);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

@@ -6,6 +6,7 @@
 //   bias / LayerNorm-affine gradient column sums, elementwise dropout (models/bert_model.py:506).
 // Dropout masks are regenerated from (seed, offset, element index) in the backward kernels.
 #include "common.h"
+#include "planes.h"
 
 #include <cstdlib>
 
@@ -26,34 +27,6 @@ struct RowCtx {
 // MODE 2 (round 5): MODE 0 with x = slab 0 + slab 1 + ... + bias, the unreduced split-K slabs of the dense product in front of
 //   it (mtvaf_gemm_f32_slabs): `x` = slab 0, `wword` = the bias, `wpos` = where the reduced x is stored (the backward pass reads
 //   it), S = the slab count, `wtype` unused; slab stride = M * H.  The sum runs in the order of the reduction launch it replaces.
-// A row's 4 consecutive values (columns col .. col + 3) as 8 bytes of each plane of the tile-blocked image [H / 32][3][M][32] --
-// the three-way RNE split of csrc/gemm_f32x3.hip, bit for bit what mtvaf_f32_split_planes writes (round 5: the LayerNorm kernels
-// emit the plane images the pre-split GEMMs of csrc/gemm_f32p.hip read, instead of a split pass behind them)
-typedef float f32x2r __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2r __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pl_cvt(const f32x2r v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2r)); }
-__device__ __forceinline__ f32x2r pl_widen(const unsigned pk) {
-  return f32x2r{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
-}
-__device__ __forceinline__ void pl_split(const f32x2r x, unsigned& h, unsigned& m, unsigned& l) {
-  h = pl_cvt(x);
-  const f32x2r r = x - pl_widen(h);
-  m = pl_cvt(r);
-  l = pl_cvt(r - pl_widen(m));
-}
-__device__ __forceinline__ void planes_store4(unsigned char* img, long M, long row, int col, f32x4 v) {
-  // (the values as they were ROUNDED for the fp32 store: under -ffp-contract=fast the residual x - bf16(x) would otherwise fuse
-  // with the multiplication that produced x and split the unrounded product -- planes that differ from a split pass in the last bits)
-  asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
-  unsigned h0, m0, l0, h1, m1, l1;
-  pl_split(f32x2r{v.x, v.y}, h0, m0, l0);
-  pl_split(f32x2r{v.z, v.w}, h1, m1, l1);
-  unsigned char* d = img + (long)(col >> 5) * 3 * M * 64 + row * 64 + (col & 31) * 2;
-  *reinterpret_cast<uint2*>(d) = uint2{h0, h1};
-  *reinterpret_cast<uint2*>(d + M * 64) = uint2{m0, m1};
-  *reinterpret_cast<uint2*>(d + 2 * M * 64) = uint2{l0, l1};
-}
-
 // PL: `out16` is not a bf16 copy but the tile-blocked PLANE IMAGE of the output (planes_store4)
 template <int MODE, bool PL = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,

@@ -198,6 +198,21 @@ def _weights_planes(w: "LayerWeights"):
     return c[2]
 
 
+def planes_for_update(w: "LayerWeights"):
+    """-> [(first element in w.flat, rows, cols, image), ...] of the layer's four weight matrices when their plane images exist (a
+    forward pass on the pre-split path has built them): ``hip.adamw_planes`` rewrites them inside the update; the caller then stamps
+    them with ``planes_written``.  None: no images to maintain."""
+    if w._pl is None or not F32_PLANES or hip.COMPUTE != "fp32":
+        return None
+    base = w.flat.data_ptr()
+    return [((t.data_ptr() - base) // 4, t.shape[0], t.shape[1], v) for t, v in zip((w.wqkv, w.wo, w.w1, w.w2), w._pl[2])]
+
+
+def planes_written(w: "LayerWeights"):
+    if w._pl is not None:
+        w._pl[0] = shadow_version(w, 1)
+
+
 def planes_rewrite(w: "LayerWeights"):
     """Called from inside ``optimizer.step()`` (or the backward pass preceding it) on the stream of the layer's update: the plane
     images are rebuilt from the updated masters and match them as they will be once this step's post-step hook has run."""

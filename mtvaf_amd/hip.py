@@ -115,6 +115,7 @@ _SIGS = {
     "mtvaf_gemm_bf16x_dw_group": (c_int, [I, P, P, P, P, P, P, P, P, I, P]),
     "mtvaf_cast_bf16": (c_int, [P, I, P, I, P, I, I, I, P]),
     "mtvaf_adamw": (c_int, [P, P, P, P, L, F, c_double, c_double, F, F, F, F, F, P, I, P]),
+    "mtvaf_adamw_planes": (c_int, [P, P, P, P, L, F, c_double, c_double, F, F, F, F, F, I, P, P, P, P, I, P]),
     "mtvaf_adamw_multi": (c_int, [I, P, P, P, P, P, F, c_double, c_double, F, F, F, F, F, P]),
     "mtvaf_grad_pack_bf16": (c_int, [P, P, L, L, P]),
     "mtvaf_grad_reduce_bf16": (c_int, [P, P, I, L, F, P]),
@@ -837,6 +838,19 @@ def colsum_small(part, out, accumulate=False):
 
 
 # ---- optimizer / gradient wire format (csrc/optim.hip) ------------------------------------------------------------
+def adamw_planes(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, segs, grad_scale=1.0, max_blocks=0):
+    """adamw over a flat buffer that also rewrites the plane images of the matrices inside it: segs = [(begin element, rows, cols,
+    image uint8 tensor), ...] (at most four)."""
+    _f32(p, g, m, v)
+    n = len(segs)
+    bc1 = 1.0 - beta1 ** step
+    bc2_sqrt = (1.0 - beta2 ** step) ** 0.5
+    _ck(lib().mtvaf_adamw_planes(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                 float(bc1), float(bc2_sqrt), float(grad_scale), n, (ctypes.c_long * n)(*[s[0] for s in segs]),
+                                 (ctypes.c_int * n)(*[s[1] for s in segs]), (ctypes.c_int * n)(*[s[2] for s in segs]),
+                                 (ctypes.c_void_p * n)(*[_p(s[3]) for s in segs]), int(max_blocks), _st()), "mtvaf_adamw_planes")
+
+
 def adamw(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, p_bf16=None, max_blocks=0):
     """In-place AdamW update of one flat fp32 tensor (torch.optim.AdamW semantics); `step` is the 1-based step count;
     max_blocks > 0: a background update on that many blocks (runs under MFMA-bound kernels without starving them)."""

@@ -152,11 +152,18 @@ class AdamW(torch.optim.Optimizer):
         b1, b2 = group["betas"]
         from . import engine
         shadow = engine.shadow_for_update(store.weights)  # bf16 compute mode: the GEMM operand image, written in the same pass
+        segs = engine.planes_for_update(store.weights) if shadow is None else None
+        if segs is not None and store.flat.numel() % 4 == 0:
+            # fp32 mode, pre-split operands: the weights' plane images are rewritten by the update kernel itself
+            hip.adamw_planes(store.flat, store.grad, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                             st["step"], segs, max_blocks=self.BACKGROUND_BLOCKS if background else 0)
+            engine.planes_written(store.weights)
+            return
         hip.adamw(store.flat, store.grad, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                   st["step"], p_bf16=shadow, max_blocks=self.BACKGROUND_BLOCKS if background else 0)
         if shadow is not None:
             engine.shadow_written(store.weights)
-        engine.planes_rewrite(store.weights)  # fp32 mode: the weights' plane images, rebuilt behind the update on its stream
+        engine.planes_rewrite(store.weights)  # (images exist but the fused form does not apply: rebuilt behind the update)
 
     def _early_layer_update(self, li: int):
         """Called from inside the backward pass (current stream: the one the layer's gradients are final on)."""

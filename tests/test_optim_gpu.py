@@ -257,3 +257,29 @@ def test_grad_wire_format_kernels():
     dst = torch.zeros(n, device=DEV)
     hip.grad_unpack_bf16(send, dst, n)
     assert torch.equal(dst, send[:n].float())
+
+
+def test_adamw_rewrites_the_plane_images_of_the_weights_inside_a_flat_buffer():
+    """Round 5: mtvaf_adamw_planes = mtvaf_adamw (same bits of p, m, v) + the tile-blocked plane images of the row-major matrices
+    inside the flat buffer, equal to a split pass over the UPDATED weights (the pre-split operand path's weight images)."""
+    from mtvaf_amd import hip
+    torch.manual_seed(3)
+    shapes = [(96, 64), (64, 64), (128, 64), (64, 128)]
+    gaps = [96, 64 + 8, 128 + 4, 64]  # (biases / LayerNorm vectors between the matrices)
+    n = sum(r * c for r, c in shapes) + sum(gaps)
+    p0 = torch.randn(n, device="cuda")
+    g = torch.randn(n, device="cuda") * 0.1
+    m0, v0 = torch.randn(n, device="cuda") * 0.01, torch.rand(n, device="cuda") * 0.01
+    segs, off = [], 0
+    for (r, c), gap in zip(shapes, gaps):
+        segs.append((off, r, c, torch.full((6 * r * c,), 0x7f, dtype=torch.uint8, device="cuda")))
+        off += r * c + gap
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    hip.adamw(pa, g, ma, va, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3)
+    hip.adamw_planes(pb, g, mb, vb, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, segs)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    for (o, r, c, img) in segs:
+        want = torch.empty_like(img)
+        hip.split_planes_blocked(pa[o:o + r * c].view(r, c), want)
+        assert torch.equal(img, want), (o, r, c)
