@@ -1,7 +1,8 @@
 #!/bin/bash
 # Everything profiles/ holds for one round, in GPU calls of <= 15 minutes:  tools/collect_profiles.sh r05 lines|stats|pmc
 # (writes gpurun_out/<tag>/; copy what is to be judged into profiles/).  The fp32 headline is the library default: split
-# products, padding-free execution (round 5); `--f32-pipe` is the fp32 MFMA pipe, `--padded` the padded layout.
+# products, padding-free execution, pre-split operand images (round 5); `--f32-pipe` is the fp32 MFMA pipe, `--padded` the padded
+# layout (in-kernel split), MTVAF_F32_PLANES=0 the in-kernel split on packed rows.
 export TMPDIR=/tmp
 T=${1:-r05}
 PHASE=${2:-lines}
@@ -40,6 +41,7 @@ fi
 if [ $PHASE = stats ]; then
 stats fp32 MTVAF_DW_STREAM=1
 stats fp32_serial MTVAF_DW_STREAM=0
+stats fp32_insplit_serial "MTVAF_DW_STREAM=0 MTVAF_F32_PLANES=0"
 stats fp32_padded_serial MTVAF_DW_STREAM=0 --padded
 stats fp32_pipe_serial MTVAF_DW_STREAM=0 --f32-pipe
 stats bf16_c3_serial MTVAF_DW_STREAM=0 --dtype bf16 --model roberta

@@ -20,7 +20,7 @@ def load(pass_dir):
     agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
     for f in glob.glob(os.path.join(src, pass_dir, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].replace("mtvaf::", "").replace("void ", "").replace("(GemmArgsX, P256SK)", "").replace("(GemmArgsX)", "").replace("(GemmArgs)", "").replace("(ab::Args, int)", "").replace("(ab::Args)", "")
+            name = r["Kernel_Name"].replace("mtvaf::", "").replace("void ", "").replace("(GemmArgsX, P256SK)", "").replace("(GemmArgsX)", "").replace("(GemmArgsP)", "").replace("(GemmArgs)", "").replace("(ab::Args, int)", "").replace("(ab::Args)", "")
             c = agg[name][r["Counter_Name"]]
             c[0] += float(r["Counter_Value"])
             c[1] += 1
