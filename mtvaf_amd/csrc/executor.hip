@@ -85,8 +85,9 @@ int mtvaf_gemm_f32p_slabs(int layout_a, const void* Aplanes, long a_plane, long 
 int mtvaf_gemm_f32p_ep(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
                        long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, void* c_planes, float* colpart, int M, int N, int K,
                        const float* bias, int epi, float* aux, int ldaux, int accumulate, hipStream_t stream);
-int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
-                             const int* M, const int* N, int K, hipStream_t stream);
+int mtvaf_gemm_f32p_dw_group_colsum(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C,
+                                    const int* ldc, const int* M, const int* N, int K, const float* cs_src, int cs_cols, int cs_ld,
+                                    float* cs_dst, hipStream_t stream);
 int mtvaf_gemm_f32_ktiles(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                           int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
                           int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits, const int* klist,
@@ -562,7 +563,7 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
       // second stream: the two bias gradients that are column sums of dY, then the four weight gradients as ONE launch
       if (ep) MTVAF_TRY(mtvaf_colsum_small(g->part, M / 128, I, g->dbi1, 0, side));
       else MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
-      MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
+      // (the QKV bias gradient = the column sums of dQ|dK|dV: extra blocks of the grouped launch below)
       {
         const void* const As[4] = {g->df_p, g->dpre_p, g->da_p, g->dqkv_p};
         const void* const Bs[4] = {L->act_p, L->h1_p, L->cx_p, L->x_p};
@@ -572,7 +573,7 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
         for (int i = 0; i < 8; ++i) {  // (every image has M rows: plane M * 64, k-row 64, k-tile 2048, 128-column block 12 * M * 64)
           strides[4 * i] = (long)M * 64; strides[4 * i + 1] = 64; strides[4 * i + 2] = 2048; strides[4 * i + 3] = (long)12 * M * 64;
         }
-        MTVAF_TRY(mtvaf_gemm_f32p_dw_group(4, As, Bs, strides, Cs, ldc, Ms, Ns, M, side));
+        MTVAF_TRY(mtvaf_gemm_f32p_dw_group_colsum(4, As, Bs, strides, Cs, ldc, Ms, Ns, M, dqkv, 3 * H, 3 * H, g->dbqkv, side));
       }
       MTVAF_TRY(p16(1, g->dqkv_p, L->wqkv_h, g->dh, H, M, H, 3 * H, nullptr, X_EPI_NONE, nullptr, 0, 1, g->ws_main, g->ws_main_bytes, nullptr,
                     mainS));

@@ -66,6 +66,12 @@ struct GemmArgsP {
     float* C;
     int ldc, tiles_n;
   } grp[4];
+  // GROUP: blocks behind the last tile are COLUMN-SUM items -- 64 columns of an fp32 matrix [cs_rows][cs_cols] (leading dimension
+  // cs_ld) each, summed over all rows into cs_dst (the QKV bias gradient: the column sums of dQ|dK|dV).  They ride in the idle CUs of
+  // the launch's last round of tiles (432 tiles on 256 CUs leave 80 of them free) instead of two launches of their own.
+  const float* cs_src;
+  float* cs_dst;
+  int cs_rows, cs_cols, cs_ld, cs_tile0;
 };
 
 namespace f32p {
@@ -142,7 +148,34 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
   const bool dma_wave = wave >= 4;
   const int w4 = wave & 3;
   const int wm = w4 >> 1, wn = w4 & 1;
-  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  if constexpr (GROUP) {
+    if (p.cs_src && (int)blockIdx.x >= p.cs_tile0) {  // (block-uniform) a column-sum item: 64 columns, 8 row groups, fixed summation order
+      float* red = reinterpret_cast<float*>(smem_p);
+      const int c = ((int)blockIdx.x - p.cs_tile0) * 64 + (tid & 63), rg = tid >> 6;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      if (c < p.cs_cols) {
+        const float* src = p.cs_src + c;
+        int r = rg;
+        for (; r + 24 < p.cs_rows; r += 32) {
+          s0 += src[(long)r * p.cs_ld];
+          s1 += src[(long)(r + 8) * p.cs_ld];
+          s2 += src[(long)(r + 16) * p.cs_ld];
+          s3 += src[(long)(r + 24) * p.cs_ld];
+        }
+        for (; r < p.cs_rows; r += 8) s0 += src[(long)r * p.cs_ld];
+      }
+      red[rg * 64 + (tid & 63)] = (s0 + s1) + (s2 + s3);
+      __syncthreads();
+      if (rg == 0 && c < p.cs_cols) {
+        float t = red[tid & 63];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) t += red[i * 64 + (tid & 63)];
+        p.cs_dst[c] = t;
+      }
+      return;
+    }
+  }
+  int bid = xcd_remap(blockIdx.x, GROUP ? p.cs_tile0 : (int)gridDim.x);  // (GROUP: cs_tile0 = the number of tiles, items or not)
   const unsigned char* Apl = p.Ap;
   const unsigned char* Bpl = p.Bp;
   long a_plane = p.a_plane, a_row = p.a_row, a_kt = p.a_kt, a_col = p.a_col, b_plane = p.b_plane, b_row = p.b_row, b_kt = p.b_kt, b_col = p.b_col;
@@ -630,8 +663,8 @@ int mtvaf_gemm_f32p_slabs(int layout_a, const void* Aplanes, long a_plane, long 
 // unsplit (research entry: what mtvaf_gemm_f32_dw_group's launch of the wave-specialised kernel would become with pre-split
 // operands; no bias sums, no k-tile list).  strides: per product eight byte strides a_plane, a_row, a_kt, a_col, b_plane, b_row,
 // b_kt, b_col (see mtvaf_gemm_f32p; tile-blocked images: row 64, k-tile 2048, col 12 x K x 64).  M_i, N_i % 128 == 0, K % 32 == 0.
-int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
-                             const int* M, const int* N, int K, hipStream_t stream) {
+static int f32p_dw_group_run(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
+                             const int* M, const int* N, int K, const float* cs_src, int cs_cols, int cs_ld, float* cs_dst, hipStream_t stream) {
   if (n < 1 || n > 4 || !Aplanes || !Bplanes || !strides || !C || !ldc || !M || !N || K <= 0 || K % 32) return MTVAF_ERR_ARG;
   GemmArgsP a = {};
   a.K = K; a.k_chunk = K; a.slab_stride = 0; a.epi = EPI_NONE; a.ngrp = n;
@@ -651,11 +684,32 @@ int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* cons
   }
   for (int i = n; i < 5; ++i) a.grp_tile_begin[i] = (int)tiles;  // (absent products own no tiles)
   a.M = M[0]; a.N = N[0]; a.tiles_n = N[0] / 128;
+  a.cs_tile0 = (int)tiles;
+  long blocks = tiles;
+  if (cs_src) {
+    if (!cs_dst || cs_cols <= 0 || cs_ld < cs_cols) return MTVAF_ERR_ARG;
+    a.cs_src = cs_src; a.cs_dst = cs_dst; a.cs_rows = K; a.cs_cols = cs_cols; a.cs_ld = cs_ld;
+    blocks += (cs_cols + 63) / 64;
+  }
   const int key[8] = {400 + 4 + 8 + 16, 1, 1, 2, (int)(tiles * 128 * 128 / 768), 768, K, 1};  // (+16: the GROUP instantiation; M x 768 = all outputs)
   const int rec = prof_begin(key, stream);
-  const int rc = launch_gemm_f32p16_group(a, dim3((unsigned)tiles, 1, 1), stream);
+  const int rc = launch_gemm_f32p16_group(a, dim3((unsigned)blocks, 1, 1), stream);
   prof_end(rec, stream);
   return rc;
+}
+
+int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
+                             const int* M, const int* N, int K, hipStream_t stream) {
+  return f32p_dw_group_run(n, Aplanes, Bplanes, strides, C, ldc, M, N, K, nullptr, 0, 0, nullptr, stream);
+}
+// ... with the column sums of an fp32 matrix [K][cs_cols] (leading dimension cs_ld) over its K rows -> cs_dst [cs_cols] as extra
+// blocks of the same launch (the QKV bias gradient = the column sums of dQ|dK|dV: they fill CUs the last round of tiles leaves
+// idle instead of two launches of their own); fixed summation order.
+int mtvaf_gemm_f32p_dw_group_colsum(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C,
+                                    const int* ldc, const int* M, const int* N, int K, const float* cs_src, int cs_cols, int cs_ld,
+                                    float* cs_dst, hipStream_t stream) {
+  if (!cs_src) return MTVAF_ERR_ARG;
+  return f32p_dw_group_run(n, Aplanes, Bplanes, strides, C, ldc, M, N, K, cs_src, cs_cols, cs_ld, cs_dst, stream);
 }
 
 }  // extern "C"

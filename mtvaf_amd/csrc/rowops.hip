@@ -271,10 +271,13 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
 
 // Same reduction for NP stacked partial rows [rows][NP][H] -> NP separate outputs in ONE launch
 // (LayerNorm backward: dgamma, dbeta, dense-bias gradient, token-type rows).  grid = ceil(NP*H / 32).
+// RG row groups per block (blockDim = 32 RG): 8 (256 threads) or 32 (round 5: the 512 partial rows of a LayerNorm backward are a
+// serial chain of 64 loads per thread with 8 groups -- the launch is latency, not bandwidth: 7 us for 4.7 MB -- and of 16 with 32)
 struct OutPtrs { float* p[4]; };
-__global__ __launch_bounds__(256) void colsum_final_multi_kernel(const float* __restrict__ x, int rows, int H, int NP,
-                                                                OutPtrs outs, int accumulate) {
-  __shared__ float red[8][32];
+template <int RG>
+__global__ __launch_bounds__(32 * RG) void colsum_final_multi_kernel(const float* __restrict__ x, int rows, int H, int NP,
+                                                                    OutPtrs outs, int accumulate) {
+  __shared__ float red[RG][32];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   const int cols = NP * H;
@@ -282,13 +285,13 @@ __global__ __launch_bounds__(256) void colsum_final_multi_kernel(const float* __
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < cols) {
     int r = rg;
-    for (; r + 24 < rows; r += 32) {
+    for (; r + 3 * RG < rows; r += 4 * RG) {
       s0 += x[(long)r * ld + c];
-      s1 += x[(long)(r + 8) * ld + c];
-      s2 += x[(long)(r + 16) * ld + c];
-      s3 += x[(long)(r + 24) * ld + c];
+      s1 += x[(long)(r + RG) * ld + c];
+      s2 += x[(long)(r + 2 * RG) * ld + c];
+      s3 += x[(long)(r + 3 * RG) * ld + c];
     }
-    for (; r < rows; r += 8) s0 += x[(long)r * ld + c];
+    for (; r < rows; r += RG) s0 += x[(long)r * ld + c];
   }
   red[rg][cl] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256) void colsum_final_multi_kernel(const float* __
     if (!out) return;
     float s = red[0][cl];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) s += red[i][cl];
+    for (int i = 1; i < RG; ++i) s += red[i][cl];
     const int cc = c % H;
     if (accumulate) s += out[cc];
     out[cc] = s;
@@ -697,8 +700,13 @@ int mtvaf_dropout_res_ln_bwd_finish(const float* part, int M, int H, float* dgam
   if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
   if (!part) return MTVAF_ERR_ARG;
   OutPtrs outs{{dgamma, dbeta, dbias_x, nullptr}};
-  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((3 * H + 31) / 32), dim3(256), 0, st, part, row_grid_bwd(M), H, 3, outs,
-                     accumulate);
+  static const int rg32 = [] { const char* e = getenv("MTVAF_LN_FINISH_RG32"); return e ? atoi(e) : 1; }();
+  if (rg32 && row_grid_bwd(M) >= 128)
+    hipLaunchKernelGGL((colsum_final_multi_kernel<32>), dim3((3 * H + 31) / 32), dim3(1024), 0, st, part, row_grid_bwd(M), H, 3, outs,
+                       accumulate);
+  else
+    hipLaunchKernelGGL((colsum_final_multi_kernel<8>), dim3((3 * H + 31) / 32), dim3(256), 0, st, part, row_grid_bwd(M), H, 3, outs,
+                       accumulate);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -751,7 +759,7 @@ int mtvaf_embed_ln_bwd(const float* dout, const int64_t* ids, const int64_t* typ
                      (__bf16*)nullptr, rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   OutPtrs outs{{dgamma, dbeta, dtype, type_vocab > 1 ? dtype + H : nullptr}};
-  hipLaunchKernelGGL(colsum_final_multi_kernel, dim3((4 * H + 31) / 32), dim3(256), 0, st, part, g, H, 4, outs,
+  hipLaunchKernelGGL((colsum_final_multi_kernel<8>), dim3((4 * H + 31) / 32), dim3(256), 0, st, part, g, H, 4, outs,
                      accumulate);
   if (!accumulate) {
     zero_f32(dword, (long)vocab * H, st);

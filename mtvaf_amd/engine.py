@@ -316,6 +316,12 @@ def _pack_granule() -> int:
     return 256 if (hip.COMPUTE == "bf16" and BF16_OPERANDS) else 128
 
 
+def _pack_min_gain() -> int:
+    """Rows a packed image must save to be worth it.  With the pre-split operand path (fp32 mode, F32_PLANES) the packed layout is
+    also the FASTER kernel set, so even a batch without any padding runs on it (0: an identity packing); otherwise one 128-row tile."""
+    return 0 if (F32_PLANES and hip.COMPUTE == "fp32" and hip.f32_split()) else 128
+
+
 class Packing:
     """Token packing of one forward pass: rowmap [Mp] packed row -> flat token (b*S + s), -1 for the rows that pad the
     image to whole 128-row tiles; inv [B*S] flat token -> packed row or -1; cu [B+1] row offsets of the sentences."""
@@ -360,7 +366,7 @@ class Packing:
             Mv = int(host[0])
             g = _pack_granule()
             Mp = max(g, (Mv + g - 1) // g * g)
-            if Mv == 0 or Mp > B * S - 128:
+            if Mv == 0 or Mp > B * S - _pack_min_gain():
                 return None
             pk = Packing()
             pk.rowmap, pk.inv, pk.cu = rowmap[:Mp], inv, cu
@@ -371,7 +377,7 @@ class Packing:
         Mv = int(idx.numel())
         g = _pack_granule()
         Mp = max(g, (Mv + g - 1) // g * g)
-        if Mv == 0 or Mp > B * S - 128:
+        if Mv == 0 or Mp > B * S - _pack_min_gain():
             return None  # nothing to gain (or nothing to compute): stay padded
         pk = Packing()
         dev = addmask.device

@@ -44,6 +44,7 @@ _SIGS = {
     "mtvaf_gemm_f32p": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, P]),
     "mtvaf_f32p_trace": (c_int, [P]),
     "mtvaf_gemm_f32p_dw_group": (c_int, [I, P, P, P, P, P, P, P, I, P]),
+    "mtvaf_gemm_f32p_dw_group_colsum": (c_int, [I, P, P, P, P, P, P, P, I, P, I, I, P, P]),
     "mtvaf_gemm_f32p_slabs": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, I, P, SZ, P, P]),
     "mtvaf_gemm_f32p_ep": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, P, P, I, I, I, P, I, P, I, I, P]),
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
@@ -389,9 +390,10 @@ def _km_strides(pl: "Planes"):
     return (pl.s_plane, 64, 32 * 64, 4 * pl.s_kt)  # tile-blocked [cols / 32][3][rows][32]: a 32-column block is pl.s_kt apart
 
 
-def gemm_planes_dw_group(items):
+def gemm_planes_dw_group(items, colsum=None):
     """items: up to four (a: Planes of dY [K, M], b: Planes of X [K, N], out [M, N] fp32): out = dY^T . X for each, one unsplit launch
-    (mtvaf_gemm_f32p_dw_group; natural or tile-blocked images)."""
+    (mtvaf_gemm_f32p_dw_group; natural or tile-blocked images).  colsum = (src fp32 [K, C], dst [C]): dst = column sums of src, as
+    extra blocks of the same launch."""
     n = len(items)
     K = items[0][0].rows
     assert all(a.rows == K and b.rows == K for a, b, _ in items)
@@ -400,6 +402,14 @@ def gemm_planes_dw_group(items):
     st = []
     for a, b, _ in items:
         st += list(_km_strides(a)) + list(_km_strides(b))
+    if colsum is not None:
+        src, dst = colsum
+        _ck(lib().mtvaf_gemm_f32p_dw_group_colsum(n, vp([a.img for a, _, _ in items]), vp([b.img for _, b, _ in items]),
+                                                  (ctypes.c_long * (8 * n))(*st), vp([o for _, _, o in items]),
+                                                  ia([o.stride(0) for _, _, o in items]), ia([a.cols for a, _, _ in items]),
+                                                  ia([b.cols for _, b, _ in items]), K, _p(src), src.shape[1], src.stride(0), _p(dst), _st()),
+            "mtvaf_gemm_f32p_dw_group_colsum")
+        return
     _ck(lib().mtvaf_gemm_f32p_dw_group(n, vp([a.img for a, _, _ in items]), vp([b.img for _, b, _ in items]), (ctypes.c_long * (8 * n))(*st),
                                        vp([o for _, _, o in items]), ia([o.stride(0) for _, _, o in items]), ia([a.cols for a, _, _ in items]),
                                        ia([b.cols for _, b, _ in items]), K, _st()), "mtvaf_gemm_f32p_dw_group")

@@ -1579,6 +1579,13 @@ def test_gemm_f32_presplit_planes_grouped_weight_gradients(hip):
             hip.gemm_planes_dw_group(list(zip(pas[:n], pbs[:n], outs)))
             for i in range(n):
                 assert torch.equal(outs[i], singles[i]), (blocked, n, i)
+        # ... with the column sums of an fp32 matrix (the QKV bias gradient) as extra blocks of the launch
+        outs = [torch.full_like(o, float("nan")) for o in singles]
+        cs = torch.full((3 * Hh,), float("nan"), device=DEV)
+        hip.gemm_planes_dw_group(list(zip(pas, pbs, outs)), colsum=(dys[3], cs))
+        for i in range(4):
+            assert torch.equal(outs[i], singles[i]), (blocked, i)
+        close(cs, dys[3].double().sum(0), rtol=1e-5, atol=1e-5 * float(dys[3].double().sum(0).abs().max()), name="column sums")
 
 
 def test_layernorm_adds_the_split_k_slabs_itself_bit_for_bit(hip):
