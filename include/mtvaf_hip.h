@@ -368,11 +368,12 @@ int mtvaf_f32p_trace(void* buf);
  * [C/32][3][K][32]: K*64, 64, 2048, 12*K*64).  M_i, N_i % 128 == 0, K % 32 == 0. */
 int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
                              const int* M, const int* N, int K, mtvaf_stream_t stream);
-/* ... with the column sums of an fp32 matrix [K][cs_cols] (leading dimension cs_ld) over its K rows -> cs_dst [cs_cols] as extra
- * blocks of the same launch: the QKV bias gradient (column sums of dQ|dK|dV) rides in the CUs the last round of tiles leaves idle. */
+/* ... with up to eight column-sum jobs as extra blocks of the same launch: job j sums the fp32 matrix cs_src[j] [cs_rows[j]][cs_cols[j]]
+ * (leading dimension cs_ld[j]) over its rows into cs_dst[j]; fixed summation order.  The small reductions of a layer's backward pass
+ * (QKV / FFN-1 bias gradients, the two LayerNorm-backward finishes) ride in the CUs the last round of tiles leaves idle. */
 int mtvaf_gemm_f32p_dw_group_colsum(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C,
-                                    const int* ldc, const int* M, const int* N, int K, const float* cs_src, int cs_cols, int cs_ld,
-                                    float* cs_dst, mtvaf_stream_t stream);
+                                    const int* ldc, const int* M, const int* N, int K, int njobs, const float* const* cs_src,
+                                    const int* cs_rows, const int* cs_cols, const int* cs_ld, float* const* cs_dst, mtvaf_stream_t stream);
 /* mtvaf_gemm_f32p with a plain epilogue that leaves a split-K plan's slabs unreduced (as mtvaf_gemm_f32_slabs: *splits_out = 1 -> C
  * holds the result; s > 1 -> `workspace` holds s slabs [M][N], bias / accumulate not applied): the LayerNorm kernels behind the Wo /
  * FFN-2 / FFN-1 dX products add them (modeling_bert.py:353-355, 433-435 and their backward). */

@@ -86,8 +86,9 @@ int mtvaf_gemm_f32p_ep(int layout_a, const void* Aplanes, long a_plane, long a_r
                        long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, void* c_planes, float* colpart, int M, int N, int K,
                        const float* bias, int epi, float* aux, int ldaux, int accumulate, hipStream_t stream);
 int mtvaf_gemm_f32p_dw_group_colsum(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C,
-                                    const int* ldc, const int* M, const int* N, int K, const float* cs_src, int cs_cols, int cs_ld,
-                                    float* cs_dst, hipStream_t stream);
+                                    const int* ldc, const int* M, const int* N, int K, int njobs, const float* const* cs_src,
+                                    const int* cs_rows, const int* cs_cols, const int* cs_ld, float* const* cs_dst, hipStream_t stream);
+size_t mtvaf_ln_bwd_workspace_bytes(int M, int H);
 int mtvaf_gemm_f32_ktiles(int layout_a, int layout_b, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                           int M, int N, int K, const float* bias, int epi, float* aux, int ldaux, int accumulate,
                           int allow_split, void* workspace, size_t workspace_bytes, int cfg, int splits, const int* klist,
@@ -508,11 +509,9 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
       // (df and da are read by GEMMs only: with per-layer partial buffers and a second stream the LayerNorm backward kernels write
       // their plane images themselves and no fp32 copy)
       const bool lnp = ln_planes_on() && g->lnpart2 && g->lnpart1 && side != mainS;
-      if (lnp) {
+      if (lnp) {  // (its column sums -- dgamma, dbeta, the FFN-2 bias gradient -- are jobs of the grouped weight-gradient launch below)
         MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_planes(g->dh, nullptr, 0, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, M, H,
                                                        L->p_hidden, L->seed, L->offset + 2, g->lnpart2, g->df_p, mainS));
-        MTVAF_TRY(fork_to(mainS, side));
-        MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart2, M, H, g->dg2, g->db2, g->dbi2, 0, side));
       } else {
         MTVAF_TRY(ln_bwd_forked(g->dh, L->f, L->h1, L->g2, L->mean2, L->rstd2, df, g->dh1, g->dg2, g->db2, g->dbi2, M, H, L->p_hidden, L->seed,
                                 L->offset + 2, g->lnpart2, g->ws_main, g->ws_main_bytes, nullptr, mainS, side));
@@ -533,8 +532,6 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
         MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_planes(g->dh1, static_cast<const float*>(g->ws_main), ns1 > 1 ? ns1 : 0, L->a, L->x, L->g1,
                                                        L->mean1, L->rstd1, nullptr, g->dh, 0, M, H, L->p_hidden, L->seed, L->offset + 1,
                                                        g->lnpart1, g->da_p, mainS));
-        MTVAF_TRY(fork_to(mainS, side));
-        MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart1, M, H, g->dg1, g->db1, g->dbo, 0, side));
       } else {
         if (ns1 > 1) {
           MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_slabs(g->dh1, static_cast<const float*>(g->ws_main), ns1, L->a, L->x, L->g1, L->mean1,
@@ -561,9 +558,10 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
       }
       MTVAF_TRY(fork_to(mainS, side));
       // second stream: the two bias gradients that are column sums of dY, then the four weight gradients as ONE launch
-      if (ep) MTVAF_TRY(mtvaf_colsum_small(g->part, M / 128, I, g->dbi1, 0, side));
-      else MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
-      // (the QKV bias gradient = the column sums of dQ|dK|dV: extra blocks of the grouped launch below)
+      if (!ep) MTVAF_TRY(mtvaf_colsum(dpre, M, I, I, g->dbi1, 0, g->ws_side, g->ws_side_bytes, side));
+      // (the small reductions of the layer are COLUMN-SUM JOBS of the grouped launch below -- extra blocks that fill the CUs its
+      // last round of tiles leaves idle: the QKV bias gradient = column sums of dQ|dK|dV, the FFN-1 bias gradient from the GELU'
+      // epilogue's per-tile sums, the two LayerNorm finishes = three column blocks of their partial rows each)
       {
         const void* const As[4] = {g->df_p, g->dpre_p, g->da_p, g->dqkv_p};
         const void* const Bs[4] = {L->act_p, L->h1_p, L->cx_p, L->x_p};
@@ -573,7 +571,18 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
         for (int i = 0; i < 8; ++i) {  // (every image has M rows: plane M * 64, k-row 64, k-tile 2048, 128-column block 12 * M * 64)
           strides[4 * i] = (long)M * 64; strides[4 * i + 1] = 64; strides[4 * i + 2] = 2048; strides[4 * i + 3] = (long)12 * M * 64;
         }
-        MTVAF_TRY(mtvaf_gemm_f32p_dw_group_colsum(4, As, Bs, strides, Cs, ldc, Ms, Ns, M, dqkv, 3 * H, 3 * H, g->dbqkv, side));
+        const float* js[8]; float* jd[8]; int jr[8], jc[8], jl[8], nj = 0;
+        auto job = [&](const float* src, int rows, int cols, int ld, float* dst) {
+          if (dst) { js[nj] = src; jr[nj] = rows; jc[nj] = cols; jl[nj] = ld; jd[nj] = dst; ++nj; }
+        };
+        job(dqkv, M, 3 * H, 3 * H, g->dbqkv);
+        if (ep) job(g->part, M / 128, I, I, g->dbi1);
+        if (lnp) {
+          const int G = (int)(mtvaf_ln_bwd_workspace_bytes(M, H) / ((size_t)16 * H));  // partial rows [G][3][H] of each LayerNorm backward
+          job(g->lnpart2, G, H, 3 * H, g->dg2); job(g->lnpart2 + H, G, H, 3 * H, g->db2); job(g->lnpart2 + 2 * H, G, H, 3 * H, g->dbi2);
+          job(g->lnpart1, G, H, 3 * H, g->dg1); job(g->lnpart1 + H, G, H, 3 * H, g->db1); job(g->lnpart1 + 2 * H, G, H, 3 * H, g->dbo);
+        }
+        MTVAF_TRY(mtvaf_gemm_f32p_dw_group_colsum(4, As, Bs, strides, Cs, ldc, Ms, Ns, M, nj, js, jr, jc, jl, jd, side));
       }
       MTVAF_TRY(p16(1, g->dqkv_p, L->wqkv_h, g->dh, H, M, H, 3 * H, nullptr, X_EPI_NONE, nullptr, 0, 1, g->ws_main, g->ws_main_bytes, nullptr,
                     mainS));

@@ -69,9 +69,11 @@ struct GemmArgsP {
   // GROUP: blocks behind the last tile are COLUMN-SUM items -- 64 columns of an fp32 matrix [cs_rows][cs_cols] (leading dimension
   // cs_ld) each, summed over all rows into cs_dst (the QKV bias gradient: the column sums of dQ|dK|dV).  They ride in the idle CUs of
   // the launch's last round of tiles (432 tiles on 256 CUs leave 80 of them free) instead of two launches of their own.
-  const float* cs_src;
-  float* cs_dst;
-  int cs_rows, cs_cols, cs_ld, cs_tile0;
+  // (up to eight jobs: job j owns blocks cs_blk0[j] .. cs_blk0[j + 1] - 1 behind the tiles -- besides the QKV bias gradient the two
+  // LayerNorm-backward finishes of the layer (dgamma, dbeta, dense-bias gradient: three column blocks of 512 partial rows each) and
+  // the FFN-1 bias gradient from the GELU' epilogue's per-tile sums)
+  struct ColJob { const float* src; float* dst; int rows, cols, ld; } cs[8];
+  int cs_n, cs_blk0[9], cs_tile0;
 };
 
 namespace f32p {
@@ -149,28 +151,33 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
   const int w4 = wave & 3;
   const int wm = w4 >> 1, wn = w4 & 1;
   if constexpr (GROUP) {
-    if (p.cs_src && (int)blockIdx.x >= p.cs_tile0) {  // (block-uniform) a column-sum item: 64 columns, 8 row groups, fixed summation order
+    if (p.cs_n > 0 && (int)blockIdx.x >= p.cs_tile0) {  // (block-uniform) a column-sum item: 64 columns, 8 row groups, fixed summation order
       float* red = reinterpret_cast<float*>(smem_p);
-      const int c = ((int)blockIdx.x - p.cs_tile0) * 64 + (tid & 63), rg = tid >> 6;
+      const int bi = (int)blockIdx.x - p.cs_tile0;
+      int j = 0;
+#pragma unroll
+      for (int q = 1; q < 8; ++q) j += (q < p.cs_n && bi >= p.cs_blk0[q]) ? 1 : 0;
+      const GemmArgsP::ColJob& jb = p.cs[j];
+      const int c = (bi - p.cs_blk0[j]) * 64 + (tid & 63), rg = tid >> 6;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      if (c < p.cs_cols) {
-        const float* src = p.cs_src + c;
+      if (c < jb.cols) {
+        const float* src = jb.src + c;
         int r = rg;
-        for (; r + 24 < p.cs_rows; r += 32) {
-          s0 += src[(long)r * p.cs_ld];
-          s1 += src[(long)(r + 8) * p.cs_ld];
-          s2 += src[(long)(r + 16) * p.cs_ld];
-          s3 += src[(long)(r + 24) * p.cs_ld];
+        for (; r + 24 < jb.rows; r += 32) {
+          s0 += src[(long)r * jb.ld];
+          s1 += src[(long)(r + 8) * jb.ld];
+          s2 += src[(long)(r + 16) * jb.ld];
+          s3 += src[(long)(r + 24) * jb.ld];
         }
-        for (; r < p.cs_rows; r += 8) s0 += src[(long)r * p.cs_ld];
+        for (; r < jb.rows; r += 8) s0 += src[(long)r * jb.ld];
       }
       red[rg * 64 + (tid & 63)] = (s0 + s1) + (s2 + s3);
       __syncthreads();
-      if (rg == 0 && c < p.cs_cols) {
+      if (rg == 0 && c < jb.cols) {
         float t = red[tid & 63];
 #pragma unroll
         for (int i = 1; i < 8; ++i) t += red[i * 64 + (tid & 63)];
-        p.cs_dst[c] = t;
+        jb.dst[c] = t;
       }
       return;
     }
@@ -664,7 +671,8 @@ int mtvaf_gemm_f32p_slabs(int layout_a, const void* Aplanes, long a_plane, long 
 // operands; no bias sums, no k-tile list).  strides: per product eight byte strides a_plane, a_row, a_kt, a_col, b_plane, b_row,
 // b_kt, b_col (see mtvaf_gemm_f32p; tile-blocked images: row 64, k-tile 2048, col 12 x K x 64).  M_i, N_i % 128 == 0, K % 32 == 0.
 static int f32p_dw_group_run(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
-                             const int* M, const int* N, int K, const float* cs_src, int cs_cols, int cs_ld, float* cs_dst, hipStream_t stream) {
+                             const int* M, const int* N, int K, int njobs, const float* const* cs_src, const int* cs_rows, const int* cs_cols,
+                             const int* cs_ld, float* const* cs_dst, hipStream_t stream) {
   if (n < 1 || n > 4 || !Aplanes || !Bplanes || !strides || !C || !ldc || !M || !N || K <= 0 || K % 32) return MTVAF_ERR_ARG;
   GemmArgsP a = {};
   a.K = K; a.k_chunk = K; a.slab_stride = 0; a.epi = EPI_NONE; a.ngrp = n;
@@ -686,11 +694,17 @@ static int f32p_dw_group_run(int n, const void* const* Aplanes, const void* cons
   a.M = M[0]; a.N = N[0]; a.tiles_n = N[0] / 128;
   a.cs_tile0 = (int)tiles;
   long blocks = tiles;
-  if (cs_src) {
-    if (!cs_dst || cs_cols <= 0 || cs_ld < cs_cols) return MTVAF_ERR_ARG;
-    a.cs_src = cs_src; a.cs_dst = cs_dst; a.cs_rows = K; a.cs_cols = cs_cols; a.cs_ld = cs_ld;
-    blocks += (cs_cols + 63) / 64;
+  if (njobs < 0 || njobs > 8 || (njobs && (!cs_src || !cs_rows || !cs_cols || !cs_ld || !cs_dst))) return MTVAF_ERR_ARG;
+  a.cs_n = njobs;
+  int cb = 0;
+  for (int j = 0; j < njobs; ++j) {
+    if (!cs_src[j] || !cs_dst[j] || cs_rows[j] <= 0 || cs_cols[j] <= 0 || cs_ld[j] < cs_cols[j]) return MTVAF_ERR_ARG;
+    a.cs[j].src = cs_src[j]; a.cs[j].dst = cs_dst[j]; a.cs[j].rows = cs_rows[j]; a.cs[j].cols = cs_cols[j]; a.cs[j].ld = cs_ld[j];
+    a.cs_blk0[j] = cb;
+    cb += (cs_cols[j] + 63) / 64;
   }
+  for (int j = njobs; j < 9; ++j) a.cs_blk0[j] = cb;
+  blocks += cb;
   const int key[8] = {400 + 4 + 8 + 16, 1, 1, 2, (int)(tiles * 128 * 128 / 768), 768, K, 1};  // (+16: the GROUP instantiation; M x 768 = all outputs)
   const int rec = prof_begin(key, stream);
   const int rc = launch_gemm_f32p16_group(a, dim3((unsigned)blocks, 1, 1), stream);
@@ -700,16 +714,18 @@ static int f32p_dw_group_run(int n, const void* const* Aplanes, const void* cons
 
 int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
                              const int* M, const int* N, int K, hipStream_t stream) {
-  return f32p_dw_group_run(n, Aplanes, Bplanes, strides, C, ldc, M, N, K, nullptr, 0, 0, nullptr, stream);
+  return f32p_dw_group_run(n, Aplanes, Bplanes, strides, C, ldc, M, N, K, 0, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
-// ... with the column sums of an fp32 matrix [K][cs_cols] (leading dimension cs_ld) over its K rows -> cs_dst [cs_cols] as extra
-// blocks of the same launch (the QKV bias gradient = the column sums of dQ|dK|dV: they fill CUs the last round of tiles leaves
-// idle instead of two launches of their own); fixed summation order.
+// ... with up to eight COLUMN-SUM jobs as extra blocks of the same launch: job j sums the fp32 matrix cs_src[j] [cs_rows[j]][cs_cols[j]]
+// (leading dimension cs_ld[j]) over its rows into cs_dst[j] [cs_cols[j]], fixed summation order.  The small reductions of a layer's
+// backward pass -- the QKV bias gradient (column sums of dQ|dK|dV), the FFN-1 bias gradient (the GELU' epilogue's per-tile sums), the
+// two LayerNorm-backward finishes (dgamma, dbeta, dense-bias gradient from 512 partial rows each) -- fill CUs the last round of tiles
+// leaves idle instead of five launches of their own.
 int mtvaf_gemm_f32p_dw_group_colsum(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C,
-                                    const int* ldc, const int* M, const int* N, int K, const float* cs_src, int cs_cols, int cs_ld,
-                                    float* cs_dst, hipStream_t stream) {
-  if (!cs_src) return MTVAF_ERR_ARG;
-  return f32p_dw_group_run(n, Aplanes, Bplanes, strides, C, ldc, M, N, K, cs_src, cs_cols, cs_ld, cs_dst, stream);
+                                    const int* ldc, const int* M, const int* N, int K, int njobs, const float* const* cs_src,
+                                    const int* cs_rows, const int* cs_cols, const int* cs_ld, float* const* cs_dst, hipStream_t stream) {
+  if (njobs < 1) return MTVAF_ERR_ARG;
+  return f32p_dw_group_run(n, Aplanes, Bplanes, strides, C, ldc, M, N, K, njobs, cs_src, cs_rows, cs_cols, cs_ld, cs_dst, stream);
 }
 
 }  // extern "C"

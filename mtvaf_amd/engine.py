@@ -171,8 +171,13 @@ BF16_WCACHE = os.environ.get("MTVAF_BF16_WCACHE", "1") != "0" and _HAVE_OPT_HOOK
 F32_PLANES = os.environ.get("MTVAF_F32_PLANES", "1") != "0" and _HAVE_OPT_HOOK
 
 
+# (few-token layers -- BASELINE configs[0]: 256 rows -- are a handful of 128 x 128 tiles: the planner's small-tile kernels win there)
+F32_PLANES_MIN_ROWS = int(os.environ.get("MTVAF_F32_PLANES_MIN_ROWS", "1024"))
+
+
 def _f32_planes_on(use_h, pack, H, I) -> bool:
-    return bool(F32_PLANES and not use_h and pack is not None and H % 128 == 0 and I % 128 == 0 and hip.f32_split())
+    return bool(F32_PLANES and not use_h and pack is not None and pack.Mp >= F32_PLANES_MIN_ROWS and H % 128 == 0 and I % 128 == 0
+                and hip.f32_split())
 
 
 def _wplane_fill(w: "LayerWeights", views):
@@ -316,10 +321,11 @@ def _pack_granule() -> int:
     return 256 if (hip.COMPUTE == "bf16" and BF16_OPERANDS) else 128
 
 
-def _pack_min_gain() -> int:
-    """Rows a packed image must save to be worth it.  With the pre-split operand path (fp32 mode, F32_PLANES) the packed layout is
-    also the FASTER kernel set, so even a batch without any padding runs on it (0: an identity packing); otherwise one 128-row tile."""
-    return 0 if (F32_PLANES and hip.COMPUTE == "fp32" and hip.f32_split()) else 128
+def _pack_min_gain(rows: int) -> int:
+    """Rows a packed image must save to be worth it.  With the pre-split operand path (fp32 mode, F32_PLANES, enough rows) the packed
+    layout is also the FASTER kernel set, so even a batch without any padding runs on it (0: an identity packing); otherwise one
+    128-row tile."""
+    return 0 if (F32_PLANES and rows >= F32_PLANES_MIN_ROWS and hip.COMPUTE == "fp32" and hip.f32_split()) else 128
 
 
 class Packing:
@@ -366,7 +372,7 @@ class Packing:
             Mv = int(host[0])
             g = _pack_granule()
             Mp = max(g, (Mv + g - 1) // g * g)
-            if Mv == 0 or Mp > B * S - _pack_min_gain():
+            if Mv == 0 or Mp > B * S - _pack_min_gain(Mp):
                 return None
             pk = Packing()
             pk.rowmap, pk.inv, pk.cu = rowmap[:Mp], inv, cu
@@ -377,7 +383,7 @@ class Packing:
         Mv = int(idx.numel())
         g = _pack_granule()
         Mp = max(g, (Mv + g - 1) // g * g)
-        if Mv == 0 or Mp > B * S - _pack_min_gain():
+        if Mv == 0 or Mp > B * S - _pack_min_gain(Mp):
             return None  # nothing to gain (or nothing to compute): stay padded
         pk = Packing()
         dev = addmask.device

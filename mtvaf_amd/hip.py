@@ -44,7 +44,7 @@ _SIGS = {
     "mtvaf_gemm_f32p": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, P]),
     "mtvaf_f32p_trace": (c_int, [P]),
     "mtvaf_gemm_f32p_dw_group": (c_int, [I, P, P, P, P, P, P, P, I, P]),
-    "mtvaf_gemm_f32p_dw_group_colsum": (c_int, [I, P, P, P, P, P, P, P, I, P, I, I, P, P]),
+    "mtvaf_gemm_f32p_dw_group_colsum": (c_int, [I, P, P, P, P, P, P, P, I, I, P, P, P, P, P, P]),
     "mtvaf_gemm_f32p_slabs": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, I, P, SZ, P, P]),
     "mtvaf_gemm_f32p_ep": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, P, P, I, I, I, P, I, P, I, I, P]),
     "mtvaf_gemm_bf16": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P]),
@@ -393,7 +393,7 @@ def _km_strides(pl: "Planes"):
 def gemm_planes_dw_group(items, colsum=None):
     """items: up to four (a: Planes of dY [K, M], b: Planes of X [K, N], out [M, N] fp32): out = dY^T . X for each, one unsplit launch
     (mtvaf_gemm_f32p_dw_group; natural or tile-blocked images).  colsum = (src fp32 [K, C], dst [C]): dst = column sums of src, as
-    extra blocks of the same launch."""
+    extra blocks of the same launch; or a list of up to eight such pairs."""
     n = len(items)
     K = items[0][0].rows
     assert all(a.rows == K and b.rows == K for a, b, _ in items)
@@ -403,11 +403,16 @@ def gemm_planes_dw_group(items, colsum=None):
     for a, b, _ in items:
         st += list(_km_strides(a)) + list(_km_strides(b))
     if colsum is not None:
-        src, dst = colsum
+        jobs = [colsum] if isinstance(colsum, tuple) else list(colsum)
+        nj = len(jobs)
+        pj = lambda ts: (ctypes.c_void_p * nj)(*[_p(t) for t in ts])
+        ij = lambda xs: (ctypes.c_int * nj)(*xs)
         _ck(lib().mtvaf_gemm_f32p_dw_group_colsum(n, vp([a.img for a, _, _ in items]), vp([b.img for _, b, _ in items]),
                                                   (ctypes.c_long * (8 * n))(*st), vp([o for _, _, o in items]),
                                                   ia([o.stride(0) for _, _, o in items]), ia([a.cols for a, _, _ in items]),
-                                                  ia([b.cols for _, b, _ in items]), K, _p(src), src.shape[1], src.stride(0), _p(dst), _st()),
+                                                  ia([b.cols for _, b, _ in items]), K, nj, pj([s_ for s_, _ in jobs]),
+                                                  ij([s_.shape[0] for s_, _ in jobs]), ij([s_.shape[1] for s_, _ in jobs]),
+                                                  ij([s_.stride(0) for s_, _ in jobs]), pj([d for _, d in jobs]), _st()),
             "mtvaf_gemm_f32p_dw_group_colsum")
         return
     _ck(lib().mtvaf_gemm_f32p_dw_group(n, vp([a.img for a, _, _ in items]), vp([b.img for _, b, _ in items]), (ctypes.c_long * (8 * n))(*st),

@@ -1582,10 +1582,13 @@ def test_gemm_f32_presplit_planes_grouped_weight_gradients(hip):
         # ... with the column sums of an fp32 matrix (the QKV bias gradient) as extra blocks of the launch
         outs = [torch.full_like(o, float("nan")) for o in singles]
         cs = torch.full((3 * Hh,), float("nan"), device=DEV)
-        hip.gemm_planes_dw_group(list(zip(pas, pbs, outs)), colsum=(dys[3], cs))
+        part = rnd(37, 3 * 200, seed=50).to(DEV)  # (a second job of another shape: a column block of stacked partial rows)
+        cs2 = torch.full((200,), float("nan"), device=DEV)
+        hip.gemm_planes_dw_group(list(zip(pas, pbs, outs)), colsum=[(dys[3], cs), (part[:, 200:400], cs2)])
         for i in range(4):
             assert torch.equal(outs[i], singles[i]), (blocked, i)
         close(cs, dys[3].double().sum(0), rtol=1e-5, atol=1e-5 * float(dys[3].double().sum(0).abs().max()), name="column sums")
+        close(cs2, part[:, 200:400].double().sum(0), rtol=1e-5, atol=1e-5, name="column sums of a column block")
 
 
 def test_layernorm_adds_the_split_k_slabs_itself_bit_for_bit(hip):
