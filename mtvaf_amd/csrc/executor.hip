@@ -85,6 +85,8 @@ int mtvaf_gemm_f32p_slabs(int layout_a, const void* Aplanes, long a_plane, long 
 int mtvaf_gemm_f32p_ep(int layout_a, const void* Aplanes, long a_plane, long a_row, long a_kt, long a_col, int layout_b, const void* Bplanes,
                        long b_plane, long b_row, long b_kt, long b_col, float* C, int ldc, void* c_planes, float* colpart, int M, int N, int K,
                        const float* bias, int epi, float* aux, int ldaux, int accumulate, hipStream_t stream);
+int mtvaf_gemm_f32p_dw_group(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C, const int* ldc,
+                             const int* M, const int* N, int K, hipStream_t stream);
 int mtvaf_gemm_f32p_dw_group_colsum(int n, const void* const* Aplanes, const void* const* Bplanes, const long* strides, float* const* C,
                                     const int* ldc, const int* M, const int* N, int K, int njobs, const float* const* cs_src,
                                     const int* cs_rows, const int* cs_cols, const int* cs_ld, float* const* cs_dst, hipStream_t stream);
@@ -571,6 +573,15 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
         for (int i = 0; i < 8; ++i) {  // (every image has M rows: plane M * 64, k-row 64, k-tile 2048, 128-column block 12 * M * 64)
           strides[4 * i] = (long)M * 64; strides[4 * i + 1] = 64; strides[4 * i + 2] = 2048; strides[4 * i + 3] = (long)12 * M * 64;
         }
+        static const int jobs_on = [] { const char* e = getenv("MTVAF_DW_JOBS"); return e ? atoi(e) : 1; }();  // (0: one launch per reduction)
+        if (!jobs_on) {
+          MTVAF_TRY(mtvaf_colsum(dqkv, M, 3 * H, 3 * H, g->dbqkv, 0, g->ws_side, g->ws_side_bytes, side));
+          if (ep) MTVAF_TRY(mtvaf_colsum_small(g->part, M / 128, I, g->dbi1, 0, side));
+          if (lnp) {
+            MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart2, M, H, g->dg2, g->db2, g->dbi2, 0, side));
+            MTVAF_TRY(mtvaf_dropout_res_ln_bwd_finish(g->lnpart1, M, H, g->dg1, g->db1, g->dbo, 0, side));
+          }
+        }
         const float* js[8]; float* jd[8]; int jr[8], jc[8], jl[8], nj = 0;
         auto job = [&](const float* src, int rows, int cols, int ld, float* dst) {
           if (dst) { js[nj] = src; jr[nj] = rows; jc[nj] = cols; jl[nj] = ld; jd[nj] = dst; ++nj; }
@@ -582,7 +593,9 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
           job(g->lnpart2, G, H, 3 * H, g->dg2); job(g->lnpart2 + H, G, H, 3 * H, g->db2); job(g->lnpart2 + 2 * H, G, H, 3 * H, g->dbi2);
           job(g->lnpart1, G, H, 3 * H, g->dg1); job(g->lnpart1 + H, G, H, 3 * H, g->db1); job(g->lnpart1 + 2 * H, G, H, 3 * H, g->dbo);
         }
-        MTVAF_TRY(mtvaf_gemm_f32p_dw_group_colsum(4, As, Bs, strides, Cs, ldc, Ms, Ns, M, nj, js, jr, jc, jl, jd, side));
+        if (!jobs_on) nj = 0;
+        if (nj > 0) MTVAF_TRY(mtvaf_gemm_f32p_dw_group_colsum(4, As, Bs, strides, Cs, ldc, Ms, Ns, M, nj, js, jr, jc, jl, jd, side));
+        else MTVAF_TRY(mtvaf_gemm_f32p_dw_group(4, As, Bs, strides, Cs, ldc, Ms, Ns, M, side));
       }
       MTVAF_TRY(p16(1, g->dqkv_p, L->wqkv_h, g->dh, H, M, H, 3 * H, nullptr, X_EPI_NONE, nullptr, 0, 1, g->ws_main, g->ws_main_bytes, nullptr,
                     mainS));
