@@ -510,7 +510,7 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
       // pre-split operands (round 5): the dX chain and the grouped weight gradients on the kernels of csrc/gemm_f32p.hip
       // (df and da are read by GEMMs only: with per-layer partial buffers and a second stream the LayerNorm backward kernels write
       // their plane images themselves and no fp32 copy)
-      const bool lnp = ln_planes_on() && g->lnpart2 && g->lnpart1 && side != mainS;
+      const bool lnp = ln_planes_on() && g->lnpart2 && g->lnpart1;
       if (lnp) {  // (its column sums -- dgamma, dbeta, the FFN-2 bias gradient -- are jobs of the grouped weight-gradient launch below)
         MTVAF_TRY(mtvaf_dropout_res_ln_bwd_rows_planes(g->dh, nullptr, 0, L->f, L->h1, L->g2, L->mean2, L->rstd2, nullptr, g->dh1, 0, M, H,
                                                        L->p_hidden, L->seed, L->offset + 2, g->lnpart2, g->df_p, mainS));
@@ -527,7 +527,7 @@ int mtvaf_encoder_layer_bwd(const mtvaf_layer_t* L, const mtvaf_layer_grads_t* g
         MTVAF_TRY(planes_of(dpre, g->dpre_p, M, I, mainS));
       }
       int ns1 = 1;
-      const bool slabs1 = ln_slabs_on() && g->lnpart1 && side != mainS;
+      const bool slabs1 = ln_slabs_on() && g->lnpart1 && (lnp || side != mainS);  // (the LayerNorm's partials must not share the slabs' scratch)
       MTVAF_TRY(p16(1, g->dpre_p, L->w1_h, g->dh1, H, M, H, I, nullptr, X_EPI_NONE, nullptr, 0, 1, g->ws_main, g->ws_main_bytes,
                     slabs1 ? &ns1 : nullptr, mainS));
       if (lnp) {
