@@ -1598,6 +1598,8 @@ def test_layernorm_adds_the_split_k_slabs_itself_bit_for_bit(hip):
     outputs, statistics, the stored dense output the backward pass reads, dx / dres and the column-sum partials."""
     import ctypes
     L_ = hip.lib()
+    if not hip.f32_split():
+        pytest.skip("the planner of the fp32 MFMA pipe does not split these products: nothing to hand over")
     M, H, K = 2432, 768, 3072   # 19 x 6 tiles: the planner splits
     x = rnd(M, K, seed=1).to(DEV)
     w = (rnd(H, K, seed=2) * 0.05).to(DEV)

@@ -386,3 +386,4 @@ def test_presplit_operand_path_against_the_in_kernel_split_path():
         # -- so: no element further apart than the three steps can carry a sign flip (3 lr), all but a handful within 0.3 lr
         err = (w1[n] - w0[n]).abs()
         assert float(err.max()) <= 3e-4 and float((err > 3e-5).float().mean()) <= 1e-5, (n, float(err.max()), int((err > 3e-5).sum()))
+
