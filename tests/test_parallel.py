@@ -484,6 +484,30 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
 
 
 @pytest.mark.gpu
+def test_bench_self_launch_two_ranks_at_the_headline_shape_on_the_pre_split_path():
+    """The N > 1 bench at the shape the driver runs per rank (bs 32, S 128, fp32 wire): every rank packs > 1024 rows, so the
+    encoder runs on the pre-split operand path UNDER GradSync -- the per-layer AdamW updates (and the weights' plane images they
+    rewrite) are issued from the communication stream behind each layer's all-reduce.  Two ranks on the one GPU over gloo: loss
+    finite and equal to the single-rank run of the same global batch is not asked here (different data per rank); asked: it runs,
+    the line says which operand form was timed, the collective-sequence check passes on every pass."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MTVAF_BENCH_ONE_DEVICE"] = "1"
+    env["MTVAF_CHECK_COLLECTIVES"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-roofline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_ranks_seen"] == 2 and d["value"] > 0
+    assert d["config"]["global_batch"] == 64 and "pre-split plane images" in d["config"]["workload"]
+    import math
+    assert math.isfinite(d["loss"])
+
+
+@pytest.mark.gpu
 def test_bench_self_launch_four_ranks_on_one_gpu_bf16_wire_with_sequence_check():
     """The N > 1 bench path with more ranks than a test has had so far, on the one GPU this lease has: `python bench.py --gpus 4`
     (no launcher: the parent starts four ranks; the box admits at most SIX processes on its card and this test process holds
