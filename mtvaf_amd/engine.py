@@ -171,8 +171,10 @@ BF16_WCACHE = os.environ.get("MTVAF_BF16_WCACHE", "1") != "0" and _HAVE_OPT_HOOK
 F32_PLANES = os.environ.get("MTVAF_F32_PLANES", "1") != "0" and _HAVE_OPT_HOOK
 
 
-# (few-token layers -- BASELINE configs[0]: 256 rows -- are a handful of 128 x 128 tiles: the planner's small-tile kernels win there)
-F32_PLANES_MIN_ROWS = int(os.environ.get("MTVAF_F32_PLANES_MIN_ROWS", "1024"))
+# (few-token layers -- BASELINE configs[0]: 256 rows -- are a handful of 128 x 128 tiles: the planner's small-tile kernels win there.
+# Measured, bench.py --batch b, same box, path on / off: bs 4 x S 64 832 / 903 sentences/s, bs 4 x 128 770 / 812, bs 8 (640 packed
+# rows) 1374 / 1238, bs 12 2015 / 1708, bs 16 2443 / 2342, bs 24 2726 / 2480)
+F32_PLANES_MIN_ROWS = int(os.environ.get("MTVAF_F32_PLANES_MIN_ROWS", "512"))
 
 
 def _f32_planes_on(use_h, pack, H, I) -> bool:
