@@ -144,6 +144,9 @@ class AdamW(torch.optim.Optimizer):
     # only pile up behind the pass
     BACKGROUND_MIN_ROWS = int(os.environ.get("MTVAF_ADAMW_BG_MIN_ROWS", "2048"))
     BACKGROUND_BLOCKS = int(os.environ.get("MTVAF_ADAMW_BG_BLOCKS", "128"))
+    # (the pre-split path's second stream is lighter -- one grouped launch per layer -- and the update also writes the weights' plane
+    # images: 256 blocks measured best there, 3257 - 3260 sentences/s against 3237 - 3238 at 128, 3220 - 3225 at 512, 3128 - 3133 at 64)
+    BACKGROUND_BLOCKS_PLANES = int(os.environ.get("MTVAF_ADAMW_BG_BLOCKS", "256"))
 
     def _update_layer_flat(self, li: int, group: dict, store, background: bool = False):
         st = self._layer_state(li, store)
@@ -156,7 +159,7 @@ class AdamW(torch.optim.Optimizer):
         if segs is not None and store.flat.numel() % 4 == 0:
             # fp32 mode, pre-split operands: the weights' plane images are rewritten by the update kernel itself
             hip.adamw_planes(store.flat, store.grad, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                             st["step"], segs, max_blocks=self.BACKGROUND_BLOCKS if background else 0)
+                             st["step"], segs, max_blocks=self.BACKGROUND_BLOCKS_PLANES if background else 0)
             engine.planes_written(store.weights)
             return
         hip.adamw(store.flat, store.grad, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
