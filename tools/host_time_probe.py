@@ -1,0 +1,63 @@
+"""Where does the HOST spend its time enqueueing one default training step (bs 32 / S 128, padding-free, pre-split path)?
+Wall-clock segments without any synchronisation of our own (forward incl. the packing wait, backward, optimizer), then a cProfile
+of 20 steps.
+
+    python tools/host_time_probe.py [steps]
+"""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from mtvaf_amd.optim import AdamW  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dev = torch.device("cuda:0")
+torch.manual_seed(1)
+model, cfg = bench.build_model(dev, "bert", 128)
+model.train()
+opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model, overlap=True)
+ids, mask, tt, labels, feats, aux = bench.synthetic_batch(32, 128, 8, cfg.vocab_size, 1234, dev)
+kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None, images=feats, aux_imgs=aux)
+seg = [0.0, 0.0, 0.0, 0.0]
+
+
+def step(timed=False):
+    t0 = time.perf_counter()
+    out = model(**kw)
+    t1 = time.perf_counter()
+    out.loss.backward()
+    t2 = time.perf_counter()
+    opt.step()
+    t3 = time.perf_counter()
+    opt.zero_grad(set_to_none=True)
+    t4 = time.perf_counter()
+    if timed:
+        for i, d in enumerate((t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            seg[i] += d
+
+
+for _ in range(8):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    step(True)
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / steps * 1e3
+print(f"step {ms:.3f} ms; host: forward (incl. the wait for the packed row count) {seg[0] / steps * 1e3:.3f}, backward "
+      f"{seg[1] / steps * 1e3:.3f}, optimizer.step {seg[2] / steps * 1e3:.3f}, zero_grad {seg[3] / steps * 1e3:.3f} ms", flush=True)
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(20):
+    step()
+pr.disable()
+torch.cuda.synchronize()
+st = pstats.Stats(pr, stream=sys.stdout)
+st.sort_stats("tottime").print_stats(35)
+st.sort_stats("cumulative").print_stats(45)
