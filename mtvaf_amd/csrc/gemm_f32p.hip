@@ -54,6 +54,10 @@ struct GemmArgsP {
   unsigned char* Cpl;
   float* colpart;
   int ablate;        // research switches: 1 = no MFMAs, 2 = no DMA requests, 4 = no fragment reads
+  // tile walk (placement only: results never depend on it): 0 = row-major; G > 0 = bands of G tile rows walked column by column, so
+  // that the tiles an XCD runs at one time (its 32 CUs: a contiguous run of the walk) share G A panels and 32 / G B panels instead
+  // of one or two A panels and a whole row of B panels
+  int walk_g;
   long long* trace;  // [8 waves][64 k-tiles][2] shader-clock stamps of block 0 (arrive at / leave the tile barrier) + 17, or NULL
   // GROUP (weight gradients): blockIdx.x walks the 128 x 128 tiles of up to four products that share the reduction axis back to
   // back; product q owns tiles grp_tile_begin[q] .. grp_tile_begin[q + 1] - 1 (as GemmArgs::grp of the wave-specialised kernel)
@@ -196,8 +200,19 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16_kernel(GemmArgsP p) {
     a_plane = pb.a_plane; a_row = pb.a_row; a_kt = pb.a_kt; a_col = pb.a_col;
     b_plane = pb.b_plane; b_row = pb.b_row; b_kt = pb.b_kt; b_col = pb.b_col;
   }
-  const int m0 = (bid / tiles_n) * BM;
-  const int n0 = (bid % tiles_n) * BN;
+  int tm = bid / tiles_n, tn = bid % tiles_n;
+  if constexpr (!GROUP) {
+    if (p.walk_g > 0) {
+      const int tiles_m = (p.M + BM - 1) / BM, G = p.walk_g;
+      const int band = bid / (G * tiles_n), first = band * G;
+      const int gsz = tiles_m - first < G ? tiles_m - first : G;
+      const int rem = bid - band * G * tiles_n;
+      tm = first + rem % gsz;
+      tn = rem / gsz;
+    }
+  }
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
   const int kbeg = blockIdx.z * p.k_chunk;
   const int kend = min(p.K, kbeg + p.k_chunk);
   const int nk = (kend - kbeg) / 32;
@@ -620,6 +635,10 @@ static int gemm_f32p_run(int layout_a, const void* Aplanes, long a_plane, long a
   a.Cpl = static_cast<unsigned char*>(c_planes);
   a.colpart = colpart;
   a.ablate = ablate;
+  // (measured at the headline shape, same box, two runs each: G = 0 / 2 / 4 / 8 -> 3394 - 3397 / 3406 - 3421 / 3418 - 3418 / 3407 - 3410
+  // sentences/s, all GEMMs 0.436 - 0.452 / 0.453 / 0.454 - 0.455 / 0.454 of the split-product peak)
+  static const int walk_env = [] { const char* e = getenv("MTVAF_P16_WALK_G"); return e ? atoi(e) : 4; }();
+  a.walk_g = walk_env;
   a.trace = g_f32p_trace;
   dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
   // (launch profiler of gemm.hip: key 400 + 4 [k-major A] + 8 [k-major B]; hip.kernel_symbol names the instantiation)

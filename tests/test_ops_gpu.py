@@ -1372,7 +1372,8 @@ def test_gemm_f32_split_tile64_epilogues_splitk_ktiles_and_planner(hip):
         hip.f32_split(was)
 
 
-@pytest.mark.parametrize("M,N,K,spread", [(256, 384, 768, 0), (128, 128, 32, 12), (128, 256, 64, 20), (384, 128, 96, 3), (512, 768, 3072, 6)])
+@pytest.mark.parametrize("M,N,K,spread", [(256, 384, 768, 0), (128, 128, 32, 12), (128, 256, 64, 20), (384, 128, 96, 3), (512, 768, 3072, 6),
+                                          (640, 256, 64, 3), (896, 384, 32, 0)])  # (5 and 7 tile rows: a ragged last band of the tile walk)
 def test_gemm_f32_presplit_planes_accuracy_and_epilogues(hip, M, N, K, spread):
     """mtvaf_f32_split_planes + mtvaf_gemm_f32p (csrc/gemm_f32p.hip, round 5: both operands as pre-split bf16 plane images,
     v_mfma_f32_16x16x32_bf16, nothing split inside the k-loop): the planes are those of the in-kernel split (x = p1 + p2 + p3 to
