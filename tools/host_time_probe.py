@@ -2,7 +2,7 @@
 Wall-clock segments without any synchronisation of our own (forward incl. the packing wait, backward, optimizer), then a cProfile
 of 20 steps.
 
-    python tools/host_time_probe.py [steps]
+    python tools/host_time_probe.py [steps] [fp32|bf16] [bert|roberta]
 """
 import cProfile
 import os
@@ -17,9 +17,13 @@ import bench  # noqa: E402
 from mtvaf_amd.optim import AdamW  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+dtype = sys.argv[2] if len(sys.argv) > 2 else "fp32"      # fp32 | bf16
+arch = sys.argv[3] if len(sys.argv) > 3 else "bert"        # bert | roberta
+from mtvaf_amd import hip  # noqa: E402
+hip.set_compute_dtype(dtype)
 dev = torch.device("cuda:0")
 torch.manual_seed(1)
-model, cfg = bench.build_model(dev, "bert", 128)
+model, cfg = bench.build_model(dev, arch, 128)
 model.train()
 opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model, overlap=True)
 ids, mask, tt, labels, feats, aux = bench.synthetic_batch(32, 128, 8, cfg.vocab_size, 1234, dev)
