@@ -2,7 +2,7 @@
 Wall-clock segments without any synchronisation of our own (forward incl. the packing wait, backward, optimizer), then a cProfile
 of 20 steps.
 
-    python tools/host_time_probe.py [steps] [fp32|bf16] [bert|roberta]
+    python tools/host_time_probe.py [steps] [fp32|bf16] [bert|roberta] [batch] [seq]
 """
 import cProfile
 import os
@@ -19,14 +19,16 @@ from mtvaf_amd.optim import AdamW  # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 dtype = sys.argv[2] if len(sys.argv) > 2 else "fp32"      # fp32 | bf16
 arch = sys.argv[3] if len(sys.argv) > 3 else "bert"        # bert | roberta
+BS = int(sys.argv[4]) if len(sys.argv) > 4 else 32
+SEQ = int(sys.argv[5]) if len(sys.argv) > 5 else 128
 from mtvaf_amd import hip  # noqa: E402
 hip.set_compute_dtype(dtype)
 dev = torch.device("cuda:0")
 torch.manual_seed(1)
-model, cfg = bench.build_model(dev, arch, 128)
+model, cfg = bench.build_model(dev, arch, SEQ)
 model.train()
 opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model, overlap=True)
-ids, mask, tt, labels, feats, aux = bench.synthetic_batch(32, 128, 8, cfg.vocab_size, 1234, dev)
+ids, mask, tt, labels, feats, aux = bench.synthetic_batch(BS, SEQ, 8, cfg.vocab_size, 1234, dev)
 kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None, images=feats, aux_imgs=aux)
 seg = [0.0, 0.0, 0.0, 0.0]
 
@@ -65,3 +67,23 @@ torch.cuda.synchronize()
 st = pstats.Stats(pr, stream=sys.stdout)
 st.sort_stats("tottime").print_stats(35)
 st.sort_stats("cumulative").print_stats(45)
+
+# the encoder's backward pass runs on the autograd engine's thread: profile it from inside
+from mtvaf_amd import engine  # noqa: E402
+_nb = engine._native_backward
+pr2 = cProfile.Profile()
+
+
+def _profiled(*a, **k):
+    return pr2.runcall(_nb, *a, **k)
+
+
+engine._native_backward = _profiled
+for _ in range(20):
+    step()
+torch.cuda.synchronize()
+engine._native_backward = _nb
+print("== inside engine._native_backward (autograd thread), 20 steps ==")
+st2 = pstats.Stats(pr2, stream=sys.stdout)
+st2.sort_stats("tottime").print_stats(25)
+st2.sort_stats("cumulative").print_stats(25)
