@@ -336,7 +336,8 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3,
 LINE_LIMIT = 4096  # the driver keeps ~8 KB of stdout tail: the final line stays far below it (tests/test_bench_line.py)
 _HEAD_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "median_ms_per_step", "loss", "mfma_fraction_of_step", "mfma_fraction_of_step_executed",
-              "value_fp32_pipe", "ms_per_step_fp32_pipe", "n_ranks_seen", "backend", "rank_ms_spread")
+              "value_fp32_pipe", "ms_per_step_fp32_pipe", "n_ranks_seen", "backend", "rccl_version", "rank_ms_spread",
+              "rank_token_rows", "sharding")
 _ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us", "launches_per_step")
 
 
@@ -364,6 +365,10 @@ def compact_line(res):
         line["roofline_fp32_pipe"] = _short_roofline(res["roofline_fp32_pipe"])
     if "cpu_baseline" in res:
         line["cpu_baseline"] = {k: res["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "sample") if k in res["cpu_baseline"]}
+    if isinstance(res.get("parity"), dict):  # measured deviations from the oracle at the timed shape (tests/parity_report.py)
+        line["parity"] = {k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in res["parity"].items()
+                          if k in ("emissions_max_rel", "emissions_elem_rel_p99", "emissions_elem_rel_max", "loss_rel", "tags_equal",
+                                   "worst_grad_rel", "error")}
     if isinstance(res.get("grad_sync"), dict):
         line["grad_sync"] = {k: v for k, v in res["grad_sync"].items() if k != "note"}
     if isinstance(res.get("padded"), dict):
@@ -384,7 +389,7 @@ def compact_line(res):
         line["secondary"] = sec
     line["detail"] = "bench_detail.json (also on stderr)"
     # shrink until it fits: the contract's keys, roofline and cpu_baseline are never dropped
-    for drop in ("fwd_bwd_without_optimizer", "roofline_fp32_pipe", "grad_sync", "full_length", "padded"):
+    for drop in ("fwd_bwd_without_optimizer", "roofline_fp32_pipe", "full_length", "padded", "parity"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(drop, None)
@@ -513,6 +518,10 @@ def main():
     ap.add_argument("--grad-buckets", type=int, default=4,
                     help="N > 1, bf16 wire: encoder layers are exchanged in this many all_to_all + all_gather pairs per step (4 = "
                          "three BERT-base layers, 85 MB, per exchange); 0 = one exchange per layer")
+    ap.add_argument("--no-balance", action="store_true",
+                    help="N > 1: every rank draws its own ragged batch (seed 1234 + rank) instead of taking its length-balanced share "
+                         "of ONE global batch of N x batch sentences (mtvaf_amd.parallel.balanced_shards: sort by length, deal in "
+                         "snake order) -- under padding-free execution a rank's step time follows its token rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -585,7 +594,18 @@ def main():
         from mtvaf_amd.optim import AdamW
         opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model,
                     overlap=not (a.graph or a.no_overlap_optimizer), grad_sync=sync)  # (a captured backward cannot carry the per-step learning rate)
-    batch = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, a.full_length)
+    sharding = None
+    if world > 1 and not a.no_balance:
+        # ONE global batch (the same on every rank: seed 1234), dealt by length so that the ranks' token-row counts agree
+        from mtvaf_amd.parallel import balanced_shards
+        gb = synthetic_batch(world * B, S, a.aux, cfg.vocab_size, 1234, "cpu", a.full_length)
+        mine = torch.tensor(balanced_shards(gb[1].sum(1).tolist(), world)[rank])
+        batch = tuple(t[mine].to(device) for t in gb)
+        sharding = "length-balanced shares of one global batch (sort by length, snake deal)"
+    else:
+        batch = synthetic_batch(B, S, a.aux, cfg.vocab_size, 1234 + rank, device, a.full_length)
+        if world > 1:
+            sharding = "independent per-rank batches (seed 1234 + rank)"
     ids, mask, tt, labels, feats, aux = batch
 
     def step():
@@ -772,6 +792,16 @@ def main():
            "padding": "skipped (default): every fraction counts EXECUTED flops" if a.unpad else "computed (reference behaviour)",
            "padded": padded, "full_length": full_length}
     res["rank_ms_spread"] = rank_ms_spread
+    if world > 1:
+        rows = torch.zeros(world, device=device, dtype=torch.float64)
+        rows[rank] = float(mask.sum())
+        dist.all_reduce(rows)
+        res["rank_token_rows"] = [int(rows.min()), int(rows.max())]  # unmasked token rows per rank: what a padding-free step computes
+        res["sharding"] = sharding
+        try:
+            res["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+        except Exception:
+            res["rccl_version"] = None
     if rank_ms_spread is not None and rank_ms_spread >= 0.03:
         log(f"per-rank step times differ by {100 * rank_ms_spread:.1f} % (>= 3 %): the slowest rank sets `value`")
     res["n_ranks_seen"] = dist.get_world_size() if world > 1 else 1
@@ -783,7 +813,8 @@ def main():
             step()
         tm = sync.take_timing()
         sync.timing = False
-        res["grad_sync"] = {"wire": sync.compress or "fp32", "layer_exchanges_per_step": sync.layer_buckets or len(sync.encoder.layer),
+        res["grad_sync"] = {"wire": sync.compress or "fp32", "wire_fallback": "--grad-wire fp32 (RCCL all_reduce(AVG) in place)",
+                            "layer_exchanges_per_step": sync.layer_buckets or len(sync.encoder.layer),
                             "comm_stream_ms_per_step": round(tm["comm_stream_ms"] / max(1, tm["passes"]), 3),
                             "exposed_tail_ms_per_step": round(tm["exposed_tail_ms"] / max(1, tm["passes"]), 3),
                             "note": "rank 0, 3 extra steps: time the communication stream spent in exchanges (and the per-layer "
@@ -816,15 +847,18 @@ def main():
         res["secondary"] = {}
         for key, (dt_, arch_, b_, s_, aux_) in {"c1_fp32": ("fp32", "bert", 4, 64, 3), "c1_fp32_graph": ("fp32", "bert", 4, 64, 3),
                                                 ("c2_fp32_pipe" if split_mode else "c2_fp32_split"): ("fp32", "bert", 32, 128, 8),
-                                                "c3_bf16": ("bf16", "roberta", 32, 128, 8), "c4_bf16": ("bf16", "bert", 64, 128, 8)}.items():
+                                                "c3_bf16": ("bf16", "roberta", 32, 128, 8), "c4_bf16": ("bf16", "bert", 64, 128, 8),
+                                                # configs[4], the roofline stress shape (65 536 token rows before packing): five
+                                                # training steps each, in both compute modes
+                                                "c5_bf16": ("bf16", "bert", 128, 512, 8), "c5_fp32": ("fp32", "bert", 128, 512, 8)}.items():
             try:
                 # (C1 is the one host-bound configuration: 10 steps behind 3 warm-up steps read 750-930 sentences/s from call
                 # to call, 40 behind 10 read what `bench.py --batch 4 --seq 64 --aux 3` reads)
                 res["secondary"][key] = secondary_config(key, device, dt_, arch_, b_, s_, aux_,
                                                          split=("_split" in key) or (bool(split_mode) and "_pipe" not in key),
                                                          unpad=not key.endswith("_graph"), graph=key.endswith("_graph"),
-                                                         steps=40 if key.startswith("c1_") else 10,
-                                                         warmup=10 if key.startswith("c1_") else 5)
+                                                         steps=40 if key.startswith("c1_") else (5 if key.startswith("c5_") else 10),
+                                                         warmup=10 if key.startswith("c1_") else (2 if key.startswith("c5_") else 5))
             except Exception as e:  # a secondary figure must never cost the headline line
                 res["secondary"][key] = {"error": repr(e)}
             torch.cuda.empty_cache()
@@ -845,6 +879,16 @@ def main():
             res["frontend_cache_build"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(B, S, a.aux)
+        if (B, S, a.aux, a.dtype, a.model) == (32, 128, 8, "fp32", "bert") and not a.graph:
+            # measured deviation of the assembled HIP path from the oracle at this very shape, in the arithmetic and layout that
+            # were timed (one more oracle step on the host: the checker, after the timed region)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                import parity_report
+                res["parity"] = parity_report.report(B, S, a.aux, device=device)
+                log(parity_report.fmt(res["parity"]))
+            except Exception as e:  # (must never cost the line)
+                res["parity"] = {"error": repr(e)}
         if (B, S, a.aux) == (32, 128, 8):  # second entry: the reference's own CPU-runnable configuration (configs[0])
             res["cpu_baseline_c1"] = cpu_baseline(4, 64, 3, seconds_budget=10.0)
         log("cpu baseline done")

@@ -139,7 +139,23 @@ def _weights_bf16(w: LayerWeights):
 
 
 def shadow_version(w: LayerWeights, epoch_ahead: int = 0):
-    return (_OPT_EPOCH[0] + epoch_ahead,) + tuple(p._version for p in w.wparams)
+    return (_OPT_EPOCH[0] + epoch_ahead, _IMAGE_GEN[0]) + tuple(p._version for p in w.wparams)
+
+
+_IMAGE_GEN = [0]
+
+
+def invalidate_weight_images(model=None):
+    """Declare every cached GEMM-operand image of the encoder weights stale (the bf16 shadows of the mixed-precision mode and the
+    plane images of the fp32 pre-split path): the next forward pass rebuilds them from the fp32 masters.
+
+    Freshness is otherwise tracked through the optimizer-step epoch and the weight Parameters' version counters, which see
+    ``optimizer.step()``, ``load_state_dict`` and in-place updates THROUGH the Parameter -- but not a write through ``p.data``
+    (EMA / SWA swaps, ``p.data.copy_``, ``p.data.mul_``) or straight into a layer's flat buffer.  Code that writes weights that way
+    calls this afterwards; ``MTVAF_WEIGHT_IMAGES=rebuild`` rebuilds the images in every forward pass instead (a debugging aid:
+    one cast / split pass over 85 M parameters per step).  ``model`` is accepted for symmetry with the other helpers; the
+    generation counter is process-wide (one process per GPU)."""
+    _IMAGE_GEN[0] += 1
 
 
 def shadow_for_update(w: LayerWeights):
@@ -162,7 +178,8 @@ try:  # every optimizer step invalidates the bf16 weight shadows
     _HAVE_OPT_HOOK = True
 except Exception:  # pragma: no cover - very old torch: never cache
     _HAVE_OPT_HOOK = False
-BF16_WCACHE = os.environ.get("MTVAF_BF16_WCACHE", "1") != "0" and _HAVE_OPT_HOOK
+WEIGHT_IMAGES_REBUILD = os.environ.get("MTVAF_WEIGHT_IMAGES", "cache") == "rebuild"  # every forward rebuilds (debug: .data writes)
+BF16_WCACHE = os.environ.get("MTVAF_BF16_WCACHE", "1") != "0" and _HAVE_OPT_HOOK and not WEIGHT_IMAGES_REBUILD
 # fp32 mode, PRE-SPLIT OPERANDS (round 5; csrc/gemm_f32p.hip): on packed rows every GEMM operand of an encoder layer is read as a
 # tile-blocked plane image (the three bf16 planes of the split arithmetic, written once per tensor) by kernels that split nothing
 # inside their k-loops -- the eight forward / dX products and the layer's four weight gradients as one grouped launch.  Weights:
@@ -175,6 +192,7 @@ F32_PLANES = os.environ.get("MTVAF_F32_PLANES", "1") != "0" and _HAVE_OPT_HOOK
 # Measured, bench.py --batch b, same box, path on / off: bs 4 x S 64 832 / 903 sentences/s, bs 4 x 128 770 / 812, bs 8 (640 packed
 # rows) 1374 / 1238, bs 12 2015 / 1708, bs 16 2443 / 2342, bs 24 2726 / 2480)
 F32_PLANES_MIN_ROWS = int(os.environ.get("MTVAF_F32_PLANES_MIN_ROWS", "512"))
+P16_EP = os.environ.get("MTVAF_P16_EP", "1") != "0"  # (the same switch csrc/executor.hip reads)
 
 
 def _f32_planes_on(use_h, pack, H, I) -> bool:
@@ -189,7 +207,7 @@ def _wplane_fill(w: "LayerWeights", views):
 
 def _weights_planes(w: "LayerWeights"):
     """-> the plane images of the layer's four weight matrices (uint8 views of one buffer), rebuilt when stale."""
-    ver = shadow_version(w) if not FORCE_SHADOW_REFRESH else None
+    ver = shadow_version(w) if not (FORCE_SHADOW_REFRESH or WEIGHT_IMAGES_REBUILD) else None
     c = w._pl
     if ver is None or c is None or c[0] != ver:
         if c is None:
@@ -199,9 +217,10 @@ def _weights_planes(w: "LayerWeights"):
             for t in mats:
                 views.append(img[off:off + 6 * t.numel()])
                 off += 6 * t.numel()
-            c = w._pl = [None, img, tuple(views)]
+            c = w._pl = [None, img, tuple(views), True]
         _wplane_fill(w, c[2])
         c[0] = ver
+    c[3] = True  # read by a forward pass since the last optimizer update (planes_for_update)
     return c[2]
 
 
@@ -211,6 +230,14 @@ def planes_for_update(w: "LayerWeights"):
     them with ``planes_written``.  None: no images to maintain."""
     if w._pl is None or not F32_PLANES or hip.COMPUTE != "fp32":
         return None
+    if not w._pl[3]:
+        # no forward pass has read the images since the last update (the run went padded, below F32_PLANES_MIN_ROWS or switched the
+        # path off): stop paying 6 bytes per weight per step for them; the next pre-split forward rebuilds them
+        w._pl = None
+        if w._st is not None:
+            w._st[2] = False  # (never `is` a tuple of views: _layer_struct re-points the weight-image fields)
+        return None
+    w._pl[3] = False
     base = w.flat.data_ptr()
     return [((t.data_ptr() - base) // 4, t.shape[0], t.shape[1], v) for t, v in zip((w.wqkv, w.wo, w.w1, w.w2), w._pl[2])]
 
@@ -323,11 +350,12 @@ def _pack_granule() -> int:
     return 256 if (hip.COMPUTE == "bf16" and BF16_OPERANDS) else 128
 
 
-def _pack_min_gain(rows: int) -> int:
-    """Rows a packed image must save to be worth it.  With the pre-split operand path (fp32 mode, F32_PLANES, enough rows) the packed
-    layout is also the FASTER kernel set, so even a batch without any padding runs on it (0: an identity packing); otherwise one
-    128-row tile."""
-    return 0 if (F32_PLANES and rows >= F32_PLANES_MIN_ROWS and hip.COMPUTE == "fp32" and hip.f32_split()) else 128
+def _pack_min_gain(rows: int, H: int = 128, I: int = 128) -> int:
+    """Rows a packed image must save to be worth it.  With the pre-split operand path (fp32 mode, F32_PLANES, enough rows, H and I
+    whole 128-column tiles: the predicate of ``_f32_planes_on``) the packed layout is also the FASTER kernel set, so even a batch
+    without any padding runs on it (0: an identity packing); otherwise one 128-row tile."""
+    return 0 if (F32_PLANES and rows >= F32_PLANES_MIN_ROWS and hip.COMPUTE == "fp32" and H % 128 == 0 and I % 128 == 0
+                 and hip.f32_split()) else 128
 
 
 class Packing:
@@ -365,7 +393,7 @@ class Packing:
         _PENDING_PACK = (addmask.data_ptr(), B, S, Pn, cu, inv, rowmap, host, ev)
 
     @staticmethod
-    def build(addmask: torch.Tensor, Pn: int, B: int, S: int) -> Optional["Packing"]:
+    def build(addmask: torch.Tensor, Pn: int, B: int, S: int, H: int = 128, I: int = 128) -> Optional["Packing"]:
         global _PENDING_PACK
         pend, _PENDING_PACK = _PENDING_PACK, None
         if pend is not None and pend[:4] == (addmask.data_ptr(), B, S, Pn):
@@ -374,7 +402,7 @@ class Packing:
             Mv = int(host[0])
             g = _pack_granule()
             Mp = max(g, (Mv + g - 1) // g * g)
-            if Mv == 0 or Mp > B * S - _pack_min_gain(Mp):
+            if Mv == 0 or Mp > B * S - _pack_min_gain(Mp, H, I):
                 return None
             pk = Packing()
             pk.rowmap, pk.inv, pk.cu = rowmap[:Mp], inv, cu
@@ -385,7 +413,7 @@ class Packing:
         Mv = int(idx.numel())
         g = _pack_granule()
         Mp = max(g, (Mv + g - 1) // g * g)
-        if Mv == 0 or Mp > B * S - _pack_min_gain(Mp):
+        if Mv == 0 or Mp > B * S - _pack_min_gain(Mp, H, I):
             return None  # nothing to gain (or nothing to compute): stay padded
         pk = Packing()
         dev = addmask.device
@@ -427,9 +455,12 @@ def _fwd_layout(M, H, I, B, NH, S, use_h, planes=False):
     if lay is None:
         e = 2 if use_h else 4
         pl = 6 if planes else 0
+        # (pre-split path: the GELU output leaves the FFN-1 epilogue as a plane image only -- csrc/executor.hip, p16_ep_on -- so no
+        # fp32 `act` exists; MTVAF_P16_EP=0 puts the fp32 tensor + split pass back)
+        act_b = 0 if (planes and P16_EP) else M * I * e
         lay = _layouts[key] = _layout([("qkv", M * 3 * H * e), ("cx", M * H * e), ("lse", B * NH * S * 4), ("a", M * H * 4),
                                        ("h1", M * H * 4), ("h1_h", M * H * 2 if use_h else 0), ("mean1", M * 4), ("rstd1", M * 4),
-                                       ("pre", M * I * e), ("act", M * I * e), ("f", M * H * 4), ("h2", M * H * 4),
+                                       ("pre", M * I * e), ("act", act_b), ("f", M * H * 4), ("h2", M * H * 4),
                                        ("h2_h", M * H * 2 if use_h else 0), ("mean2", M * 4), ("rstd2", M * 4),
                                        ("cx_p", M * H * pl), ("h1_p", M * H * pl), ("act_p", M * I * pl), ("h2_p", M * H * pl)])
     return lay
@@ -507,7 +538,7 @@ def _native_forward(ctx, h0, pkv, addmask, cfg, weights, grad_sink, params):
     seed = RNG.seed()
     dev = x.device
     # (the caller vouches that nothing downstream reads hidden states at masked positions: cfg[5], BertModel.allow_unpad)
-    pack = Packing.build(addmask, Pn, B, S) if (UNPAD and len(cfg) > 5 and cfg[5]) else None
+    pack = Packing.build(addmask, Pn, B, S, H, I) if (UNPAD and len(cfg) > 5 and cfg[5]) else None
     if pack is not None:
         x = pack.pack(x)
         M = pack.Mp

@@ -52,6 +52,25 @@ import torch
 import torch.distributed as dist
 
 
+def balanced_shards(lengths, world: int):
+    """Deal the sentences of a global batch to `world` ranks so that every rank gets the same NUMBER of sentences (the remainder
+    of len(lengths) / world is dropped from the short end, as DistributedSampler(drop_last=True) does) and nearly the same number
+    of TOKEN ROWS: sorted by length (longest first, ties by index: deterministic on every rank without communication) and dealt in
+    snake order (0 .. W-1, W-1 .. 0, ...).  -> list of `world` index lists.
+
+    Why: under padding-free execution (engine.UNPAD, the default) a rank's step time follows its packed row count, not B x S, so
+    per-rank batches drawn independently differ by ~10 % in work (ragged U{16..128} at bs 32: 2377 +- 250 rows) and the slowest
+    rank sets the step -- SURVEY 8e assumed "identical per-rank work (fixed S padding)".  The reference shards with a plain
+    DistributedSampler (MTVAF_training.py:328-331); this is the length-aware replacement for it."""
+    n = (len(lengths) // world) * world
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))[:n]
+    shards = [[] for _ in range(world)]
+    for j, i in enumerate(order):
+        r, c = divmod(j, world)
+        shards[c if r % 2 == 0 else world - 1 - c].append(i)
+    return shards
+
+
 class GradSync:
     def __init__(self, model: torch.nn.Module, process_group=None, force: bool = False, big_numel: int = 1 << 20,
                  compress: Optional[str] = "auto", seed_per_rank: bool = True, layer_buckets: Optional[int] = None,
@@ -432,24 +451,17 @@ class GradSync:
     # -- runs once when the autograd pass is complete ---------------------------------------------------------
     def _finish(self):
         self._armed = False
-        if self._bucket_acc:  # a bucket that never filled (a layer did not report in this pass): exchange what it holds
-            pairs = [(l, g) for acc in self._bucket_acc.values() for l, g in acc if g is not None]
+        if self._bucket_acc:
+            # a bucket that never filled (a layer did not report in this pass): what it holds goes THROUGH THE SCHEDULE like a
+            # full bucket -- issued directly here it could overtake planned items that still wait for a predecessor on this
+            # rank but not on another (a large parameter whose gradient is None here), and the ranks' collective sequences
+            # would differ
+            left = sorted(self._bucket_acc.items())
             self._bucket_acc = {}
-            if pairs:
-                left = [g for _, g in pairs]
-                if self._comm is None:
-                    self._allreduce_mean_bf16_multi(left)
-                    if self.after_layer_reduced is not None:
-                        self._pending.extend((None, l) for l, _ in pairs)
-                else:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    with torch.cuda.stream(self._comm):
-                        self._comm.wait_event(ev)
-                        self._timed(self._allreduce_mean_bf16_multi, left)
-                        if self.after_layer_reduced is not None:
-                            for l, _ in pairs:
-                                self.after_layer_reduced(l)
+            for b, acc in left:
+                pairs = [(l, g) for l, g in acc if g is not None]
+                if pairs:
+                    self._submit(("L", b), self._layer_issue(pairs))
         first = self._plan is None
         if first:
             self._make_plan()
@@ -457,6 +469,7 @@ class GradSync:
         # gradient is None on THIS rank (exchanged as zeros: this rank adds nothing to the mean).  A layer exchange that did not
         # report in this pass (every rank alike: gradient accumulation sends those layers through the tail) is passed over.
         flush = []
+        zero_filled: List[int] = []  # planned parameters whose gradient is None on THIS rank in this pass (indices into _outer)
         for key in self._plan[self._next:]:
             if first and key in self._issued_first:
                 continue
@@ -465,6 +478,7 @@ class GradSync:
                 p = self._outer[key[1]]
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
+                    zero_filled.append(key[1])
                 fn = self._param_issue(p, p.grad)
             if fn is not None:
                 flush.append(fn)
@@ -473,7 +487,14 @@ class GradSync:
             p = self._outer[i]
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
+                zero_filled.append(i)
         planned = set(self._plan_small) | {k[1] for k in self._plan if k[0] == "P"}
+        # presence flags ride in the tail bucket: one float per planned parameter, 1 where this rank had a real gradient.  Their
+        # mean is > 0 iff SOME rank had one; a parameter nobody had a gradient for gets `.grad = None` back (below), so that the
+        # optimizer skips it as it would in a single-process run instead of applying weight decay and momentum to a zero gradient.
+        planned_order = sorted(planned)
+        zf = set(zero_filled)
+        flags = [0.0 if i in zf else 1.0 for i in planned_order]
         unplanned = [i for i, p in enumerate(self._outer) if p.grad is not None and i not in planned]
         if unplanned:
             raise RuntimeError(f"GradSync: parameters {unplanned} (indices outside the encoder) received a gradient on rank {self.rank} "
@@ -497,6 +518,7 @@ class GradSync:
         for li in self._slow_layers:
             rest.extend(p for p in self.encoder.layer[li].ordered_params() if p.grad is not None)
         self._slow_layers, self._fast_layers = [], []
+        flags_out = None
         if self._comm is not None:
             if self.timing:
                 t_main = torch.cuda.Event(enable_timing=True)
@@ -505,7 +527,7 @@ class GradSync:
             for fn in flush:
                 fn()
             with torch.cuda.stream(self._comm):
-                self._timed(self._reduce_bucket, rest)
+                flags_out = self._timed(self._reduce_bucket, rest, flags)
                 if self.timing:
                     t_comm = torch.cuda.Event(enable_timing=True)
                     t_comm.record()
@@ -524,7 +546,13 @@ class GradSync:
             self._pending = []
             for li in hooks:
                 self.after_layer_reduced(li)
-            self._reduce_bucket(rest)
+            flags_out = self._reduce_bucket(rest, flags)
+        if zero_filled and flags_out is not None:
+            # (only a rank that filled zeros in has anything to undo; the read synchronises with the tail exchange)
+            seen = flags_out.tolist()
+            for j, i in enumerate(planned_order):
+                if i in zf and seen[j] <= 0.0:
+                    self._outer[i].grad = None
         for li in copied:
             views = stores[li].grad_views()
             with torch.no_grad():
@@ -537,18 +565,26 @@ class GradSync:
             self._check_sequence()
         self._seq = []
 
-    def _reduce_bucket(self, params):
+    def _reduce_bucket(self, params, flags=None):
         """The small non-encoder rest (position / type tables, LayerNorms, fc, crf, projectors ...: ~3 MB) through one
-        PERSISTENT flat buffer: a gather (torch.cat into the buffer), the collective, a multi-tensor scatter back."""
-        if not params:
-            return
+        PERSISTENT flat buffer: a gather (torch.cat into the buffer), the collective, a multi-tensor scatter back.  `flags`
+        (one float per planned parameter, the same count on every rank) travel behind the gradients; -> their means."""
+        nf = len(flags) if flags else 0
+        if not params and not nf:
+            return None
         grads = [p.grad for p in params]
         n = sum(g.numel() for g in grads)
-        flat = self._buf("tail", n, torch.float32, grads[0].device)[:n]
-        torch.cat([g.reshape(-1) for g in grads], out=flat)
+        dev = grads[0].device if grads else (self._outer[0].device if self._comm is not None else torch.device("cpu"))
+        flat = self._buf("tail", n + nf, torch.float32, dev)[:n + nf]
+        if grads:
+            torch.cat([g.reshape(-1) for g in grads], out=flat[:n])
+        if nf:
+            flat[n:].copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
         self._allreduce_mean(flat)
         views, off = [], 0
         for g in grads:
             views.append(flat[off:off + g.numel()].view(g.shape))
             off += g.numel()
-        torch._foreach_copy_(grads, views)
+        if grads:
+            torch._foreach_copy_(grads, views)
+        return flat[n:] if nf else None

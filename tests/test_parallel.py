@@ -58,6 +58,7 @@ class _FakeEncoder(torch.nn.Module):
         self.layer = torch.nn.ModuleList([_FakeLayer(n) for _ in range(L)])
         self._stores = [_FakeStore(l) for l in self.layer]
         self._sink = GradSink(self._stores)
+        self.skip = set()  # layers that do not report in this pass (every rank alike)
 
     @property
     def grad_sink(self):
@@ -93,7 +94,8 @@ class _FakeEncoder(torch.nn.Module):
                             out[j] = views[j]
                         else:
                             out[j] = val
-                    enc._sink.layer_done(li)
+                    if li not in enc.skip:
+                        enc._sink.layer_done(li)
                 return (None, *out)
 
         params = [p for l in self.layer for p in l.ordered_params()]
@@ -686,6 +688,9 @@ _PARTIAL_USE = [
     {0: (True, True, True), 1: (False, True, True), 2: (True, True, False)},
     {0: (True, False, True), 1: (True, True, True), 2: (True, True, True)},
     {0: (True, True, True), 1: (True, True, True), 2: (False, False, False)},
+    # pass 3: NOBODY has a gradient for table_b and the head: they are exchanged (as zeros: the plan is fixed) but end as
+    # `.grad is None` on every rank, as in a single-process run -- the optimizer must not decay them on a zero gradient
+    {0: (True, False, False), 1: (True, False, False), 2: (True, False, False)},
 ]
 
 
@@ -743,6 +748,11 @@ def test_gradsync_large_parameter_without_gradient_on_one_rank_never_hangs(wire)
                 assert all(out[r]["grads"][k][n] is None for r in range(world))  # trained nowhere: in no exchange, stays None
                 continue
             want = sum(l[n] for l in local) / world
+            nobody = not any((n.startswith("table_a") and use[r][0]) or (n.startswith("table_b") and use[r][1])
+                             or (n.startswith("head") and use[r][2]) or n.startswith("encoder") for r in range(world))
+            if nobody:
+                assert all(out[r]["grads"][k][n] is None for r in range(world)), (k, n)
+                continue
             for r in range(world):
                 got = out[r]["grads"][k][n]
                 assert got is not None, (k, r, n)
@@ -754,6 +764,64 @@ def test_gradsync_large_parameter_without_gradient_on_one_rank_never_hangs(wire)
         assert out[r]["plan"] == out[0]["plan"]
         assert sorted(k[0] for k in out[r]["plan"]) == ["L", "L", "L", "P", "P"]
         assert out[r]["plan_small"] == out[0]["plan_small"] and len(out[r]["plan_small"]) == 2
+
+
+def _worker_partial_bucket(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mtvaf_amd.parallel import GradSync
+    torch.manual_seed(0)
+    m = _PartialModel()
+    m.encoder = _FakeEncoder(L=4, n=8)
+    sync = GradSync(m, big_numel=256, compress="bf16", layer_buckets=2, check_every=1)
+    x = torch.arange(8, dtype=torch.float32) * (rank + 1) * 0.25
+    res = []
+    # pass 0: everything everywhere (the plan).  Passes 1, 2: layer 0 does not report (bucket 1 = layers 1, 0 never fills and is
+    # exchanged at the end of the pass) while rank 1 / rank 2 lack the gradient of a large parameter planned BEFORE that bucket
+    for skip, use in [(set(), {0: (True, True), 1: (True, True), 2: (True, True)}),
+                      ({0}, {0: (True, True), 1: (True, False), 2: (True, True)}),
+                      ({0}, {0: (True, True), 1: (True, True), 2: (False, True)})]:
+        m.zero_grad(set_to_none=True)
+        m.encoder.skip = skip
+        a, b = use[rank]
+        m(x, a, b, True).backward()
+        res.append({n: (None if p.grad is None else p.grad.tolist()) for n, p in m.named_parameters()})
+    q.put((rank, {"grads": res, "plan": [list(k) for k in sync._plan]}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_partially_filled_bucket_goes_through_the_plan():
+    """a bucket of the bf16 wire that never filled used to be exchanged directly at the end of the pass, BEFORE the
+    plan-ordered flush -- a rank whose large parameter (planned ahead of it) had no gradient then issued [partial bucket, P]
+    where the others had issued [P, partial bucket].  Now it takes its planned place: the per-pass sequence check passes on
+    three ranks, nobody hangs, and layer 1's gradients (the reported half of the partial bucket) are the mean over the ranks."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_partial_bucket, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        assert out[r]["plan"] == out[0]["plan"]
+        assert sorted(k[0] for k in out[r]["plan"]) == ["L", "L", "P", "P"]
+    for k in (1, 2):
+        for n in out[0]["grads"][k]:
+            if n.startswith("encoder.layer.0.") or n.startswith("never"):
+                continue  # (layer 0 did not report: its gradients stay local in this fake)
+            for r in range(world):
+                assert out[r]["grads"][k][n] == out[0]["grads"][k][n], (k, r, n)  # reduced: identical on every rank
+    # layer 1's reduced gradient = mean over ranks of x.sum() * (j + 1) (the fake encoder's arithmetic), up to bf16 rounding
+    xs = [float((torch.arange(8, dtype=torch.float32) * (r + 1) * 0.25).sum()) for r in range(world)]
+    got = torch.tensor(out[0]["grads"][1]["encoder.layer.1.intermediate.dense.weight"])
+    want = torch.full_like(got, sum(xs) / world * 4)  # parameter index j = 3 (layer 1's first): val = x.sum() * (j + 1)
+    torch.testing.assert_close(got, want, rtol=2e-2, atol=1e-2)
 
 
 def _worker_unplanned(rank, world, port, q):
@@ -843,3 +911,21 @@ def test_layer_buckets_on_the_fp32_wire_warn():
     run(0, 1, port, qq)
     msgs = qq.get()
     assert msgs[-1] is None and any("bf16 wire only" in m for m in msgs[:-1])
+
+
+def test_balanced_shards_deals_equal_sentence_counts_and_nearly_equal_token_rows():
+    """bench.py --gpus N (and a length-aware sampler for the reference trainer): one global ragged batch dealt to the ranks by
+    length -- every index at most once, the same count per rank, token rows within a few per cent (independent per-rank draws of
+    the same distribution differ by 25 % at bs 32), deterministic, and a remainder that does not divide is dropped."""
+    from mtvaf_amd.parallel import balanced_shards
+    g = torch.Generator().manual_seed(1234)
+    for world, per in ((2, 32), (4, 32), (8, 32), (8, 64), (3, 5)):
+        lens = torch.randint(16, 129, (world * per + (1 if world == 3 else 0),), generator=g).tolist()
+        sh = balanced_shards(lens, world)
+        assert sh == balanced_shards(list(lens), world)
+        assert [len(s) for s in sh] == [per] * world
+        flat = [i for s in sh for i in s]
+        assert len(set(flat)) == len(flat) and all(0 <= i < len(lens) for i in flat)
+        rows = [sum(lens[i] for i in s) for s in sh]
+        assert max(rows) - min(rows) <= max(lens), (world, rows)  # snake dealing: never further apart than one sentence
+    assert balanced_shards([5, 9, 7], 1) == [[1, 2, 0]]

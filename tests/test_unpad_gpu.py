@@ -387,3 +387,53 @@ def test_presplit_operand_path_against_the_in_kernel_split_path():
         err = (w1[n] - w0[n]).abs()
         assert float(err.max()) <= 3e-4 and float((err > 3e-5).float().mean()) <= 1e-5, (n, float(err.max()), int((err > 3e-5).sum()))
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_weight_images_after_a_write_through_data_need_invalidation(mode):
+    """the cached GEMM-operand images of the weights (plane images of the fp32 pre-split path, bf16 shadows of
+    the mixed-precision mode) are checked for freshness through the optimizer epoch and the Parameters' version counters; a write
+    through `p.data` moves neither.  The documented contract: such a writer calls `engine.invalidate_weight_images()`; the next
+    forward then multiplies by the NEW weights (the same loss as a model that was loaded with them), and the debugging switch
+    `engine.WEIGHT_IMAGES_REBUILD` (MTVAF_WEIGHT_IMAGES=rebuild) makes every forward rebuild without being told."""
+    from mtvaf_amd import hip
+    if mode == "fp32" and not hip.f32_split():
+        pytest.skip("plane images belong to the split arithmetic")
+    was_mode = hip.COMPUTE
+    hip.set_compute_dtype(mode)
+    try:
+        cfg = P.EncCfg(vocab_size=30522, hidden=768, heads=12, inter=3072, layers=2, max_pos=512)
+        B, S = 16, 128
+        ids, mask, tt, labels = (t.to(DEV) for t in P.text_batch(cfg, 95, B, S, lo_id=1000))
+        feats, aux, _ = (t.to(DEV) for t in _prompt_inputs(96, B, 8))
+        kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, images=feats, aux_imgs=aux)
+        with engine.padding_free(True):
+            m = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+            with torch.no_grad():
+                l0 = float(m(**kw).loss)
+                w = m.bert.encoder.layer[1].intermediate.dense.weight
+                w.data.mul_(0.5)                      # behind the version counter's back (an EMA / SWA swap looks like this)
+                l_stale = float(m(**kw).loss)
+                engine.invalidate_weight_images(m)
+                l_new = float(m(**kw).loss)
+                # the reference value: a fresh model loaded with the modified weights
+                m2 = _props_model(cfg, "bert-base-uncased", dropout=0.0).eval()
+                m2.load_state_dict(m.state_dict())
+                l_ref = float(m2(**kw).loss)
+                # the debugging switch: no call needed
+                w.data.mul_(2.0)
+                was = engine.WEIGHT_IMAGES_REBUILD, engine.BF16_WCACHE
+                engine.WEIGHT_IMAGES_REBUILD, engine.BF16_WCACHE = True, False
+                try:
+                    l_back = float(m(**kw).loss)
+                finally:
+                    engine.WEIGHT_IMAGES_REBUILD, engine.BF16_WCACHE = was
+        st = m.bert.encoder._stores[0].weights
+        assert (st._pl is not None) if mode == "fp32" else (st._h is not None), "the run did not use the cached weight images"
+        assert l_stale == l0, "the .data write was seen without invalidation: the caveat this test documents is gone -- update it"
+        assert abs(l_new - l_ref) <= 2e-6 * abs(l_ref), (l_new, l_ref)
+        assert abs(l_new - l0) > 1e-4 * abs(l0), "halving an FFN weight did not move the loss"
+        assert abs(l_back - l0) <= 2e-6 * abs(l0), (l_back, l0)
+    finally:
+        hip.set_compute_dtype(was_mode)
