@@ -44,6 +44,8 @@ def deviations(em, oem, loss, oloss, tags, otags, grads, ograds, valid=None):
     """The report dict from the two runs' results (emissions restricted to `valid` [B,S] bool when given: padding-free execution
     does not compute masked positions)."""
     em, oem = em.detach().float().cpu(), oem.detach().float().cpu()
+    loss = float(loss.detach()) if torch.is_tensor(loss) else float(loss)
+    oloss = float(oloss.detach()) if torch.is_tensor(oloss) else float(oloss)
     if valid is not None:
         em, oem = em[valid], oem[valid]
     p99, emax, share = elementwise_rel(em, oem)
@@ -56,7 +58,7 @@ def deviations(em, oem, loss, oloss, tags, otags, grads, ograds, valid=None):
     mism = sum(a != b for ta, tb in zip(tags, otags) for a, b in zip(ta, tb)) + sum(len(a) != len(b) for a, b in zip(tags, otags))
     return {"emissions_max_rel": float((em - oem).abs().max() / oem.abs().max()),
             "emissions_elem_rel_p99": p99, "emissions_elem_rel_max": emax, "elem_floor": FLOOR, "elem_share": round(share, 4),
-            "loss_rel": abs(float(loss) - float(oloss)) / abs(float(oloss)), "tags_equal": mism == 0, "tag_mismatches": int(mism),
+            "loss_rel": abs(loss - oloss) / abs(oloss), "tags_equal": mism == 0, "tag_mismatches": int(mism),
             "worst_grad_rel": worst, "worst_grad": wname}
 
 

@@ -204,7 +204,10 @@ def _bf16(fn):
 # gradient norms 0.3-3.3e-2 -- the largest on the prompt generator's weights, whose gradient sums over every layer's prefix
 # slots) plus a margin.  bf16 operands carry 2^-9 relative rounding, so north_star's 1e-3 / bit-exact tags cannot hold by
 # construction in this mode.
-BF16_EM, BF16_LOSS, BF16_TAGS, BF16_GRAD = 1.5e-2, 2e-3, 0.97, 5e-2
+# Round 6: the bounds are 1.25 x the WORST deviation observed over rounds 3 - 6 (the kernels are
+# deterministic: the figures do not move from run to run) -- emissions 1.014e-2 (C4), loss 6.1e-4, tag disagreement 0.72 % of 4.8 k
+# tokens (C4; 0.9 % bound), gradient norms 2.28e-2 at the BASELINE shapes and 3.31e-2 on the odd shapes (`encoder_conv.2.weight`).
+BF16_EM, BF16_LOSS, BF16_TAGS, BF16_GRAD, BF16_GRAD_ODD = 1.27e-2, 7.6e-4, 0.991, 2.9e-2, 4.2e-2
 
 
 @pytest.mark.parametrize("B", [8, 32])
@@ -266,7 +269,7 @@ def test_ragged_odd_shapes_in_bf16_mode_track_the_fp32_oracle(B, S, n_aux, lengt
     rel, lrel, agree, g = _bf16_report(f"odd shape B={B} S={S} unpad={unpad}", em.cpu()[valid], oem[valid], float(out.loss), oloss,
                                        list(out.logits), otags, {n: (named[n].grad.cpu(), ograds[n]) for n in GRADS[:3]})
     assert rel < BF16_EM and lrel < BF16_LOSS and agree >= 0.95, (rel, lrel, agree)
-    assert all(v < BF16_GRAD for v in g.values()), g
+    assert all(v < BF16_GRAD_ODD for v in g.values()), g
 
 
 def _props_model(cfg, bert_name, dropout=0.0):
@@ -523,7 +526,13 @@ def test_config5_full_size_training_step(dtype):
             lsum += lc
             tags += tc
             acc = gc if acc is None else {n: acc[n] + gc[n] for n in acc}
-        assert tags == t1, "decoded tags of the chunks differ from the full batch's"
+        if dtype == "fp32":
+            assert tags == t1, "decoded tags of the chunks differ from the full batch's"
+        else:
+            # (mixed precision: another packed row count is another tile / split plan, i.e. another fp32 summation order in front
+            # of the bf16 roundings: a near-tie of the random-init emissions may flip)
+            agree = sum(a == b for ta, tb in zip(tags, t1) for a, b in zip(ta, tb)) / sum(len(t) for t in t1)
+            assert agree >= 0.995, agree
         assert abs(lsum / 4 - l1) <= (2e-3 if dtype == "bf16" else 1e-5) * abs(l1), (lsum / 4, l1)
         worst = 0.0
         for n in g1:
@@ -532,7 +541,8 @@ def test_config5_full_size_training_step(dtype):
             worst = max(worst, err)
             # (the same products in another summation order: rounding only -- in bf16 mode the operands are the same bf16 values
             # either way, the results' fp32 sums differ as in fp32 mode, but bf16-rounded activations of the chain amplify them)
-            assert err <= (2e-2 if dtype == "bf16" else 2e-4), (n, err)
+            # (measured, round 6: 6.9e-6 in fp32 mode, 3.7e-3 in bf16 mode; the kernels are deterministic)
+            assert err <= (5e-3 if dtype == "bf16" else 2e-5), (n, err)
         print(f"[C5 full-size training step, {dtype}] {rows} packed rows, loss {l1:.4f}, worst gradient deviation from the "
               f"chunk mean {worst:.2e}", flush=True)
     finally:

@@ -1,7 +1,7 @@
 """Which host lines issue the device-to-device copies (and other small torch kernels) of one training step at the bench
 workload: torch.profiler with Python stacks, grouped by the innermost frame inside this repository.
 
-    python tools/find_copies.py            # -> stdout
+    python tools/find_copies.py [fp32|bf16] [bert|roberta] [batch] [seq] [aux]            # -> stdout
 """
 import collections
 import os
@@ -13,11 +13,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from mtvaf_amd.optim import AdamW  # noqa: E402
 
+dtype = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+arch = sys.argv[2] if len(sys.argv) > 2 else "bert"
+BS = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+SEQ = int(sys.argv[4]) if len(sys.argv) > 4 else 128
+AUX = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+from mtvaf_amd import hip  # noqa: E402
+hip.set_compute_dtype(dtype)
 dev = torch.device("cuda:0")
-model, cfg = bench.build_model(dev, "bert", 128)
+model, cfg = bench.build_model(dev, arch, SEQ)
 model.train()
 opt = AdamW([p for p in model.parameters() if p.requires_grad], lr=3e-5, weight_decay=1e-2, model=model, overlap=True)
-ids, mask, tt, labels, feats, aux = bench.synthetic_batch(32, 128, 8, cfg.vocab_size, 1234, dev)
+ids, mask, tt, labels, feats, aux = bench.synthetic_batch(BS, SEQ, AUX, cfg.vocab_size, 1234, dev)
 kw = dict(input_ids=ids, attention_mask=mask, token_type_ids=tt, labels=labels, imagelabel=None, images=feats, aux_imgs=aux)
 
 
@@ -43,10 +50,10 @@ dur = collections.Counter()
 for ev in prof.events():
     if ev.device_type != torch.autograd.DeviceType.CPU or not ev.name.startswith("aten::"):
         continue
-    if ev.name not in ("aten::copy_", "aten::cat", "aten::add", "aten::zero_", "aten::fill_", "aten::mul", "aten::clone", "aten::add_", "aten::_to_copy"):
-        continue
     if ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
         continue  # nested op
+    if ev.device_time_total <= 0:
+        continue  # (views, allocations: no device work)
     where = "?"
     for fr in ev.stack or []:
         if root in fr and "tools/find_copies" not in fr:
@@ -54,5 +61,7 @@ for ev in prof.events():
             break
     by[(ev.name, where)] += 1
     dur[(ev.name, where)] += ev.device_time_total
-for (name, where), n in by.most_common(60):
+print(f"== {dtype} {arch} bs {BS} S {SEQ}: top-level aten ops with device work in ONE training step, by the innermost repository frame ==")
+print(f"   {sum(by.values())} ops, {sum(dur.values()):.1f} us of device time")
+for (name, where), n in by.most_common(80):
     print(f"{n:4d} x {name:16s} {dur[(name, where)]:8.1f} us  {where}")
