@@ -15,7 +15,9 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+# MTVAF_LIBDIR: build into another directory (A/B variants with MTVAF_EXTRA_FLAGS; load them with MTVAF_LIB=<dir>/libmtvaf_hip.so).
+# The flags are part of every object's stamp, so a variant can never be mistaken for the product build.
+LIBDIR = os.environ.get("MTVAF_LIBDIR") or os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmtvaf_hip.so")
 SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16x.hip", "gemm_bf16p.hip", "gemm_f32x3.hip", "gemm_f32p.hip", "attention.hip", "attention_bf16.hip", "rowops.hip", "crf.hip", "prompt.hip", "span.hip", "optim.hip", "executor.hip", "runtime.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"] + os.environ.get("MTVAF_EXTRA_FLAGS", "").split()

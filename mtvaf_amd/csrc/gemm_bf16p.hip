@@ -65,6 +65,17 @@ namespace mtvaf {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// MTVAF_P256_REBALANCE (compile-time A/B, a bit mask; where the 8 LDS-DMA requests of a k-tile sit among its four phases):
+//   bit 0: (t+2).A-h0 is requested in phase 4 instead of phase 3 (phase 3: 8 fragment reads + 2 requests, phase 4: 4 requests;
+//          0: 8 reads + 4 requests against 2 requests).  A-h0 of tile t was last read in phase 1;
+//   bit 1: (t+1).A-h1 is requested in phase 2 instead of phase 1 (phase 1: 12 reads, phase 2: 4 reads + 2 requests).
+// Request ORDER is unchanged (A-h1, then the three half-tiles of t+2), so the counted waits keep their meaning.
+// Measured (round 6, tools/p256_bench.py 4864 38912, one box, profiles/r06_p256_rebalance.txt): mask 0 / 1 / 2 / 3 -> a layer's twelve
+// products on this kernel at 38912 rows 2180 / 2152 / 2098 / 2113 us, the grouped weight gradients 666.7 / 663.5 / 656.8 / 659.5 us
+// (4864 rows: 98.3 / 94.0 / 92.6 / 96.8): 2 is the default.
+#ifndef MTVAF_P256_REBALANCE
+#define MTVAF_P256_REBALANCE 2
+#endif
 #define P256_BAR()                      \
   do {                                  \
     __builtin_amdgcn_s_barrier();       \
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK
     /* phase 1 */                                                                 \
     load_B(FB0, cur, 0);                                                          \
     load_A(FA0, cur, 0);                                                          \
-    if (I1) stage_A(cur ^ 1, 1, t + 1);                                           \
+    if (I1 && !(MTVAF_P256_REBALANCE & 2)) stage_A(cur ^ 1, 1, t + 1);            \
     P256_SB();                                                                    \
     P256_BAR();                                                                   \
     P256_LGKM0();                                                                 \
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK
     P256_BAR();                                                                   \
     /* phase 2 */                                                                 \
     load_B(FB1, cur, 1);                                                          \
+    if (I1 && (MTVAF_P256_REBALANCE & 2)) stage_A(cur ^ 1, 1, t + 1);             \
     P256_SB();                                                                    \
     P256_BAR();                                                                   \
     P256_LGKM0();                                                                 \
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK
     load_A(FA1, cur, 1);                                                          \
     if (I2) {                                                                     \
       stage_B(cur, 0, t + 2);                                                     \
-      stage_A(cur, 0, t + 2);                                                     \
+      if (!(MTVAF_P256_REBALANCE & 1)) stage_A(cur, 0, t + 2);                    \
     }                                                                             \
     P256_SB();                                                                    \
     P256_BAR();                                                                   \
@@ -263,6 +275,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK
     P256_BAR();                                                                   \
     /* phase 4 */                                                                 \
     if (I2) {                                                                     \
+      if (MTVAF_P256_REBALANCE & 1) stage_A(cur, 0, t + 2);                       \
       stage_B(cur, 1, t + 2);                                                     \
       wait_vm<6>();                                                               \
     } else {                                                                      \

@@ -13,7 +13,9 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmtvaf_hip.so")
+# MTVAF_LIB: another build of the library (an A/B variant made by `MTVAF_LIBDIR=... MTVAF_EXTRA_FLAGS=-D... python -m mtvaf_amd.build`:
+# ablation builds never overwrite the product library)
+LIB_PATH = os.environ.get("MTVAF_LIB") or os.path.join(_HERE, "lib", "libmtvaf_hip.so")
 
 _ERR = {-1: "bad shape", -2: "bad alignment", -3: "bad argument", -4: "workspace too small"}
 
