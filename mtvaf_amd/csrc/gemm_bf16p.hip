@@ -59,6 +59,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <type_traits>
 
 namespace mtvaf {
@@ -484,7 +485,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK
   // its finisher: with x reversed and y slowest in the dispatch order, contributions are handed to CUs before the pieces
   // that wait for them (dispatch order is a speed matter only: waits are bounded and flagged) ----
   const int KT = sk.KT;
-  const int run = (int)gridDim.x - 1 - bid;  // (bid: XCD-aware, so neighbouring runs -- which share operand panels -- share an L2)
+  // Which run a block takes is placement only (flags and slabs are indexed by RUN; every piece of a planned launch is resident at
+  // once: tiles x S <= CUs).  bid is XCD-aware: consecutive values share an XCD, i.e. an L2.
+  //  * tile-major (kmajor 0, the general cut): neighbouring runs = the pieces of ONE tile (different k-ranges: they share no
+  //    operand byte) and of the tiles next to it;
+  //  * k-major (round 6; equal pieces): an XCD's ~32 blocks take the SAME piece index -- the same rows of the reduction axis -- of
+  //    ~32 consecutive tiles, which share their A / B panels: with S = 2 pieces and the [3 x 12] / [12 x 3] tile grids of a layer's
+  //    weight gradients an XCD fetches ~15 panels per k-step for its 27 blocks where the tile-major order fetched ~28 for 32.
+  int run = (int)gridDim.x - 1 - bid;
+  if (sk.kmajor && gridDim.y == 1 && KT % sk.W == 0) {
+    const int S = KT / sk.W, T = (int)gridDim.x / S;
+    if (T * S == (int)gridDim.x) {
+      const int s = bid / T, tp = bid - s * T;
+      run = tp * S + (S - 1 - s);  // (contributions -- pieces with k0 > 0 -- take the low block ids: dispatched first)
+    }
+  }
   const long rs = (long)run * sk.W, re = min(rs + (long)sk.W, sk.total);
   long ps = rs;                                   // piece start
   if (blockIdx.y > 0) ps = (rs / KT + blockIdx.y) * KT;
@@ -615,6 +630,11 @@ int launch_p256_streamk(const GemmArgsX& a, P256SK sk, int layout_a, int layout_
   // choice -- equal pieces in whole rounds of the CUs); 0: the step line is cut into grid_blocks equal runs wherever they fall
   const long g = std::min<long>(grid_blocks, sk.total);
   sk.W = steps_per_run > 0 ? steps_per_run : (int)((sk.total + g - 1) / g);
+  static const int kmajor_env = [] { const char* e = getenv("MTVAF_P256_SK_KMAJOR"); return e ? atoi(e) : 0; }();
+  // (measured, round 6, profiles/r06_p256_sk_kmajor.txt: 2560 / 4864 / 38912 token rows 65.1 / 93.4 / 649 us tile-major against 70.7 /
+  // 97.9 / 642 us k-major; C4 8387 vs 8402, C5 3385 vs 3399 sentences/s -- the launch is not bound by the fabric traffic the k-major
+  // placement saves: off by default)
+  sk.kmajor = kmajor_env;
   const long runs = (sk.total + sk.W - 1) / sk.W;
   if (steps_per_run > 0 && sk.KT % steps_per_run) return MTVAF_ERR_ARG;
   if (runs > grid_blocks && !(sk.W % sk.KT == 0)) return MTVAF_ERR_WORKSPACE;  // one slab / flag per run (runs of whole tiles need none)

@@ -67,6 +67,7 @@ struct P256SK {
   int nprob;        // 0: the single product of the GemmArgsX; 1..4: products sharing the launch (same K, same layouts)
   int KT;           // k-tiles per output tile
   int W;            // steps per block (set by the launcher)
+  int kmajor;       // equal pieces only (KT % W == 0): blocks that share an XCD take the SAME k-range of DIFFERENT tiles (see the kernel)
   long total;       // tiles * KT
   float* slabs;     // [blocks][256 * 256] fp32 contributions, in the kernel's register order
   unsigned* flags;  // [blocks], zero between launches
