@@ -467,15 +467,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_p256_kernel(GemmArgsX p, P256SK
     else direct(std::integral_constant<int, K_PLAIN>{});
   };
 
-  if (!SK) {  // one tile (and one split of its reduction) per block
+  if (!SK) {
+    // one tile (and one split of its reduction) per block -- or, PERSISTENT (round 6; sk.total = the number of tiles, unsplit launches
+    // of more than one round of the CUs): block b walks tiles b, b + gridDim.x, ...  A tile's epilogue stores are only ISSUED when the
+    // wave moves on: they drain while the next tile's first operand tiles are on their way (one tile per block pays the store burst
+    // of a whole round of tiles -- 64 MB at once -- and the next round's cold start one after the other).
     const int kbeg = blockIdx.z * p.k_chunk;
     const int kend = min(p.K, kbeg + p.k_chunk);
-    bind(p.A, p.B, p.lda, p.ldb, (bid / p.tiles_n) * 256, (bid % p.tiles_n) * 256, kbeg, (kend - kbeg) >> 6);
     const bool split = gridDim.z > 1;
+    const int ntiles = sk.total > 0 ? (int)sk.total : (int)gridDim.x;
     Cout = p.C32 ? p.C32 + (long)blockIdx.z * p.slab_stride : nullptr;
     ldc32 = p.ldc32;
-    mainloop();
-    epilogue(split, split ? nullptr : p.C16);
+    for (int tile = bid; tile < ntiles; tile += (int)gridDim.x) {
+      bind(p.A, p.B, p.lda, p.ldb, (tile / p.tiles_n) * 256, (tile % p.tiles_n) * 256, kbeg, (kend - kbeg) >> 6);
+      mainloop();
+      epilogue(split, split ? nullptr : p.C16);
+      if (tile + (int)gridDim.x < ntiles) P256_BAR();  // (block-uniform) the staging images of the epilogue are free before the next tile's requests
+    }
     return;
   }
 
@@ -610,6 +618,12 @@ static int p256_check(const GemmArgsX& a) {
 int launch_p256(const GemmArgsX& a, int layout_a, int layout_b, dim3 grid, hipStream_t st) {
   if (int rc = p256_check(a)) return rc;
   P256SK sk = {};
+  // more than one round of tiles, unsplit: one block per CU walks the tiles (MTVAF_P256_PERSIST=0: one tile per block as before)
+  static const int persist = [] { const char* e = getenv("MTVAF_P256_PERSIST"); return e ? atoi(e) : 1; }();
+  if (persist && grid.z == 1 && grid.x > 256) {
+    sk.total = grid.x;
+    grid.x = 256;
+  }
   if (layout_a == 0 && layout_b == 0) return launch_p256_t<false, false, false>(a, sk, grid, st);
   if (layout_a == 0) return launch_p256_t<false, true, false>(a, sk, grid, st);
   return launch_p256_t<true, true, false>(a, sk, grid, st);
