@@ -131,6 +131,12 @@ int mtvaf_gather_rows(const float* src, const int* map, float* dst, int rows_dst
  * the kept rows), mv_out[0] = number of kept rows.  All int32, device. */
 int mtvaf_build_packing(const float* addmask, int B, int T, int P, int S, int* cu, int* inv, int* rowmap, int* mv_out,
                         mtvaf_stream_t stream);
+/* Round 6: the same with cu [2 B + 1]: behind the offsets, cu[B + 1 + z] = the sentence that the varlen attention launches
+ * (mtvaf_prefix_attn_varlen_* / _bf16_varlen_*) run in slot z of their grid -- longest first -- and cu[0] = -1 marks the list as
+ * present (a cu with cu[0] = 0 means sentence z in slot z).  Placement only: a launch lasts as long as its busiest CU, and in sorted
+ * order the blocks a CU receives come from the long, the middle and the short third of the batch; results are bit-identical. */
+int mtvaf_build_packing_ordered(const float* addmask, int B, int T, int P, int S, int* cu, int* inv, int* rowmap, int* mv_out,
+                                mtvaf_stream_t stream);
 /* k-tile list for mtvaf_gemm_f32_ktiles: the bk-row tiles of the [B*S] token axis that hold at least one unmasked token
  * (additive mask [B, T = P + S], kept: > -5000), in order; kcnt[0] = how many.  (B*S) % bk == 0.  Device int32 arrays. */
 int mtvaf_build_ktiles(const float* addmask, int B, int T, int P, int S, int bk, int* klist, int* kcnt,

@@ -78,11 +78,13 @@ struct Sent {
 };
 __device__ __forceinline__ Sent sentence(const AttnArgs& a, int b) {
   if (a.cu) {
-    const int c0 = a.cu[b];
+    const int c0 = b ? a.cu[b] : 0;  // (cu[0] = -1 marks a launch order behind the offsets: slot_sentence)
     return Sent{(long)c0, a.cu[b + 1] - c0};
   }
   return Sent{(long)b * a.S, a.S};
 }
+// the sentence of grid slot z (mtvaf_build_packing_ordered: longest first; identity without the list)
+__device__ __forceinline__ int slot_sentence(const AttnArgs& a, int z) { return (a.cu && a.cu[0] < 0) ? a.cu[a.B + 1 + z] : z; }
 __device__ __forceinline__ float mask_at(const AttnArgs& a, int b, int Tf, int t) {
   return a.cu ? 0.f : a.addmask[(long)b * Tf + t];
 }
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       store_ctx(a, (long)(r0 + r), h * D + (threadIdx.x & 15) * 4, f32x4{0.f, 0.f, 0.f, 0.f});
     return;
   }
+  b = slot_sentence(a, b);
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
   if (bx * 64 >= Sb) return;  // (block-uniform; packed rows: a query tile beyond the sentence)
@@ -182,6 +185,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   __shared__ int t_eff_slot;
   const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
   const bool qok = q < Sb;
+  // Round 6: the last query tile of a sentence is rarely full (74 tokens: queries 64 .. 73 live in wave 0 of the second tile);
+  // its other waves used to run every product and exponential of the key loop for rows nobody stores -- on the fp32 matrix pipe
+  // they share with the live waves of the other blocks on their SIMD.  They now skip the arithmetic (same results: bit-identical).
+  const bool wave_live = __builtin_amdgcn_readfirstlane(q - lq) < Sb;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;  // scores are kept in the log2 domain: one v_exp_f32 per probability
@@ -224,6 +231,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? mreg * LOG2E : NEG_BIG;
     __syncthreads();
     if (t0 + KT < T) fetch(t0 + KT);
+    if (!wave_live) continue;  // (wave-uniform) a wave whose 16 queries all lie beyond the sentence only stages and synchronises
     const int nsub = min(4, (T - t0 + 15) >> 4);  // 16-key sub-tiles of this tile that hold real keys
     f32x4 s[4];
     float tmax = NEG_BIG;
@@ -301,6 +309,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, i
   const int Tf = a.P + a.S;
   const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
   const bool qok = q < Sb;
+  const bool wave_live = __builtin_amdgcn_readfirstlane(q - lq) < Sb;
   if (a.zero_tail && !a.cu && qtile * 64 >= T - a.P) {  // (block-uniform) a tile of trailing padding: dQ = 0, nothing to read
     if (qok) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -390,6 +399,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& a, int qtile, i
     if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? mreg * LOG2E : NEG_BIG;
     __syncthreads();
     if (t0 + KT < T) fetch(t0 + KT);
+    if (!wave_live) continue;  // (wave-uniform; as in the forward kernel)
     const int nsub = min(4, (T - t0 + 15) >> 4);
     const uint32_t cterm0 = (uint32_t)(t0 + 4 * g) * ATTN_DROP_C2;
 #pragma unroll
@@ -633,6 +643,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_kernel(AttnArgs a, int nq) { 
   }
   int bx = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   xcd_group(gridDim.x, gridDim.y, a.B, bx, h, b);
+  b = slot_sentence(a, b);
   if (bx < nq) {
     attn_bwd_dq_body(a, bx, b, h, tile0, tile1, small, &t_eff_slot);
   } else {

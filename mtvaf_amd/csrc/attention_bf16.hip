@@ -66,11 +66,13 @@ struct Sent {
 };
 __device__ __forceinline__ Sent sentence(const Args& a, int b) {
   if (a.cu) {
-    const int c0 = a.cu[b];
+    const int c0 = b ? a.cu[b] : 0;  // (cu[0] = -1 marks a launch order behind the offsets: slot_sentence)
     return Sent{(long)c0, a.cu[b + 1] - c0};
   }
   return Sent{(long)b * a.S, a.S};
 }
+// the sentence of grid slot z (mtvaf_build_packing_ordered: longest first; identity without the list)
+__device__ __forceinline__ int slot_sentence(const Args& a, int z) { return (a.cu && a.cu[0] < 0) ? a.cu[a.B + 1 + z] : z; }
 __device__ __forceinline__ float mask_at(const Args& a, int b, int Tf, int t) {
   return a.cu ? 0.f : a.addmask[(long)b * Tf + t];
 }
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
   __shared__ __attribute__((aligned(16))) float Ms[KT];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int b = blockIdx.z;
+  const int h = blockIdx.y;
   const int q = blockIdx.x * 64 + wave * 16 + lq;
   if (a.cu && b == a.B) {  // (block-uniform) the rows that pad the packed image: zeros
     const int r0 = a.cu[a.B];
@@ -163,6 +166,7 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
       *reinterpret_cast<bf16x8*>(a.ctx + (long)(r0 + r) * a.H + h * D + (threadIdx.x & 7) * 8) = z;
     return;
   }
+  b = slot_sentence(a, b);
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
   if ((int)blockIdx.x * 64 >= Sb) return;  // (block-uniform; packed rows: a query tile beyond the sentence)
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
   __shared__ int t_eff_slot;
   const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, &t_eff_slot);  // trailing padding keys are skipped
   const bool qok = q < Sb;
+  const bool wave_live = __builtin_amdgcn_readfirstlane(q - lq) < Sb;  // (round 6, as attention.hip: dead waves skip the arithmetic)
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(256) void attn_bf16_fwd_kernel(Args a) {
     tile_store(Vs, vreg);
     if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? mreg * LOG2E : NEG_BIG;
     __syncthreads();
+    if (!wave_live) continue;  // (wave-uniform) a wave whose 16 queries all lie beyond the sentence only stages and synchronises
     const int nsub = min(4, (T - t0 + 15) >> 4);  // 16-key blocks of this tile that hold real keys
     f32x4 s[4];
     float tmax = NEG_BIG;
@@ -270,7 +276,7 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
                                             int* t_eff_slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lq = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = slot_sentence(a, blockIdx.z), h = blockIdx.y;
   const int q = qtile * 64 + wave * 16 + lq;
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
@@ -281,6 +287,7 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
   const int Tf = a.P + a.S;
   const int T = a.cu ? a.P + Sb : effective_keys(a.addmask + (long)b * Tf, a.P, a.S, t_eff_slot);
   const bool qok = q < Sb;
+  const bool wave_live = __builtin_amdgcn_readfirstlane(q - lq) < Sb;
   const float inv_keep = a.p_drop > 0.f ? 1.f / (1.f - a.p_drop) : 1.f;
   const uint32_t rowh = attn_dropout_rowhash(attn_epoch_key(a.drop_key, a.epoch), (uint32_t)((b * a.NH + h) * a.S + q));
   const float sc2 = a.scale * LOG2E;
@@ -332,6 +339,7 @@ __device__ __forceinline__ void bwd_dq_body(const Args& a, int qtile, unsigned c
     if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? mreg * LOG2E : NEG_BIG;
     __syncthreads();
     if (t0 + KT < T) fetch(t0 + KT);
+    if (!wave_live) continue;  // (wave-uniform; dq stays zero: the column sums below read it through qok)
     const int nsub = min(4, (T - t0 + 15) >> 4);
     const uint32_t cterm0 = (uint32_t)(t0 + 4 * g) * ATTN_DROP_C2;
     f32x4 ds[4];
@@ -396,7 +404,7 @@ __device__ __forceinline__ void bwd_dkv_body(const Args& a, int ktile, unsigned 
                                              float* del_s, uint32_t* rh_s, float* red, int* t_eff_slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lk = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const int b = slot_sentence(a, blockIdx.z), h = blockIdx.y;
   const Sent sn = sentence(a, b);
   const int Sb = sn.n;
   const int nkt = (a.P + a.S + 63) / 64;  // rows of partkv per sentence (allocation: the padded key count)

@@ -337,6 +337,10 @@ SKIP_PAD_DW_BF16 = os.environ.get("MTVAF_SKIP_PAD_DW", "1") == "2"
 # masked positions (or a model that sets BertModel.allow_unpad wrongly) raises here instead of training on silently different
 # gradients.  One host synchronisation per backward pass: a debugging aid, off by default.
 CHECK_CONTRACT = os.environ.get("MTVAF_CHECK_CONTRACT", "0") == "1"
+# Padding-free execution: the varlen attention launches take the sentences longest first (placement only, bit-identical results: a
+# launch lasts as long as its busiest CU, and in sorted order a CU's blocks come from the long, middle and short third of the
+# batch).  MTVAF_ATTN_ORDER=0: sentence z in grid slot z, as before round 6.
+ATTN_ORDER = os.environ.get("MTVAF_ATTN_ORDER", "1") != "0"
 LAST_PACK = None  # the Packing of the most recent native forward (None: it ran padded)
 _PENDING_PACK = None  # packing started by Packing.begin, consumed by the next Packing.build
 _PACK_HOST = {}
@@ -377,12 +381,13 @@ class Packing:
             return  # (the row count cannot reach the host inside a capture: this step runs the padded layout)
         B, T = addmask.shape
         dev = addmask.device
-        cu = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        # (cu: B + 1 row offsets and, behind them, the sentence order of the attention launches -- longest first: ATTN_ORDER)
+        cu = torch.empty(2 * B + 1, dtype=torch.int32, device=dev)
         inv = torch.empty(B * S, dtype=torch.int32, device=dev)
         rowmap = torch.empty(B * S, dtype=torch.int32, device=dev)
         mv = torch.empty(1, dtype=torch.int32, device=dev)
-        hip._ck(hip.lib().mtvaf_build_packing(hip._p(addmask), B, T, Pn, S, hip._p(cu), hip._p(inv), hip._p(rowmap), hip._p(mv),
-                                              hip._st()), "mtvaf_build_packing")
+        build = hip.lib().mtvaf_build_packing_ordered if ATTN_ORDER else hip.lib().mtvaf_build_packing
+        hip._ck(build(hip._p(addmask), B, T, Pn, S, hip._p(cu), hip._p(inv), hip._p(rowmap), hip._p(mv), hip._st()), "mtvaf_build_packing")
         key = dev.index or 0
         host = _PACK_HOST.get(key)
         if host is None:

@@ -61,6 +61,7 @@ _SIGS = {
     "mtvaf_prefix_attn_bf16_varlen_bwd": (c_int, [P, P, P, P, P, I, P, P, P, P, P, P, P, I, I, I, I, I, F, U64, U64, P]),
     "mtvaf_gather_rows": (c_int, [P, P, P, I, I, P]),
     "mtvaf_build_packing": (c_int, [P, I, I, I, I, P, P, P, P, P]),
+    "mtvaf_build_packing_ordered": (c_int, [P, I, I, I, I, P, P, P, P, P]),
     "mtvaf_build_ktiles": (c_int, [P, I, I, I, I, I, P, P, P]),
     "mtvaf_gemm_f32_ktiles": (c_int, [I, I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, I, P, P, P]),
     "mtvaf_zero_f32": (c_int, [P, L, P]),
