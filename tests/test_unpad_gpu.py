@@ -437,3 +437,68 @@ def test_weight_images_after_a_write_through_data_need_invalidation(mode):
         assert abs(l_back - l0) <= 2e-6 * abs(l0), (l_back, l0)
     finally:
         hip.set_compute_dtype(was_mode)
+
+
+@pytest.mark.gpu
+def test_ordered_packing_is_placement_only():
+    """Round 6: `mtvaf_build_packing_ordered` stores, behind the B + 1 row offsets, the order in which the varlen attention launches
+    take the sentences (longest first, ties by index; cu[0] = -1 marks the list).  Placement only: the offsets are those of
+    `mtvaf_build_packing`, the list is a permutation sorted by length, and forward + backward attention produce the same bits with
+    and without it (fp32 and bf16 kernels)."""
+    from mtvaf_amd import hip
+    L_ = hip.lib()
+    rnd = lambda *shape, seed=0: torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+    B, S, Pn, NH, p = 7, 100, 36, 4, 0.1
+    H = NH * 64
+    lens = [S, 1, 53, 20, 77, 53, 99]
+    mask = torch.zeros(B, S)
+    for b, n in enumerate(lens):
+        mask[b, :n] = 1
+    addmask = torch.cat([torch.zeros(B, Pn), (1 - mask) * -10000.0], 1).to(DEV).contiguous()
+
+    def pack(fn, ncu):
+        cu = torch.full((ncu,), 12345, dtype=torch.int32, device=DEV)
+        inv = torch.empty(B * S, dtype=torch.int32, device=DEV)
+        rowmap = torch.empty(B * S, dtype=torch.int32, device=DEV)
+        mv = torch.empty(1, dtype=torch.int32, device=DEV)
+        hip._ck(fn(hip._p(addmask), B, Pn + S, Pn, S, hip._p(cu), hip._p(inv), hip._p(rowmap), hip._p(mv), hip._st()), "packing")
+        return cu, inv, rowmap, int(mv)
+    cu0, inv0, map0, mv0 = pack(L_.mtvaf_build_packing, B + 1)
+    cu1, inv1, map1, mv1 = pack(L_.mtvaf_build_packing_ordered, 2 * B + 1)
+    assert mv0 == mv1 == sum(lens) and torch.equal(inv0, inv1) and torch.equal(map0, map1)
+    assert int(cu0[0]) == 0 and int(cu1[0]) == -1 and torch.equal(cu0[1:], cu1[1:B + 1])
+    order = cu1[B + 1:].tolist()
+    assert order == sorted(range(B), key=lambda b: (-lens[b], b)), order
+    Mv = mv0
+    Mp = (Mv + 127) // 128 * 128 + 128
+    for dtype in ("fp32", "bf16"):
+        tdt = torch.float32 if dtype == "fp32" else torch.bfloat16
+        qkv = torch.zeros(Mp, 3 * H, device=DEV, dtype=tdt)
+        qkv[:Mv] = rnd(Mv, 3 * H, seed=81).to(DEV).to(tdt)
+        pk, pv = rnd(B, Pn * H, seed=82).to(DEV).to(tdt), rnd(B, Pn * H, seed=83).to(DEV).to(tdt)
+        dctx = torch.zeros(Mp, H, device=DEV, dtype=tdt)
+        dctx[:Mv] = rnd(Mv, H, seed=84).to(DEV).to(tdt)
+        res = []
+        for cu in (cu0, cu1):
+            ctx = torch.full((Mp, H), float("nan"), device=DEV, dtype=tdt)
+            lse = torch.zeros(B, NH, S, device=DEV)
+            dqkv = torch.full((Mp, 3 * H), float("nan"), device=DEV, dtype=tdt)
+            dk, dv = torch.zeros(B, Pn * H, device=DEV), torch.zeros(B, Pn * H, device=DEV)
+            if dtype == "fp32":
+                de = torch.zeros(B, NH, S, device=DEV)
+                hip.prefix_attn_varlen_fwd(qkv, pk, pv, cu, Mp - Mv, ctx, lse, B, S, Pn, NH, p, 11, 5)
+                hip.prefix_attn_varlen_bwd(dctx, qkv, pk, pv, cu, Mp - Mv, ctx, lse, de, dqkv, dk, dv, B, S, Pn, NH, p, 11, 5)
+                res.append((ctx, lse, dqkv, dk, dv, de))
+            else:
+                nqt, nkt = (S + 63) // 64, (Pn + S + 63) // 64
+                pq, pkv = torch.zeros(B * nqt, H, device=DEV), torch.zeros(B * nkt, 2 * H, device=DEV)
+                hip._ck(L_.mtvaf_prefix_attn_bf16_varlen_fwd(hip._p(qkv), hip._p(pk), hip._p(pv), hip._p(cu), Mp - Mv, hip._p(ctx), hip._p(lse),
+                                                             B, S, Pn, NH, 64, p, 11, 5, hip._st()), "bf16 varlen fwd")
+                hip._ck(L_.mtvaf_prefix_attn_bf16_varlen_bwd(hip._p(dctx), hip._p(qkv), hip._p(pk), hip._p(pv), hip._p(cu), Mp - Mv, hip._p(ctx),
+                                                             hip._p(lse), hip._p(dqkv), hip._p(dk), hip._p(dv), hip._p(pq), hip._p(pkv), B, S, Pn,
+                                                             NH, 64, p, 11, 5, hip._st()), "bf16 varlen bwd")
+                res.append((ctx, lse, dqkv, dk, dv, pq, pkv))
+        torch.cuda.synchronize()
+        for x, y in zip(*res):
+            assert torch.equal(x.view(torch.int16 if x.dtype == torch.bfloat16 else torch.int32),
+                               y.view(torch.int16 if y.dtype == torch.bfloat16 else torch.int32)), dtype
