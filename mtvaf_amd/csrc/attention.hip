@@ -17,116 +17,26 @@
 // softmax statistics are lane-local plus two shuffles, and the probability registers are directly
 // the B operand of the P.V product (O^T[d][q] = V^T.P^T) -- no LDS round trip for P.  The k index of
 // every product is permuted (step t, lane group g <-> k = 4g + t) identically on both operands.
-#include "common.h"
-#include "planes.h"
+#include "attention_args.h"
+
+#include <cstdlib>
 
 namespace mtvaf {
 
-constexpr int D = 64;      // head dim (asserted by the launcher)
 constexpr int LDT = 68;    // LDS row stride (floats) for 64-wide tiles: conflict-free b32 column reads
-constexpr int KT = 64;     // keys (or queries) per LDS tile
-constexpr float NEG_BIG = -1.0e30f;
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
-struct AttnArgs {
-  const float* qkv;
-  const float* pk;
-  const float* pv;
-  const float* addmask;
-  float* ctx;
-  float* lse;
-  // backward
-  const float* dctx;
-  float* delta;
-  float* dqkv;
-  float* dpk;
-  float* dpv;
-  int B, S, P, NH, H;
-  float scale, p_drop;
-  uint32_t drop_key, drop_thr;
-  const uint64_t* epoch;  // device-side dropout epoch (captured launches), or NULL
-  // PACKED token rows (padding-free execution): sentence b owns rows cu[b] .. cu[b+1]-1 of qkv / ctx / dctx / dqkv (its
-  // unmasked tokens, in order), every kept key is unmasked (addmask is not read), queries beyond the sentence do not
-  // exist.  NULL: the padded [B, S] layout.  lse / delta / the dropout row ids keep the [B, NH, S] indexing either way.
-  const int* cu;
-  int pad_rows;  // packed rows: this many rows behind the last sentence pad the image; the z-slice b == B zero-fills them
-  // backward, padded layout: the caller vouches that dctx is EXACTLY zero for the queries behind the last unmasked text position
-  // of a sentence (trailing padding: nothing downstream reads those rows -- the contract of the k-tile lists of the weight
-  // gradients).  Their dQ is exactly zero and they add exactly nothing to dK / dV: the key side stops its query loop there.
-  int zero_tail;
-  // pre-split operands (round 5; packed rows only): ALSO write the tile-blocked plane image of the context ([H / 32][3][Mrows][32])
-  // / of dQ | dK | dV ([3H / 32][3][Mrows][32]) -- what the Wo / QKV-dX products and the weight gradients read -- or NULL
-  unsigned char* ctx_p;
-  unsigned char* dqkv_p;
-  long Mrows;
-};
-
-// the stores of the two results that are GEMM operands downstream: fp32, and the plane image when the caller asked for it
-__device__ __forceinline__ void store_ctx(const AttnArgs& a, long row, int col, const f32x4 v) {
-  *reinterpret_cast<f32x4*>(a.ctx + row * a.H + col) = v;
-  if (a.ctx_p) planes_store4(a.ctx_p, a.Mrows, row, col, v);
-}
-__device__ __forceinline__ void store_dqkv(const AttnArgs& a, long row, int col, const f32x4 v) {
-  *reinterpret_cast<f32x4*>(a.dqkv + row * 3 * a.H + col) = v;
-  if (a.dqkv_p) planes_store4(a.dqkv_p, a.Mrows, row, col, v);
-}
-
-struct Sent {
-  long tok0;  // first token row of the sentence
-  int n;      // its text tokens (queries; text keys)
-};
-__device__ __forceinline__ Sent sentence(const AttnArgs& a, int b) {
-  if (a.cu) {
-    const int c0 = b ? a.cu[b] : 0;  // (cu[0] = -1 marks a launch order behind the offsets: slot_sentence)
-    return Sent{(long)c0, a.cu[b + 1] - c0};
-  }
-  return Sent{(long)b * a.S, a.S};
-}
-// the sentence of grid slot z (mtvaf_build_packing_ordered: longest first; identity without the list)
-__device__ __forceinline__ int slot_sentence(const AttnArgs& a, int z) { return (a.cu && a.cu[0] < 0) ? a.cu[a.B + 1 + z] : z; }
-__device__ __forceinline__ float mask_at(const AttnArgs& a, int b, int Tf, int t) {
-  return a.cu ? 0.f : a.addmask[(long)b * Tf + t];
-}
-
-
-// Keys behind the LAST unmasked text position of a sentence (trailing padding: additive mask -10000) contribute exactly 0
-// to every probability sum -- exp2 underflows to 0 -- and leave the running maximum untouched, so whole key tiles made of
-// them can be skipped with bit-identical results.  -> T_eff = P + 1 + max{s : addmask[b][P+s] > -5000}; the full T when
-// no text key is unmasked (nothing is skipped then).  Masked keys BEFORE that position ("holes") stay in the loop.
-__device__ __forceinline__ int effective_keys(const float* __restrict__ addmask_row, int P, int S, int* lds_slot) {
-  if (threadIdx.x == 0) *lds_slot = -1;
-  __syncthreads();
-  int last = -1;
-  for (int t = threadIdx.x; t < S; t += blockDim.x)
-    if (addmask_row[P + t] > -5000.f) last = t;
-  if (last >= 0) atomicMax(lds_slot, last);
-  __syncthreads();
-  const int l = *lds_slot;
-  return l >= 0 ? P + l + 1 : P + S;
-}
+// timing-only ablations of the forward kernel for variant builds (MTVAF_EXTRA_FLAGS=-DMTVAF_ATTN_ABL=n; wrong results; the product
+// build has 0): 1 no QK^T products, 2 no PV products, 4 no exponentials / dropout, 8 one barrier per key tile (racy)
+#ifndef MTVAF_ATTN_ABL
+#define MTVAF_ATTN_ABL 0
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // forward: grid (ceil(S/64), NH, B), 256 threads; wave w owns queries q0+16w .. +15
 // ---------------------------------------------------------------------------------------------
 constexpr int LDK = 72;  // K tile row stride: conflict-free ds_read_b128 row fragments (slot = 2*row + k-chunk mod 16)
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
-// Branch-free staging of [64][64] tiles of the [prefix ; text] key axis: rows beyond T re-read row T-1 (finite
-// values; their probabilities are exactly 0 through the -1e30 entry of the mask tile).  The source pointer is
-// selected with bit arithmetic (a ternary on pointers compiles to divergent branches whose loads the compiler
-// then serialises with vmcnt(0) waits), and all loads of a tile are issued before the first LDS store.
-struct KvSrc {
-  const float* pre;  // prefix slab of this (b, h), + the thread's column offset
-  const float* txt;  // text rows of this (b, h), + the thread's column offset
-};
-__device__ __forceinline__ const float* kv_row_ptr(const KvSrc& s, int t, int P, int ld_txt) {
-  const bool ispre = t < P;
-  const uint64_t m = ispre ? ~0ull : 0ull;
-  const uint64_t base = (uint64_t)s.txt ^ (((uint64_t)s.txt ^ (uint64_t)s.pre) & m);
-  const int off = ispre ? t * D : (t - P) * ld_txt;
-  return reinterpret_cast<const float*>(base) + off;
-}
 template <int N>
 __device__ __forceinline__ void kv_load(f32x4 (&reg)[N], const KvSrc& s, int P, int T, int ld_txt, int t0) {
 #pragma unroll
@@ -140,26 +50,6 @@ __device__ __forceinline__ void kv_store(float* dst, const f32x4 (&reg)[N]) {
 #pragma unroll
   for (int i = 0; i < N; ++i)
     *reinterpret_cast<f32x4*>(dst + ((threadIdx.x >> 4) + 16 * i) * LD + (threadIdx.x & 15) * 4) = reg[i];
-}
-
-// XCD-aware block order (round 5).  Workgroups are dealt round-robin over the 8 XCDs by their linear id, x fastest: the nx blocks
-// of one (sentence, head) -- 2 query tiles forward; 2 query + 3 key tiles backward, which all read the same q / k / v / dO / O
-// slices (3.5x the unique bytes: 165 - 205 MB per backward launch by the PMC counters against ~50 MB) -- landed on nx different
-// XCDs, each with a private L2.  This bijective remap gives the k-th group of nx consecutive slots of ONE XCD to one
-// (sentence, head), so the re-reads hit that XCD's L2.  Placement is a speed hint only: results never depend on it.
-// Identity when the number of (sentence, head) pairs is not a multiple of 8.  nz = the sentences (the zero-fill slice z == B of a
-// packed launch is dispatched behind them and keeps its index).
-#ifndef MTVAF_ATTN_XCD_GROUP
-#define MTVAF_ATTN_XCD_GROUP 1
-#endif
-__device__ __forceinline__ void xcd_group(int nx, int ny, int nz, int& x, int& y, int& z) {
-  if (!MTVAF_ATTN_XCD_GROUP || ((ny * nz) & 7) || z >= nz) return;
-  const int L = x + nx * (y + ny * z);
-  const int xcd = L & 7, slot = L >> 3;
-  const int gi = (slot / nx) * 8 + xcd;
-  x = slot % nx;
-  y = gi % ny;
-  z = gi / ny;
 }
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
@@ -225,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   };
   fetch(0);
   for (int t0 = 0; t0 < T; t0 += KT) {
-    __syncthreads();
+    if constexpr (!(MTVAF_ATTN_ABL & 8)) __syncthreads();
     kv_store<LDK>(Ks, kreg);
     kv_store<LDT>(Vs, vreg);
     if (threadIdx.x < KT) Ms[threadIdx.x] = (t0 + (int)threadIdx.x < T) ? mreg * LOG2E : NEG_BIG;
@@ -244,7 +134,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int db = 0; db < 4; ++db) {
           const f32x4 kf = *reinterpret_cast<const f32x4*>(kfrag + 16 * j * LDK + 16 * db);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc = MFMA16(kf[t], qreg[db][t], acc);
+          for (int t = 0; t < 4; ++t) {
+            if constexpr (!(MTVAF_ATTN_ABL & 1)) acc = MFMA16(kf[t], qreg[db][t], acc);
+            else acc[t] += kf[t] * qreg[db][t];
+          }
         }
         const f32x4 mv = *reinterpret_cast<const f32x4*>(Ms + 16 * j + 4 * g);
         s[j] = acc * sc2 + mv;
@@ -261,11 +154,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[j][r] - m_new);
+        float p = s[j][r] - m_new;
+        if constexpr (!(MTVAF_ATTN_ABL & 4)) p = __builtin_amdgcn_exp2f(p);
         psum += p;
         float pd = p;
-        if (a.p_drop > 0.f)
-          pd = attn_dropout_keep2(rowh, cterm0 + (uint32_t)(16 * j + r) * ATTN_DROP_C2, a.drop_thr) ? p * inv_keep : 0.f;
+        if constexpr (!(MTVAF_ATTN_ABL & 4)) {
+          if (a.p_drop > 0.f)
+            pd = attn_dropout_keep2(rowh, cterm0 + (uint32_t)(16 * j + r) * ATTN_DROP_C2, a.drop_thr) ? p * inv_keep : 0.f;
+        }
         s[j][r] = pd;
       }
     psum += __shfl_xor(psum, 16, 64);
@@ -281,7 +177,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         for (int t = 0; t < 4; ++t) {
           const float* vrow = vcol + (16 * j + t) * LDT;
 #pragma unroll
-          for (int dt = 0; dt < 4; ++dt) oacc[dt] = MFMA16(vrow[16 * dt], s[j][t], oacc[dt]);
+          for (int dt = 0; dt < 4; ++dt) {
+            if constexpr (!(MTVAF_ATTN_ABL & 2)) oacc[dt] = MFMA16(vrow[16 * dt], s[j][t], oacc[dt]);
+            else oacc[dt][t] += vrow[16 * dt] * s[j][t];
+          }
         }
       }
     }
@@ -665,6 +564,16 @@ using namespace mtvaf;
 
 extern "C" {
 
+int mtvaf_f32_split(int on);  // (gemm.hip)
+
+// Round 6: under the split arithmetic (the library default: mtvaf_f32_split) the attention products are split bf16 products too
+// (csrc/attention_f32s.hip: same interface, geometry and outputs); the fp32 MFMA pipe keeps the kernels of this file.
+// MTVAF_ATTN_SPLIT=0: the kernels of this file in either arithmetic.
+static bool attn_split_on() {
+  static const int env = [] { const char* e = getenv("MTVAF_ATTN_SPLIT"); return e ? atoi(e) : 1; }();
+  return env != 0 && mtvaf_f32_split(-1) != 0;
+}
+
 static void fill_common(AttnArgs& a, int B, int S, int P, int NH, float p_drop, uint64_t seed, uint64_t offset) {
   a.B = B; a.S = S; a.P = P; a.NH = NH; a.H = NH * D;
   a.scale = 0.125f; a.p_drop = p_drop;
@@ -688,7 +597,9 @@ static int attn_fwd_launch(const float* qkv, const float* pk, const float* pv, c
   int rc = check(a);
   if (rc) return rc;
   if (pad_rows < 0 || (pad_rows && !cu)) return MTVAF_ERR_ARG;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((S + 63) / 64, NH, B + (pad_rows > 0 ? 1 : 0)), dim3(256), 0, st, a);
+  const dim3 grid((S + 63) / 64, NH, B + (pad_rows > 0 ? 1 : 0));
+  if (attn_split_on()) return launch_attn_f32s_fwd(a, grid, st);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, st, a);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -711,7 +622,9 @@ static int attn_bwd_launch(const float* dctx, const float* qkv, const float* pk,
   if (P > 0 && (!dpk || !dpv)) return MTVAF_ERR_ARG;
   if (pad_rows < 0 || (pad_rows && !cu)) return MTVAF_ERR_ARG;
   const int nq = (S + 63) / 64;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nq + (P + S + 63) / 64, NH, B + (pad_rows > 0 ? 1 : 0)), dim3(256), 0, st, a, nq);
+  const dim3 grid(nq + (P + S + 63) / 64, NH, B + (pad_rows > 0 ? 1 : 0));
+  if (attn_split_on()) return launch_attn_f32s_bwd(a, nq, grid, st);
+  hipLaunchKernelGGL(attn_bwd_kernel, grid, dim3(256), 0, st, a, nq);
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
