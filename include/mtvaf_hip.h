@@ -367,6 +367,12 @@ int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row,
                     float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
                     mtvaf_stream_t stream);
 int mtvaf_f32p_trace(void* buf);
+/* The tile of mtvaf_gemm_f32p* (round 6): which products with N % 256 == 0 run on the 128 x 256 tile (csrc/gemm_f32pw.hip) instead of
+ * the 128 x 128 tile -- a mask: 1 = forward products (layout_b 0), 2 = dX products (layout_b 1), 4 = the grouped weight gradients
+ * (every N_i % 256 == 0), 8 = also products with N < 1024 or fewer than 128 wide tiles (tests); mask >= 0 sets, -1 queries; returns
+ * the mask in force (default: MTVAF_P16_WIDE, 7 if unset).  Process-global; placement only -- the two kernels issue the same MFMA products in the same order for every
+ * output element and agree bit for bit. */
+int mtvaf_f32p_wide(int mask);
 /* research entry: up to four weight-gradient products C_i [M_i][N_i] = A_i^T . B_i from plane images (A_i [K][M_i], B_i [K][N_i], the
  * token rows K shared) in ONE unsplit launch over the 128 x 128 tiles of all of them -- what the grouped launch of
  * mtvaf_gemm_f32_dw_group becomes with pre-split operands (no bias sums, no k-tile list).  strides: eight byte strides per product

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 # The flags are part of every object's stamp, so a variant can never be mistaken for the product build.
 LIBDIR = os.environ.get("MTVAF_LIBDIR") or os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmtvaf_hip.so")
-SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16x.hip", "gemm_bf16p.hip", "gemm_f32x3.hip", "gemm_f32p.hip", "attention.hip", "attention_f32s.hip", "attention_bf16.hip", "rowops.hip", "crf.hip", "prompt.hip", "span.hip", "optim.hip", "executor.hip", "runtime.hip"]
+SOURCES = ["gemm.hip", "gemm_bf16.hip", "gemm_bf16x.hip", "gemm_bf16p.hip", "gemm_f32x3.hip", "gemm_f32p.hip", "gemm_f32pw.hip", "attention.hip", "attention_f32s.hip", "attention_bf16.hip", "rowops.hip", "crf.hip", "prompt.hip", "span.hip", "optim.hip", "executor.hip", "runtime.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"] + os.environ.get("MTVAF_EXTRA_FLAGS", "").split()
 # The attention kernels read their MFMA results with VALU code every 16 products (softmax, dS): keeping the
 # accumulators in architectural VGPRs saves ~200 v_accvgpr moves per key tile (gfx950 has one unified file).

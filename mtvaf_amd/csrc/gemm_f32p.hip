@@ -24,82 +24,9 @@
 // address.  Plane images in memory are addressed by three byte strides (plane, row, k-tile): the natural form ([3][rows][ld], the
 // fp32 tensor's own layout) and the tile-blocked form ([k-tile][plane][rows][32]: every 1-KiB request reads 1 KiB of contiguous
 // memory) are both served.
-#include "gemm_bf16x.h"
+#include "gemm_f32p.h"
 
 namespace mtvaf {
-
-typedef float f32x2p __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x4p __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
-typedef unsigned fragp_t __attribute__((ext_vector_type(4)));
-
-struct GemmArgsP {
-  const unsigned char* Ap;  // plane 0 of A (bf16), byte addressed
-  const unsigned char* Bp;
-  long a_plane, a_row, a_kt;  // byte strides: plane -> plane, row -> row, k-tile (32 k) -> k-tile
-  long a_col;                 // k-major A only: byte stride from one 128-column block of A to the next (natural image: 256)
-  long b_plane, b_row, b_kt;
-  long b_col;  // k-major B only: byte stride from one 128-column block of B to the next (natural image: 256)
-  float* C;
-  const float* bias;
-  float* aux;
-  int M, N, K;
-  int ldc, ldaux;
-  int k_chunk;
-  long slab_stride;
-  int epi, accumulate, tiles_n;
-  // the result ALSO (C != NULL) or ONLY (C == NULL) as a tile-blocked plane image [N / 32][3][M][32] -- the operand form of the
-  // product that reads it next (FFN-1 forward -> FFN-2 forward, FFN-2 dX -> FFN-1 dX and both weight gradients) -- written by the
-  // epilogue of an UNSPLIT launch; colpart [M / 128][N]: per-tile column sums of the result (the bias gradient behind a dX product)
-  unsigned char* Cpl;
-  float* colpart;
-  int ablate;        // research switches: 1 = no MFMAs, 2 = no DMA requests, 4 = no fragment reads
-  // tile walk (placement only: results never depend on it): 0 = row-major; G > 0 = bands of G tile rows walked column by column, so
-  // that the tiles an XCD runs at one time (its 32 CUs: a contiguous run of the walk) share G A panels and 32 / G B panels instead
-  // of one or two A panels and a whole row of B panels
-  int walk_g;
-  long long* trace;  // [8 waves][64 k-tiles][2] shader-clock stamps of block 0 (arrive at / leave the tile barrier) + 17, or NULL
-  // GROUP (weight gradients): blockIdx.x walks the 128 x 128 tiles of up to four products that share the reduction axis back to
-  // back; product q owns tiles grp_tile_begin[q] .. grp_tile_begin[q + 1] - 1 (as GemmArgs::grp of the wave-specialised kernel)
-  int ngrp;
-  int grp_tile_begin[5];
-  struct Prob {
-    const unsigned char* Ap;
-    const unsigned char* Bp;
-    long a_plane, a_row, a_kt, a_col, b_plane, b_row, b_kt, b_col;
-    float* C;
-    int ldc, tiles_n;
-  } grp[4];
-  // GROUP: blocks behind the last tile are COLUMN-SUM items -- 64 columns of an fp32 matrix [cs_rows][cs_cols] (leading dimension
-  // cs_ld) each, summed over all rows into cs_dst (the QKV bias gradient: the column sums of dQ|dK|dV).  They ride in the idle CUs of
-  // the launch's last round of tiles (432 tiles on 256 CUs leave 80 of them free) instead of two launches of their own.
-  // (up to eight jobs: job j owns blocks cs_blk0[j] .. cs_blk0[j + 1] - 1 behind the tiles -- besides the QKV bias gradient the two
-  // LayerNorm-backward finishes of the layer (dgamma, dbeta, dense-bias gradient: three column blocks of 512 partial rows each) and
-  // the FFN-1 bias gradient from the GELU' epilogue's per-tile sums)
-  struct ColJob { const float* src; float* dst; int rows, cols, ld; } cs[8];
-  int cs_n, cs_blk0[9], cs_tile0;
-};
-
-namespace f32p {
-
-// the RNE three-way split of gemm_f32x3.hip (same planes bit for bit)
-__device__ __forceinline__ unsigned cvt_pk(const f32x2p v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2p)); }
-__device__ __forceinline__ f32x2p widen(const unsigned pk) {
-  return f32x2p{__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
-}
-__device__ __forceinline__ void split3_pair(const f32x2p x, unsigned& h, unsigned& m, unsigned& l) {
-  h = cvt_pk(x);
-  const f32x2p r = x - widen(h);
-  m = cvt_pk(r);
-  l = cvt_pk(r - widen(m));
-}
-
-__device__ __forceinline__ int swz(int row) {  // G[(row >> 2) & 3], G = {0, 2, 3, 1}
-  const int q = (row >> 2) & 3;
-  return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1);
-}
-
-}  // namespace f32p
 
 // fp32 [rows][cols] (leading dimension ld) -> plane image at dst with the byte strides (plane, row, k-tile); a thread takes 8
 // consecutive columns (one 16-byte chunk of each plane)
@@ -595,6 +522,21 @@ int mtvaf_f32_split_planes(const float* src, void* dst, int rows, int cols, int 
 }
 
 static long long* g_f32p_trace = nullptr;
+// Which products take the 128 x 256 tile (gemm_f32pw.hip): a mask -- 1: forward products (both operands k-contiguous), 2: dX products
+// (k-major B), 4: weight gradients (k-major A and B; the grouped launch), 8: ALSO products with N < 1024 or fewer than 128 wide tiles
+// (tests; research).
+static int g_p16_wide = -1;  // -1: MTVAF_P16_WIDE
+static int p16_wide_mask() {
+  static const int v = [] { const char* e = getenv("MTVAF_P16_WIDE"); return e ? atoi(e) & 15 : 7; }();
+  return g_p16_wide < 0 ? v : g_p16_wide;
+}
+// mask >= 0: set; -1: only query.  Returns the mask in force.  Process-global, like mtvaf_f32_split; placement only -- the two
+// kernels agree bit for bit.
+int mtvaf_f32p_wide(int mask) {
+  if (mask >= 0) g_p16_wide = mask & 15;
+  return p16_wide_mask();
+}
+
 int mtvaf_f32p_trace(void* buf) {
   g_f32p_trace = static_cast<long long*>(buf);
   return MTVAF_OK;
@@ -631,7 +573,12 @@ static int gemm_f32p_run(int layout_a, const void* Aplanes, long a_plane, long a
   a.k_chunk = kc;
   if (splits > 1) { a.C = (float*)workspace; a.ldc = N; a.slab_stride = (long)M * N; }
   else { a.C = C; a.ldc = ldc; a.slab_stride = 0; }
-  a.tiles_n = N / 128;
+  // the 128 x 256 tile (gemm_f32pw.hip; MTVAF_P16_WIDE: 0 = never, 1 = wherever N % 256 == 0): same bits, a quarter less LDS traffic
+  // (N = 768 at 2432 rows would be 57 tiles: measured slower with two slabs and equal with four, tools/p16_wide_probe.py; a launch of fewer
+  // than 128 wide tiles leaves more than half of the CUs idle)
+  const bool wide = (p16_wide_mask() & (layout_a ? 4 : layout_b ? 2 : 1)) && N % 256 == 0 &&
+                    ((N >= 1024 && (long)(M / 128) * (N / 256) >= 128) || (p16_wide_mask() & 8));
+  a.tiles_n = wide ? N / 256 : N / 128;
   a.Cpl = static_cast<unsigned char*>(c_planes);
   a.colpart = colpart;
   a.ablate = ablate;
@@ -641,10 +588,10 @@ static int gemm_f32p_run(int layout_a, const void* Aplanes, long a_plane, long a
   a.walk_g = walk_env;
   a.trace = g_f32p_trace;
   dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
-  // (launch profiler of gemm.hip: key 400 + 4 [k-major A] + 8 [k-major B]; hip.kernel_symbol names the instantiation)
-  const int key[8] = {400 + 4 * layout_a + 8 * layout_b, layout_a, layout_b, 2, M, N, K, splits};
+  // (launch profiler of gemm.hip: key 400 + 4 [k-major A] + 8 [k-major B] + 32 [128 x 256 tile]; hip.kernel_symbol names the instantiation)
+  const int key[8] = {400 + 4 * layout_a + 8 * layout_b + (wide ? 32 : 0), layout_a, layout_b, 2, M, N, K, splits};
   const int rec = prof_begin(key, stream);
-  const int rc = launch_gemm_f32p16(a, layout_a, layout_b, grid, stream);
+  const int rc = wide ? launch_gemm_f32p16w(a, layout_a, layout_b, grid, stream) : launch_gemm_f32p16(a, layout_a, layout_b, grid, stream);
   prof_end(rec, stream);
   if (rc != MTVAF_OK) return rc;
   if (keep_slabs) {  // (the caller's next kernel adds the slabs itself, in the reduction's order)
@@ -696,6 +643,9 @@ static int f32p_dw_group_run(int n, const void* const* Aplanes, const void* cons
   GemmArgsP a = {};
   a.K = K; a.k_chunk = K; a.slab_stride = 0; a.epi = EPI_NONE; a.ngrp = n;
   long tiles = 0;
+  bool wide = (p16_wide_mask() & 4) != 0;
+  for (int i = 0; i < n && wide; ++i) wide = N[i] > 0 && N[i] % 256 == 0;
+  const int bn = wide ? 256 : 128;
   for (int i = 0; i < n; ++i) {
     if (!Aplanes[i] || !Bplanes[i] || !C[i] || M[i] <= 0 || N[i] <= 0 || M[i] % 128 || N[i] % 128 || ldc[i] % 4) return MTVAF_ERR_SHAPE;
     if ((((uintptr_t)Aplanes[i] | (uintptr_t)Bplanes[i] | (uintptr_t)C[i]) & 15)) return MTVAF_ERR_ALIGN;
@@ -705,12 +655,12 @@ static int f32p_dw_group_run(int n, const void* const* Aplanes, const void* cons
     q.Ap = static_cast<const unsigned char*>(Aplanes[i]); q.Bp = static_cast<const unsigned char*>(Bplanes[i]);
     q.a_plane = strides[8 * i]; q.a_row = strides[8 * i + 1]; q.a_kt = strides[8 * i + 2]; q.a_col = strides[8 * i + 3];
     q.b_plane = strides[8 * i + 4]; q.b_row = strides[8 * i + 5]; q.b_kt = strides[8 * i + 6]; q.b_col = strides[8 * i + 7];
-    q.C = C[i]; q.ldc = ldc[i]; q.tiles_n = N[i] / 128;
+    q.C = C[i]; q.ldc = ldc[i]; q.tiles_n = N[i] / bn;
     a.grp_tile_begin[i] = (int)tiles;
-    tiles += (long)(M[i] / 128) * (N[i] / 128);
+    tiles += (long)(M[i] / 128) * (N[i] / bn);
   }
   for (int i = n; i < 5; ++i) a.grp_tile_begin[i] = (int)tiles;  // (absent products own no tiles)
-  a.M = M[0]; a.N = N[0]; a.tiles_n = N[0] / 128;
+  a.M = M[0]; a.N = N[0]; a.tiles_n = N[0] / bn;
   a.cs_tile0 = (int)tiles;
   long blocks = tiles;
   if (njobs < 0 || njobs > 8 || (njobs && (!cs_src || !cs_rows || !cs_cols || !cs_ld || !cs_dst))) return MTVAF_ERR_ARG;
@@ -724,9 +674,9 @@ static int f32p_dw_group_run(int n, const void* const* Aplanes, const void* cons
   }
   for (int j = njobs; j < 9; ++j) a.cs_blk0[j] = cb;
   blocks += cb;
-  const int key[8] = {400 + 4 + 8 + 16, 1, 1, 2, (int)(tiles * 128 * 128 / 768), 768, K, 1};  // (+16: the GROUP instantiation; M x 768 = all outputs)
+  const int key[8] = {400 + 4 + 8 + 16 + (wide ? 32 : 0), 1, 1, 2, (int)(tiles * 128 * bn / 768), 768, K, 1};  // (+16: the GROUP instantiation; M x 768 = all outputs)
   const int rec = prof_begin(key, stream);
-  const int rc = launch_gemm_f32p16_group(a, dim3((unsigned)blocks, 1, 1), stream);
+  const int rc = wide ? launch_gemm_f32p16w_group(a, dim3((unsigned)blocks, 1, 1), stream) : launch_gemm_f32p16_group(a, dim3((unsigned)blocks, 1, 1), stream);
   prof_end(rec, stream);
   return rc;
 }

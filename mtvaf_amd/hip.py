@@ -45,6 +45,7 @@ _SIGS = {
     "mtvaf_f32_split_planes": (c_int, [P, P, I, I, I, L, L, L, P]),
     "mtvaf_gemm_f32p": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, P, I, I, I, P, SZ, I, P]),
     "mtvaf_f32p_trace": (c_int, [P]),
+    "mtvaf_f32p_wide": (c_int, [I]),
     "mtvaf_gemm_f32p_dw_group": (c_int, [I, P, P, P, P, P, P, P, I, P]),
     "mtvaf_gemm_f32p_dw_group_colsum": (c_int, [I, P, P, P, P, P, P, P, I, I, P, P, P, P, P, P]),
     "mtvaf_gemm_f32p_slabs": (c_int, [I, P, L, L, L, L, I, P, L, L, L, L, P, I, I, I, I, P, I, I, P, SZ, P, P]),
@@ -265,6 +266,8 @@ def kernel_symbol(cfg, la, lb, fast):
         return f"gemm_f32_dma_group_kernel<128, 96, 4, 1, 2, {b(klist)}>"
     if 400 <= cfg < 500:  # pre-split operands (csrc/gemm_f32p.hip): gemm_f32p16_kernel<ABL, TRACE, B_KM, A_KM, GROUP>
         c = cfg - 400
+        if c & 32:  # the 128 x 256 tile (csrc/gemm_f32pw.hip): gemm_f32p16w_kernel<B_KM, A_KM, GROUP, ABL, TRACE>
+            return f"gemm_f32p16w_kernel<{b(c & 8)}, {b(c & 4)}, {b(c & 16)}, 0, false>"
         return f"gemm_f32p16_kernel<0, false, {b(c & 8)}, {b(c & 4)}, {b(c & 16)}>"
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>
         c = cfg - 300
@@ -312,6 +315,15 @@ def f32_split(on=None) -> bool:
     mtvaf_gemm_f32 / _ktiles call of the process (Python orchestration and native executor alike); None queries.
     Default: ON (MTVAF_F32_SPLIT=0 in the environment keeps the fp32 MFMA pipe)."""
     return bool(lib().mtvaf_f32_split(-1 if on is None else int(bool(on))))
+
+
+def f32p_wide(mask=None) -> int:
+    """The pre-split GEMM's tile (csrc/gemm_f32pw.hip, round 6): which products with N % 256 == 0 run on the 128 x 256 tile -- a mask
+    (1 forward products, 2 dX products, 4 weight gradients, 8 also products with N < 1024 or fewer than 128 wide tiles; True = 15,
+    False = 0), None queries.  Placement only: the kernels agree bit for bit.  Default: MTVAF_P16_WIDE (7 if unset)."""
+    if mask is True:
+        mask = 15
+    return int(lib().mtvaf_f32p_wide(-1 if mask is None else int(mask)))
 
 
 class Planes:

@@ -1592,6 +1592,96 @@ def test_gemm_f32_presplit_planes_grouped_weight_gradients(hip):
         close(cs2, part[:, 200:400].double().sum(0), rtol=1e-5, atol=1e-5, name="column sums of a column block")
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 256, 32), (256, 512, 64), (640, 768, 96), (384, 1024, 768), (896, 256, 2304), (2432, 2304, 160)])
+def test_gemm_f32_presplit_wide_tile_same_bits(hip, M, N, K):
+    """The 128 x 256 tile of the pre-split kernel (csrc/gemm_f32pw.hip, round 6; mtvaf_f32p_wide) issues the same MFMA products in the
+    same order for every output element as the 128 x 128 tile: the SAME BITS in all three operand layouts (tile-blocked and natural
+    images), with 1, 2, 3 k-tiles (prologue / drain of the two-stage ring) and many, a ragged last band of the tile walk (5, 7, 19
+    tile rows), bias + GELU (saved pre-activation), accumulate, deterministic split-K, the plane-image epilogues (GELU forward; GELU'
+    backward with per-tile column sums) and the grouped weight-gradient launch with column-sum jobs riding along."""
+    was = hip.f32p_wide()
+
+    def both(fn, mk, mask=15):
+        res = []
+        for m in (0, mask):
+            hip.f32p_wide(m)
+            o = mk()
+            fn(o)
+            res.append(o)
+        return res
+    eq = lambda x, y: torch.equal(x.view(torch.int32), y.view(torch.int32))  # (NaN-proof: a tile that was not written fails)
+    nan = lambda *s_: torch.full(s_, float("nan"), device=DEV)
+    try:
+        bias = rnd(N, seed=5).to(DEV)
+        for blocked in (True, False):
+            a, b, ref, mag = _x3_operands(M, N, K, 0, 0, seed=M + N + K, spread=6)
+            pa, pb = hip.Planes(a, blocked), hip.Planes(b, blocked)
+            o0, o1 = both(lambda o: hip.gemm_planes(pa, pb, o), lambda: nan(M, N))
+            assert eq(o0, o1), ("forward", blocked)
+            assert float(((o1.double().cpu() - ref).abs() / mag).max()) <= 2.0 ** -24 * (4 + K ** 0.5)
+            (o0, x0), (o1, x1) = both(lambda o: hip.gemm_planes(pa, pb, o[0], bias=bias, epi=hip.EPI_GELU, aux=o[1]), lambda: (nan(M, N), nan(M, N)))
+            assert eq(o0, o1) and eq(x0, x1), ("GELU", blocked)
+            acc0 = rnd(M, N, seed=6).to(DEV)
+            o0, o1 = both(lambda o: hip.gemm_planes(pa, pb, o, accumulate=True), lambda: acc0.clone())
+            assert eq(o0, o1), ("accumulate", blocked)
+            if K >= 64:
+                o0, o1 = both(lambda o: hip.gemm_planes(pa, pb, o, bias=bias, splits=2), lambda: nan(M, N))
+                assert eq(o0, o1), ("split-K", blocked)
+            a2, b2, ref2, mag2 = _x3_operands(M, N, K, 0, 1, seed=M + N + K + 1, spread=6)
+            pa2, pb2 = hip.Planes(a2, True), hip.Planes(b2, blocked)
+            o0, o1 = both(lambda o: hip.gemm_planes(pa2, pb2, o, layout_b=hip.KM), lambda: nan(M, N))
+            assert eq(o0, o1), ("dX", blocked)
+            assert float(((o1.double().cpu() - ref2).abs() / mag2).max()) <= 2.0 ** -24 * (4 + K ** 0.5)
+            a3, b3, ref3, mag3 = _x3_operands(M, N, K, 1, 1, seed=M + N + K + 2, spread=6)
+            pa3, pb3 = hip.Planes(a3, blocked), hip.Planes(b3, blocked)
+            o0, o1 = both(lambda o: hip.gemm_planes(pa3, pb3, o, layout_a=hip.KM, layout_b=hip.KM), lambda: nan(M, N))
+            assert eq(o0, o1), ("dW", blocked)
+            assert float(((o1.double().cpu() - ref3).abs() / mag3).max()) <= 2.0 ** -24 * (4 + K ** 0.5)
+        # the plane-image epilogues
+        pa, pb = hip.Planes(a, True), hip.Planes(b, True)
+
+        def mk_ep():
+            im = hip.Planes(torch.empty(M, N, device=DEV), True, fill=False)
+            im.img.fill_(float("nan"))
+            return im, nan(M, N), nan(M, N), nan(M // 128, N)
+        r0, r1 = both(lambda o: hip.gemm_planes_ep(pa, pb, o[0], out=o[1], bias=bias, epi=hip.EPI_GELU, aux=o[2]), mk_ep)
+        assert torch.equal(r0[0].img.view(torch.int16), r1[0].img.view(torch.int16)) and eq(r0[1], r1[1]) and eq(r0[2], r1[2])
+        pre = r0[2]
+        r0, r1 = both(lambda o: hip.gemm_planes_ep(pa2, hip.Planes(b2, True), o[0], epi=hip.EPI_DGELU, aux=pre, colpart=o[3], layout_b=hip.KM), mk_ep)
+        assert torch.equal(r0[0].img.view(torch.int16), r1[0].img.view(torch.int16)) and eq(r0[3], r1[3]), "GELU' + column partials"
+        # the default mask leaves small launches (< 128 wide tiles) and N < 1024 on the 128 x 128 tile: same bits trivially, no fault
+        o0, o1 = both(lambda o: hip.gemm_planes(pa, pb, o), lambda: nan(M, N), mask=7)
+        assert eq(o0, o1)
+    finally:
+        hip.f32p_wide(was)
+
+
+def test_gemm_f32_presplit_wide_tile_grouped_weight_gradients_same_bits(hip):
+    """... and the grouped weight-gradient launch (four products, 128 x 256 tiles back to back, column-sum jobs as extra blocks)."""
+    was = hip.f32p_wide()
+    K, Hh, Ii = 416, 256, 512
+    dys = [rnd(K, w, seed=30 + i).to(DEV) for i, w in enumerate((Hh, Ii, Hh, 3 * Hh))]
+    xs = [rnd(K, w, seed=40 + i).to(DEV) for i, w in enumerate((Ii, Hh, Hh, Hh))]
+    part = rnd(37, 3 * 200, seed=50).to(DEV)
+    try:
+        for blocked in (False, True):
+            pas, pbs = [hip.Planes(t, blocked) for t in dys], [hip.Planes(t, blocked) for t in xs]
+            res = []
+            for m in (0, 4):
+                hip.f32p_wide(m)
+                outs = [torch.full((pa.cols, pb.cols), float("nan"), device=DEV) for pa, pb in zip(pas, pbs)]
+                cs, cs2 = torch.full((3 * Hh,), float("nan"), device=DEV), torch.full((200,), float("nan"), device=DEV)
+                hip.gemm_planes_dw_group(list(zip(pas, pbs, outs)), colsum=[(dys[3], cs), (part[:, 200:400], cs2)])
+                outs2 = [torch.full_like(o, float("nan")) for o in outs[:2]]
+                hip.gemm_planes_dw_group(list(zip(pas[:2], pbs[:2], outs2)))
+                res.append(outs + [cs, cs2] + outs2)
+            for x, y in zip(*res):
+                assert torch.equal(x.view(torch.int32), y.view(torch.int32)), blocked
+            close(res[1][0], dys[0].double().cpu().t() @ xs[0].double().cpu(), rtol=3e-6, name="one product of the group")
+    finally:
+        hip.f32p_wide(was)
+
+
 def test_layernorm_adds_the_split_k_slabs_itself_bit_for_bit(hip):
     """Round 5: mtvaf_gemm_f32_slabs leaves a split-K plan's slabs unreduced and the LayerNorm behind the product adds them in the
     reduction launch's order (slab 0 + slab 1 + ... + bias; backward: (slab 0 + ...) + dout) -- forward Wo / FFN-2, backward the
