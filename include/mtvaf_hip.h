@@ -369,7 +369,8 @@ int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row,
 int mtvaf_f32p_trace(void* buf);
 /* The tile of mtvaf_gemm_f32p* (round 6): which products with N % 256 == 0 run on the 128 x 256 tile (csrc/gemm_f32pw.hip) instead of
  * the 128 x 128 tile -- a mask: 1 = forward products (layout_b 0), 2 = dX products (layout_b 1), 4 = the grouped weight gradients
- * (every N_i % 256 == 0), 8 = also products with N < 1024 or fewer than 128 wide tiles (tests); mask >= 0 sets, -1 queries; returns
+ * (every N_i % 256 == 0), 8 = also products with N < 1024 or fewer than 128 wide tiles (tests), 16 = never the 128 x 192 tile (which an unsplit forward
+ * product takes when its 256-column tiles would fill less than 80 % of one round of CUs: QKV forward at 2432 rows); mask >= 0 sets, -1 queries; returns
  * the mask in force (default: MTVAF_P16_WIDE, 7 if unset).  Process-global; placement only -- the two kernels issue the same MFMA products in the same order for every
  * output element and agree bit for bit. */
 int mtvaf_f32p_wide(int mask);

@@ -78,7 +78,7 @@ __device__ __forceinline__ int swz(int row) {  // G[(row >> 2) & 3], G = {0, 2, 
 
 }  // namespace f32p
 
-int launch_gemm_f32p16w(const GemmArgsP& a, int a_km, int b_km, dim3 grid, hipStream_t st);  // gemm_f32pw.hip
+int launch_gemm_f32p16w(const GemmArgsP& a, int a_km, int b_km, dim3 grid, hipStream_t st, int bn);  // gemm_f32pw.hip: bn = 256 / 192
 int launch_gemm_f32p16w_group(const GemmArgsP& a, dim3 grid, hipStream_t st);
 
 }  // namespace mtvaf

@@ -524,16 +524,16 @@ int mtvaf_f32_split_planes(const float* src, void* dst, int rows, int cols, int 
 static long long* g_f32p_trace = nullptr;
 // Which products take the 128 x 256 tile (gemm_f32pw.hip): a mask -- 1: forward products (both operands k-contiguous), 2: dX products
 // (k-major B), 4: weight gradients (k-major A and B; the grouped launch), 8: ALSO products with N < 1024 or fewer than 128 wide tiles
-// (tests; research).
+// (tests; research), 16: never the 128 x 192 tile (forward products that fill less than 80 % of one round of CUs with 256-column tiles).
 static int g_p16_wide = -1;  // -1: MTVAF_P16_WIDE
 static int p16_wide_mask() {
-  static const int v = [] { const char* e = getenv("MTVAF_P16_WIDE"); return e ? atoi(e) & 15 : 7; }();
+  static const int v = [] { const char* e = getenv("MTVAF_P16_WIDE"); return e ? atoi(e) & 31 : 7; }();
   return g_p16_wide < 0 ? v : g_p16_wide;
 }
 // mask >= 0: set; -1: only query.  Returns the mask in force.  Process-global, like mtvaf_f32_split; placement only -- the two
 // kernels agree bit for bit.
 int mtvaf_f32p_wide(int mask) {
-  if (mask >= 0) g_p16_wide = mask & 15;
+  if (mask >= 0) g_p16_wide = mask & 31;
   return p16_wide_mask();
 }
 
@@ -576,9 +576,18 @@ static int gemm_f32p_run(int layout_a, const void* Aplanes, long a_plane, long a
   // the 128 x 256 tile (gemm_f32pw.hip; MTVAF_P16_WIDE: 0 = never, 1 = wherever N % 256 == 0): same bits, a quarter less LDS traffic
   // (N = 768 at 2432 rows would be 57 tiles: measured slower with two slabs and equal with four, tools/p16_wide_probe.py; a launch of fewer
   // than 128 wide tiles leaves more than half of the CUs idle)
-  const bool wide = (p16_wide_mask() & (layout_a ? 4 : layout_b ? 2 : 1)) && N % 256 == 0 &&
-                    ((N >= 1024 && (long)(M / 128) * (N / 256) >= 128) || (p16_wide_mask() & 8));
-  a.tiles_n = wide ? N / 256 : N / 128;
+  const int wmask = p16_wide_mask();
+  const long tm = M / 128;
+  bool wide = (wmask & (layout_a ? 4 : layout_b ? 2 : 1)) && N % 256 == 0 && ((N >= 1024 && tm * (N / 256) >= 128) || (wmask & 8));
+  int bn = wide ? 256 : 128;
+  // a forward product whose 256-column tiles fill less than 80 % of one round of CUs (QKV forward at 2432 rows: 171 tiles) takes the
+  // 192-column tile if that makes one fuller round (228)
+  if ((wmask & 1) && !(wmask & 16) && !layout_a && !layout_b && !c_planes && !ablate && !g_f32p_trace && N % 192 == 0 && splits == 1 && tm * (N / 192) <= 256 &&
+      tm * (N / 192) >= 128 && (!wide || tm * (N / 256) * 5 < 256 * 4)) {
+    wide = true;
+    bn = 192;
+  }
+  a.tiles_n = N / bn;
   a.Cpl = static_cast<unsigned char*>(c_planes);
   a.colpart = colpart;
   a.ablate = ablate;
@@ -588,10 +597,10 @@ static int gemm_f32p_run(int layout_a, const void* Aplanes, long a_plane, long a
   a.walk_g = walk_env;
   a.trace = g_f32p_trace;
   dim3 grid((unsigned)((M / 128) * a.tiles_n), 1, (unsigned)splits);
-  // (launch profiler of gemm.hip: key 400 + 4 [k-major A] + 8 [k-major B] + 32 [128 x 256 tile]; hip.kernel_symbol names the instantiation)
-  const int key[8] = {400 + 4 * layout_a + 8 * layout_b + (wide ? 32 : 0), layout_a, layout_b, 2, M, N, K, splits};
+  // (launch profiler of gemm.hip: key 400 + 4 [k-major A] + 8 [k-major B] + 32 [128 x 256 tile] + 64 [128 x 192]; hip.kernel_symbol names the instantiation)
+  const int key[8] = {400 + 4 * layout_a + 8 * layout_b + (wide ? 32 : 0) + (bn == 192 ? 64 : 0), layout_a, layout_b, 2, M, N, K, splits};
   const int rec = prof_begin(key, stream);
-  const int rc = wide ? launch_gemm_f32p16w(a, layout_a, layout_b, grid, stream) : launch_gemm_f32p16(a, layout_a, layout_b, grid, stream);
+  const int rc = wide ? launch_gemm_f32p16w(a, layout_a, layout_b, grid, stream, bn) : launch_gemm_f32p16(a, layout_a, layout_b, grid, stream);
   prof_end(rec, stream);
   if (rc != MTVAF_OK) return rc;
   if (keep_slabs) {  // (the caller's next kernel adds the slabs itself, in the reduction's order)

@@ -25,15 +25,20 @@ namespace mtvaf {
 
 // ABL / TRACE: the timing-only research switches and the shader-clock stamps of gemm_f32p16_kernel (1 = no MFMAs, 2 = no requests, 4 =
 // no fragment reads; stamps of block 0: [wave][k-tile][arrive at / leave the tile barrier] + 17)
-template <bool B_KM, bool A_KM, bool GROUP, int ABL = 0, bool TRACE = false>
+// NJ: 16-column blocks per wave = 8 (the 128 x 256 tile) or 6 (128 x 192, forward products only: QKV forward at 2432 rows is 228
+// tiles instead of 171 on 256 CUs).
+template <bool B_KM, bool A_KM, bool GROUP, int ABL = 0, bool TRACE = false, int NJ = 8>
 __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
   static_assert(!A_KM || B_KM, "k-major A comes with k-major B (weight gradients)");
   static_assert(!GROUP || A_KM, "grouped launches are weight gradients");
-  constexpr int BM = 128, BN = 256;
-  constexpr int PL_B = 128 * 64;      // one plane of a 128-wide panel
-  constexpr int PAN_B = 3 * PL_B;     // a panel: 24 KiB
-  constexpr int STAGE_B = 3 * PAN_B;  // A panel, B panel 0, B panel 1: 72 KiB
-  constexpr int IWA = 6, IWB = 12;    // requests per DMA wave and k-tile
+  static_assert(NJ == 8 || (NJ == 6 && !B_KM), "the 192-column tile serves k-contiguous operands");
+  constexpr int BM = 128, BN = 32 * NJ;
+  constexpr int PL_B = 128 * 64;              // one plane of the A panel (128 rows)
+  constexpr int PAN_A = 3 * PL_B;             // the A panel: 24 KiB
+  constexpr int PLB_B = NJ * 16 * 64;         // one plane of a B panel (16 NJ rows or columns)
+  constexpr int PAN_B = 3 * PLB_B;            // a B panel: 24 KiB (18 at NJ = 6)
+  constexpr int STAGE_B = PAN_A + 2 * PAN_B;  // A panel, B panel 0, B panel 1: 72 KiB (60)
+  constexpr int IWA = 6, IWB = 3 * NJ / 2;    // requests per DMA wave and k-tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
 
   const int tid = threadIdx.x;
@@ -107,11 +112,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
   long long* const tr = (TRACE && p.trace && blockIdx.x == 0 && blockIdx.z == 0) ? p.trace : nullptr;
   if (TRACE && tr && tid == 0) tr[8 * 64 * 2] = __builtin_amdgcn_s_memtime();
 
-  f32x4 acc[4][8];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (dma_wave) {
     // ---- request issue.  A: piece I = w4 * 6 + i of the A panel (plane I / 8, 16 rows or 4 k-rows (I % 8) * ..) as in the 128 x 128
@@ -132,19 +137,19 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
     }
 #pragma unroll
     for (int i = 0; i < IWB; ++i) {
-      const int I = (w4 & 1) * IWB + i, plane = I >> 3, half = w4 >> 1;
+      const int J = w4 * IWB + i, half = J / (3 * NJ), I = J % (3 * NJ), plane = I / NJ, sub = I % NJ;
       if constexpr (!B_KM) {
-        const int row = (I & 7) * 16 + (lane >> 2), sc = (lane & 3) ^ f32p::swz(row);
-        pb[i] = Bpl + plane * b_plane + (long)(n0 + half * 128 + row) * b_row + (long)(kbeg / 32) * b_kt + sc * 16;
+        const int row = sub * 16 + (lane >> 2), sc = (lane & 3) ^ f32p::swz(row);
+        pb[i] = Bpl + plane * b_plane + (long)(n0 + half * (16 * NJ) + row) * b_row + (long)(kbeg / 32) * b_kt + sc * 16;
       } else {
-        const int kr = (I & 7) * 4 + (lane >> 4), scb = (lane & 15) ^ km_swz(kr);
+        const int kr = sub * 4 + (lane >> 4), scb = (lane & 15) ^ km_swz(kr);
         pb[i] = Bpl + plane * b_plane + (long)kr * b_row + (long)(kbeg / 32) * b_kt + (long)(n0 / 128 + half) * b_col + (long)(scb >> 2) * (b_col >> 2) +
                 ((scb & 3) << 4);
       }
     }
     auto issue = [&](int stage) __attribute__((always_inline)) {
       unsigned char* sa = smem_w + stage * STAGE_B + w4 * IWA * 1024;
-      unsigned char* sb = smem_w + stage * STAGE_B + PAN_B + w4 * IWB * 1024;
+      unsigned char* sb = smem_w + stage * STAGE_B + PAN_A + w4 * IWB * 1024;
 #pragma unroll
       for (int i = 0; i < IWA; ++i) {
         glds16x(pa[i], sa + i * 1024);
@@ -177,7 +182,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
   } else {
     const int r15 = lane & 15, ch = lane >> 4;
     const int offA = (wm * 64 + r15) * 64 + ((ch ^ f32p::swz(r15)) << 4);                       // + i * 1024 (+ plane)
-    const int offB = PAN_B * (1 + wn) + r15 * 64 + ((ch ^ f32p::swz(r15)) << 4);                // + j * 1024 (+ plane)
+    const int offB = PAN_A + PAN_B * wn + r15 * 64 + ((ch ^ f32p::swz(r15)) << 4);              // + j * 1024 (+ plane)
     // k-major images (32 k-rows x 256 B per plane and panel): lane (g, q, pp) addresses row 8 g + q (+ 4), the 4 columns 4 pp .. of
     // the 16-column block c >> 1 ...; for B the block is j itself (the panel is the wave's own): the chunk (2 j + (pp >> 1)) ^ swizzle
     // differs from the chunk of j = 0 in the bits of j alone -- offset(j) = offset(0) ^ (j << 5)
@@ -186,8 +191,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
     if constexpr (B_KM) {
       const int g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
       const int r0 = 8 * g + q, r1 = r0 + 4;
-      offB0 = PAN_B * (1 + wn) + r0 * 256 + (((pp >> 1) ^ km_swz(r0)) << 4) + 8 * (pp & 1);
-      offB1 = PAN_B * (1 + wn) + r1 * 256 + (((pp >> 1) ^ km_swz(r1)) << 4) + 8 * (pp & 1);
+      offB0 = PAN_A + PAN_B * wn + r0 * 256 + (((pp >> 1) ^ km_swz(r0)) << 4) + 8 * (pp & 1);
+      offB1 = PAN_A + PAN_B * wn + r1 * 256 + (((pp >> 1) ^ km_swz(r1)) << 4) + 8 * (pp & 1);
       if constexpr (A_KM) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -203,8 +208,8 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
       if constexpr (!do_rd) return;
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        if constexpr (!B_KM) f[q] = *reinterpret_cast<const fragp_t*>(s + q * PL_B + offB + j * 1024);
-        else f[q] = __builtin_bit_cast(fragp_t, tr_read8(s + q * PL_B + (offB0 ^ (j << 5)), s + q * PL_B + (offB1 ^ (j << 5))));
+        if constexpr (!B_KM) f[q] = *reinterpret_cast<const fragp_t*>(s + q * PLB_B + offB + j * 1024);
+        else f[q] = __builtin_bit_cast(fragp_t, tr_read8(s + q * PLB_B + (offB0 ^ (j << 5)), s + q * PLB_B + (offB1 ^ (j << 5))));
       }
     };
     auto rd_a = [&](const unsigned char* s, const int i) __attribute__((always_inline)) {
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
       spread(24, RA + RB);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 1; j < 7; ++j) {
+      for (int j = 1; j < NJ - 1; ++j) {
         rd_b(s, j + 1, fbs[(j + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) mm(i, j, fbs[j & 1]);
@@ -274,20 +279,20 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
       asm volatile("" ::: "memory");
       if (TRACE && tr && t < 64 && lane == 0) tr[(wave * 64 + t) * 2 + 1] = __builtin_amdgcn_s_memtime();
       st ^= 1;
-      {  // column block 7, row block by row block; behind each the row block's fragments of the NEXT tile (unconditional: past the end a
+      {  // the last column block, row block by row block; behind each the row block's fragments of the NEXT tile (unconditional: past the end a
          // harmless read of the other stage -- see gemm_f32p16_kernel)
         const unsigned char* sn = smem_w + st * STAGE_B;
         rd_b(sn, 0, fbs[0]);
-        mm(0, 7, fbs[1]);
+        mm(0, NJ - 1, fbs[1]);
         spread(6, RB);
         rd_a(sn, 0);
-        mm(1, 7, fbs[1]);
+        mm(1, NJ - 1, fbs[1]);
         spread(6, RA);
         rd_a(sn, 1);
-        mm(2, 7, fbs[1]);
+        mm(2, NJ - 1, fbs[1]);
         spread(6, RA);
         rd_a(sn, 2);
-        mm(3, 7, fbs[1]);
+        mm(3, NJ - 1, fbs[1]);
         spread(6, RA);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -308,12 +313,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) smem[(wm * 64 + i * 16 + rq * 4 + r) * LDE + wn * 128 + j * 16 + c15] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r) smem[(wm * 64 + i * 16 + rq * 4 + r) * LDE + wn * (16 * NJ) + j * 16 + c15] = acc[i][j][r];
     }
     __syncthreads();
-    if (p.Cpl && !split) {
+    if (NJ == 8 && p.Cpl && !split) {  // (the 192-column tile is launched without a plane-image result)
       const int c8 = tid & 15, rr = tid >> 4;
       const long pl_b = (long)p.M * 64;
       f32x4 cs[2][2];
@@ -413,10 +418,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
   if (TRACE && tr && lane == 0) tr[8 * 64 * 2 + 9 + wave] = __builtin_amdgcn_s_memtime();
 }
 
-template <bool B_KM, bool A_KM, bool GROUP, int ABL = 0, bool TRACE = false>
+template <bool B_KM, bool A_KM, bool GROUP, int ABL = 0, bool TRACE = false, int NJ = 8>
 static int launch_p16w(const GemmArgsP& a, dim3 grid, hipStream_t st) {
-  constexpr size_t smem = (size_t)2 * 3 * 3 * 128 * 64;  // 147456
-  auto kern = gemm_f32p16w_kernel<B_KM, A_KM, GROUP, ABL, TRACE>;
+  constexpr size_t smem = (size_t)2 * 3 * (128 + 32 * NJ) * 64;  // 147456 (122880 at NJ = 6)
+  auto kern = gemm_f32p16w_kernel<B_KM, A_KM, GROUP, ABL, TRACE, NJ>;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -430,8 +435,10 @@ static int launch_p16w(const GemmArgsP& a, dim3 grid, hipStream_t st) {
 
 int launch_gemm_f32p16w_group(const GemmArgsP& a, dim3 grid, hipStream_t st) { return launch_p16w<true, true, true>(a, grid, st); }
 
-int launch_gemm_f32p16w(const GemmArgsP& a, int a_km, int b_km, dim3 grid, hipStream_t st) {
+int launch_gemm_f32p16w(const GemmArgsP& a, int a_km, int b_km, dim3 grid, hipStream_t st, int bn) {
   if (a_km && !b_km) return MTVAF_ERR_ARG;
+  if (bn == 192) return (a_km || b_km || a.trace || a.ablate || a.Cpl) ? MTVAF_ERR_ARG : launch_p16w<false, false, false, 0, false, 6>(a, grid, st);
+  if (bn != 256) return MTVAF_ERR_ARG;
   if (a_km) return a.trace ? launch_p16w<true, true, false, 0, true>(a, grid, st) : (a.ablate ? MTVAF_ERR_ARG : launch_p16w<true, true, false>(a, grid, st));
   if (b_km) return a.trace ? launch_p16w<true, false, false, 0, true>(a, grid, st) : (a.ablate ? MTVAF_ERR_ARG : launch_p16w<true, false, false>(a, grid, st));
   if (a.trace) return launch_p16w<false, false, false, 0, true>(a, grid, st);

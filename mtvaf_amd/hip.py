@@ -267,7 +267,7 @@ def kernel_symbol(cfg, la, lb, fast):
     if 400 <= cfg < 500:  # pre-split operands (csrc/gemm_f32p.hip): gemm_f32p16_kernel<ABL, TRACE, B_KM, A_KM, GROUP>
         c = cfg - 400
         if c & 32:  # the 128 x 256 tile (csrc/gemm_f32pw.hip): gemm_f32p16w_kernel<B_KM, A_KM, GROUP, ABL, TRACE>
-            return f"gemm_f32p16w_kernel<{b(c & 8)}, {b(c & 4)}, {b(c & 16)}, 0, false>"
+            return f"gemm_f32p16w_kernel<{b(c & 8)}, {b(c & 4)}, {b(c & 16)}, 0, false, {6 if c & 64 else 8}>"
         return f"gemm_f32p16_kernel<0, false, {b(c & 8)}, {b(c & 4)}, {b(c & 16)}>"
     if cfg >= 300:  # gemm_bf16x_kernel<BM, BN, WM, WN, A_KM, B_KM, NSTAGE, KLIST>
         c = cfg - 300
