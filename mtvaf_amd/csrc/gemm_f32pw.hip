@@ -256,7 +256,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
     rd_a(smem_w, 2);
     rd_b(smem_w, 0, fbs[0]);
     int st = 0;
-    for (int t = 0; t < nk; ++t) {
+    // (two k-tiles per trip: across the loop's back edge hipcc waits for EVERY outstanding fragment read -- lgkmcnt(0) in front of the
+    // first MFMA of a tile whose operands were read long before the row blocks issued last)
+    auto tile = [&](const int t) __attribute__((always_inline)) {
       const unsigned char* s = smem_w + st * STAGE_B;
       // column block 0 -- beside it the last row block of this tile's A and column block 1
       rd_a(s, 3);
@@ -296,7 +298,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
         spread(6, RA);
         __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      tile(t);
+      tile(t + 1);
     }
+    if (t < nk) tile(t);
   }
 
   if (TRACE && tr && lane == 0) tr[8 * 64 * 2 + 1 + wave] = __builtin_amdgcn_s_memtime();  // this wave's k-loop is over
