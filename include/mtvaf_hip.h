@@ -367,12 +367,14 @@ int mtvaf_gemm_f32p(int layout_a, const void* Aplanes, long a_plane, long a_row,
                     float* aux, int ldaux, int accumulate, int splits, void* workspace, size_t workspace_bytes, int ablate,
                     mtvaf_stream_t stream);
 int mtvaf_f32p_trace(void* buf);
-/* The tile of mtvaf_gemm_f32p* (round 6): which products with N % 256 == 0 run on the 128 x 256 tile (csrc/gemm_f32pw.hip) instead of
- * the 128 x 128 tile -- a mask: 1 = forward products (layout_b 0), 2 = dX products (layout_b 1), 4 = the grouped weight gradients
- * (every N_i % 256 == 0), 8 = also products with N < 1024 or fewer than 128 wide tiles (tests), 16 = never the 128 x 192 tile (which an unsplit forward
- * product takes when its 256-column tiles would fill less than 80 % of one round of CUs: QKV forward at 2432 rows); mask >= 0 sets, -1 queries; returns
- * the mask in force (default: MTVAF_P16_WIDE, 7 if unset).  Process-global; placement only -- the two kernels issue the same MFMA products in the same order for every
- * output element and agree bit for bit. */
+/* The tile of mtvaf_gemm_f32p* (round 6): which products may run on the 128 x 256 tile (csrc/gemm_f32pw.hip; N % 256 == 0) instead of
+ * the 128 x 128 tile -- a mask: 1 = forward products (layout_b 0; these may also take a 128 x 192 tile when N % 192 == 0 and no
+ * plane-image result is asked for), 2 = dX products (layout_b 1), 4 = weight gradients (layout_a 1; the grouped launch when every
+ * N_i % 256 == 0).  Among the admitted tiles a launch takes the cheapest by an estimate of rounds x tile time (QKV forward at 2432
+ * rows: 192 columns, one round of 228 tiles; FFN-1: 256; N = 768 and 4096-row launches: mostly 128 x 128).  8 = never the 128 x 128
+ * tile where another can serve (tests), 16 = never the 128 x 192 tile.  mask >= 0 sets, -1 queries; returns the mask in force
+ * (default: MTVAF_P16_WIDE, 7 if unset).  Process-global; placement only -- the kernels issue the same MFMA products in the same
+ * order for every output element and agree bit for bit. */
 int mtvaf_f32p_wide(int mask);
 /* research entry: up to four weight-gradient products C_i [M_i][N_i] = A_i^T . B_i from plane images (A_i [K][M_i], B_i [K][N_i], the
  * token rows K shared) in ONE unsplit launch over the 128 x 128 tiles of all of them -- what the grouped launch of

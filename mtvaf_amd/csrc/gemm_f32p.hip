@@ -25,6 +25,7 @@
 // fp32 tensor's own layout) and the tile-blocked form ([k-tile][plane][rows][32]: every 1-KiB request reads 1 KiB of contiguous
 // memory) are both served.
 #include "gemm_f32p.h"
+#include <climits>
 
 namespace mtvaf {
 
@@ -523,8 +524,9 @@ int mtvaf_f32_split_planes(const float* src, void* dst, int rows, int cols, int 
 
 static long long* g_f32p_trace = nullptr;
 // Which products take the 128 x 256 tile (gemm_f32pw.hip): a mask -- 1: forward products (both operands k-contiguous), 2: dX products
-// (k-major B), 4: weight gradients (k-major A and B; the grouped launch), 8: ALSO products with N < 1024 or fewer than 128 wide tiles
-// (tests; research), 16: never the 128 x 192 tile (forward products that fill less than 80 % of one round of CUs with 256-column tiles).
+// (k-major B), 4: weight gradients (k-major A and B; the grouped launch) -- among the tiles the mask admits a launch takes the
+// cheapest by gemm_f32p_run's rounds x tile-time estimate; 8: never the 128 x 128 tile where another can serve (tests; research);
+// 16: never the 128 x 192 tile (unsplit or split forward products without a plane-image result, N % 192 == 0).
 static int g_p16_wide = -1;  // -1: MTVAF_P16_WIDE
 static int p16_wide_mask() {
   static const int v = [] { const char* e = getenv("MTVAF_P16_WIDE"); return e ? atoi(e) & 31 : 7; }();
@@ -573,20 +575,32 @@ static int gemm_f32p_run(int layout_a, const void* Aplanes, long a_plane, long a
   a.k_chunk = kc;
   if (splits > 1) { a.C = (float*)workspace; a.ldc = N; a.slab_stride = (long)M * N; }
   else { a.C = C; a.ldc = ldc; a.slab_stride = 0; }
-  // the 128 x 256 tile (gemm_f32pw.hip; MTVAF_P16_WIDE: 0 = never, 1 = wherever N % 256 == 0): same bits, a quarter less LDS traffic
-  // (N = 768 at 2432 rows would be 57 tiles: measured slower with two slabs and equal with four, tools/p16_wide_probe.py; a launch of fewer
-  // than 128 wide tiles leaves more than half of the CUs idle)
+  // Tile choice (128 x 128 here; 128 x 256 / 128 x 192 in gemm_f32pw.hip: the same bits): the launch runs ceil(tiles / 256 CUs) rounds of
+  // one tile each, a tile = nk k-tiles + prologue and epilogue, in shader-clock ticks from the block-0 traces (tools/p16_wide_probe.py,
+  // profiles/r06_p16_wide_tile_probe.txt): per k-tile 1850 / 3378 / 2560 (k-major B: 1975 / 3493), fixed 13 k / 21 k / 17 k (+ 5 k with
+  // a plane-image epilogue).  Ties go to the larger tile.  (At 2432 rows: QKV forward 2 rounds of 342 / 1 of 171 / 1 of 228 -> 192;
+  // FFN-1 forward 2 of 456 / 1 of 228 / 2 of 304 -> 256; at 4096 rows 3 of 768 / 2 of 384 -> 128 x 128 again.)
   const int wmask = p16_wide_mask();
-  const long tm = M / 128;
-  bool wide = (wmask & (layout_a ? 4 : layout_b ? 2 : 1)) && N % 256 == 0 && ((N >= 1024 && tm * (N / 256) >= 128) || (wmask & 8));
-  int bn = wide ? 256 : 128;
-  // a forward product whose 256-column tiles fill less than 80 % of one round of CUs (QKV forward at 2432 rows: 171 tiles) takes the
-  // 192-column tile if that makes one fuller round (228)
-  if ((wmask & 1) && !(wmask & 16) && !layout_a && !layout_b && !c_planes && !ablate && !g_f32p_trace && N % 192 == 0 && splits == 1 && tm * (N / 192) <= 256 &&
-      tm * (N / 192) >= 128 && (!wide || tm * (N / 256) * 5 < 256 * 4)) {
-    wide = true;
-    bn = 192;
+  const long tm = M / 128, nkb = kc / 32;
+  auto cost = [&](int bn_, long per_k, long fixed) {
+    const long tiles = tm * (N / bn_) * splits, t = nkb * per_k + fixed + (c_planes ? 5000 : 0) * (bn_ / 128);
+    // (a few rounds run in lockstep; many rounds drift apart and the CUs stay busy to the last partial round)
+    return tiles <= 1024 ? ((tiles + 255) / 256) * t : (tiles * t + 128 * t) / 256;
+  };
+  const bool ok256 = (wmask & (layout_a ? 4 : layout_b ? 2 : 1)) && N % 256 == 0;
+  const bool ok192 = (wmask & 1) && !(wmask & 16) && !layout_a && !layout_b && !c_planes && !ablate && !g_f32p_trace && N % 192 == 0;
+  int bn = 128;
+  long best = cost(128, layout_b ? 1975 : 1850, 13000);
+  if ((wmask & 8) && (ok256 || ok192)) best = LONG_MAX;  // (tests: never the 128 x 128 tile where another one can serve)
+  if (ok256) {
+    const long c = cost(256, layout_b ? 3493 : 3378, 21000);
+    if (c <= best) { best = c; bn = 256; }
   }
+  if (ok192) {
+    const long c = cost(192, 2560, 17000);
+    if (c < best) { best = c; bn = 192; }
+  }
+  const bool wide = bn != 128;
   a.tiles_n = N / bn;
   a.Cpl = static_cast<unsigned char*>(c_planes);
   a.colpart = colpart;

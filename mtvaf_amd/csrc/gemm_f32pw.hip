@@ -256,8 +256,11 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
     rd_a(smem_w, 2);
     rd_b(smem_w, 0, fbs[0]);
     int st = 0;
-    // (two k-tiles per trip: across the loop's back edge hipcc waits for EVERY outstanding fragment read -- lgkmcnt(0) in front of the
-    // first MFMA of a tile whose operands were read long before the row blocks issued last)
+    // (-DMTVAF_PW_UNROLL2: two k-tiles per trip -- across the loop's back edge hipcc waits for EVERY outstanding fragment read, lgkmcnt(0)
+    // in front of the first MFMA of a tile; unrolled, 3378 instead of 3429 ticks per k-tile in the block-0 trace -- and 5 % SLOWER as a
+    // training step (3350 against 3555 sentences/s, same box): the unrolled kernels hold 214 - 248 registers instead of 204 - 228, and
+    // at two waves per SIMD that is the difference between a CU that can take a wave of the other stream's kernel beside a GEMM block
+    // and one that cannot; profiles/r06_p16_wide_tile_step_ab.txt)
     auto tile = [&](const int t) __attribute__((always_inline)) {
       const unsigned char* s = smem_w + st * STAGE_B;
       // column block 0 -- beside it the last row block of this tile's A and column block 1
@@ -300,11 +303,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32p16w_kernel(GemmArgsP p) {
       }
     };
     int t = 0;
+#ifdef MTVAF_PW_UNROLL2
     for (; t + 1 < nk; t += 2) {
       tile(t);
       tile(t + 1);
     }
-    if (t < nk) tile(t);
+#endif
+    for (; t < nk; ++t) tile(t);
   }
 
   if (TRACE && tr && lane == 0) tr[8 * 64 * 2 + 1 + wave] = __builtin_amdgcn_s_memtime();  // this wave's k-loop is over

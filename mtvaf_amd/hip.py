@@ -318,9 +318,10 @@ def f32_split(on=None) -> bool:
 
 
 def f32p_wide(mask=None) -> int:
-    """The pre-split GEMM's tile (csrc/gemm_f32pw.hip, round 6): which products with N % 256 == 0 run on the 128 x 256 tile -- a mask
-    (1 forward products, 2 dX products, 4 weight gradients, 8 also products with N < 1024 or fewer than 128 wide tiles; True = 15,
-    False = 0), None queries.  Placement only: the kernels agree bit for bit.  Default: MTVAF_P16_WIDE (7 if unset)."""
+    """The pre-split GEMM's tiles (csrc/gemm_f32pw.hip, round 6): a mask of the products that may leave the 128 x 128 tile -- 1 forward
+    (128 x 256, or 128 x 192 without a plane-image result), 2 dX, 4 weight gradients; a launch takes the cheapest admitted tile by the
+    library's rounds x tile-time estimate; 8 = never 128 x 128 where another tile can serve (tests), 16 = never 128 x 192; True = 15,
+    False = 0, None queries.  Placement only: the kernels agree bit for bit.  Default: MTVAF_P16_WIDE (7 if unset)."""
     if mask is True:
         mask = 15
     return int(lib().mtvaf_f32p_wide(-1 if mask is None else int(mask)))
