@@ -2,12 +2,16 @@
 # scratch: one GPU call
 set -o pipefail
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
 mkdir -p gpurun_out
-rm -rf gpurun_out/ovp
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/ovp -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline > gpurun_out/ovp.log 2>&1 || exit 1
-T=$(find gpurun_out/ovp -name "*kernel_trace.csv" | tail -1)
-python tools/overlap_probe.py $T 2 8.5 > gpurun_out/overlap_tail.txt
-python tools/overlap_probe.py $T 2 0 3.2 > gpurun_out/overlap_head.txt
-rm -rf gpurun_out/ovp
-echo done
+O=$PWD/gpurun_out/padded_ab_prev.txt
+: > $O
+for v in prev cur prev cur; do
+  D=$GRAFT_REPO_ROOT
+  [ $v = prev ] && D=$GRAFT_REPO_ROOT/_prev
+  echo "== $v" >> $O
+  ( cd $D && timeout -k 10 200 python bench.py --steps 20 --warmup 5 --padded --no-cpu-baseline --no-secondary 2>$GRAFT_REPO_ROOT/gpurun_out/wide_ab.err | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print(d['value'], d['ms_per_step'], r['kernel'][:44], r['avg_launch_us'], r['frac'], r.get('all_gemm_frac'), d.get('mfma_fraction_of_step_executed'))" >> $O ) || exit 1
+done
+cat $O
