@@ -9,6 +9,7 @@
 #include "planes.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace mtvaf {
 
@@ -238,6 +239,147 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     }
     __syncthreads();
   }
+}
+
+// MODE 0 in a form that fits INTO the CUs a one-round GEMM launch occupies (round 6).  The grouped weight gradients of a layer run
+// on the second stream as one block per CU on 216 of 256 CUs (228 registers x 2 waves per SIMD, 144 of 160 KiB of LDS), and the
+// LayerNorm backward of the main stream (169 registers, 16 KiB) was confined to the 40 free CUs: 91 us instead of 18
+// (profiles/r06_coresident_probe.txt).  Here a ROW is spread over the block (H / 4 threads: one float4 column chunk per lane, 192
+// threads at H = 768) instead of over one wave, so a lane carries 4 instead of 16 elements of every row vector and the column
+// partials of its own chunk only: <= 48 registers, 64 bytes of LDS (the two row statistics cross the waves through it, one barrier
+// per row, double-buffered).  Same arithmetic per element as ln_bwd_kernel<0>; the row sums s1 / s2 and the column partials are
+// summed in another (fixed) order.  H % 256 == 0, H <= 1024.  partials: [gridDim.x][3][H] as in ln_bwd_kernel.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// every access of a row = a buffer descriptor (scalar registers, built from kernel arguments) + ONE 32-bit lane offset + the row's
+// byte offset in a scalar register: the 64-bit vector addresses of ten arrays would cost the lane more registers than its data
+#define LEAN_RSRC(p, bytes) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(p)), 0, (int)(bytes), 0x00020000)
+__device__ __forceinline__ f32x4 lean_ld(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned sb) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, v, sb, 0));
+}
+__device__ __forceinline__ void lean_st(__amdgpu_buffer_rsrc_t r, unsigned v, unsigned sb, f32x4 x) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), r, v, sb, 0);
+}
+// sum over the 64 lanes by DPP row operations (no index registers, unlike __shfl_xor's ds_bpermute): -> the sum, wave-uniform
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  auto dpp = [](float x, auto ctrl, auto rmask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xF, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});  // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});  // row_mirror: every lane = its row of 16
+  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast15 into rows 1 and 3
+  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+
+// NS: the slab count as a compile-time constant (0, 1, 2: straight-line loads, all of a row's requests in flight together) or -1 (any)
+template <bool PL, int NS>
+__global__ __launch_bounds__(256) void ln_bwd_lean_kernel(const float* __restrict__ dout, const float* __restrict__ slabs, int nslab,
+                                                         const float* __restrict__ x, const float* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                         const float* __restrict__ rstd_i, float* __restrict__ dx,
+                                                         float* __restrict__ dres, int dres_acc, float* __restrict__ partials, int M,
+                                                         int H, float p_drop, uint64_t seed, uint64_t offset,
+                                                         __bf16* __restrict__ dx16, const uint64_t* __restrict__ epoch) {
+  offset = epoch_offset(offset, epoch);
+  __shared__ float red[2][4][2];
+  const int c = threadIdx.x;  // this lane's float4 column chunk; blockDim.x == H / 4
+  const int lane = c & 63, wave = c >> 6;
+  const int nch = H >> 2;
+  const float scale = uni(p_drop > 0.f ? 1.f / (1.f - p_drop) : 1.f);
+  const float invH = uni(1.f / H);
+  const uint32_t thr = __builtin_amdgcn_readfirstlane((uint32_t)fminf(p_drop * 4294967296.0f, 4294967040.0f));
+  const unsigned rowb = (unsigned)H * 4u;        // bytes of a row
+  const unsigned tb = (unsigned)M * rowb;        // bytes of a [M, H] tensor (the host checks nslab * tb, 1.5 * tb < 2^32)
+  const unsigned lo = (unsigned)c * 16u;         // byte offset of the lane's chunk in a row ...
+  const unsigned lp = (unsigned)(c >> 3) * 3u * (unsigned)M * 64u + (unsigned)(c & 7) * 8u;  // ... and in the plane image [H / 32][3][M][32]
+  const auto r_dout = LEAN_RSRC(dout, tb), r_x = LEAN_RSRC(x, tb), r_res = LEAN_RSRC(res, tb), r_dres = LEAN_RSRC(dres, tb);
+  const auto r_sl = LEAN_RSRC(slabs, slabs ? (unsigned)nslab * tb : 0u);
+  const auto r_dx = LEAN_RSRC(dx, dx ? tb : 0u);                          // (a zero-record descriptor drops the store)
+  const auto r_16 = LEAN_RSRC(dx16, dx16 ? (PL ? tb / 2u * 3u : tb / 2u) : 0u);
+  if (c < 16) reinterpret_cast<float*>(red)[c] = 0.f;  // (entries of waves this block does not have read as zero)
+  __syncthreads();
+  const auto r_gam = LEAN_RSRC(gamma, rowb);
+  f32x4 ag = f32x4{0.f, 0.f, 0.f, 0.f}, ab = ag, at0 = ag;
+  int par = 0;
+  for (int row = blockIdx.x; row < M; row += gridDim.x, par ^= 1) {
+    const unsigned rb = (unsigned)row * rowb;
+    const float mu = mean_i[row], rstd = rstd_i[row];
+    uint32_t keep = 0xF;
+    if (p_drop > 0.f) {  // dropout_keep4 with its threshold in a scalar register
+      const uint64_t idx4 = (uint64_t)row * nch + c;
+      const uint4_ r = philox4x32((uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+      keep = (r.x >= thr ? 1u : 0u) | (r.y >= thr ? 2u : 0u) | (r.z >= thr ? 4u : 0u) | (r.w >= thr ? 8u : 0u);
+    }
+    f32x4 dy = lean_ld(r_dout, lo, rb);
+    f32x4 xv = lean_ld(r_x, lo, rb);
+    const f32x4 rv = lean_ld(r_res, lo, rb);
+    const f32x4 gam = lean_ld(r_gam, lo, 0);  // (re-read per row from the cache: four registers less across the loop)
+    // dout = (slab 0 + slab 1 + ...) + dout, in the order of the reduction launch this replaces
+    if constexpr (NS == 1) {
+      dy = lean_ld(r_sl, lo, rb) + dy;
+    } else if constexpr (NS == 2) {
+      const f32x4 s0 = lean_ld(r_sl, lo, rb), s1_ = lean_ld(r_sl, lo, tb + rb);
+      dy = (s0 + s1_) + dy;
+    } else if constexpr (NS < 0) {
+      f32x4 sl = lean_ld(r_sl, lo, rb);
+      for (int zs = 1; zs < nslab; ++zs) sl += lean_ld(r_sl, lo, (unsigned)zs * tb + rb);
+      dy = sl + dy;
+    }
+    f32x4 xh;
+    {
+      if (p_drop > 0.f) {
+        xv.x = (keep & 1) ? xv.x * scale : 0.f; xv.y = (keep & 2) ? xv.y * scale : 0.f;
+        xv.z = (keep & 4) ? xv.z * scale : 0.f; xv.w = (keep & 8) ? xv.w * scale : 0.f;
+      }
+      xh = ((xv + rv) - mu) * rstd;
+    }
+    ag += dy * xh;
+    ab += dy;
+    const f32x4 g = dy * gam;
+    float s1 = wave_sum_dpp(g.x + g.y + g.z + g.w);
+    float s2 = wave_sum_dpp(g.x * xh.x + g.y * xh.y + g.z * xh.z + g.w * xh.w);
+    if (lane == 0) { red[par][wave][0] = s1; red[par][wave][1] = s2; }
+    __syncthreads();
+    s1 = ((red[par][0][0] + red[par][1][0]) + red[par][2][0]) + red[par][3][0];
+    s2 = ((red[par][0][1] + red[par][1][1]) + red[par][2][1]) + red[par][3][1];
+    const float m1 = s1 * invH, m2 = s2 * invH;
+    const f32x4 dz = (g - m1 - xh * m2) * rstd;
+    {
+      f32x4 r = dz;
+      if (dres_acc) r += lean_ld(r_dres, lo, rb);
+      lean_st(r_dres, lo, rb, r);
+    }
+    f32x4 d = dz;
+    if (p_drop > 0.f) {
+      d.x = (keep & 1) ? d.x * scale : 0.f; d.y = (keep & 2) ? d.y * scale : 0.f;
+      d.z = (keep & 4) ? d.z * scale : 0.f; d.w = (keep & 8) ? d.w * scale : 0.f;
+    }
+    lean_st(r_dx, lo, rb, d);
+    if constexpr (PL) {  // planes_store4 with the row's share of the address in scalar registers: bit for bit the same image
+      f32x4 v = d;
+      asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+      unsigned h0, m0, l0, h1, m1_, l1;
+      pl_split(pl_f32x2{v.x, v.y}, h0, m0, l0);
+      pl_split(pl_f32x2{v.z, v.w}, h1, m1_, l1);
+      const unsigned pr = (unsigned)row * 64u, ps = (unsigned)M * 64u;
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{h0, h1}, r_16, lp, pr, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{m0, m1_}, r_16, lp, pr + ps, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{l0, l1}, r_16, lp, pr + 2u * ps, 0);
+    } else {
+      const bf16x4 q = bf16x4{(__bf16)d.x, (__bf16)d.y, (__bf16)d.z, (__bf16)d.w};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, q), r_16, lo >> 1, rb >> 1, 0);
+    }
+    at0 += d;
+  }
+  float* pp = partials + (size_t)blockIdx.x * 3 * H + c * 4;
+  *reinterpret_cast<f32x4*>(pp) = ag;
+  *reinterpret_cast<f32x4*>(pp + H) = ab;
+  *reinterpret_cast<f32x4*>(pp + 2 * H) = at0;
 }
 
 // out[c] = (acc ? out[c] : 0) + sum_r x[r*ld + c].  Block = 32 columns x 8 row groups; the 8 partial sums
@@ -571,6 +713,29 @@ static inline int row_grid_bwd(int M) {
   return std::max(1, std::min((M + 3) / 4, cap));
 }
 
+// the lean LayerNorm backward (ln_bwd_lean_kernel) wherever its shape rule holds; MTVAF_LN_LEAN=0: the one-wave-per-row kernel
+static inline bool ln_lean(int M, int H, int nslab) {
+  const char* e = getenv("MTVAF_LN_LEAN");  // (read per call: the parity test switches between the two kernels in one process)
+  const int on = e ? atoi(e) : 1;
+  // (32-bit buffer offsets: the slab stack and the plane image must stay below 2 GiB)
+  return on && H % 256 == 0 && H <= 1024 && (size_t)std::max(nslab, 2) * M * H * 4 < ((size_t)1 << 31);
+}
+
+template <bool PL>
+static void ln_bwd_lean(int g, hipStream_t st, const float* dout, const float* slabs, int nslab, const float* x, const float* res,
+                        const float* gamma, const float* mean, const float* rstd, float* dx, float* dres, int dres_acc, float* part, int M,
+                        int H, float p_drop, uint64_t seed, uint64_t offset, __bf16* dx16) {
+  if (!slabs) nslab = 0;
+#define MTVAF_LEAN(NS_)                                                                                                             \
+  hipLaunchKernelGGL((ln_bwd_lean_kernel<PL, NS_>), dim3(g), dim3(H / 4), 0, st, dout, slabs, nslab, x, res, gamma, mean, rstd, dx, \
+                     dres, dres_acc, part, M, H, p_drop, seed, offset, dx16, rng_epoch_ptr())
+  if (nslab == 0) MTVAF_LEAN(0);
+  else if (nslab == 1) MTVAF_LEAN(1);
+  else if (nslab == 2) MTVAF_LEAN(2);
+  else MTVAF_LEAN(-1);
+#undef MTVAF_LEAN
+}
+
 }  // namespace mtvaf
 
 using namespace mtvaf;
@@ -640,9 +805,13 @@ int mtvaf_dropout_res_ln_bwd_rows(const float* dout, const float* x, const float
   if (H % 4 || H > MAXC * 256 || M <= 0) return MTVAF_ERR_SHAPE;
   if ((!dx && !dx_bf16) || !part) return MTVAF_ERR_ARG;
   const int g = row_grid_bwd(M);
-  hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
-                     offset, static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
+  if (ln_lean(M, H, 1))
+    ln_bwd_lean<false>(g, st, dout, nullptr, 0, x, res, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, H, p_drop, seed, offset,
+                       static_cast<__bf16*>(dx_bf16));
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout, x, res, nullptr, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, 1, H, p_drop, seed,
+                       offset, static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -655,9 +824,13 @@ int mtvaf_dropout_res_ln_bwd_rows_slabs(const float* dout_base, const float* sla
   if (H % 4 || H > MAXC * 256 || M <= 0 || nslab < 1) return MTVAF_ERR_SHAPE;
   if ((!dx && !dx_bf16) || !part || !slabs || !dout_base) return MTVAF_ERR_ARG;
   const int g = row_grid_bwd(M);
-  hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout_base, x, res, nullptr, nullptr, nullptr, slabs, nullptr,
-                     nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, nslab, H, p_drop, seed, offset,
-                     static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
+  if (ln_lean(M, H, nslab))
+    ln_bwd_lean<false>(g, st, dout_base, slabs, nslab, x, res, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, H, p_drop, seed, offset,
+                       static_cast<__bf16*>(dx_bf16));
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<0>), dim3(g), dim3(256), 0, st, dout_base, x, res, nullptr, nullptr, nullptr, slabs, nullptr,
+                       nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M, nslab, H, p_drop, seed, offset,
+                       static_cast<__bf16*>(dx_bf16), rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }
@@ -689,9 +862,13 @@ int mtvaf_dropout_res_ln_bwd_rows_planes(const float* dout_base, const float* sl
   if (H % 32 || H > MAXC * 256 || M <= 0 || nslab < 0) return MTVAF_ERR_SHAPE;
   if (!dx_planes || !part || !dout_base || (nslab >= 1 && !slabs) || (((uintptr_t)dx_planes) & 15)) return MTVAF_ERR_ARG;
   const int g = row_grid_bwd(M);
-  hipLaunchKernelGGL((ln_bwd_kernel<0, true>), dim3(g), dim3(256), 0, st, dout_base, x, res, nullptr, nullptr, nullptr,
-                     nslab >= 1 ? slabs : nullptr, nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M,
-                     nslab >= 1 ? nslab : 1, H, p_drop, seed, offset, static_cast<__bf16*>(dx_planes), rng_epoch_ptr());
+  if (ln_lean(M, H, nslab))
+    ln_bwd_lean<true>(g, st, dout_base, nslab >= 1 ? slabs : nullptr, nslab, x, res, gamma, mean, rstd, dx, dres, dres_accumulate, part, M,
+                      H, p_drop, seed, offset, static_cast<__bf16*>(dx_planes));
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<0, true>), dim3(g), dim3(256), 0, st, dout_base, x, res, nullptr, nullptr, nullptr,
+                       nslab >= 1 ? slabs : nullptr, nullptr, nullptr, gamma, mean, rstd, dx, dres, dres_accumulate, part, M,
+                       nslab >= 1 ? nslab : 1, H, p_drop, seed, offset, static_cast<__bf16*>(dx_planes), rng_epoch_ptr());
   MTVAF_LAUNCH_CHECK();
   return MTVAF_OK;
 }

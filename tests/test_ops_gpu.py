@@ -1809,3 +1809,67 @@ def test_gemm_f32_split_epilogues_splitk_ktiles_and_fallback(hip):
     finally:
         hip.f32_split(was)
     assert hip.f32_split() == was
+
+
+@pytest.mark.parametrize("M,H,nslab", [(2432, 768, 2), (2432, 768, 0), (333, 768, 1), (100, 1024, 3), (64, 256, 2)])
+def test_layernorm_backward_lean_kernel_against_the_wave_per_row_kernel(hip, M, H, nslab):
+    """Round 6: ln_bwd_lean_kernel (a row over the block, <= 48 registers, 64 B of LDS: fits into the CUs a one-round GEMM launch
+    occupies) against ln_bwd_kernel<0> (MTVAF_LN_LEAN=0) in ONE process: the dropout mask, dres accumulation and the slab sum are
+    bit-identical by construction, the row statistics and column partials are summed in another order -> dx / dres / plane image
+    within a few ulp of the row's scale, the finished column sums within 1e-5; and both against fp64 (modeling_bert.py:354-355)."""
+    import os
+    L_ = hip.lib()
+    E = lambda *s_: torch.empty(*s_, device=DEV)
+    x, res, dout = rnd(M, H, seed=1).to(DEV), rnd(M, H, seed=2).to(DEV), rnd(M, H, seed=3).to(DEV)
+    gamma, beta = (1 + 0.1 * rnd(H, seed=4)).to(DEV), (0.1 * rnd(H, seed=5)).to(DEV)
+    slabs = rnd(max(nslab, 1), M, H, seed=6).to(DEV)
+    out, mu, rs = E(M, H), E(M), E(M)
+    p, seed, off = 0.1, 77, 5
+    hip._ck(L_.mtvaf_dropout_res_ln_fwd(hip._p(x), hip._p(res), hip._p(gamma), hip._p(beta), hip._p(out), hip._p(mu), hip._p(rs), M, H,
+                                        1e-12, p, seed, off, None, hip._st()), "ln")
+    nb = L_.mtvaf_ln_bwd_workspace_bytes(M, H)
+    got = {}
+    for lean in ("0", "1"):
+        os.environ["MTVAF_LN_LEAN"] = lean
+        try:
+            part = torch.zeros(nb // 4, device=DEV)
+            dx, dres = E(M, H), torch.ones(M, H, device=DEV)
+            pl = hip.Planes(torch.zeros(M, H, device=DEV), True)
+            hip._ck(L_.mtvaf_dropout_res_ln_bwd_rows_planes(hip._p(dout), hip._p(slabs) if nslab else None, nslab, hip._p(x), hip._p(res),
+                                                            hip._p(gamma), hip._p(mu), hip._p(rs), hip._p(dx), hip._p(dres), 1, M, H, p, seed,
+                                                            off, hip._p(part), hip._p(pl.img), hip._st()), "bwd rows planes")
+            dg, db, dbx = E(H), E(H), E(H)
+            hip._ck(L_.mtvaf_dropout_res_ln_bwd_finish(hip._p(part), M, H, hip._p(dg), hip._p(db), hip._p(dbx), 0, hip._st()), "finish")
+            # the fp32 / bf16-copy entry points take the same kernel with PL = false
+            dx2, dres2, part2 = E(M, H), E(M, H), torch.zeros(nb // 4, device=DEV)
+            dsum = (slabs[:nslab].sum(0) + dout) if nslab else dout
+            hip._ck(L_.mtvaf_dropout_res_ln_bwd_rows(hip._p(dsum), hip._p(x), hip._p(res), hip._p(gamma), hip._p(mu), hip._p(rs), hip._p(dx2),
+                                                     hip._p(dres2), 0, M, H, p, seed, off, hip._p(part2), None, hip._st()), "bwd rows")
+            got[lean] = (dx.clone(), dres.clone(), pl.img.clone(), dg, db, dbx, dx2, dres2)
+        finally:
+            os.environ.pop("MTVAF_LN_LEAN", None)
+    a, b = got["0"], got["1"]
+    scale = float(a[0].abs().max())
+    for i, name in enumerate(("dx", "dres")):
+        assert float((a[i] - b[i]).abs().max()) <= 4e-6 * max(scale, 1.0), name
+    assert torch.equal(a[0] == 0, b[0] == 0)  # the same dropout mask
+    for lean in ("0", "1"):  # the plane image is the three-way split of the dx beside it
+        img = got[lean][2].view(H // 32, 3, M, 32).float().sum(1).permute(1, 0, 2).reshape(M, H)
+        assert float((img - got[lean][0]).abs().max()) <= 1e-6 * max(scale, 1.0), lean
+    for i, name in ((3, "dgamma"), (4, "dbeta"), (5, "dbias_x")):
+        close(b[i], a[i], rtol=2e-5, name=name)
+    # fp64 reference (dropout mask recovered from dx == 0 is not needed: compare the mask-free quantities)
+    keep = torch.empty(M, H, device=DEV)
+    hip.dropout(torch.ones(M, H, device=DEV), keep, p, seed, off)
+    xd, rd = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    y = F.layer_norm(xd * keep.double() + rd, (H,), gd, beta.double(), 1e-12)
+    dsum = ((slabs[:nslab].double().sum(0) if nslab else 0) + dout.double())
+    (y * dsum).sum().backward()
+    for lean in ("0", "1"):
+        dx, dres, _, dg, db, dbx, dx2, dres2 = got[lean]
+        close(dx, xd.grad, name=f"dx lean={lean}")
+        close(dres - 1, rd.grad, name=f"dres lean={lean}")
+        close(dg, gd.grad, rtol=5e-4, name=f"dgamma lean={lean}")
+        close(dx2, xd.grad, name=f"dx (fp32 entry) lean={lean}")
+        close(dres2, rd.grad, name=f"dres (fp32 entry) lean={lean}")
