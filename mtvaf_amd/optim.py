@@ -147,8 +147,12 @@ class AdamW(torch.optim.Optimizer):
     # (the pre-split path's second stream is lighter -- one grouped launch per layer -- and the update also writes the weights' plane
     # images: 256 blocks measured best there, 3257 - 3260 sentences/s against 3237 - 3238 at 128, 3220 - 3225 at 512, 3128 - 3133 at 64)
     BACKGROUND_BLOCKS_PLANES = int(os.environ.get("MTVAF_ADAMW_BG_BLOCKS", "256"))
+    # (bf16 mode below 4096 token rows -- C3: a layer's backward pass is 260 us, shorter than a 128-block trickle of its update --
+    # 256 blocks: 5.52 - 5.54 -> 5.41 - 5.43 ms median step, same box; at 4864 rows (C4) 128 / 192 / 256 measure equal)
+    BACKGROUND_BLOCKS_SHORT = int(os.environ.get("MTVAF_ADAMW_BG_BLOCKS", "256"))
+    BACKGROUND_SHORT_ROWS = 4096
 
-    def _update_layer_flat(self, li: int, group: dict, store, background: bool = False):
+    def _update_layer_flat(self, li: int, group: dict, store, background: bool = False, rows: int = 0):
         st = self._layer_state(li, store)
         st["step"] += 1
         st["step_t"].fill_(st["step"])  # the 16 per-parameter state entries share this 0-dim tensor
@@ -163,7 +167,8 @@ class AdamW(torch.optim.Optimizer):
             engine.planes_written(store.weights)
             return
         hip.adamw(store.flat, store.grad, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                  st["step"], p_bf16=shadow, max_blocks=self.BACKGROUND_BLOCKS if background else 0)
+                  st["step"], p_bf16=shadow,
+                  max_blocks=(self.BACKGROUND_BLOCKS_SHORT if 0 < rows < self.BACKGROUND_SHORT_ROWS else self.BACKGROUND_BLOCKS) if background else 0)
         if shadow is not None:
             engine.shadow_written(store.weights)
         engine.planes_rewrite(store.weights)  # (images exist but the fused form does not apply: rebuilt behind the update)
@@ -181,7 +186,7 @@ class AdamW(torch.optim.Optimizer):
         rows = getattr(self._encoder._sink, "token_rows", 0)
         # (layer 0 is the last one of the pass: nothing left to hide behind)
         background = self._background_ok and li > 0 and rows >= self.BACKGROUND_MIN_ROWS
-        self._update_layer_flat(li, group, stores[li], background=background)
+        self._update_layer_flat(li, group, stores[li], background=background, rows=rows)
         self._early.add(li)
 
     # -- the step ------------------------------------------------------------------------------------------------

@@ -35,7 +35,7 @@ small = {
     "dropout_kernel (22 regs)": lambda: hip.dropout(a_, c_, 0.1, 1, 0),
     "torch add (aten)": lambda: torch.add(a_, b_, out=c_),
     "ln_fwd (82-112 regs)": lambda: hip.dropout_res_ln_fwd(a_, b_, gamma, beta, c_, mean, rstd, 1e-12, 0.1, 1, 0),
-    "ln_bwd + finish (169 regs, 16 KiB)": lambda: hip.dropout_res_ln_bwd(a_, b_, c_, gamma, mean, rstd, dx, dres, False, dgamma, dbeta, False, 0.1, 1, 0, dbias_x=dbias),
+    "ln_bwd + finish (lean: 44 regs; MTVAF_LN_LEAN=0: 169 regs, 16 KiB)": lambda: hip.dropout_res_ln_bwd(a_, b_, c_, gamma, mean, rstd, dx, dres, False, dgamma, dbeta, False, 0.1, 1, 0, dbias_x=dbias),
     "adamw (51 regs), 7.1 M parameters": lambda: hip.adamw(p, gr, m_, v_, 1e-5, 0.9, 0.999, 1e-8, 0.01, 1),
     "splitk reduce (torch sum of 2 slabs)": lambda: torch.sum(slab, 0, out=c_),
 }
