@@ -649,12 +649,19 @@ def main():
 
     if rank == 0:
         log("model and batch built")
-    for _ in range(a.warmup):
+    import gc
+    for i in range(a.warmup):
+        if i == a.warmup - 1:
+            # set-up garbage (model construction, the first steps' graphs) is collected BEFORE the last warm-up step, not inside a
+            # timed step -- and not between the warm-up and the timed region either: the collection idles the GPU for ~0.1 s, its
+            # clocks drop, and the first timed step then read 11.2 ms against 8.9 - 9.0 for the other 39 (profiles/r06_step_ms.txt)
+            torch.cuda.synchronize()
+            gc.collect()
         step()
+    if a.warmup == 0:
+        gc.collect()
     if rank == 0:
         log(f"{a.warmup} warm-up steps enqueued")
-    import gc
-    gc.collect()  # (set-up garbage -- model construction, warm-up graphs -- is collected here, not inside a timed step)
     barrier()
     # per-step HIP events on the main stream (no host sync inside the timed region): the median step is reported next to
     # the bracketed wall-clock figure, which stays `value` (the driver's contract)
@@ -779,6 +786,7 @@ def main():
                       "global_batch": B * world, "seq_len": S, "prefix": P,
                       "parallelism": f"dp{world}" + (" (RCCL all-reduce overlapped with backward)" if world > 1 else "")},
            "median_ms_per_step": round(med_ms, 3), "value_median": round(world * B / (med_ms * 1e-3), 2),
+           "step_ms": [round(x, 3) for x in step_ms],  # (detail file only: HIP events on the main stream around every timed step)
            "loss": round(loss_val, 4),
            # padding-free: the flops of the rows that are real tokens (per sentence with its own length); padded: SURVEY 8d's F_train
            "mfma_fraction_of_step": round(per_gpu * (f_exec if a.unpad else ftrain) / (PEAK_TFLOPS[peak_key] * 1e12), 4),
