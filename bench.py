@@ -284,11 +284,13 @@ def secondary_config(name, device, dtype, arch, B, S, n_aux, steps=10, warmup=3,
             opt.zero_grad(set_to_none=True)
             assert len(out.logits) == B
             return out
-        for _ in range(warmup):
+        import gc
+        for i in range(warmup):
+            if i == warmup - 1:  # (the garbage of the configurations measured before: collected before the LAST warm-up step, see main())
+                torch.cuda.synchronize()
+                gc.collect()
             step()
         torch.cuda.synchronize()
-        import gc
-        gc.collect()  # (the garbage of the configurations measured before must not be collected inside this one's timed steps)
         t0 = time.perf_counter()
         for _ in range(steps):
             out = step()
