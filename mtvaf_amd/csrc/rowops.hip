@@ -9,7 +9,6 @@
 #include "planes.h"
 
 #include <cstdlib>
-#include <type_traits>
 
 namespace mtvaf {
 
@@ -261,16 +260,14 @@ __device__ __forceinline__ void lean_st(__amdgpu_buffer_rsrc_t r, unsigned v, un
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), r, v, sb, 0);
 }
 // sum over the 64 lanes by DPP row operations (no index registers, unlike __shfl_xor's ds_bpermute): -> the sum, wave-uniform
+#define LEAN_DPP(x, ctrl, rows) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rows), 0xF, false))
 __device__ __forceinline__ float wave_sum_dpp(float v) {
-  auto dpp = [](float x, auto ctrl, auto rmask) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xF, false));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xF>{});   // quad_perm [1,0,3,2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xF>{});   // quad_perm [2,3,0,1]
-  v += dpp(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xF>{});  // row_half_mirror
-  v += dpp(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xF>{});  // row_mirror: every lane = its row of 16
-  v += dpp(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});  // row_bcast15 into rows 1 and 3
-  v += dpp(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});  // row_bcast31 into rows 2 and 3
+  v += LEAN_DPP(v, 0xB1, 0xF);   // quad_perm [1,0,3,2]
+  v += LEAN_DPP(v, 0x4E, 0xF);   // quad_perm [2,3,0,1]
+  v += LEAN_DPP(v, 0x141, 0xF);  // row_half_mirror
+  v += LEAN_DPP(v, 0x140, 0xF);  // row_mirror: every lane = the sum of its row of 16
+  v += LEAN_DPP(v, 0x142, 0xA);  // row_bcast15 into rows 1 and 3 (the other rows add 0)
+  v += LEAN_DPP(v, 0x143, 0xC);  // row_bcast31 into rows 2 and 3: lane 63 = the sum
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float uni(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
